@@ -1,0 +1,1125 @@
+// gsx_oracle.cpp — CPU ORACLE (TEST INFRASTRUCTURE ONLY, never the product path).
+//
+// A CPU restatement, in plain C++ (no torch, no glm), of the arithmetic of the reference's
+// `--gut` hot path (MrNeRF/gaussian-splatting-cuda @ 2025-10-17, gsplat/Ops.h operator surface).
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+//
+// Parity status:
+//   * spherical harmonics fwd/bwd, tile intersection (keys, counts, order) and quat->rotmat are
+//     PINNED against the reference's own tests/torch_impl.cpp compiled unmodified
+//     (oracle/_ref, see oracle/build_ref.sh and tests/test_oracle_vs_ref.py) and against the
+//     golden vectors under tests/golden/ generated from it.
+//   * UT projection, intersect_offset, blend forward and blend backward are "PARITY UNPINNED":
+//     the reference has no CPU implementation, no golden vectors and no known-answer tests for
+//     them and its CUDA kernels cannot be compiled here (no nvcc, no glm).
+//     They are cross-validated instead (float64 re-evaluation, torch autograd of an independent
+//     differentiable forward, finite differences) in tests/.
+//
+// Every function cites the reference file:line it follows.  All functions are templated on the
+// scalar type: the `_f32` entry points follow the reference's fp32 operation order, the `_f64`
+// entry points re-evaluate the same formulas in double (used to measure fp32 conditioning).
+//
+// glm semantics are restated by hand (glm is a vcpkg dependency of the reference pinned only by
+// vcpkg.json "builtin-baseline" 4334d8b4c8916018600212ab4dd4bbdc343065d1; not vendored):
+// column-major matrices, quat ctor order (w,x,y,z), quat_cast largest-component branch,
+// rotate(q,v) = v + 2(w (u x v) + u x (u x v)), slerp with lerp fallback.
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+namespace {
+
+template <typename T> struct V2 { T x, y; };
+template <typename T> struct V3 { T x, y, z; };
+template <typename T> struct Q4 { T w, x, y, z; };
+// math (row, col) indexing; glm's m[c][r] == a[r][c] here.
+template <typename T> struct M3 { T a[3][3]; };
+
+template <typename T> inline V3<T> add(V3<T> a, V3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename T> inline V3<T> sub(V3<T> a, V3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename T> inline V3<T> mul(V3<T> a, T s) { return {a.x * s, a.y * s, a.z * s}; }
+template <typename T> inline T dot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// glm::cross
+template <typename T> inline V3<T> cross(V3<T> x, V3<T> y) {
+    return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y};
+}
+// glm mat3 * vec3 : m[0][r]*v.x + m[1][r]*v.y + m[2][r]*v.z
+template <typename T> inline V3<T> mv(const M3<T>& m, V3<T> v) {
+    return {m.a[0][0] * v.x + m.a[0][1] * v.y + m.a[0][2] * v.z,
+            m.a[1][0] * v.x + m.a[1][1] * v.y + m.a[1][2] * v.z,
+            m.a[2][0] * v.x + m.a[2][1] * v.y + m.a[2][2] * v.z};
+}
+template <typename T> inline M3<T> transpose(const M3<T>& m) {
+    M3<T> r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) r.a[i][j] = m.a[j][i];
+    return r;
+}
+
+// glm::quat_cast(mat3) — SURVEY Appendix B; call sites gsplat/Cameras.cuh:42,58
+template <typename T> inline Q4<T> quat_cast(const M3<T>& m) {
+    T fx = m.a[0][0] - m.a[1][1] - m.a[2][2];
+    T fy = m.a[1][1] - m.a[0][0] - m.a[2][2];
+    T fz = m.a[2][2] - m.a[0][0] - m.a[1][1];
+    T fw = m.a[0][0] + m.a[1][1] + m.a[2][2];
+    int big_i = 0;
+    T big = fw;
+    if (fx > big) { big = fx; big_i = 1; }
+    if (fy > big) { big = fy; big_i = 2; }
+    if (fz > big) { big = fz; big_i = 3; }
+    T bv = std::sqrt(big + T(1)) * T(0.5);
+    T mult = T(0.25) / bv;
+    switch (big_i) {
+    case 0: return {bv, (m.a[2][1] - m.a[1][2]) * mult, (m.a[0][2] - m.a[2][0]) * mult, (m.a[1][0] - m.a[0][1]) * mult};
+    case 1: return {(m.a[2][1] - m.a[1][2]) * mult, bv, (m.a[1][0] + m.a[0][1]) * mult, (m.a[0][2] + m.a[2][0]) * mult};
+    case 2: return {(m.a[0][2] - m.a[2][0]) * mult, (m.a[1][0] + m.a[0][1]) * mult, bv, (m.a[2][1] + m.a[1][2]) * mult};
+    default: return {(m.a[1][0] - m.a[0][1]) * mult, (m.a[0][2] + m.a[2][0]) * mult, (m.a[2][1] + m.a[1][2]) * mult, bv};
+    }
+}
+// glm::mat3_cast(quat) — no normalisation (Cameras.cuh:262,1046)
+template <typename T> inline M3<T> mat3_cast(Q4<T> q) {
+    T qxx = q.x * q.x, qyy = q.y * q.y, qzz = q.z * q.z;
+    T qxz = q.x * q.z, qxy = q.x * q.y, qyz = q.y * q.z;
+    T qwx = q.w * q.x, qwy = q.w * q.y, qwz = q.w * q.z;
+    M3<T> r;
+    r.a[0][0] = T(1) - T(2) * (qyy + qzz);
+    r.a[1][0] = T(2) * (qxy + qwz);
+    r.a[2][0] = T(2) * (qxz - qwy);
+    r.a[0][1] = T(2) * (qxy - qwz);
+    r.a[1][1] = T(1) - T(2) * (qxx + qzz);
+    r.a[2][1] = T(2) * (qyz + qwx);
+    r.a[0][2] = T(2) * (qxz + qwy);
+    r.a[1][2] = T(2) * (qyz - qwx);
+    r.a[2][2] = T(1) - T(2) * (qxx + qyy);
+    return r;
+}
+template <typename T> inline Q4<T> quat_inverse(Q4<T> q) {
+    T d = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    return {q.w / d, -q.x / d, -q.y / d, -q.z / d};
+}
+template <typename T> inline Q4<T> quat_normalize(Q4<T> q) {
+    T len = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    if (len <= T(0)) return {T(1), T(0), T(0), T(0)};
+    T o = T(1) / len;
+    return {q.w * o, q.x * o, q.y * o, q.z * o};
+}
+// glm::rotate(quat, vec3)
+template <typename T> inline V3<T> quat_rotate(Q4<T> q, V3<T> v) {
+    V3<T> u{q.x, q.y, q.z};
+    V3<T> uv = cross(u, v);
+    V3<T> uuv = cross(u, uv);
+    return add(v, mul(add(mul(uv, q.w), uuv), T(2)));
+}
+// glm::slerp
+template <typename T> inline Q4<T> quat_slerp(Q4<T> x, Q4<T> y, T a) {
+    Q4<T> z = y;
+    T c = x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    if (c < T(0)) { z = {-y.w, -y.x, -y.y, -y.z}; c = -c; }
+    if (c > T(1) - std::numeric_limits<T>::epsilon()) {
+        auto mix = [&](T p, T q) { return p * (T(1) - a) + q * a; };
+        return {mix(x.w, z.w), mix(x.x, z.x), mix(x.y, z.y), mix(x.z, z.z)};
+    }
+    T ang = std::acos(c);
+    T s0 = std::sin((T(1) - a) * ang), s1 = std::sin(a * ang), sd = std::sin(ang);
+    return {(s0 * x.w + s1 * z.w) / sd, (s0 * x.x + s1 * z.x) / sd, (s0 * x.y + s1 * z.y) / sd, (s0 * x.z + s1 * z.z) / sd};
+}
+
+// gsplat/Utils.cuh:80-102 quat_to_rotmat (wxyz, normalises with rsqrt)
+template <typename T> inline M3<T> quat_to_rotmat(const T* quat) {
+    T w = quat[0], x = quat[1], y = quat[2], z = quat[3];
+    T inv_norm = T(1) / std::sqrt(x * x + y * y + z * z + w * w);
+    x *= inv_norm; y *= inv_norm; z *= inv_norm; w *= inv_norm;
+    T x2 = x * x, y2 = y * y, z2 = z * z;
+    T xy = x * y, xz = x * z, yz = y * z;
+    T wx = w * x, wy = w * y, wz = w * z;
+    M3<T> R;
+    R.a[0][0] = T(1) - T(2) * (y2 + z2);
+    R.a[1][0] = T(2) * (xy + wz);
+    R.a[2][0] = T(2) * (xz - wy);
+    R.a[0][1] = T(2) * (xy - wz);
+    R.a[1][1] = T(1) - T(2) * (x2 + z2);
+    R.a[2][1] = T(2) * (yz + wx);
+    R.a[0][2] = T(2) * (xz + wy);
+    R.a[1][2] = T(2) * (yz - wx);
+    R.a[2][2] = T(1) - T(2) * (x2 + y2);
+    return R;
+}
+
+// ------------------------------------------------------------------------------------------
+// Cameras (gsplat/Cameras.cuh)
+// ------------------------------------------------------------------------------------------
+enum { SHUTTER_ROLLING_TOP_TO_BOTTOM = 0, SHUTTER_ROLLING_LEFT_TO_RIGHT = 1, SHUTTER_ROLLING_BOTTOM_TO_TOP = 2,
+       SHUTTER_ROLLING_RIGHT_TO_LEFT = 3, SHUTTER_GLOBAL = 4 };          // gsplat/Cameras.h:16-22
+enum { CAM_PINHOLE = 0, CAM_ORTHO = 1, CAM_FISHEYE = 2 };                  // gsplat/Common.h:46-50
+
+// Cameras.cuh:33-71
+template <typename T> struct RSParams {
+    V3<T> t_start, t_end;
+    Q4<T> q_start, q_end;
+    RSParams(const T* s, const T* e) {
+        M3<T> m;
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) m.a[r][c] = s[r * 4 + c];
+        q_start = quat_cast(m);
+        t_start = {s[3], s[7], s[11]};
+        if (!e) { q_end = q_start; t_end = t_start; }
+        else {
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) m.a[r][c] = e[r * 4 + c];
+            q_end = quat_cast(m);
+            t_end = {e[3], e[7], e[11]};
+        }
+    }
+};
+template <typename T> struct Pose { V3<T> t; Q4<T> q; };
+// Cameras.cuh:268-280
+template <typename T> inline Pose<T> interpolate_shutter_pose(T rt, const RSParams<T>& rs) {
+    V3<T> t = add(mul(rs.t_start, T(1) - rt), mul(rs.t_end, rt));
+    return {t, quat_slerp(rs.q_start, rs.q_end, rt)};
+}
+
+template <typename T> struct CamParams {
+    int model;              // CAM_*
+    bool distorted;         // any of radial/tangential/thin-prism present (pinhole only)
+    uint32_t W, H;
+    int shutter;
+    T fx, fy, cx, cy;
+    T radial[6];            // pinhole: k1..k6 ; fisheye: k1..k4
+    T tang[2];
+    T prism[4];
+    // fisheye derived (Cameras.cuh:833-884)
+    T fwd_poly[5], dfwd_poly[5], approx_bwd[2], max_angle, min_2d_norm;
+};
+
+// Cameras.cuh:228-240
+template <typename T> inline bool in_bounds_margin(V2<T> p, uint32_t W, uint32_t H, T mf) {
+    const T MX = T(W) * mf, MY = T(H) * mf;
+    bool v = true;
+    v &= (-MX) <= p.x && p.x < (T(W) + MX);
+    v &= (-MY) <= p.y && p.y < (T(H) + MY);
+    return v;
+}
+
+template <typename T> inline T horner(const T* c, int n, T x) {
+    T y = T(0);
+    for (int i = n - 1; i >= 0; --i) y = x * y + c[i];
+    return y;
+}
+template <typename T> inline T horner_odd(const T* c, int n, T x) { return x * horner(c, n, x * x); }
+template <typename T> inline T horner_even(const T* c, int n, T x) { return horner(c, n, x * x); }
+
+// Cameras.cuh:760-815
+template <typename T> inline T fisheye_max_angle(T a, T b, T c) {
+    const T INF = std::numeric_limits<T>::max();
+    const T PI_ = T(3.14159265358979323846);
+    if (c == T(0)) {
+        if (b == T(0)) { if (a >= T(0)) return INF; else return T(-1) / a; }
+        T delta = a * a - T(4) * b;
+        if (delta >= T(0)) { delta = std::sqrt(delta) - a; if (delta > T(0)) return T(2) / delta; }
+    } else {
+        T boc = b / c, boc2 = boc * boc;
+        T t1 = (T(9) * a * boc - T(2) * b * boc2 - T(27)) / c;
+        T t2 = T(3) * a / c - boc2;
+        T delta = t1 * t1 + T(4) * t2 * t2 * t2;
+        if (delta >= T(0)) {
+            T d2 = std::sqrt(delta);
+            T cr = std::cbrt((d2 + t1) / T(2));
+            if (cr != T(0)) { T s = (cr - (t2 / cr) - boc) / T(3); if (s > T(0)) return s; }
+        } else {
+            T theta = std::atan2(std::sqrt(-delta), t1) / T(3);
+            const T ttp = T(2) * PI_ / T(3);
+            T t3 = T(2) * std::sqrt(-t2);
+            T soln = INF;
+            for (int i = -1; i <= 1; ++i) {
+                T s = (t3 * std::cos(theta + T(i) * ttp) - boc) / T(3);
+                if (s > T(0)) soln = std::min(soln, s);
+            }
+            return soln;
+        }
+    }
+    return INF;
+}
+
+// Cameras.cuh:833-884 (fisheye constructor)
+template <typename T> inline void fisheye_init(CamParams<T>& p) {
+    T k1 = p.radial[0], k2 = p.radial[1], k3 = p.radial[2], k4 = p.radial[3];
+    p.min_2d_norm = T(1e-6);
+    p.fwd_poly[0] = T(1); p.fwd_poly[1] = k1; p.fwd_poly[2] = k2; p.fwd_poly[3] = k3; p.fwd_poly[4] = k4;
+    p.dfwd_poly[0] = T(1); p.dfwd_poly[1] = T(3) * k1; p.dfwd_poly[2] = T(5) * k2; p.dfwd_poly[3] = T(7) * k3; p.dfwd_poly[4] = T(9) * k4;
+    T mdx = std::max(T(p.W) - p.cx, p.cx), mdy = std::max(T(p.H) - p.cy, p.cy);
+    T max_r = std::sqrt(mdx * mdx + mdy * mdy);
+    if (k4 == T(0)) {
+        p.max_angle = std::sqrt(fisheye_max_angle(T(3) * k1, T(5) * k2, T(7) * k3));
+    } else {
+        T dd[4] = {T(6) * k1, T(20) * k2, T(42) * k3, T(72) * k4};
+        bool conv = false;
+        T x = T(1.57);  // approx poly of degree 0 (EVEN, 1 coeff)
+        for (int j = 0; j < 20; ++j) {
+            T dfdx = horner_odd(dd, 4, x);
+            T res = horner_even(p.dfwd_poly, 5, x) - T(0);
+            T dx = res / dfdx;
+            x -= dx;
+            if (std::fabs(dx) < T(1e-6)) { conv = true; break; }
+        }
+        p.max_angle = x;
+        if (!conv || p.max_angle <= T(0)) p.max_angle = std::numeric_limits<T>::max();
+    }
+    p.max_angle = std::min(p.max_angle, std::max(max_r / p.fx, max_r / p.fy));
+    T mnd = std::max(T(p.W) / T(2) / p.fx, T(p.H) / T(2) / p.fy);
+    p.approx_bwd[0] = T(0);
+    p.approx_bwd[1] = p.max_angle / mnd;
+}
+
+template <typename T> struct ImgPt { V2<T> p; bool valid; };
+
+// OpenCV pinhole distortion, Cameras.cuh:504-533
+template <typename T> inline void compute_distortion(const CamParams<T>& p, V2<T> uv, T& icD, V2<T>& delta, T& r2) {
+    T ux2 = uv.x * uv.x, uy2 = uv.y * uv.y;
+    r2 = ux2 + uy2;
+    T a1 = T(2) * uv.x * uv.y, a2 = r2 + T(2) * ux2, a3 = r2 + T(2) * uy2;
+    T num = T(1) + r2 * (p.radial[0] + r2 * (p.radial[1] + r2 * p.radial[2]));
+    T den = T(1) + r2 * (p.radial[3] + r2 * (p.radial[4] + r2 * p.radial[5]));
+    icD = num / den;
+    delta.x = p.tang[0] * a1 + p.tang[1] * a2 + r2 * (p.prism[0] + r2 * p.prism[1]);
+    delta.y = p.tang[0] * a3 + p.tang[1] * a1 + r2 * (p.prism[2] + r2 * p.prism[3]);
+}
+
+// camera_ray_to_image_point for the three models: Cameras.cuh:431-455, 535-597, 893-959
+template <typename T> inline ImgPt<T> camera_ray_to_image_point(const CamParams<T>& p, V3<T> r, T mf) {
+    if (p.model == CAM_PINHOLE && !p.distorted) {
+        if (r.z <= T(0)) return {{T(0), T(0)}, false};
+        V2<T> ip{(r.x / r.z) * p.fx + p.cx, (r.y / r.z) * p.fy + p.cy};
+        return {ip, in_bounds_margin(ip, p.W, p.H, mf)};
+    } else if (p.model == CAM_PINHOLE) {
+        if (r.z <= T(0)) return {{T(0), T(0)}, false};
+        V2<T> uvn{r.x / r.z, r.y / r.z};
+        T icD, r2; V2<T> d;
+        compute_distortion(p, uvn, icD, d, r2);
+        bool valid_radial = icD > T(0.8);
+        V2<T> uvND{icD * uvn.x + d.x, icD * uvn.y + d.y};
+        V2<T> ip{uvND.x * p.fx + p.cx, uvND.y * p.fy + p.cy};
+        bool valid = valid_radial;
+        valid &= in_bounds_margin(ip, p.W, p.H, mf);
+        return {ip, valid};
+    } else {  // fisheye
+        if (r.z <= T(0)) return {{T(0), T(0)}, false};
+        T ax = std::fabs(r.x), ay = std::fabs(r.y);
+        T mn = std::fmin(ax, ay), mx = std::fmax(ax, ay);
+        T nrm = T(0);
+        if (mx > T(0)) { T q = mn / mx; nrm = mx * std::sqrt(T(1) + q * q); }
+        if (nrm <= T(0)) nrm = std::numeric_limits<T>::epsilon();
+        T theta_full = std::atan2(nrm, r.z);
+        T theta = theta_full < p.max_angle ? theta_full : p.max_angle;
+        T delta = horner_odd(p.fwd_poly, 5, theta) / nrm;
+        if (delta <= T(0)) return {{T(0), T(0)}, false};
+        V2<T> ip{p.fx * delta * r.x + p.cx, p.fy * delta * r.y + p.cy};
+        bool valid = true;
+        valid &= in_bounds_margin(ip, p.W, p.H, mf);
+        valid &= theta <= p.max_angle;
+        return {ip, valid};
+    }
+}
+
+template <typename T> struct CamRay { V3<T> d; bool valid; };
+
+// image_point_to_camera_ray: Cameras.cuh:457-470, 742-754 (+599-740 newton), 961-1000
+template <typename T> inline CamRay<T> image_point_to_camera_ray(const CamParams<T>& p, V2<T> ip) {
+    if (p.model == CAM_PINHOLE && !p.distorted) {
+        V3<T> c{(ip.x - p.cx) / p.fx, (ip.y - p.cy) / p.fy, T(1)};
+        T len = std::sqrt(dot(c, c));
+        return {{c.x / len, c.y / len, c.z / len}, true};
+    } else if (p.model == CAM_PINHOLE) {
+        // compute_undistortion_newton, N_MAX_UNDISTORTION_ITERATIONS = 5
+        T xd = (ip.x - p.cx) / p.fx, yd = (ip.y - p.cy) / p.fy;
+        T x = xd, y = yd;
+        const T eps = T(1e-6);
+        bool converged = false;
+        const T k1 = p.radial[0], k2 = p.radial[1], k3 = p.radial[2], k4 = p.radial[3], k5 = p.radial[4], k6 = p.radial[5];
+        const T p1 = p.tang[0], p2 = p.tang[1];
+        const T s1 = p.prism[0], s2 = p.prism[1], s3 = p.prism[2], s4 = p.prism[3];
+        for (int iter = 0; iter < 5; ++iter) {
+            // compute_residual_and_jacobian, Cameras.cuh:634-696
+            const T r = x * x + y * y;
+            const T r2 = r * r;
+            const T alpha = T(1) + r * (k1 + r * (k2 + r * k3));
+            const T beta = T(1) + r * (k4 + r * (k5 + r * k6));
+            const T d = alpha / beta;
+            if (d <= T(0)) break;
+            T fxv = d * x + 2 * p1 * x * y + p2 * (r + 2 * x * x) + s1 * r + s2 * r2 - xd;
+            T fyv = d * y + 2 * p2 * x * y + p1 * (r + 2 * y * y) + s3 * r + s4 * r2 - yd;
+            const T alpha_r = T(k1 + r * (2.0 * k2 + r * (3.0 * k3)));
+            const T beta_r = T(k4 + r * (2.0 * k5 + r * (3.0 * k6)));
+            const T d_r = (alpha_r * beta - alpha * beta_r) / (beta * beta);
+            const T d_x = T(2.0 * x * d_r);
+            const T d_y = T(2.0 * y * d_r);
+            T fx_x = T(d + d_x * x + 2.0 * p1 * y + 6.0 * p2 * x);
+            fx_x = T(fx_x + 2.0 * x * (s1 + 2.0 * s2 * r));
+            T fx_y = T(d_y * x + 2.0 * p1 * x + 2.0 * p2 * y);
+            fx_y = T(fx_y + 2.0 * y * (s1 + 2.0 * s2 * r));
+            T fy_x = T(d_x * y + 2.0 * p2 * y + 2.0 * p1 * x);
+            fy_x = T(fy_x + 2.0 * x * (s3 + 2.0 * s4 * r));
+            T fy_y = T(d + d_y * y + 2.0 * p2 * x + 6.0 * p1 * y);
+            fy_y = T(fy_y + 2.0 * y * (s3 + 2.0 * s4 * r));
+            const T det = fx_y * fy_x - fx_x * fy_y;
+            if (std::fabs(det) < eps) break;
+            const T dx = (fxv * fy_y - fyv * fx_y) / det;
+            const T dy = (fyv * fx_x - fxv * fy_x) / det;
+            x += dx; y += dy;
+            if (std::fabs(dx) < eps && std::fabs(dy) < eps) { converged = true; break; }
+        }
+        V3<T> c{x, y, T(1)};
+        T len = std::sqrt(dot(c, c));
+        return {{c.x / len, c.y / len, c.z / len}, converged};
+    } else {
+        V2<T> uv{(ip.x - p.cx) / p.fx, (ip.y - p.cy) / p.fy};
+        T delta = std::sqrt(uv.x * uv.x + uv.y * uv.y);
+        bool conv = false;
+        T th = horner(p.approx_bwd, 2, delta);
+        for (int j = 0; j < 20; ++j) {
+            T dfdx = horner_even(p.dfwd_poly, 5, th);
+            T res = horner_odd(p.fwd_poly, 5, th) - delta;
+            T dx = res / dfdx;
+            th -= dx;
+            if (std::fabs(dx) < T(1e-6)) { conv = true; break; }
+        }
+        if (th < T(0) || th >= p.max_angle || !conv) return {{T(0), T(0), T(1)}, false};
+        if (delta >= p.min_2d_norm) {
+            T sf = std::sin(th) / delta;
+            return {{sf * uv.x, sf * uv.y, std::cos(th)}, true};
+        }
+        return {{T(0), T(0), T(1)}, true};
+    }
+}
+
+// Cameras.cuh:293-320
+template <typename T> inline T shutter_relative_frame_time(const CamParams<T>& p, V2<T> ip) {
+    T t = T(0);
+    switch (p.shutter) {
+    case SHUTTER_ROLLING_TOP_TO_BOTTOM: t = std::floor(ip.y) / T(p.H - 1); break;
+    case SHUTTER_ROLLING_LEFT_TO_RIGHT: t = std::floor(ip.x) / T(p.W - 1); break;
+    case SHUTTER_ROLLING_BOTTOM_TO_TOP: t = (T(p.H) - std::ceil(ip.y)) / T(p.H - 1); break;
+    case SHUTTER_ROLLING_RIGHT_TO_LEFT: t = (T(p.W) - std::ceil(ip.x)) / T(p.W - 1); break;
+    default: break;
+    }
+    return t;
+}
+
+template <typename T> struct WorldRay { V3<T> o, d; bool valid; };
+
+// Cameras.cuh:322-339 + 261-265
+template <typename T> inline WorldRay<T> image_point_to_world_ray(const CamParams<T>& p, V2<T> ip, const RSParams<T>& rs) {
+    CamRay<T> cr = image_point_to_camera_ray(p, ip);
+    if (!cr.valid) return {{T(0), T(0), T(0)}, {T(0), T(0), T(0)}, false};
+    Pose<T> pose = interpolate_shutter_pose(shutter_relative_frame_time(p, ip), rs);
+    M3<T> Rinv = mat3_cast(quat_inverse(pose.q));
+    M3<T> nR;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) nR.a[i][j] = -Rinv.a[i][j];
+    return {mv(nR, pose.t), mv(Rinv, cr.d), true};
+}
+
+// Cameras.cuh:346-413
+template <typename T> inline ImgPt<T> world_point_to_image_point(const CamParams<T>& p, V3<T> wp, const RSParams<T>& rs, T mf) {
+    ImgPt<T> st = camera_ray_to_image_point(p, add(quat_rotate(rs.q_start, wp), rs.t_start), mf);
+    if (p.shutter == SHUTTER_GLOBAL) return st;
+    ImgPt<T> en = camera_ray_to_image_point(p, add(quat_rotate(rs.q_end, wp), rs.t_end), mf);
+    V2<T> init;
+    if (st.valid) init = st.p;
+    else if (en.valid) init = en.p;
+    else return {en.p, false};
+    V2<T> prev = init;
+    for (int j = 0; j < 10; ++j) {
+        T rt = shutter_relative_frame_time(p, prev);
+        V3<T> t = add(mul(rs.t_start, T(1) - rt), mul(rs.t_end, rt));
+        Q4<T> q = quat_slerp(rs.q_start, rs.q_end, rt);
+        ImgPt<T> r = camera_ray_to_image_point(p, add(quat_rotate(q, wp), t), mf);
+        prev = r.p;
+    }
+    return {prev, true};
+}
+
+template <typename T>
+inline CamParams<T> make_cam(int model, uint32_t W, uint32_t H, int shutter, const T* K, const T* radial, const T* tang, const T* prism) {
+    CamParams<T> p{};
+    p.model = model; p.W = W; p.H = H; p.shutter = shutter;
+    p.fx = K[0]; p.fy = K[4]; p.cx = K[2]; p.cy = K[5];
+    if (model == CAM_PINHOLE) {
+        p.distorted = radial || tang || prism;
+        if (radial) for (int i = 0; i < 6; ++i) p.radial[i] = radial[i];
+        if (tang) for (int i = 0; i < 2; ++i) p.tang[i] = tang[i];
+        if (prism) for (int i = 0; i < 4; ++i) p.prism[i] = prism[i];
+    } else if (model == CAM_FISHEYE) {
+        if (radial) for (int i = 0; i < 4; ++i) p.radial[i] = radial[i];
+        fisheye_init(p);
+    }
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------
+// a1: projection_ut_3dgs_fused — gsplat/ProjectionUT3DGSFused.cu:48-202, Cameras.cuh:1028-1150
+// ------------------------------------------------------------------------------------------
+template <typename T>
+void projection_ut(uint32_t C, uint32_t N, const T* means, const T* quats, const T* scales, const T* opacities,
+                   const T* viewmats0, const T* viewmats1, const T* Ks, uint32_t W, uint32_t H, T eps2d, T near_plane,
+                   T far_plane, T radius_clip, int camera_model, T ut_alpha, T ut_beta, T ut_kappa, T ut_margin,
+                   int ut_require_all, int shutter, const T* radial, const T* tang, const T* prism,
+                   int32_t* radii, T* means2d, T* depths, T* conics, T* compensations) {
+    const int n_rad = camera_model == CAM_FISHEYE ? 4 : 6;
+    for (uint32_t cid = 0; cid < C; ++cid) {
+        const CamParams<T> cam = make_cam<T>(camera_model, W, H, shutter, Ks + cid * 9, radial ? radial + cid * n_rad : nullptr,
+                                             tang ? tang + cid * 2 : nullptr, prism ? prism + cid * 4 : nullptr);
+        const RSParams<T> rs(viewmats0 + cid * 16, viewmats1 ? viewmats1 + cid * 16 : nullptr);
+        const Pose<T> centre = interpolate_shutter_pose(T(0.5), rs);
+#pragma omp parallel for schedule(static)
+        for (int64_t gid = 0; gid < (int64_t)N; ++gid) {
+            const int64_t idx = (int64_t)cid * N + gid;
+            auto cull = [&]() { radii[idx * 2] = 0; radii[idx * 2 + 1] = 0; };
+            V3<T> mean{means[gid * 3], means[gid * 3 + 1], means[gid * 3 + 2]};
+            V3<T> scale{scales[gid * 3], scales[gid * 3 + 1], scales[gid * 3 + 2]};
+            Q4<T> quat = quat_normalize(Q4<T>{quats[gid * 4], quats[gid * 4 + 1], quats[gid * 4 + 2], quats[gid * 4 + 3]});
+            V3<T> mean_c = add(quat_rotate(centre.q, mean), centre.t);
+            if (mean_c.z < near_plane || mean_c.z > far_plane) { cull(); continue; }
+            // sigma points, Cameras.cuh:1034-1083
+            const T D = T(3);
+            const T lambda = ut_alpha * ut_alpha * (D + ut_kappa) - D;
+            M3<T> R = mat3_cast(quat);
+            V3<T> pts[7];
+            T wm[7], wc[7];
+            pts[0] = mean;
+            const T sq = std::sqrt(D + lambda);
+            const T sc[3] = {scale.x, scale.y, scale.z};
+            for (int i = 0; i < 3; ++i) {
+                T f = sq * sc[i];
+                V3<T> delta{f * R.a[0][i], f * R.a[1][i], f * R.a[2][i]};
+                pts[i + 1] = add(mean, delta);
+                pts[i + 4] = sub(mean, delta);
+            }
+            wm[0] = lambda / (D + lambda);
+            wc[0] = lambda / (D + lambda) + (T(1) - ut_alpha * ut_alpha + ut_beta);
+            for (int i = 0; i < 6; ++i) { wm[i + 1] = T(1) / (T(2) * (D + lambda)); wc[i + 1] = T(1) / (T(2) * (D + lambda)); }
+            // Cameras.cuh:1091-1150
+            bool valid = ut_require_all != 0;
+            V2<T> ipts[7];
+            V2<T> im{T(0), T(0)};
+            bool early = false;
+            for (int i = 0; i < 7; ++i) {
+                ImgPt<T> r = world_point_to_image_point(cam, pts[i], rs, ut_margin);
+                if (ut_require_all) { valid &= r.valid; if (!r.valid) { early = true; break; } }
+                else valid |= r.valid;
+                ipts[i] = r.p;
+                im.x += wm[i] * r.p.x;
+                im.y += wm[i] * r.p.y;
+            }
+            if (early || !valid) { cull(); continue; }
+            T c00 = T(0), c01 = T(0), c10 = T(0), c11 = T(0);  // glm [col][row]
+            for (int i = 0; i < 7; ++i) {
+                T dx = ipts[i].x - im.x, dy = ipts[i].y - im.y;
+                c00 += wc[i] * (dx * dx);
+                c01 += wc[i] * (dy * dx);  // col0,row1
+                c10 += wc[i] * (dx * dy);  // col1,row0
+                c11 += wc[i] * (dy * dy);
+            }
+            // add_blur, Utils.cuh:171-179
+            T det_orig = c00 * c11 - c01 * c10;
+            c00 += eps2d; c11 += eps2d;
+            T det = c00 * c11 - c01 * c10;
+            T compensation = std::sqrt(std::max(T(0), det_orig / det));
+            if (det <= T(0)) { cull(); continue; }
+            T ood = T(1) / (c00 * c11 - c10 * c01);
+            T i00 = c11 * ood, i01 = -c01 * ood, i11 = c00 * ood;  // glm::inverse(mat2): [0][0],[0][1],[1][1]
+            T extend = T(3.33);
+            if (opacities) {
+                T opacity = opacities[gid];
+                opacity *= compensation;
+                if (opacity < T(1) / T(255)) { cull(); continue; }
+                extend = std::min(extend, std::sqrt(T(2) * std::log(opacity / (T(1) / T(255)))));
+            }
+            T b = T(0.5) * (c00 + c11);
+            T tmp = std::sqrt(std::max(T(0.01), b * b - det));
+            T v1 = b + tmp;
+            T r1 = extend * std::sqrt(v1);
+            T radius_x = std::ceil(std::min(extend * std::sqrt(c00), r1));
+            T radius_y = std::ceil(std::min(extend * std::sqrt(c11), r1));
+            if (radius_x <= radius_clip && radius_y <= radius_clip) { cull(); continue; }
+            if (im.x + radius_x <= 0 || im.x - radius_x >= T(W) || im.y + radius_y <= 0 || im.y - radius_y >= T(H)) { cull(); continue; }
+            radii[idx * 2] = (int32_t)radius_x;
+            radii[idx * 2 + 1] = (int32_t)radius_y;
+            means2d[idx * 2] = im.x;
+            means2d[idx * 2 + 1] = im.y;
+            depths[idx] = mean_c.z;
+            conics[idx * 3] = i00;
+            conics[idx * 3 + 1] = i01;
+            conics[idx * 3 + 2] = i11;
+            if (compensations) compensations[idx] = compensation;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a3/a4: spherical harmonics — gsplat/SphericalHarmonicsCUDA.cu:20-110 (fwd), :112-371 (vjp)
+// Basis: P.-P. Sloan, "Efficient Spherical Harmonic Evaluation", JCGT 2013 (same constants).
+// Y[k] and its partial derivatives wrt the *normalised* direction are produced together.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+inline void sh_basis(uint32_t degree, T x, T y, T z, T* Y, T* Yx, T* Yy, T* Yz) {
+    for (int k = 0; k < 25; ++k) { Y[k] = Yx[k] = Yy[k] = Yz[k] = T(0); }
+    Y[0] = T(0.2820947917738781);
+    if (degree < 1) return;
+    const T c1 = T(0.48860251190292);
+    Y[1] = -c1 * y; Yy[1] = -c1;
+    Y[2] = c1 * z;  Yz[2] = c1;
+    Y[3] = -c1 * x; Yx[3] = -c1;
+    if (degree < 2) return;
+    const T z2 = z * z;
+    const T fTmp0B = T(-1.092548430592079) * z;
+    const T fC1 = x * x - y * y, fS1 = T(2) * x * y;
+    const T fC1_x = T(2) * x, fC1_y = T(-2) * y, fS1_x = T(2) * y, fS1_y = T(2) * x;
+    const T k2 = T(0.5462742152960395);
+    Y[4] = k2 * fS1;  Yx[4] = k2 * fS1_x; Yy[4] = k2 * fS1_y;
+    Y[5] = fTmp0B * y; Yy[5] = fTmp0B; Yz[5] = T(-1.092548430592079) * y;
+    Y[6] = T(0.9461746957575601) * z2 - T(0.3153915652525201); Yz[6] = T(2) * T(0.9461746957575601) * z;
+    Y[7] = fTmp0B * x; Yx[7] = fTmp0B; Yz[7] = T(-1.092548430592079) * x;
+    Y[8] = k2 * fC1;  Yx[8] = k2 * fC1_x; Yy[8] = k2 * fC1_y;
+    if (degree < 3) return;
+    const T fTmp0C = T(-2.285228997322329) * z2 + T(0.4570457994644658);
+    const T fTmp1B = T(1.445305721320277) * z;
+    const T fC2 = x * fC1 - y * fS1, fS2 = x * fS1 + y * fC1;
+    const T fTmp0C_z = T(-2.285228997322329) * T(2) * z;
+    const T fC2_x = fC1 + x * fC1_x - y * fS1_x, fC2_y = x * fC1_y - fS1 - y * fS1_y;
+    const T fS2_x = fS1 + x * fS1_x + y * fC1_x, fS2_y = x * fS1_y + fC1 + y * fC1_y;
+    const T k3 = T(-0.5900435899266435);
+    Y[9] = k3 * fS2;   Yx[9] = k3 * fS2_x; Yy[9] = k3 * fS2_y;
+    Y[10] = fTmp1B * fS1; Yx[10] = fTmp1B * fS1_x; Yy[10] = fTmp1B * fS1_y; Yz[10] = T(1.445305721320277) * fS1;
+    Y[11] = fTmp0C * y; Yy[11] = fTmp0C; Yz[11] = fTmp0C_z * y;
+    Y[12] = z * (T(1.865881662950577) * z2 - T(1.119528997770346));
+    const T pSH12_z = T(3) * T(1.865881662950577) * z2 - T(1.119528997770346);
+    Yz[12] = pSH12_z;
+    Y[13] = fTmp0C * x; Yx[13] = fTmp0C; Yz[13] = fTmp0C_z * x;
+    Y[14] = fTmp1B * fC1; Yx[14] = fTmp1B * fC1_x; Yy[14] = fTmp1B * fC1_y; Yz[14] = T(1.445305721320277) * fC1;
+    Y[15] = k3 * fC2;  Yx[15] = k3 * fC2_x; Yy[15] = k3 * fC2_y;
+    if (degree < 4) return;
+    const T fTmp0D = z * (T(-4.683325804901025) * z2 + T(2.007139630671868));
+    const T fTmp1C = T(3.31161143515146) * z2 - T(0.47308734787878);
+    const T fTmp2B = T(-1.770130769779931) * z;
+    const T fC3 = x * fC2 - y * fS2, fS3 = x * fS2 + y * fC2;
+    const T fTmp0D_z = T(3) * T(-4.683325804901025) * z2 + T(2.007139630671868);
+    const T fTmp1C_z = T(2) * T(3.31161143515146) * z;
+    const T fC3_x = fC2 + x * fC2_x - y * fS2_x, fC3_y = x * fC2_y - fS2 - y * fS2_y;
+    const T fS3_x = fS2 + y * fC2_x + x * fS2_x, fS3_y = x * fS2_y + fC2 + y * fC2_y;
+    const T k4 = T(0.6258357354491763);
+    Y[16] = k4 * fS3;  Yx[16] = k4 * fS3_x; Yy[16] = k4 * fS3_y;
+    Y[17] = fTmp2B * fS2; Yx[17] = fTmp2B * fS2_x; Yy[17] = fTmp2B * fS2_y; Yz[17] = T(-1.770130769779931) * fS2;
+    Y[18] = fTmp1C * fS1; Yx[18] = fTmp1C * fS1_x; Yy[18] = fTmp1C * fS1_y; Yz[18] = fTmp1C_z * fS1;
+    Y[19] = fTmp0D * y; Yy[19] = fTmp0D; Yz[19] = fTmp0D_z * y;
+    Y[20] = T(1.984313483298443) * z * Y[12] - T(1.006230589874905) * Y[6];
+    Yz[20] = T(1.984313483298443) * (Y[12] + z * pSH12_z) + T(-1.006230589874905) * Yz[6];
+    Y[21] = fTmp0D * x; Yx[21] = fTmp0D; Yz[21] = fTmp0D_z * x;
+    Y[22] = fTmp1C * fC1; Yx[22] = fTmp1C * fC1_x; Yy[22] = fTmp1C * fC1_y; Yz[22] = fTmp1C_z * fC1;
+    Y[23] = fTmp2B * fC2; Yx[23] = fTmp2B * fC2_x; Yy[23] = fTmp2B * fC2_y; Yz[23] = T(-1.770130769779931) * fC2;
+    Y[24] = k4 * fC3;  Yx[24] = k4 * fC3_x; Yy[24] = k4 * fC3_y;
+}
+
+static const int SH_LO[5] = {0, 1, 4, 9, 16};
+static const int SH_HI[5] = {1, 4, 9, 16, 25};
+
+template <typename T>
+void sh_fwd(uint32_t N, uint32_t K, uint32_t degree, const T* dirs, const T* coeffs, const uint8_t* masks, T* colors) {
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < (int64_t)N; ++e) {
+        if (masks && !masks[e]) continue;  // output left untouched (reference leaves it uninitialised)
+        T x = dirs[e * 3], y = dirs[e * 3 + 1], z = dirs[e * 3 + 2];
+        T Y[25], Yx[25], Yy[25], Yz[25];
+        if (degree >= 1) {
+            T inorm = T(1) / std::sqrt(x * x + y * y + z * z);
+            x *= inorm; y *= inorm; z *= inorm;
+        }
+        sh_basis(degree, x, y, z, Y, Yx, Yy, Yz);
+        const T* cf = coeffs + e * K * 3;
+        for (int c = 0; c < 3; ++c) {
+            T result = Y[0] * cf[c];
+            if (degree >= 1)  // SphericalHarmonicsCUDA.cu:38-41 groups the three l=1 terms under one factor
+                result += T(0.48860251190292) * (-y * cf[1 * 3 + c] + z * cf[2 * 3 + c] - x * cf[3 * 3 + c]);
+            for (uint32_t l = 2; l <= degree && l <= 4; ++l) {
+                T part = T(0);
+                for (int k = SH_LO[l]; k < SH_HI[l]; ++k) part += Y[k] * cf[k * 3 + c];
+                result += part;
+            }
+            colors[e * 3 + c] = result;
+        }
+    }
+}
+
+template <typename T>
+void sh_bwd(uint32_t N, uint32_t K, uint32_t degree, const T* dirs, const T* coeffs, const uint8_t* masks,
+            const T* v_colors, T* v_coeffs /* zero-initialised by caller */, T* v_dirs /* optional, zero-init */) {
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < (int64_t)N; ++e) {
+        if (masks && !masks[e]) continue;
+        T x = dirs[e * 3], y = dirs[e * 3 + 1], z = dirs[e * 3 + 2];
+        T inorm = T(1);
+        if (degree >= 1) {
+            inorm = T(1) / std::sqrt(x * x + y * y + z * z);
+            x *= inorm; y *= inorm; z *= inorm;
+        }
+        T Y[25], Yx[25], Yy[25], Yz[25];
+        sh_basis(degree, x, y, z, Y, Yx, Yy, Yz);
+        const T* cf = coeffs + e * K * 3;
+        const int nb = SH_HI[std::min<uint32_t>(degree, 4)];
+        T vd[3] = {T(0), T(0), T(0)};
+        for (int c = 0; c < 3; ++c) {
+            const T vc = v_colors[e * 3 + c];
+            for (int k = 0; k < nb; ++k) v_coeffs[(e * K + k) * 3 + c] = Y[k] * vc;
+            if (v_dirs && degree >= 1) {
+                T vx = T(0), vy = T(0), vz = T(0);
+                for (int k = 1; k < nb; ++k) {
+                    vx += Yx[k] * cf[k * 3 + c] * vc;
+                    vy += Yy[k] * cf[k * 3 + c] * vc;
+                    vz += Yz[k] * cf[k * 3 + c] * vc;
+                }
+                // through the normalisation, SphericalHarmonicsCUDA.cu:157-165
+                T d = vx * x + vy * y + vz * z;
+                vd[0] += (vx - d * x) * inorm;
+                vd[1] += (vy - d * y) * inorm;
+                vd[2] += (vz - d * z) * inorm;
+            }
+        }
+        if (v_dirs) { v_dirs[e * 3] += vd[0]; v_dirs[e * 3 + 1] += vd[1]; v_dirs[e * 3 + 2] += vd[2]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a5/a6: tile intersection — gsplat/IntersectTile.cu:23-114, 206-252; Intersect.cpp:15-137
+// ------------------------------------------------------------------------------------------
+inline uint32_t f2u_sat(float v) {  // CUDA float->uint32 conversion saturates (negative -> 0)
+    if (!(v > 0.f)) return 0u;
+    if (v >= 4294967296.f) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+}
+inline uint32_t bit_width_u32(uint32_t v) { uint32_t n = 0; while (v) { ++n; v >>= 1; } return n; }
+
+template <typename T>
+inline void tile_rect(const T* means2d, const int32_t* radii, int64_t idx, uint32_t tile_size, uint32_t tw, uint32_t th,
+                      uint32_t& x0, uint32_t& y0, uint32_t& x1, uint32_t& y1, bool& ok) {
+    const float rx = (float)radii[idx * 2], ry = (float)radii[idx * 2 + 1];
+    if (rx <= 0 || ry <= 0) { ok = false; return; }
+    ok = true;
+    float trx = rx / (float)tile_size, try_ = ry / (float)tile_size;
+    float tx = (float)means2d[idx * 2] / (float)tile_size, ty = (float)means2d[idx * 2 + 1] / (float)tile_size;
+    x0 = std::min(f2u_sat(std::floor(tx - trx)), tw);
+    y0 = std::min(f2u_sat(std::floor(ty - try_)), th);
+    x1 = std::min(f2u_sat(std::ceil(tx + trx)), tw);
+    y1 = std::min(f2u_sat(std::ceil(ty + try_)), th);
+}
+
+template <typename T>
+int64_t isect_count(uint32_t C, uint32_t N, const T* means2d, const int32_t* radii, uint32_t tile_size, uint32_t tw,
+                    uint32_t th, int32_t* tiles_per_gauss) {
+    int64_t total = 0;
+    for (int64_t idx = 0; idx < (int64_t)C * N; ++idx) {
+        uint32_t x0, y0, x1, y1; bool ok;
+        tile_rect(means2d, radii, idx, tile_size, tw, th, x0, y0, x1, y1, ok);
+        int32_t n = ok ? (int32_t)((y1 - y0) * (x1 - x0)) : 0;
+        tiles_per_gauss[idx] = n;
+        total += n;
+    }
+    return total;
+}
+
+// fill + stable sort by the low (32 + tile_n_bits + cam_n_bits) key bits (CUB radix sort is stable)
+template <typename T>
+void isect_fill(uint32_t C, uint32_t N, const T* means2d, const int32_t* radii, const T* depths, uint32_t tile_size,
+                uint32_t tw, uint32_t th, int sort, int64_t* isect_ids, int32_t* flatten_ids) {
+    const uint32_t n_tiles = tw * th;
+    const uint32_t tile_n_bits = bit_width_u32(n_tiles);  // == floor(log2(n_tiles)) + 1
+    const uint32_t cam_n_bits = bit_width_u32(C);
+    int64_t cur = 0;
+    for (int64_t idx = 0; idx < (int64_t)C * N; ++idx) {
+        uint32_t x0, y0, x1, y1; bool ok;
+        tile_rect(means2d, radii, idx, tile_size, tw, th, x0, y0, x1, y1, ok);
+        if (!ok) continue;
+        const int64_t cid = idx / N;
+        const int64_t cid_enc = cid << (32 + tile_n_bits);
+        float d32 = (float)depths[idx];
+        uint32_t dbits;
+        std::memcpy(&dbits, &d32, 4);
+        const int64_t depth_enc = (int64_t)dbits;
+        for (uint32_t i = y0; i < y1; ++i)
+            for (uint32_t j = x0; j < x1; ++j) {
+                int64_t tile_id = (int64_t)i * tw + j;
+                isect_ids[cur] = cid_enc | (tile_id << 32) | depth_enc;
+                flatten_ids[cur] = (int32_t)idx;
+                ++cur;
+            }
+    }
+    if (sort && cur > 0) {
+        const uint32_t nbits = 32 + tile_n_bits + cam_n_bits;
+        const uint64_t mask = nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
+        std::vector<int64_t> perm(cur);
+        for (int64_t i = 0; i < cur; ++i) perm[i] = i;
+        std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) {
+            return ((uint64_t)isect_ids[a] & mask) < ((uint64_t)isect_ids[b] & mask);
+        });
+        std::vector<int64_t> k(cur);
+        std::vector<int32_t> v(cur);
+        for (int64_t i = 0; i < cur; ++i) { k[i] = isect_ids[perm[i]]; v[i] = flatten_ids[perm[i]]; }
+        std::memcpy(isect_ids, k.data(), cur * 8);
+        std::memcpy(flatten_ids, v.data(), cur * 4);
+    }
+}
+
+// IntersectTile.cu:206-252 (+ launch :268-271: fill 0 when empty)
+void isect_offsets(int64_t n_isects, const int64_t* isect_ids, uint32_t C, uint32_t tw, uint32_t th, int32_t* offsets) {
+    const uint32_t n_tiles = tw * th;
+    if (n_isects == 0) { for (uint32_t i = 0; i < C * n_tiles; ++i) offsets[i] = 0; return; }
+    const uint32_t tile_n_bits = bit_width_u32(n_tiles);
+    for (int64_t idx = 0; idx < n_isects; ++idx) {
+        int64_t cur = isect_ids[idx] >> 32;
+        int64_t cid = cur >> tile_n_bits, tid = cur & ((1 << tile_n_bits) - 1);
+        int64_t id_curr = cid * n_tiles + tid;
+        if (idx == 0) for (int64_t i = 0; i < id_curr + 1; ++i) offsets[i] = (int32_t)idx;
+        if (idx == n_isects - 1) for (int64_t i = id_curr + 1; i < (int64_t)C * n_tiles; ++i) offsets[i] = (int32_t)n_isects;
+        if (idx > 0) {
+            int64_t prev = isect_ids[idx - 1] >> 32;
+            if (prev == cur) continue;
+            int64_t cp = prev >> tile_n_bits, tp = prev & ((1 << tile_n_bits) - 1);
+            int64_t id_prev = cp * n_tiles + tp;
+            for (int64_t i = id_prev + 1; i < id_curr + 1; ++i) offsets[i] = (int32_t)idx;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a7: blend forward — gsplat/RasterizeToPixelsFromWorld3DGSFwd.cu:58-278
+// One "block" per tile, one "thread" per pixel; the batch staging of the CUDA kernel has no
+// arithmetic effect and is dropped, the tile-level early exit (:188-190) is honoured implicitly
+// (a done pixel never reads further Gaussians).
+// `fragile` (optional, [C,H,W] uint8): set when a discrete decision of that pixel (alpha < 1/255
+// skip, next_T <= 1e-4 stop) was taken within relative margin `frag_rel` of its threshold — two
+// correct fp32 implementations may legitimately disagree there.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+void raster_fwd(uint32_t C, uint32_t N, int64_t n_isects, const T* means, const T* quats, const T* scales, const T* colors,
+                const T* opacities, const T* backgrounds, const uint8_t* masks, uint32_t W, uint32_t H, uint32_t tile_size,
+                const T* viewmats0, const T* viewmats1, const T* Ks, int camera_model, int shutter, const T* radial,
+                const T* tang, const T* prism, const int32_t* tile_offsets, const int32_t* flatten_ids, T* render_colors,
+                T* render_alphas, int32_t* last_ids, uint8_t* fragile, T frag_rel) {
+    const uint32_t tw = (W + tile_size - 1) / tile_size, th = (H + tile_size - 1) / tile_size;
+    const int n_rad = camera_model == CAM_FISHEYE ? 4 : 6;
+    for (uint32_t cid = 0; cid < C; ++cid) {
+        const CamParams<T> cam = make_cam<T>(camera_model, W, H, shutter, Ks + cid * 9, radial ? radial + cid * n_rad : nullptr,
+                                             tang ? tang + cid * 2 : nullptr, prism ? prism + cid * 4 : nullptr);
+        const RSParams<T> rs(viewmats0 + cid * 16, viewmats1 ? viewmats1 + cid * 16 : nullptr);
+        const int32_t* toff = tile_offsets + (int64_t)cid * th * tw;
+        const T* bg = backgrounds ? backgrounds + cid * 3 : nullptr;
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int64_t tile_id = 0; tile_id < (int64_t)tw * th; ++tile_id) {
+            const uint32_t ty = tile_id / tw, tx = tile_id % tw;
+            const bool tile_masked = masks && !masks[(int64_t)cid * th * tw + tile_id];
+            const int32_t range_start = toff[tile_id];
+            const int32_t range_end = (cid == C - 1 && tile_id == (int64_t)tw * th - 1) ? (int32_t)n_isects : toff[tile_id + 1];
+            // stage the tile's Gaussians once (what the CUDA kernel does per batch in smem, :196-220)
+            const int32_t cnt = std::max(0, range_end - range_start);
+            std::vector<M3<T>> iscl(cnt);
+            std::vector<V3<T>> xyz(cnt);
+            std::vector<T> opac(cnt);
+            if (!tile_masked)
+                for (int32_t k = 0; k < cnt; ++k) {
+                    int32_t g = flatten_ids[range_start + k];
+                    int32_t gi = g % (int32_t)N;  // means/quats/scales are [N]; colours/opacities are [C,N]
+                    xyz[k] = {means[gi * 3], means[gi * 3 + 1], means[gi * 3 + 2]};
+                    opac[k] = opacities[g];
+                    M3<T> R = quat_to_rotmat(quats + gi * 4);
+                    for (int r = 0; r < 3; ++r)
+                        for (int c = 0; c < 3; ++c) iscl[k].a[r][c] = (T(1) / scales[gi * 3 + r]) * R.a[c][r];
+                }
+            for (uint32_t py_ = 0; py_ < tile_size; ++py_)
+                for (uint32_t px_ = 0; px_ < tile_size; ++px_) {
+                    const uint32_t i = ty * tile_size + py_, j = tx * tile_size + px_;
+                    if (!(i < H && j < W)) continue;
+                    const int64_t pix = (int64_t)cid * H * W + (int64_t)i * W + j;
+                    if (tile_masked) {
+                        for (int k = 0; k < 3; ++k) render_colors[pix * 3 + k] = bg ? bg[k] : T(0);
+                        continue;  // alphas / last_ids left untouched, as upstream (:143-150)
+                    }
+                    WorldRay<T> ray = image_point_to_world_ray(cam, V2<T>{T(j) + T(0.5), T(i) + T(0.5)}, rs);
+                    bool done = !ray.valid;
+                    T Tr = T(1);
+                    uint32_t cur_idx = 0;
+                    T out[3] = {T(0), T(0), T(0)};
+                    bool frag = false;
+                    for (int32_t k = 0; k < cnt && !done; ++k) {
+                        V3<T> gro = mv(iscl[k], sub(ray.o, xyz[k]));
+                        V3<T> grd = mv(iscl[k], ray.d);
+                        T l = dot(grd, grd);  // safe_normalize, Utils.cuh:181-184
+                        if (l > T(0)) grd = mul(grd, T(1) / std::sqrt(l));
+                        V3<T> gc = cross(grd, gro);
+                        T power = T(-0.5) * dot(gc, gc);
+                        T alpha = std::min(T(0.999), opac[k] * std::exp(power));
+                        const T thr = T(1) / T(255);
+                        if (fragile && std::fabs(alpha - thr) <= frag_rel * thr) frag = true;
+                        if (alpha < thr) continue;
+                        T next_T = Tr * (T(1) - alpha);
+                        if (fragile && std::fabs(next_T - T(1e-4)) <= frag_rel * T(1e-4)) frag = true;
+                        if (next_T <= T(1e-4)) { done = true; break; }
+                        int32_t g = flatten_ids[range_start + k];
+                        T vis = alpha * Tr;
+                        for (int c = 0; c < 3; ++c) out[c] += colors[(int64_t)g * 3 + c] * vis;
+                        cur_idx = (uint32_t)(range_start + k);
+                        Tr = next_T;
+                    }
+                    render_alphas[pix] = T(1) - Tr;
+                    for (int c = 0; c < 3; ++c) render_colors[pix * 3 + c] = bg ? (out[c] + Tr * bg[c]) : out[c];
+                    last_ids[pix] = (int32_t)cur_idx;
+                    if (fragile) fragile[pix] = frag ? 1 : 0;
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a8: blend backward — gsplat/RasterizeToPixelsFromWorld3DGSBwd.cu:63-372, Utils.cuh:104-158,186-194
+// Per-pixel terms are evaluated in T; the cross-pixel / cross-tile sums (warp reduce + atomicAdd
+// upstream, order unspecified) are accumulated in double and rounded once at the end.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+void raster_bwd(uint32_t C, uint32_t N, int64_t n_isects, const T* means, const T* quats, const T* scales, const T* colors,
+                const T* opacities, const T* backgrounds, const uint8_t* masks, uint32_t W, uint32_t H, uint32_t tile_size,
+                const T* viewmats0, const T* viewmats1, const T* Ks, int camera_model, int shutter, const T* radial,
+                const T* tang, const T* prism, const int32_t* tile_offsets, const int32_t* flatten_ids,
+                const T* render_alphas, const int32_t* last_ids, const T* v_render_colors, const T* v_render_alphas,
+                T* v_means, T* v_quats, T* v_scales, T* v_colors, T* v_opacities) {
+    const uint32_t tw = (W + tile_size - 1) / tile_size, th = (H + tile_size - 1) / tile_size;
+    const int n_rad = camera_model == CAM_FISHEYE ? 4 : 6;
+    std::vector<double> a_means((size_t)N * 3, 0.0), a_quats((size_t)N * 4, 0.0), a_scales((size_t)N * 3, 0.0);
+    std::vector<double> a_colors((size_t)C * N * 3, 0.0), a_opac((size_t)C * N, 0.0);
+    for (uint32_t cid = 0; cid < C; ++cid) {
+        const CamParams<T> cam = make_cam<T>(camera_model, W, H, shutter, Ks + cid * 9, radial ? radial + cid * n_rad : nullptr,
+                                             tang ? tang + cid * 2 : nullptr, prism ? prism + cid * 4 : nullptr);
+        const RSParams<T> rs(viewmats0 + cid * 16, viewmats1 ? viewmats1 + cid * 16 : nullptr);
+        const int32_t* toff = tile_offsets + (int64_t)cid * th * tw;
+        const T* bg = backgrounds ? backgrounds + cid * 3 : nullptr;
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int64_t tile_id = 0; tile_id < (int64_t)tw * th; ++tile_id) {
+            if (masks && !masks[(int64_t)cid * th * tw + tile_id]) continue;
+            const uint32_t ty = tile_id / tw, tx = tile_id % tw;
+            const int32_t range_start = toff[tile_id];
+            const int32_t range_end = (cid == C - 1 && tile_id == (int64_t)tw * th - 1) ? (int32_t)n_isects : toff[tile_id + 1];
+            const int32_t cnt = std::max(0, range_end - range_start);
+            if (cnt == 0) continue;
+            // per-(tile, Gaussian) partial sums: rgb3, mean3, scale3, quat4, opac1
+            std::vector<double> acc((size_t)cnt * 14, 0.0);
+            for (uint32_t py_ = 0; py_ < tile_size; ++py_)
+                for (uint32_t px_ = 0; px_ < tile_size; ++px_) {
+                    const uint32_t i = ty * tile_size + py_, j = tx * tile_size + px_;
+                    if (!(i < H && j < W)) continue;
+                    WorldRay<T> ray = image_point_to_world_ray(cam, V2<T>{T(j) + T(0.5), T(i) + T(0.5)}, rs);
+                    if (!ray.valid) continue;
+                    const int64_t pix = (int64_t)cid * H * W + (int64_t)i * W + j;
+                    const T T_final = T(1) - render_alphas[pix];
+                    T Tr = T_final;
+                    T buffer[3] = {T(0), T(0), T(0)};
+                    const int32_t bin_final = last_ids[pix];
+                    const T vrc[3] = {v_render_colors[pix * 3], v_render_colors[pix * 3 + 1], v_render_colors[pix * 3 + 2]};
+                    const T vra = v_render_alphas[pix];
+                    for (int32_t idx = std::min(range_end - 1, bin_final); idx >= range_start; --idx) {
+                        const int32_t k = idx - range_start;
+                        const int32_t g = flatten_ids[idx];
+                        const int32_t gi = g % (int32_t)N;
+                        const T opac = opacities[g];
+                        const V3<T> xyz{means[gi * 3], means[gi * 3 + 1], means[gi * 3 + 2]};
+                        const T* quat = quats + gi * 4;
+                        const T sc[3] = {scales[gi * 3], scales[gi * 3 + 1], scales[gi * 3 + 2]};
+                        const M3<T> R = quat_to_rotmat(quat);
+                        M3<T> Mt;  // transpose(R*S): Mt(r,c) = R(c,r) / s_r
+                        for (int r = 0; r < 3; ++r)
+                            for (int c = 0; c < 3; ++c) Mt.a[r][c] = R.a[c][r] * (T(1) / sc[r]);
+                        const V3<T> omu = sub(ray.o, xyz);
+                        const V3<T> gro = mv(Mt, omu);
+                        const V3<T> grd = mv(Mt, ray.d);
+                        V3<T> grd_n = grd;
+                        { T l = dot(grd, grd); if (l > T(0)) grd_n = mul(grd, T(1) / std::sqrt(l)); }
+                        const V3<T> gc = cross(grd_n, gro);
+                        const T power = T(-0.5) * dot(gc, gc);
+                        const T vis = std::exp(power);
+                        const T alpha = std::min(T(0.999), opac * vis);
+                        if (power > T(0) || alpha < T(1) / T(255)) continue;
+                        const T ra = T(1) / (T(1) - alpha);
+                        Tr *= ra;
+                        const T fac = alpha * Tr;
+                        double* a = &acc[(size_t)k * 14];
+                        T v_alpha = T(0);
+                        for (int c = 0; c < 3; ++c) {
+                            a[c] += (double)(fac * vrc[c]);
+                            v_alpha += (colors[(int64_t)g * 3 + c] * Tr - buffer[c] * ra) * vrc[c];
+                        }
+                        v_alpha += T_final * ra * vra;
+                        if (bg) {
+                            T accum = T(0);
+                            for (int c = 0; c < 3; ++c) accum += bg[c] * vrc[c];
+                            v_alpha += -T_final * ra * accum;
+                        }
+                        if (opac * vis <= T(0.999)) {
+                            const T v_vis = opac * v_alpha;
+                            const T v_gd = T(-0.5) * vis * v_vis;
+                            const V3<T> v_gc = mul(gc, T(2) * v_gd);
+                            const V3<T> cx = cross(v_gc, gro);
+                            const V3<T> v_grd_n{-cx.x, -cx.y, -cx.z};
+                            const V3<T> v_gro = cross(v_gc, grd_n);
+                            // safe_normalize_bw(grd, v_grd_n)
+                            V3<T> v_grd = v_grd_n;
+                            {
+                                T l = dot(grd, grd);
+                                if (l > T(0)) {
+                                    T il = T(1) / std::sqrt(l), il3 = il * il * il;
+                                    T dd = dot(v_grd_n, grd);
+                                    v_grd = sub(mul(v_grd_n, il), mul(grd, il3 * dd));
+                                }
+                            }
+                            // v_Mt = outer(v_grd, ray_d) + outer(v_gro, omu)  (math: v_Mt(r,c))
+                            M3<T> v_Mt;
+                            const T vg[3] = {v_grd.x, v_grd.y, v_grd.z}, rd[3] = {ray.d.x, ray.d.y, ray.d.z};
+                            const T vo[3] = {v_gro.x, v_gro.y, v_gro.z}, om[3] = {omu.x, omu.y, omu.z};
+                            for (int r = 0; r < 3; ++r)
+                                for (int c = 0; c < 3; ++c) v_Mt.a[r][c] = vg[r] * rd[c] + vo[r] * om[c];
+                            // v_o_minus_mu = transpose(Mt) * v_gro ; v_mean = -that
+                            const V3<T> v_omu = mv(transpose(Mt), v_gro);
+                            a[3] += (double)(-v_omu.x); a[4] += (double)(-v_omu.y); a[5] += (double)(-v_omu.z);
+                            // quat_scale_to_preci_half_vjp(quat, scale, R, v_M = transpose(v_Mt))  Utils.cuh:128-158
+                            // v_M(r,c) = v_Mt(c,r) is dL/dM with M = R*S (S = diag(1/s)).
+                            M3<T> v_M = transpose(v_Mt);
+                            M3<T> v_R;  // v_R = v_M * S
+                            for (int r = 0; r < 3; ++r)
+                                for (int c = 0; c < 3; ++c) v_R.a[r][c] = v_M.a[r][c] * (T(1) / sc[c]);
+                            // quat_to_rotmat_vjp, Utils.cuh:104-126 — glm v_R[i][j] == v_R.a[j][i]
+                            {
+                                T w = quat[0], x = quat[1], y = quat[2], z = quat[3];
+                                T inv_norm = T(1) / std::sqrt(x * x + y * y + z * z + w * w);
+                                x *= inv_norm; y *= inv_norm; z *= inv_norm; w *= inv_norm;
+                                auto G = [&](int i, int j) { return v_R.a[j][i]; };
+                                T vq[4];
+                                vq[0] = T(2) * (x * (G(1, 2) - G(2, 1)) + y * (G(2, 0) - G(0, 2)) + z * (G(0, 1) - G(1, 0)));
+                                vq[1] = T(2) * (T(-2) * x * (G(1, 1) + G(2, 2)) + y * (G(0, 1) + G(1, 0)) + z * (G(0, 2) + G(2, 0)) + w * (G(1, 2) - G(2, 1)));
+                                vq[2] = T(2) * (x * (G(0, 1) + G(1, 0)) - T(2) * y * (G(0, 0) + G(2, 2)) + z * (G(1, 2) + G(2, 1)) + w * (G(2, 0) - G(0, 2)));
+                                vq[3] = T(2) * (x * (G(0, 2) + G(2, 0)) + y * (G(1, 2) + G(2, 1)) - T(2) * z * (G(0, 0) + G(1, 1)) + w * (G(0, 1) - G(1, 0)));
+                                const T qn[4] = {w, x, y, z};
+                                T dq = vq[0] * qn[0] + vq[1] * qn[1] + vq[2] * qn[2] + vq[3] * qn[3];
+                                for (int q = 0; q < 4; ++q) a[9 + q] += (double)((vq[q] - dq * qn[q]) * inv_norm);
+                            }
+                            // v_scale[k] += -(1/s_k)^2 * sum_r R(r,k) * v_M(r,k)   (glm R[k][r]*v_M[k][r])
+                            for (int kk = 0; kk < 3; ++kk) {
+                                T is = T(1) / sc[kk];
+                                T s_ = R.a[0][kk] * v_M.a[0][kk] + R.a[1][kk] * v_M.a[1][kk] + R.a[2][kk] * v_M.a[2][kk];
+                                a[6 + kk] += (double)(-is * is * s_);
+                            }
+                            a[13] += (double)(vis * v_alpha);
+                        }
+                        for (int c = 0; c < 3; ++c) buffer[c] += colors[(int64_t)g * 3 + c] * fac;
+                    }
+                }
+            for (int32_t k = 0; k < cnt; ++k) {
+                const int32_t g = flatten_ids[range_start + k];
+                const int32_t gi = g % (int32_t)N;
+                const double* a = &acc[(size_t)k * 14];
+                bool any = false;
+                for (int q = 0; q < 14; ++q) any |= a[q] != 0.0;
+                if (!any) continue;
+                for (int q = 0; q < 3; ++q) {
+#pragma omp atomic
+                    a_colors[(size_t)g * 3 + q] += a[q];
+#pragma omp atomic
+                    a_means[(size_t)gi * 3 + q] += a[3 + q];
+#pragma omp atomic
+                    a_scales[(size_t)gi * 3 + q] += a[6 + q];
+                }
+                for (int q = 0; q < 4; ++q) {
+#pragma omp atomic
+                    a_quats[(size_t)gi * 4 + q] += a[9 + q];
+                }
+#pragma omp atomic
+                a_opac[(size_t)g] += a[13];
+            }
+        }
+    }
+    for (size_t i = 0; i < a_means.size(); ++i) v_means[i] = (T)a_means[i];
+    for (size_t i = 0; i < a_quats.size(); ++i) v_quats[i] = (T)a_quats[i];
+    for (size_t i = 0; i < a_scales.size(); ++i) v_scales[i] = (T)a_scales[i];
+    for (size_t i = 0; i < a_colors.size(); ++i) v_colors[i] = (T)a_colors[i];
+    for (size_t i = 0; i < a_opac.size(); ++i) v_opacities[i] = (T)a_opac[i];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// extern "C" surface (loaded with ctypes by oracle/oracle.py)
+// ------------------------------------------------------------------------------------------
+#define GSX_ORACLE_INSTANTIATE(SUF, T)                                                                                   \
+    extern "C" void gsx_oracle_quat_to_rotmat_##SUF(int64_t n, const T* quats, T* out) {                                 \
+        for (int64_t i = 0; i < n; ++i) {                                                                                \
+            M3<T> R = quat_to_rotmat(quats + i * 4);                                                                     \
+            for (int r = 0; r < 3; ++r)                                                                                  \
+                for (int c = 0; c < 3; ++c) out[i * 9 + r * 3 + c] = R.a[r][c];                                          \
+        }                                                                                                                \
+    }                                                                                                                    \
+    extern "C" void gsx_oracle_projection_ut_##SUF(                                                                      \
+        uint32_t C, uint32_t N, const T* means, const T* quats, const T* scales, const T* opacities, const T* viewmats0, \
+        const T* viewmats1, const T* Ks, uint32_t W, uint32_t H, T eps2d, T near_plane, T far_plane, T radius_clip,      \
+        int camera_model, T ut_alpha, T ut_beta, T ut_kappa, T ut_margin, int ut_require_all, int shutter,               \
+        const T* radial, const T* tang, const T* prism, int32_t* radii, T* means2d, T* depths, T* conics,                \
+        T* compensations) {                                                                                              \
+        projection_ut<T>(C, N, means, quats, scales, opacities, viewmats0, viewmats1, Ks, W, H, eps2d, near_plane,       \
+                         far_plane, radius_clip, camera_model, ut_alpha, ut_beta, ut_kappa, ut_margin, ut_require_all,   \
+                         shutter, radial, tang, prism, radii, means2d, depths, conics, compensations);                   \
+    }                                                                                                                    \
+    extern "C" void gsx_oracle_sh_fwd_##SUF(uint32_t N, uint32_t K, uint32_t degree, const T* dirs, const T* coeffs,     \
+                                            const uint8_t* masks, T* colors) {                                           \
+        sh_fwd<T>(N, K, degree, dirs, coeffs, masks, colors);                                                            \
+    }                                                                                                                    \
+    extern "C" void gsx_oracle_sh_bwd_##SUF(uint32_t N, uint32_t K, uint32_t degree, const T* dirs, const T* coeffs,     \
+                                            const uint8_t* masks, const T* v_colors, T* v_coeffs, T* v_dirs) {           \
+        sh_bwd<T>(N, K, degree, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs);                                        \
+    }                                                                                                                    \
+    extern "C" int64_t gsx_oracle_isect_count_##SUF(uint32_t C, uint32_t N, const T* means2d, const int32_t* radii,      \
+                                                    uint32_t tile_size, uint32_t tw, uint32_t th, int32_t* tpg) {        \
+        return isect_count<T>(C, N, means2d, radii, tile_size, tw, th, tpg);                                             \
+    }                                                                                                                    \
+    extern "C" void gsx_oracle_isect_fill_##SUF(uint32_t C, uint32_t N, const T* means2d, const int32_t* radii,          \
+                                                const T* depths, uint32_t tile_size, uint32_t tw, uint32_t th, int sort, \
+                                                int64_t* isect_ids, int32_t* flatten_ids) {                              \
+        isect_fill<T>(C, N, means2d, radii, depths, tile_size, tw, th, sort, isect_ids, flatten_ids);                    \
+    }                                                                                                                    \
+    extern "C" void gsx_oracle_raster_fwd_##SUF(                                                                         \
+        uint32_t C, uint32_t N, int64_t n_isects, const T* means, const T* quats, const T* scales, const T* colors,      \
+        const T* opacities, const T* backgrounds, const uint8_t* masks, uint32_t W, uint32_t H, uint32_t tile_size,      \
+        const T* viewmats0, const T* viewmats1, const T* Ks, int camera_model, int shutter, const T* radial,             \
+        const T* tang, const T* prism, const int32_t* tile_offsets, const int32_t* flatten_ids, T* render_colors,        \
+        T* render_alphas, int32_t* last_ids, uint8_t* fragile, T frag_rel) {                                             \
+        raster_fwd<T>(C, N, n_isects, means, quats, scales, colors, opacities, backgrounds, masks, W, H, tile_size,      \
+                      viewmats0, viewmats1, Ks, camera_model, shutter, radial, tang, prism, tile_offsets, flatten_ids,   \
+                      render_colors, render_alphas, last_ids, fragile, frag_rel);                                        \
+    }                                                                                                                    \
+    extern "C" void gsx_oracle_raster_bwd_##SUF(                                                                         \
+        uint32_t C, uint32_t N, int64_t n_isects, const T* means, const T* quats, const T* scales, const T* colors,      \
+        const T* opacities, const T* backgrounds, const uint8_t* masks, uint32_t W, uint32_t H, uint32_t tile_size,      \
+        const T* viewmats0, const T* viewmats1, const T* Ks, int camera_model, int shutter, const T* radial,             \
+        const T* tang, const T* prism, const int32_t* tile_offsets, const int32_t* flatten_ids, const T* render_alphas,  \
+        const int32_t* last_ids, const T* v_render_colors, const T* v_render_alphas, T* v_means, T* v_quats,             \
+        T* v_scales, T* v_colors, T* v_opacities) {                                                                      \
+        raster_bwd<T>(C, N, n_isects, means, quats, scales, colors, opacities, backgrounds, masks, W, H, tile_size,      \
+                      viewmats0, viewmats1, Ks, camera_model, shutter, radial, tang, prism, tile_offsets, flatten_ids,   \
+                      render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors,   \
+                      v_opacities);                                                                                      \
+    }
+
+GSX_ORACLE_INSTANTIATE(f32, float)
+GSX_ORACLE_INSTANTIATE(f64, double)
+
+extern "C" void gsx_oracle_isect_offsets(int64_t n_isects, const int64_t* isect_ids, uint32_t C, uint32_t tw, uint32_t th,
+                                         int32_t* offsets) {
+    isect_offsets(n_isects, isect_ids, C, tw, th, offsets);
+}
+
+extern "C" int gsx_oracle_abi_version(void) { return 1; }
