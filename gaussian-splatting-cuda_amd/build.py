@@ -1,0 +1,91 @@
+"""In-tree build of the native pieces (no JIT cache: the .so files must travel with the repo snapshot).
+
+  libgsx.so                      hipcc --offload-arch=gfx950  csrc/*.hip      (kernels + C ABI, no torch)
+  _gsx_ops.<abi>.so              g++                           csrc/ops_shim.cpp (namespace gsplat on at::Tensor + pybind11)
+
+hipcc is invoked directly (not torch.utils.cpp_extension, which would run hipify over the sources).
+"""
+import os
+import subprocess
+import sys
+import sysconfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIBGSX = os.path.join(HERE, "libgsx.so")
+HIP_SOURCES = ["gsx_capi.hip", "gsx_sh.hip", "gsx_projection.hip", "gsx_intersect.hip", "gsx_raster.hip"]
+HIP_HEADERS = ["gsx_device.hpp"]
+
+
+def ops_module_path():
+    return os.path.join(HERE, "_gsx_ops" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout)
+        raise RuntimeError("build failed: " + " ".join(cmd[:4]) + " ...")
+    return r.stdout
+
+
+def build_libgsx(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in HIP_HEADERS] + [os.path.join(INCLUDE, "gsx.h")]
+    if not (force or _newer(LIBGSX, deps)):
+        return LIBGSX
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    for s in srcs:  # compile the translation units in parallel
+        o = os.path.join(CSRC, os.path.basename(s) + ".o")
+        objs.append(o)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out)
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+        if verbose and out.strip():
+            print(out)
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIBGSX] + objs)
+    return LIBGSX
+
+
+def build_ops_module(force=False):
+    import pybind11
+    import torch
+    out = ops_module_path()
+    src = os.path.join(CSRC, "ops_shim.cpp")
+    deps = [src, os.path.join(INCLUDE, "gsx.h"), os.path.join(INCLUDE, "gsx_ops.h")]
+    if not (force or _newer(out, deps)):
+        return out
+    tp = os.path.dirname(torch.__file__)
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-DTORCH_EXTENSION_NAME=_gsx_ops", "-D_GLIBCXX_USE_CXX11_ABI=1",
+           "-I" + os.path.join(tp, "include"), "-I" + os.path.join(tp, "include", "torch", "csrc", "api", "include"),
+           "-I/opt/rocm/include", "-I" + sysconfig.get_paths()["include"], "-I" + pybind11.get_include(),
+           src, "-o", out, "-L" + HERE, "-lgsx", "-L" + os.path.join(tp, "lib"),
+           "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip", "-ltorch_python",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(tp, "lib")]
+    _run(cmd)
+    return out
+
+
+def build_all(force=False, verbose=False):
+    build_libgsx(force, verbose)
+    build_ops_module(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)
+    print("built", LIBGSX, "and", ops_module_path())

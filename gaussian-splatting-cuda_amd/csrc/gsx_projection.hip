@@ -1,0 +1,162 @@
+// gsx_projection.hip — 3DGUT unscented-transform projection for gfx950 (non-differentiable).
+//
+// Replaces gsplat::projection_ut_3dgs_fused (reference: gsplat/Projection.cpp:22-110, kernel
+// gsplat/ProjectionUT3DGSFused.cu:16-203, sigma points / UT gsplat/Cameras.cuh:1028-1150).
+//
+// Streaming op: 44 B in + 32 B out per (camera, Gaussian), ~500 flops.  One lane per Gaussian,
+// grid.y = camera so every camera quantity is block-uniform.  The seven sigma points are pushed
+// through the camera model in the reference's order (centre, +x,+y,+z, -x,-y,-z) and the weighted
+// mean / covariance are summed in that order: with alpha = 0.1 the UT weights are -99 / +16.67, so
+// summation order is what decides +-1 px radii and hence tile membership.
+#include "gsx_device.hpp"
+
+namespace gsx {
+
+void set_error(const char* msg);
+int check_launch(const char* what);
+
+constexpr int PROJ_BLOCK = 256;
+
+template <int KIND>
+__global__ __launch_bounds__(PROJ_BLOCK) void projection_ut_kernel(
+    uint32_t N, const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
+    const float* __restrict__ opacities, gsx_cameras cams, uint32_t W, uint32_t H, float eps2d, float near_plane,
+    float far_plane, float radius_clip, gsx_ut_params ut, int32_t* __restrict__ radii, float* __restrict__ means2d,
+    float* __restrict__ depths, float* __restrict__ conics, float* __restrict__ compensations) {
+    const uint32_t gid = blockIdx.x * PROJ_BLOCK + threadIdx.x;
+    const uint32_t cid = blockIdx.y;
+    if (gid >= N) return;
+    const size_t idx = (size_t)cid * N + gid;
+
+    const Camera<KIND> cam(cams, cid, W, H);
+    const ShutterPoses sp(cams.viewmats0 + cid * 16, cams.viewmats1 ? cams.viewmats1 + cid * 16 : nullptr);
+
+    const f3 mean{means[(size_t)gid * 3], means[(size_t)gid * 3 + 1], means[(size_t)gid * 3 + 2]};
+    const f3 scale{scales[(size_t)gid * 3], scales[(size_t)gid * 3 + 1], scales[(size_t)gid * 3 + 2]};
+    quat q{quats[(size_t)gid * 4], quats[(size_t)gid * 4 + 1], quats[(size_t)gid * 4 + 2], quats[(size_t)gid * 4 + 3]};
+    {   // glm::normalize(quat)
+        const float len = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+        if (len <= 0.f) q = {1.f, 0.f, 0.f, 0.f};
+        else { const float o = 1.f / len; q = {q.w * o, q.x * o, q.y * o, q.z * o}; }
+    }
+
+    // camera-space depth at the centre-of-shutter pose (ProjectionUT3DGSFused.cu:74-82)
+    f3 tc; quat qc;
+    sp.at(0.5f, tc, qc);
+    const f3 mean_c = quat_rotate(qc, mean) + tc;
+    if (mean_c.z < near_plane || mean_c.z > far_plane) { radii[idx * 2] = 0; radii[idx * 2 + 1] = 0; return; }
+
+    // sigma points and weights
+    const float D = 3.f;
+    const float lambda = ut.alpha * ut.alpha * (D + ut.kappa) - D;
+    const m33 R = quat_to_mat_raw(q);
+    const float sq = sqrtf(D + lambda);
+    const float w_m0 = lambda / (D + lambda);
+    const float w_c0 = lambda / (D + lambda) + (1.f - ut.alpha * ut.alpha + ut.beta);
+    const float w_i = 1.f / (2.f * (D + lambda));
+    const float sc[3] = {scale.x, scale.y, scale.z};
+
+    const bool require_all = ut.require_all_sigma_points_valid != 0;
+    bool valid = require_all;
+    f2 ipts[7];
+    f2 im{0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        f3 pt = mean;
+        if (i > 0) {
+            const int ax = (i - 1) % 3;
+            const float f = sq * sc[ax];
+            const f3 delta{f * R.a[0][ax], f * R.a[1][ax], f * R.a[2][ax]};
+            pt = (i <= 3) ? (mean + delta) : (mean - delta);
+        }
+        f2 ip;
+        const bool pv = cam.world_to_image(pt, sp, ut.in_image_margin_factor, ip);
+        if (require_all) {
+            if (!pv) { radii[idx * 2] = 0; radii[idx * 2 + 1] = 0; return; }
+        } else {
+            valid |= pv;
+        }
+        ipts[i] = ip;
+        const float w = (i == 0) ? w_m0 : w_i;
+        im.x += w * ip.x;
+        im.y += w * ip.y;
+    }
+    if (!valid) { radii[idx * 2] = 0; radii[idx * 2 + 1] = 0; return; }
+
+    float c00 = 0.f, c01 = 0.f, c11 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const float dx = ipts[i].x - im.x, dy = ipts[i].y - im.y;
+        const float w = (i == 0) ? w_c0 : w_i;
+        c00 += w * (dx * dx);
+        c01 += w * (dx * dy);
+        c11 += w * (dy * dy);
+    }
+    // add_blur (Utils.cuh:171-179)
+    const float det_orig = c00 * c11 - c01 * c01;
+    c00 += eps2d; c11 += eps2d;
+    const float det = c00 * c11 - c01 * c01;
+    const float compensation = sqrtf(fmaxf(0.f, det_orig / det));
+    if (det <= 0.f) { radii[idx * 2] = 0; radii[idx * 2 + 1] = 0; return; }
+    const float ood = 1.f / det;
+
+    float extend = 3.33f;
+    if (opacities != nullptr) {
+        float opacity = opacities[gid];
+        opacity *= compensation;
+        if (opacity < (1.f / 255.f)) { radii[idx * 2] = 0; radii[idx * 2 + 1] = 0; return; }
+        extend = fminf(extend, sqrtf(2.f * __logf(opacity / (1.f / 255.f))));
+    }
+    const float b = 0.5f * (c00 + c11);
+    const float tmp = sqrtf(fmaxf(0.01f, b * b - det));
+    const float r1 = extend * sqrtf(b + tmp);
+    const float radius_x = ceilf(fminf(extend * sqrtf(c00), r1));
+    const float radius_y = ceilf(fminf(extend * sqrtf(c11), r1));
+    if (radius_x <= radius_clip && radius_y <= radius_clip) { radii[idx * 2] = 0; radii[idx * 2 + 1] = 0; return; }
+    if (im.x + radius_x <= 0 || im.x - radius_x >= (float)W || im.y + radius_y <= 0 || im.y - radius_y >= (float)H) {
+        radii[idx * 2] = 0; radii[idx * 2 + 1] = 0; return;
+    }
+    radii[idx * 2] = (int32_t)radius_x;
+    radii[idx * 2 + 1] = (int32_t)radius_y;
+    means2d[idx * 2] = im.x;
+    means2d[idx * 2 + 1] = im.y;
+    depths[idx] = mean_c.z;
+    conics[idx * 3] = c11 * ood;
+    conics[idx * 3 + 1] = -c01 * ood;
+    conics[idx * 3 + 2] = c00 * ood;
+    if (compensations != nullptr) compensations[idx] = compensation;
+}
+
+}  // namespace gsx
+
+using namespace gsx;
+
+extern "C" int gsx_projection_ut_3dgs_fused(uint32_t N, const float* means, const float* quats, const float* scales,
+                                            const float* opacities, const gsx_cameras* cams, uint32_t image_width,
+                                            uint32_t image_height, float eps2d, float near_plane, float far_plane,
+                                            float radius_clip, const gsx_ut_params* ut, int32_t* radii, float* means2d,
+                                            float* depths, float* conics, float* compensations, void* stream) {
+    if (!cams || !ut) { set_error("projection_ut_3dgs_fused: cams/ut is null"); return GSX_ERR_INVALID_ARGUMENT; }
+    if (N == 0 || cams->C == 0) return GSX_OK;  // upstream skips the launch (ProjectionUT3DGSFused.cu:242-245)
+    if (!means || !quats || !scales || !cams->viewmats0 || !cams->Ks || !radii || !means2d || !depths || !conics) {
+        set_error("projection_ut_3dgs_fused: null pointer");
+        return GSX_ERR_INVALID_ARGUMENT;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((N + PROJ_BLOCK - 1) / PROJ_BLOCK, cams->C), block(PROJ_BLOCK);
+#define GSX_LAUNCH_PROJ(KIND)                                                                                            \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(projection_ut_kernel<KIND>), grid, block, 0, st, N, means, quats, scales,          \
+                       opacities, *cams, image_width, image_height, eps2d, near_plane, far_plane, radius_clip, *ut,      \
+                       radii, means2d, depths, conics, compensations)
+    if (cams->camera_model == GSX_CAMERA_PINHOLE) {
+        if (!cams->radial && !cams->tangential && !cams->thin_prism) GSX_LAUNCH_PROJ(CAM_PERFECT_PINHOLE);
+        else GSX_LAUNCH_PROJ(CAM_OPENCV_PINHOLE);
+    } else if (cams->camera_model == GSX_CAMERA_FISHEYE) {
+        GSX_LAUNCH_PROJ(CAM_OPENCV_FISHEYE);
+    } else {
+        set_error("projection_ut_3dgs_fused: unsupported camera model (only PINHOLE and FISHEYE; the reference asserts)");
+        return GSX_ERR_UNSUPPORTED;
+    }
+#undef GSX_LAUNCH_PROJ
+    return check_launch("projection_ut_3dgs_fused");
+}

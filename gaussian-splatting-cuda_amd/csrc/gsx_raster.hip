@@ -1,0 +1,473 @@
+// gsx_raster.hip — world-space (3DGUT) front-to-back alpha compositing for gfx950: forward and backward.
+//
+// Replaces gsplat::rasterize_to_pixels_from_world_3dgs_{fwd,bwd} (reference: gsplat/Rasterization.cpp:20-261,
+// kernels gsplat/RasterizeToPixelsFromWorld3DGSFwd.cu:19-279 and ...Bwd.cu:16-373, helpers gsplat/Utils.cuh).
+//
+// Mapping: one 256-thread workgroup (4 wave64) per 16x16 tile; wave w owns the 8x8 quadrant
+// (w&1, w>>1) of the tile, lane l the pixel (l&7, l>>3) inside it.  The tile's depth-sorted Gaussians
+// are processed in chunks of 256: every thread gathers one Gaussian through flatten_ids, turns it
+// into the 16-float record the pixel loop needs (M = diag(1/s) R^T, gro = M (o - mu), opacity, rgb)
+// and parks it in LDS; the pixel loop then reads records at a wave-uniform index (LDS broadcast).
+//
+// Algebra kept identical to the reference, with one hoist that is exact for a global shutter: the ray
+// origin o is the camera centre for every pixel (Cameras.cuh:261-265), so gro = M (o - mu) is a
+// per-Gaussian quantity computed once at staging instead of once per (pixel, Gaussian).
+//
+// Backward: the reference reduces 14 gradient floats over each 32-lane warp and issues 14 global
+// atomics per (warp, Gaussian) = 112 per (tile, Gaussian).  Here every lane produces the 16 sums that
+// are linear in the per-pixel terms (v_rgb[3], v_opacity, v_gro[3], v_grd (x) d [9]); they are reduced
+// over the wave with DPP row operations, added into a per-chunk LDS accumulator (ds_add_f32), and
+// after the chunk ONE thread per Gaussian applies the mean / quaternion / scale chain rule
+// (Utils.cuh:104-158) and issues the 14 global atomics: 14 per (tile, Gaussian), 8x fewer.
+#include "gsx_device.hpp"
+
+namespace gsx {
+
+void set_error(const char* msg);
+int check_launch(const char* what);
+
+constexpr int TILE = 16;
+constexpr int RB = 256;  // threads per workgroup == Gaussians per chunk
+constexpr float ALPHA_MIN = 1.f / 255.f;
+
+struct RasterArgs {
+    uint32_t C, N;
+    int64_t n_isects;
+    const float* means; const float* quats; const float* scales; const float* colors; const float* opacities;
+    const float* backgrounds; const uint8_t* masks;
+    uint32_t W, H, tw, th;
+    gsx_cameras cams;
+    const int32_t* tile_offsets; const int32_t* flatten_ids;
+};
+
+// One staged Gaussian: 4 x float4 = 64 B.
+//  r0 = (M00 M01 M02 gro.x)  r1 = (M10 M11 M12 gro.y)  r2 = (M20 M21 M22 gro.z)  r3 = (opac, r, g, b)
+// When the ray origin is per pixel (rolling shutter) the gro slots hold mu instead.
+struct Staged { float4 r0, r1, r2, r3; };
+
+template <bool HOIST>
+GSX_DEV void stage_gaussian(const RasterArgs& a, int32_t g, f3 org, Staged& s) {
+    const int32_t gi = (a.C == 1) ? g : (int32_t)((uint32_t)g % a.N);  // params are [N]; colours/opacities [C,N]
+    const f3 mu{a.means[(size_t)gi * 3], a.means[(size_t)gi * 3 + 1], a.means[(size_t)gi * 3 + 2]};
+    const float4 q = reinterpret_cast<const float4*>(a.quats)[gi];
+    const f3 sc{a.scales[(size_t)gi * 3], a.scales[(size_t)gi * 3 + 1], a.scales[(size_t)gi * 3 + 2]};
+    const m33 R = quat_to_rotmat(q.x, q.y, q.z, q.w);
+    const float is0 = 1.f / sc.x, is1 = 1.f / sc.y, is2 = 1.f / sc.z;
+    // M(r,c) = (1/s_r) R(c,r)
+    s.r0 = make_float4(is0 * R.a[0][0], is0 * R.a[1][0], is0 * R.a[2][0], 0.f);
+    s.r1 = make_float4(is1 * R.a[0][1], is1 * R.a[1][1], is1 * R.a[2][1], 0.f);
+    s.r2 = make_float4(is2 * R.a[0][2], is2 * R.a[1][2], is2 * R.a[2][2], 0.f);
+    if (HOIST) {
+        const f3 d = org - mu;
+        s.r0.w = s.r0.x * d.x + s.r0.y * d.y + s.r0.z * d.z;
+        s.r1.w = s.r1.x * d.x + s.r1.y * d.y + s.r1.z * d.z;
+        s.r2.w = s.r2.x * d.x + s.r2.y * d.y + s.r2.z * d.z;
+    } else {
+        s.r0.w = mu.x; s.r1.w = mu.y; s.r2.w = mu.z;
+    }
+    s.r3 = make_float4(a.opacities[g], a.colors[(size_t)g * 3], a.colors[(size_t)g * 3 + 1], a.colors[(size_t)g * 3 + 2]);
+}
+
+// pixel owned by this thread
+GSX_DEV void thread_pixel(uint32_t tid, uint32_t tile_x, uint32_t tile_y, uint32_t& i, uint32_t& j) {
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    j = tile_x * TILE + (wave & 1u) * 8u + (lane & 7u);
+    i = tile_y * TILE + (wave >> 1) * 8u + (lane >> 3);
+}
+
+// alpha of one (pixel, Gaussian) pair, reference order (Fwd.cu:227-239)
+template <bool HOIST>
+GSX_DEV float pair_alpha(const Staged& s, f3 ray_o, f3 ray_d, f3& gro, f3& grd, f3& grd_n, f3& gc, float& vis, float& il) {
+    if (HOIST) gro = {s.r0.w, s.r1.w, s.r2.w};
+    else {
+        const f3 d = ray_o - f3{s.r0.w, s.r1.w, s.r2.w};
+        gro = {s.r0.x * d.x + s.r0.y * d.y + s.r0.z * d.z, s.r1.x * d.x + s.r1.y * d.y + s.r1.z * d.z,
+               s.r2.x * d.x + s.r2.y * d.y + s.r2.z * d.z};
+    }
+    grd = {s.r0.x * ray_d.x + s.r0.y * ray_d.y + s.r0.z * ray_d.z, s.r1.x * ray_d.x + s.r1.y * ray_d.y + s.r1.z * ray_d.z,
+           s.r2.x * ray_d.x + s.r2.y * ray_d.y + s.r2.z * ray_d.z};
+    const float l = dot3(grd, grd);
+    il = l > 0.f ? rsqrtf(l) : 1.f;
+    grd_n = grd * il;
+    gc = cross3(grd_n, gro);
+    const float power = -0.5f * dot3(gc, gc);
+    vis = __expf(power);
+    return fminf(0.999f, s.r3.x * vis);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int KIND, bool HOIST>
+__global__ __launch_bounds__(RB) void raster_fwd_kernel(RasterArgs a, float* __restrict__ render_colors,
+                                                        float* __restrict__ render_alphas,
+                                                        int32_t* __restrict__ last_ids) {
+    __shared__ Staged s_g[RB];
+    const uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y, cid = blockIdx.z;
+    const uint32_t tile_id = tile_y * a.tw + tile_x;
+    const uint32_t tid = threadIdx.x;
+    uint32_t i, j;
+    thread_pixel(tid, tile_x, tile_y, i, j);
+    const bool inside = i < a.H && j < a.W;
+    const size_t pix = (size_t)cid * a.H * a.W + (size_t)i * a.W + j;
+    const float* bg = a.backgrounds ? a.backgrounds + cid * 3 : nullptr;
+
+    if (a.masks != nullptr && !a.masks[(size_t)cid * a.th * a.tw + tile_id]) {  // Fwd.cu:143-150
+        if (inside)
+            for (int k = 0; k < 3; ++k) render_colors[pix * 3 + k] = bg ? bg[k] : 0.f;
+        return;
+    }
+
+    const Camera<KIND> cam(a.cams, cid, a.W, a.H);
+    const ShutterPoses sp(a.cams.viewmats0 + cid * 16, a.cams.viewmats1 ? a.cams.viewmats1 + cid * 16 : nullptr);
+    f3 ray_o, ray_d;
+    const bool ray_ok = cam.pixel_to_world_ray(f2{(float)j + 0.5f, (float)i + 0.5f}, sp, ray_o, ray_d);
+    f3 cam_org = ray_o;
+    if (HOIST) {  // global shutter: identical origin for every pixel; recompute it where the ray was invalid
+        const m33 Rinv = quat_to_mat_raw(quat_conj_over_norm2(sp.q0));
+        const f3 rt = mul(Rinv, sp.t0);
+        cam_org = {-rt.x, -rt.y, -rt.z};
+    }
+    bool done = !inside || !ray_ok;
+
+    const int32_t* toff = a.tile_offsets + (size_t)cid * a.th * a.tw;
+    const int32_t range_start = toff[tile_id];
+    const int32_t range_end = (cid == a.C - 1 && tile_id == a.tw * a.th - 1) ? (int32_t)a.n_isects : toff[tile_id + 1];
+    const int32_t n_chunks = (range_end - range_start + RB - 1) / RB;
+
+    float T = 1.f;
+    uint32_t cur_idx = 0;
+    float out_r = 0.f, out_g = 0.f, out_b = 0.f;
+    for (int32_t b = 0; b < n_chunks; ++b) {
+        if (__syncthreads_and(done)) break;  // Fwd.cu:188-190
+        const int32_t chunk_start = range_start + RB * b;
+        const int32_t idx = chunk_start + (int32_t)tid;
+        if (idx < range_end) {
+            Staged s;
+            stage_gaussian<HOIST>(a, a.flatten_ids[idx], cam_org, s);
+            s_g[tid] = s;
+        }
+        __syncthreads();
+        const int32_t chunk_size = min(RB, range_end - chunk_start);
+        for (int32_t t = 0; t < chunk_size && !done; ++t) {
+            const Staged s = s_g[t];
+            f3 gro, grd, grd_n, gc; float vis, il;
+            const float alpha = pair_alpha<HOIST>(s, ray_o, ray_d, gro, grd, grd_n, gc, vis, il);
+            if (alpha < ALPHA_MIN) continue;
+            const float next_T = T * (1.f - alpha);
+            if (next_T <= 1e-4f) { done = true; break; }
+            const float w = alpha * T;
+            out_r += s.r3.y * w; out_g += s.r3.z * w; out_b += s.r3.w * w;
+            cur_idx = (uint32_t)(chunk_start + t);
+            T = next_T;
+        }
+    }
+    if (inside) {
+        render_alphas[pix] = 1.f - T;
+        render_colors[pix * 3] = bg ? out_r + T * bg[0] : out_r;
+        render_colors[pix * 3 + 1] = bg ? out_g + T * bg[1] : out_g;
+        render_colors[pix * 3 + 2] = bg ? out_b + T * bg[2] : out_b;
+        last_ids[pix] = (int32_t)cur_idx;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+constexpr int NACC = 16;  // v_rgb[3], v_opacity, v_gro[3], G = sum v_grd (x) d [9]
+
+template <int KIND, bool HOIST>
+__global__ __launch_bounds__(RB) void raster_bwd_kernel(RasterArgs a, const float* __restrict__ render_alphas,
+                                                        const int32_t* __restrict__ last_ids,
+                                                        const float* __restrict__ v_render_colors,
+                                                        const float* __restrict__ v_render_alphas,
+                                                        float* __restrict__ v_means, float* __restrict__ v_quats,
+                                                        float* __restrict__ v_scales, float* __restrict__ v_colors,
+                                                        float* __restrict__ v_opacities) {
+    __shared__ Staged s_g[RB];
+    __shared__ float s_acc[RB * NACC];
+    __shared__ int32_t s_id[RB];
+    __shared__ int32_t s_touched[RB];
+    const uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y, cid = blockIdx.z;
+    const uint32_t tile_id = tile_y * a.tw + tile_x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if (a.masks != nullptr && !a.masks[(size_t)cid * a.th * a.tw + tile_id]) return;  // Bwd.cu:84-86
+    uint32_t i, j;
+    thread_pixel(tid, tile_x, tile_y, i, j);
+    const bool inside = i < a.H && j < a.W;
+    const size_t pix = (size_t)cid * a.H * a.W + (size_t)min(i, a.H - 1) * a.W + min(j, a.W - 1);
+    const float* bg = a.backgrounds ? a.backgrounds + cid * 3 : nullptr;
+
+    const Camera<KIND> cam(a.cams, cid, a.W, a.H);
+    const ShutterPoses sp(a.cams.viewmats0 + cid * 16, a.cams.viewmats1 ? a.cams.viewmats1 + cid * 16 : nullptr);
+    f3 ray_o, ray_d;
+    const bool ray_ok = cam.pixel_to_world_ray(f2{(float)j + 0.5f, (float)i + 0.5f}, sp, ray_o, ray_d);
+    f3 cam_org = ray_o;
+    if (HOIST) {
+        const m33 Rinv = quat_to_mat_raw(quat_conj_over_norm2(sp.q0));
+        const f3 rt = mul(Rinv, sp.t0);
+        cam_org = {-rt.x, -rt.y, -rt.z};
+    }
+    const bool active = inside && ray_ok;
+
+    const int32_t* toff = a.tile_offsets + (size_t)cid * a.th * a.tw;
+    const int32_t range_start = toff[tile_id];
+    const int32_t range_end = (cid == a.C - 1 && tile_id == a.tw * a.th - 1) ? (int32_t)a.n_isects : toff[tile_id + 1];
+
+    const float T_final = 1.f - render_alphas[pix];
+    float T = T_final;
+    float buf_r = 0.f, buf_g = 0.f, buf_b = 0.f;
+    const int32_t bin_final = active ? last_ids[pix] : -1;
+    const float vr = v_render_colors[pix * 3], vg = v_render_colors[pix * 3 + 1], vb = v_render_colors[pix * 3 + 2];
+    const float va = v_render_alphas[pix];
+    float bg_dot = 0.f;
+    if (bg) bg_dot = bg[0] * vr + bg[1] * vg + bg[2] * vb;
+
+    // the last sorted index any pixel of the block needs: chunks entirely behind it are skipped
+    __shared__ int32_t s_blockmax;
+    if (tid == 0) s_blockmax = -1;
+    __syncthreads();
+    {
+        int32_t m = bin_final;
+        for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+        if (lane == 0) atomicMax(&s_blockmax, m);
+    }
+    __syncthreads();
+    const int32_t block_last = min(s_blockmax, range_end - 1);
+    if (block_last < range_start) return;
+    const int32_t n_chunks = (block_last - range_start + RB) / RB;  // chunks counted from the back
+
+    for (int32_t b = 0; b < n_chunks; ++b) {
+        __syncthreads();  // previous chunk fully consumed
+        const int32_t chunk_end = block_last - RB * b;               // inclusive, furthest-back first
+        const int32_t chunk_size = min(RB, chunk_end + 1 - range_start);
+        const int32_t idx = chunk_end - (int32_t)tid;
+        if (idx >= range_start) {
+            const int32_t g = a.flatten_ids[idx];
+            Staged s;
+            stage_gaussian<HOIST>(a, g, cam_org, s);
+            s_g[tid] = s;
+            s_id[tid] = g;
+        }
+        s_touched[tid] = 0;
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) s_acc[k * RB + tid] = 0.f;
+        __syncthreads();
+
+        for (int32_t t = 0; t < chunk_size; ++t) {
+            const int32_t gidx = chunk_end - t;
+            bool valid = active && gidx <= bin_final;
+            f3 gro, grd, grd_n, gc; float vis = 0.f, il = 1.f, alpha = 0.f;
+            Staged s;
+            if (valid) {
+                s = s_g[t];
+                alpha = pair_alpha<HOIST>(s, ray_o, ray_d, gro, grd, grd_n, gc, vis, il);
+                if (alpha < ALPHA_MIN) valid = false;
+            }
+            if (__ballot(valid) == 0ull) continue;
+            float acc[NACC];
+#pragma unroll
+            for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+            if (valid) {
+                const float ra = 1.f / (1.f - alpha);
+                T *= ra;
+                const float fac = alpha * T;
+                acc[0] = fac * vr; acc[1] = fac * vg; acc[2] = fac * vb;
+                float v_alpha = (s.r3.y * T - buf_r * ra) * vr + (s.r3.z * T - buf_g * ra) * vg + (s.r3.w * T - buf_b * ra) * vb;
+                v_alpha += T_final * ra * va;
+                if (bg) v_alpha += -T_final * ra * bg_dot;
+                if (s.r3.x * vis <= 0.999f) {
+                    const float v_vis = s.r3.x * v_alpha;
+                    const float v_gd = -0.5f * vis * v_vis;
+                    const f3 v_gc = gc * (2.f * v_gd);
+                    const f3 cx = cross3(v_gc, gro);
+                    const f3 v_grd_n{-cx.x, -cx.y, -cx.z};
+                    const f3 v_gro = cross3(v_gc, grd_n);
+                    // safe_normalize_bw (Utils.cuh:186-194)
+                    const float il3 = il * il * il;
+                    const f3 v_grd = v_grd_n * il - grd * (il3 * dot3(v_grd_n, grd));
+                    acc[3] = vis * v_alpha;
+                    acc[4] = v_gro.x; acc[5] = v_gro.y; acc[6] = v_gro.z;
+                    acc[7] = v_grd.x * ray_d.x; acc[8] = v_grd.x * ray_d.y; acc[9] = v_grd.x * ray_d.z;
+                    acc[10] = v_grd.y * ray_d.x; acc[11] = v_grd.y * ray_d.y; acc[12] = v_grd.y * ray_d.z;
+                    acc[13] = v_grd.z * ray_d.x; acc[14] = v_grd.z * ray_d.y; acc[15] = v_grd.z * ray_d.z;
+                    if (!HOIST) {
+                        // per-pixel origin: fold v_gro (x) (o - mu) into G now and keep v_gro for v_mean
+                        const f3 omu = ray_o - f3{s.r0.w, s.r1.w, s.r2.w};
+                        acc[7] += v_gro.x * omu.x; acc[8] += v_gro.x * omu.y; acc[9] += v_gro.x * omu.z;
+                        acc[10] += v_gro.y * omu.x; acc[11] += v_gro.y * omu.y; acc[12] += v_gro.y * omu.z;
+                        acc[13] += v_gro.z * omu.x; acc[14] += v_gro.z * omu.y; acc[15] += v_gro.z * omu.z;
+                    }
+                }
+                buf_r += s.r3.y * fac; buf_g += s.r3.z * fac; buf_b += s.r3.w * fac;
+            }
+#pragma unroll
+            for (int k = 0; k < NACC; ++k) acc[k] = wave_sum_to_lane63(acc[k]);
+            if (lane == 63u) {
+#pragma unroll
+                for (int k = 0; k < NACC; ++k) atomicAdd(&s_acc[k * RB + t], acc[k]);
+                s_touched[t] = 1;
+            }
+        }
+        __syncthreads();
+
+        // one thread per Gaussian of the chunk: chain rule to (mean, quat, scale) and 14 global atomics
+        if ((int32_t)tid < chunk_size && s_touched[tid]) {
+            const int32_t g = s_id[tid];
+            const int32_t gi = (a.C == 1) ? g : (int32_t)((uint32_t)g % a.N);
+            float A[NACC];
+#pragma unroll
+            for (int k = 0; k < NACC; ++k) A[k] = s_acc[k * RB + tid];
+            atomicAdd(&v_colors[(size_t)g * 3], A[0]);
+            atomicAdd(&v_colors[(size_t)g * 3 + 1], A[1]);
+            atomicAdd(&v_colors[(size_t)g * 3 + 2], A[2]);
+            atomicAdd(&v_opacities[g], A[3]);
+            const Staged s = s_g[tid];
+            const f3 v_gro{A[4], A[5], A[6]};
+            // v_mean = - M^T v_gro
+            atomicAdd(&v_means[(size_t)gi * 3], -(s.r0.x * v_gro.x + s.r1.x * v_gro.y + s.r2.x * v_gro.z));
+            atomicAdd(&v_means[(size_t)gi * 3 + 1], -(s.r0.y * v_gro.x + s.r1.y * v_gro.y + s.r2.y * v_gro.z));
+            atomicAdd(&v_means[(size_t)gi * 3 + 2], -(s.r0.z * v_gro.x + s.r1.z * v_gro.y + s.r2.z * v_gro.z));
+            // v_Mt(r,c) = G(r,c) + v_gro_r * omu_c   (Bwd.cu:325-326)
+            float vMt[3][3] = {{A[7], A[8], A[9]}, {A[10], A[11], A[12]}, {A[13], A[14], A[15]}};
+            const float4 qraw = reinterpret_cast<const float4*>(a.quats)[gi];
+            const f3 sc{a.scales[(size_t)gi * 3], a.scales[(size_t)gi * 3 + 1], a.scales[(size_t)gi * 3 + 2]};
+            if (HOIST) {
+                const f3 mu{a.means[(size_t)gi * 3], a.means[(size_t)gi * 3 + 1], a.means[(size_t)gi * 3 + 2]};
+                const f3 omu = cam_org - mu;
+                const float vgv[3] = {v_gro.x, v_gro.y, v_gro.z}, om[3] = {omu.x, omu.y, omu.z};
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) vMt[r][c] += vgv[r] * om[c];
+            }
+            // quat_scale_to_preci_half_vjp (Utils.cuh:128-158): v_M = v_Mt^T is dL/d(R S), S = diag(1/s)
+            const float isv[3] = {1.f / sc.x, 1.f / sc.y, 1.f / sc.z};
+            float w = qraw.x, x = qraw.y, y = qraw.z, z = qraw.w;
+            const float inv_norm = rsqrtf(x * x + y * y + z * z + w * w);
+            w *= inv_norm; x *= inv_norm; y *= inv_norm; z *= inv_norm;
+            const m33 R = quat_to_mat_raw(quat{w, x, y, z});
+            // v_R(r,c) = v_M(r,c) * is_c = vMt[c][r] * is_c ;  G(i,j) := glm v_R[i][j] = v_R(j,i) = vMt[i][j] * is_i
+#define GSX_G(i, j) (vMt[i][j] * isv[i])
+            float vq[4];
+            vq[0] = 2.f * (x * (GSX_G(1, 2) - GSX_G(2, 1)) + y * (GSX_G(2, 0) - GSX_G(0, 2)) + z * (GSX_G(0, 1) - GSX_G(1, 0)));
+            vq[1] = 2.f * (-2.f * x * (GSX_G(1, 1) + GSX_G(2, 2)) + y * (GSX_G(0, 1) + GSX_G(1, 0)) + z * (GSX_G(0, 2) + GSX_G(2, 0)) + w * (GSX_G(1, 2) - GSX_G(2, 1)));
+            vq[2] = 2.f * (x * (GSX_G(0, 1) + GSX_G(1, 0)) - 2.f * y * (GSX_G(0, 0) + GSX_G(2, 2)) + z * (GSX_G(1, 2) + GSX_G(2, 1)) + w * (GSX_G(2, 0) - GSX_G(0, 2)));
+            vq[3] = 2.f * (x * (GSX_G(0, 2) + GSX_G(2, 0)) + y * (GSX_G(1, 2) + GSX_G(2, 1)) - 2.f * z * (GSX_G(0, 0) + GSX_G(1, 1)) + w * (GSX_G(0, 1) - GSX_G(1, 0)));
+#undef GSX_G
+            const float qn[4] = {w, x, y, z};
+            const float dq = vq[0] * qn[0] + vq[1] * qn[1] + vq[2] * qn[2] + vq[3] * qn[3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) atomicAdd(&v_quats[(size_t)gi * 4 + k], (vq[k] - dq * qn[k]) * inv_norm);
+            // v_scale[k] = -(1/s_k)^2 * sum_r R(r,k) * v_M(r,k) = -(is_k)^2 * sum_r R(r,k) * vMt[k][r]
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float sum = R.a[0][k] * vMt[k][0] + R.a[1][k] * vMt[k][1] + R.a[2][k] * vMt[k][2];
+                atomicAdd(&v_scales[(size_t)gi * 3 + k], -isv[k] * isv[k] * sum);
+            }
+        }
+    }
+}
+
+static int fill_args(RasterArgs& a, uint32_t N, int64_t n_isects, const float* means, const float* quats,
+                     const float* scales, const float* colors, uint32_t channels, const float* opacities,
+                     const float* backgrounds, const uint8_t* masks, uint32_t W, uint32_t H, uint32_t tile_size,
+                     const gsx_cameras* cams, const int32_t* tile_offsets, const int32_t* flatten_ids, const char* who) {
+    if (!cams) { set_error("rasterize_to_pixels_from_world_3dgs: cams is null"); return GSX_ERR_INVALID_ARGUMENT; }
+    if (channels != 3) {  // Rasterization.cpp:65 asserts channels == 3
+        set_error("rasterize_to_pixels_from_world_3dgs: Unsupported number of channels (only 3)");
+        return GSX_ERR_INVALID_ARGUMENT;
+    }
+    if (tile_size != TILE) { set_error("rasterize_to_pixels_from_world_3dgs: tile_size must be 16"); return GSX_ERR_UNSUPPORTED; }
+    if (!means || !quats || !scales || !colors || !opacities || !tile_offsets || !cams->viewmats0 || !cams->Ks ||
+        (n_isects > 0 && !flatten_ids)) {
+        set_error("rasterize_to_pixels_from_world_3dgs: null pointer");
+        return GSX_ERR_INVALID_ARGUMENT;
+    }
+    if (cams->camera_model != GSX_CAMERA_PINHOLE && cams->camera_model != GSX_CAMERA_FISHEYE) {
+        set_error("rasterize_to_pixels_from_world_3dgs: unsupported camera model (ORTHO is rejected upstream too)");
+        return GSX_ERR_UNSUPPORTED;
+    }
+    (void)who;
+    a.C = cams->C; a.N = N; a.n_isects = n_isects;
+    a.means = means; a.quats = quats; a.scales = scales; a.colors = colors; a.opacities = opacities;
+    a.backgrounds = backgrounds; a.masks = masks;
+    a.W = W; a.H = H; a.tw = (W + TILE - 1) / TILE; a.th = (H + TILE - 1) / TILE;
+    a.cams = *cams;
+    a.tile_offsets = tile_offsets; a.flatten_ids = flatten_ids;
+    return GSX_OK;
+}
+
+static int cam_kind(const gsx_cameras& c) {
+    if (c.camera_model == GSX_CAMERA_FISHEYE) return CAM_OPENCV_FISHEYE;
+    return (c.radial || c.tangential || c.thin_prism) ? CAM_OPENCV_PINHOLE : CAM_PERFECT_PINHOLE;
+}
+
+}  // namespace gsx
+
+using namespace gsx;
+
+extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_fwd(
+    uint32_t N, int64_t n_isects, const float* means, const float* quats, const float* scales, const float* colors,
+    uint32_t channels, const float* opacities, const float* backgrounds, const uint8_t* masks, uint32_t image_width,
+    uint32_t image_height, uint32_t tile_size, const gsx_cameras* cams, const gsx_ut_params* ut,
+    const int32_t* tile_offsets, const int32_t* flatten_ids, float* renders, float* alphas, int32_t* last_ids,
+    void* stream) {
+    (void)ut;
+    RasterArgs a;
+    int rc = fill_args(a, N, n_isects, means, quats, scales, colors, channels, opacities, backgrounds, masks, image_width,
+                       image_height, tile_size, cams, tile_offsets, flatten_ids, "fwd");
+    if (rc != GSX_OK) return rc;
+    if (!renders || !alphas || !last_ids) { set_error("rasterize fwd: null output"); return GSX_ERR_INVALID_ARGUMENT; }
+    if (a.C == 0 || image_width == 0 || image_height == 0) return GSX_OK;
+    const dim3 grid(a.tw, a.th, a.C), block(RB);
+    hipStream_t st = (hipStream_t)stream;
+    const bool hoist = cams->shutter == GSX_SHUTTER_GLOBAL;
+#define GSX_FWD(KIND)                                                                                                  \
+    do {                                                                                                               \
+        if (hoist) hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_fwd_kernel<KIND, true>), grid, block, 0, st, a, renders, alphas, last_ids); \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_fwd_kernel<KIND, false>), grid, block, 0, st, a, renders, alphas, last_ids);      \
+    } while (0)
+    switch (cam_kind(*cams)) {
+    case CAM_PERFECT_PINHOLE: GSX_FWD(CAM_PERFECT_PINHOLE); break;
+    case CAM_OPENCV_PINHOLE: GSX_FWD(CAM_OPENCV_PINHOLE); break;
+    default: GSX_FWD(CAM_OPENCV_FISHEYE); break;
+    }
+#undef GSX_FWD
+    return check_launch("rasterize_to_pixels_from_world_3dgs_fwd");
+}
+
+extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd(
+    uint32_t N, int64_t n_isects, const float* means, const float* quats, const float* scales, const float* colors,
+    uint32_t channels, const float* opacities, const float* backgrounds, const uint8_t* masks, uint32_t image_width,
+    uint32_t image_height, uint32_t tile_size, const gsx_cameras* cams, const gsx_ut_params* ut,
+    const int32_t* tile_offsets, const int32_t* flatten_ids, const float* render_alphas, const int32_t* last_ids,
+    const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats, float* v_scales,
+    float* v_colors, float* v_opacities, void* stream) {
+    (void)ut;
+    RasterArgs a;
+    int rc = fill_args(a, N, n_isects, means, quats, scales, colors, channels, opacities, backgrounds, masks, image_width,
+                       image_height, tile_size, cams, tile_offsets, flatten_ids, "bwd");
+    if (rc != GSX_OK) return rc;
+    if (!render_alphas || !last_ids || !v_render_colors || !v_render_alphas || !v_means || !v_quats || !v_scales ||
+        !v_colors || !v_opacities) {
+        set_error("rasterize bwd: null pointer");
+        return GSX_ERR_INVALID_ARGUMENT;
+    }
+    if (n_isects == 0 || a.C == 0 || image_width == 0 || image_height == 0) return GSX_OK;  // Bwd.cu:434-437
+    const dim3 grid(a.tw, a.th, a.C), block(RB);
+    hipStream_t st = (hipStream_t)stream;
+    const bool hoist = cams->shutter == GSX_SHUTTER_GLOBAL;
+#define GSX_BWD(KIND)                                                                                                  \
+    do {                                                                                                               \
+        if (hoist) hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_kernel<KIND, true>), grid, block, 0, st, a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors, v_opacities); \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_kernel<KIND, false>), grid, block, 0, st, a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors, v_opacities);      \
+    } while (0)
+    switch (cam_kind(*cams)) {
+    case CAM_PERFECT_PINHOLE: GSX_BWD(CAM_PERFECT_PINHOLE); break;
+    case CAM_OPENCV_PINHOLE: GSX_BWD(CAM_OPENCV_PINHOLE); break;
+    default: GSX_BWD(CAM_OPENCV_FISHEYE); break;
+    }
+#undef GSX_BWD
+    return check_launch("rasterize_to_pixels_from_world_3dgs_bwd");
+}

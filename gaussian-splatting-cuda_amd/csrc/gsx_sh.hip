@@ -1,0 +1,327 @@
+// gsx_sh.hip — spherical-harmonics colour evaluation, forward and backward, for gfx950.
+//
+// Replaces gsplat::spherical_harmonics_{fwd,bwd} (reference: gsplat/SphericalHarmonics.cpp:15-75,
+// kernels gsplat/SphericalHarmonicsCUDA.cu:373-399 / 444-481, math :20-371; basis = Sloan,
+// "Efficient Spherical Harmonic Evaluation", JCGT 2013).
+//
+// Design (HBM-bound streaming op, 217 B/Gaussian fwd and 409 B/Gaussian bwd at degree 3):
+//   * one lane per Gaussian computes all three channels (the reference uses one thread per
+//     (Gaussian, channel) and re-normalises the direction three times);
+//   * the [K,3] coefficient rows of a wave's 64 Gaussians are one contiguous 64*K*12 B span of
+//     HBM: the wave streams that span with fully coalesced 16 B/lane loads into LDS (odd row
+//     stride -> conflict-free per-lane row reads) instead of 64 strided 192 B gathers;
+//   * only the (deg+1)^2 active bases are read; masked Gaussians' rows are not read at all;
+//   * backward writes v_coeffs rows (incl. the zeros above the active degree and for masked
+//     Gaussians) through the same LDS tile with coalesced stores, so no separate memset pass
+//     (the reference does at::zeros_like + a partial write).
+#include "gsx_device.hpp"
+
+namespace gsx {
+
+template <int DEG> struct ShBasis {
+    // Y[k] for k < (DEG+1)^2 at unit direction (x,y,z); optionally the partials wrt x,y,z.
+    template <bool GRAD>
+    GSX_DEV static void eval(float x, float y, float z, float* Y, float* Yx, float* Yy, float* Yz) {
+        constexpr int NB = (DEG + 1) * (DEG + 1);
+        if (GRAD) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) { Yx[k] = 0.f; Yy[k] = 0.f; Yz[k] = 0.f; }
+        }
+        Y[0] = 0.2820947917738781f;
+        if (DEG >= 1) {
+            const float c1 = 0.48860251190292f;
+            Y[1] = -c1 * y; Y[2] = c1 * z; Y[3] = -c1 * x;
+            if (GRAD) { Yy[1] = -c1; Yz[2] = c1; Yx[3] = -c1; }
+        }
+        float z2 = 0.f, fC1 = 0.f, fS1 = 0.f, fC1_x = 0.f, fC1_y = 0.f, fS1_x = 0.f, fS1_y = 0.f;
+        if (DEG >= 2) {
+            z2 = z * z;
+            const float a = -1.092548430592079f;
+            const float fT0B = a * z;
+            fC1 = x * x - y * y; fS1 = 2.f * x * y;
+            const float c2 = 0.5462742152960395f;
+            Y[4] = c2 * fS1; Y[5] = fT0B * y; Y[6] = 0.9461746957575601f * z2 - 0.3153915652525201f;
+            Y[7] = fT0B * x; Y[8] = c2 * fC1;
+            if (GRAD) {
+                fC1_x = 2.f * x; fC1_y = -2.f * y; fS1_x = 2.f * y; fS1_y = 2.f * x;
+                Yx[4] = c2 * fS1_x; Yy[4] = c2 * fS1_y;
+                Yy[5] = fT0B; Yz[5] = a * y;
+                Yz[6] = 2.f * 0.9461746957575601f * z;
+                Yx[7] = fT0B; Yz[7] = a * x;
+                Yx[8] = c2 * fC1_x; Yy[8] = c2 * fC1_y;
+            }
+        }
+        float fC2 = 0.f, fS2 = 0.f, fC2_x = 0.f, fC2_y = 0.f, fS2_x = 0.f, fS2_y = 0.f, Y12_z = 0.f;
+        if (DEG >= 3) {
+            const float fT0C = -2.285228997322329f * z2 + 0.4570457994644658f;
+            const float b = 1.445305721320277f;
+            const float fT1B = b * z;
+            fC2 = x * fC1 - y * fS1; fS2 = x * fS1 + y * fC1;
+            const float c3 = -0.5900435899266435f;
+            Y[9] = c3 * fS2; Y[10] = fT1B * fS1; Y[11] = fT0C * y;
+            Y[12] = z * (1.865881662950577f * z2 - 1.119528997770346f);
+            Y[13] = fT0C * x; Y[14] = fT1B * fC1; Y[15] = c3 * fC2;
+            if (GRAD) {
+                const float fT0C_z = -2.285228997322329f * 2.f * z;
+                fC2_x = fC1 + x * fC1_x - y * fS1_x; fC2_y = x * fC1_y - fS1 - y * fS1_y;
+                fS2_x = fS1 + x * fS1_x + y * fC1_x; fS2_y = x * fS1_y + fC1 + y * fC1_y;
+                Y12_z = 3.f * 1.865881662950577f * z2 - 1.119528997770346f;
+                Yx[9] = c3 * fS2_x; Yy[9] = c3 * fS2_y;
+                Yx[10] = fT1B * fS1_x; Yy[10] = fT1B * fS1_y; Yz[10] = b * fS1;
+                Yy[11] = fT0C; Yz[11] = fT0C_z * y;
+                Yz[12] = Y12_z;
+                Yx[13] = fT0C; Yz[13] = fT0C_z * x;
+                Yx[14] = fT1B * fC1_x; Yy[14] = fT1B * fC1_y; Yz[14] = b * fC1;
+                Yx[15] = c3 * fC2_x; Yy[15] = c3 * fC2_y;
+            }
+        }
+        if (DEG >= 4) {
+            const float fT0D = z * (-4.683325804901025f * z2 + 2.007139630671868f);
+            const float fT1C = 3.31161143515146f * z2 - 0.47308734787878f;
+            const float d = -1.770130769779931f;
+            const float fT2B = d * z;
+            const float fC3 = x * fC2 - y * fS2, fS3 = x * fS2 + y * fC2;
+            const float c4 = 0.6258357354491763f;
+            Y[16] = c4 * fS3; Y[17] = fT2B * fS2; Y[18] = fT1C * fS1; Y[19] = fT0D * y;
+            Y[20] = 1.984313483298443f * z * Y[12] - 1.006230589874905f * Y[6];
+            Y[21] = fT0D * x; Y[22] = fT1C * fC1; Y[23] = fT2B * fC2; Y[24] = c4 * fC3;
+            if (GRAD) {
+                const float fT0D_z = 3.f * -4.683325804901025f * z2 + 2.007139630671868f;
+                const float fT1C_z = 2.f * 3.31161143515146f * z;
+                const float fC3_x = fC2 + x * fC2_x - y * fS2_x, fC3_y = x * fC2_y - fS2 - y * fS2_y;
+                const float fS3_x = fS2 + y * fC2_x + x * fS2_x, fS3_y = x * fS2_y + fC2 + y * fC2_y;
+                Yx[16] = c4 * fS3_x; Yy[16] = c4 * fS3_y;
+                Yx[17] = fT2B * fS2_x; Yy[17] = fT2B * fS2_y; Yz[17] = d * fS2;
+                Yx[18] = fT1C * fS1_x; Yy[18] = fT1C * fS1_y; Yz[18] = fT1C_z * fS1;
+                Yy[19] = fT0D; Yz[19] = fT0D_z * y;
+                Yz[20] = 1.984313483298443f * (Y[12] + z * Y12_z) - 1.006230589874905f * Yz[6];
+                Yx[21] = fT0D; Yz[21] = fT0D_z * x;
+                Yx[22] = fT1C * fC1_x; Yy[22] = fT1C * fC1_y; Yz[22] = fT1C_z * fC1;
+                Yx[23] = fT2B * fC2_x; Yy[23] = fT2B * fC2_y; Yz[23] = d * fC2;
+                Yx[24] = c4 * fC3_x; Yy[24] = c4 * fC3_y;
+            }
+        }
+    }
+};
+
+constexpr int SH_BLOCK = 256;
+
+// Stage the active part (nb3 floats) of the coefficient rows of this wave's 64 elements into LDS.
+// `tile` points at the wave's LDS region, row stride `ls` floats (odd).
+GSX_DEV void sh_stage_rows(const float* __restrict__ coeffs, uint32_t n, uint32_t e0, uint32_t K3, uint32_t nb3,
+                           unsigned long long live, float* tile, uint32_t ls, uint32_t lane) {
+    const uint32_t rows = min(64u, n - e0);
+    if (nb3 == K3 && (K3 & 3u) == 0u) {
+        // rows are back to back: stream float4s (16 B per lane, 1 KiB per wave instruction)
+        const uint32_t q_per_row = K3 >> 2;
+        const uint32_t total = rows * q_per_row;
+        const float4* src = reinterpret_cast<const float4*>(coeffs + (size_t)e0 * K3);
+        for (uint32_t j = lane; j < total; j += 64) {
+            const uint32_t e = j / q_per_row, r = (j - e * q_per_row) << 2;
+            if (!((live >> e) & 1ull)) continue;
+            const float4 v = src[j];
+            float* d = tile + e * ls + r;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    } else {
+        const uint32_t total = rows * nb3;
+        for (uint32_t j = lane; j < total; j += 64) {
+            const uint32_t e = j / nb3, r = j - e * nb3;
+            if (!((live >> e) & 1ull)) continue;
+            tile[e * ls + r] = coeffs[(size_t)(e0 + e) * K3 + r];
+        }
+    }
+}
+
+template <int DEG>
+__global__ __launch_bounds__(SH_BLOCK) void sh_fwd_kernel(uint32_t n, uint32_t K, const float* __restrict__ dirs,
+                                                          const float* __restrict__ coeffs,
+                                                          const uint8_t* __restrict__ masks,
+                                                          float* __restrict__ colors) {
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    constexpr uint32_t NB3 = NB * 3;
+    constexpr uint32_t LS = NB3 | 1u;
+    extern __shared__ __attribute__((aligned(16))) float sh_lds[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t e0 = blockIdx.x * SH_BLOCK + wave * 64u;
+    const uint32_t e = e0 + lane;
+    const bool live = e < n && (masks == nullptr || masks[e] != 0);
+    const unsigned long long live_mask = __ballot(live);
+    float* tile = sh_lds + wave * 64u * LS;
+    if (e0 < n) sh_stage_rows(coeffs, n, e0, K * 3u, NB3, live_mask, tile, LS, lane);
+    __syncthreads();
+    if (!live) return;
+    float x = dirs[(size_t)e * 3], y = dirs[(size_t)e * 3 + 1], z = dirs[(size_t)e * 3 + 2];
+    if (DEG >= 1) {
+        const float inorm = rsqrtf(x * x + y * y + z * z);
+        x *= inorm; y *= inorm; z *= inorm;
+    }
+    float Y[NB];
+    ShBasis<DEG>::template eval<false>(x, y, z, Y, nullptr, nullptr, nullptr);
+    const float* row = tile + lane * LS;
+    float r = 0.f, g = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        r += Y[k] * row[k * 3];
+        g += Y[k] * row[k * 3 + 1];
+        b += Y[k] * row[k * 3 + 2];
+    }
+    colors[(size_t)e * 3] = r;
+    colors[(size_t)e * 3 + 1] = g;
+    colors[(size_t)e * 3 + 2] = b;
+}
+
+template <int DEG, bool VDIRS>
+__global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(uint32_t n, uint32_t K, const float* __restrict__ dirs,
+                                                          const float* __restrict__ coeffs,
+                                                          const uint8_t* __restrict__ masks,
+                                                          const float* __restrict__ v_colors,
+                                                          float* __restrict__ v_coeffs, float* __restrict__ v_dirs) {
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    constexpr uint32_t NB3 = NB * 3;
+    extern __shared__ __attribute__((aligned(16))) float sh_lds[];
+    const uint32_t K3 = K * 3u;
+    const uint32_t LS = K3 | 1u;  // the tile holds full output rows
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t e0 = blockIdx.x * SH_BLOCK + wave * 64u;
+    const uint32_t e = e0 + lane;
+    const bool live = e < n && (masks == nullptr || masks[e] != 0);
+    float* tile = sh_lds + wave * 64u * LS;
+    float* row = tile + lane * LS;
+    if (VDIRS && DEG >= 1 && e0 < n) {
+        const unsigned long long live_mask = __ballot(live);
+        sh_stage_rows(coeffs, n, e0, K3, NB3, live_mask, tile, LS, lane);
+    }
+    __syncthreads();
+    float vx = 0.f, vy = 0.f, vz = 0.f, inorm = 1.f;
+    float x = 0.f, y = 0.f, z = 1.f;
+    float Y[NB], Yx[NB], Yy[NB], Yz[NB];
+    float vr = 0.f, vg = 0.f, vb = 0.f;
+    if (live) {
+        x = dirs[(size_t)e * 3]; y = dirs[(size_t)e * 3 + 1]; z = dirs[(size_t)e * 3 + 2];
+        if (DEG >= 1) {
+            inorm = rsqrtf(x * x + y * y + z * z);
+            x *= inorm; y *= inorm; z *= inorm;
+        }
+        vr = v_colors[(size_t)e * 3]; vg = v_colors[(size_t)e * 3 + 1]; vb = v_colors[(size_t)e * 3 + 2];
+        ShBasis<DEG>::template eval<VDIRS>(x, y, z, Y, Yx, Yy, Yz);
+        if (VDIRS && DEG >= 1) {
+#pragma unroll
+            for (int k = 1; k < NB; ++k) {
+                const float gk = row[k * 3] * vr + row[k * 3 + 1] * vg + row[k * 3 + 2] * vb;
+                vx += Yx[k] * gk; vy += Yy[k] * gk; vz += Yz[k] * gk;
+            }
+        }
+    }
+    __syncthreads();  // all reads of the staged coefficients are done; reuse the tile for the output rows
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            row[k * 3] = Y[k] * vr; row[k * 3 + 1] = Y[k] * vg; row[k * 3 + 2] = Y[k] * vb;
+        }
+        for (uint32_t j = NB3; j < K3; ++j) row[j] = 0.f;
+    } else if (e < n) {
+        for (uint32_t j = 0; j < K3; ++j) row[j] = 0.f;
+    }
+    __syncthreads();
+    if (e0 < n) {   // coalesced store of the wave's rows*K3 contiguous output floats
+        const uint32_t rows = min(64u, n - e0);
+        float* dst = v_coeffs + (size_t)e0 * K3;
+        if ((K3 & 3u) == 0u) {
+            const uint32_t q_per_row = K3 >> 2, total = rows * q_per_row;
+            for (uint32_t j = lane; j < total; j += 64) {
+                const uint32_t er = j / q_per_row, r = (j - er * q_per_row) << 2;
+                const float* s = tile + er * LS + r;
+                reinterpret_cast<float4*>(dst)[j] = make_float4(s[0], s[1], s[2], s[3]);
+            }
+        } else {
+            const uint32_t total = rows * K3;
+            for (uint32_t j = lane; j < total; j += 64) {
+                const uint32_t er = j / K3, r = j - er * K3;
+                dst[j] = tile[er * LS + r];
+            }
+        }
+    }
+    if (VDIRS && e < n) {
+        float ox = 0.f, oy = 0.f, oz = 0.f;
+        if (live && DEG >= 1) {  // through the normalisation d/|d|
+            const float d = vx * x + vy * y + vz * z;
+            ox = (vx - d * x) * inorm; oy = (vy - d * y) * inorm; oz = (vz - d * z) * inorm;
+        }
+        v_dirs[(size_t)e * 3] = ox; v_dirs[(size_t)e * 3 + 1] = oy; v_dirs[(size_t)e * 3 + 2] = oz;
+    }
+}
+
+void set_error(const char* msg);
+
+template <int DEG> static int launch_sh_fwd(uint32_t n, uint32_t K, const float* dirs, const float* coeffs,
+                                            const uint8_t* masks, float* colors, hipStream_t st) {
+    constexpr uint32_t LS = ((DEG + 1) * (DEG + 1) * 3) | 1;
+    const size_t lds = (size_t)SH_BLOCK * LS * sizeof(float);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(sh_fwd_kernel<DEG>), dim3((n + SH_BLOCK - 1) / SH_BLOCK), dim3(SH_BLOCK), lds, st,
+                       n, K, dirs, coeffs, masks, colors);
+    return 0;
+}
+template <int DEG> static int launch_sh_bwd(uint32_t n, uint32_t K, const float* dirs, const float* coeffs,
+                                            const uint8_t* masks, const float* v_colors, float* v_coeffs, float* v_dirs,
+                                            hipStream_t st) {
+    const uint32_t LS = (K * 3u) | 1u;
+    const size_t lds = (size_t)SH_BLOCK * LS * sizeof(float);
+    const dim3 grid((n + SH_BLOCK - 1) / SH_BLOCK), block(SH_BLOCK);
+    if (v_dirs)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sh_bwd_kernel<DEG, true>), grid, block, lds, st, n, K, dirs, coeffs, masks,
+                           v_colors, v_coeffs, v_dirs);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sh_bwd_kernel<DEG, false>), grid, block, lds, st, n, K, dirs, coeffs, masks,
+                           v_colors, v_coeffs, v_dirs);
+    return 0;
+}
+
+int check_launch(const char* what);
+
+}  // namespace gsx
+
+using namespace gsx;
+
+extern "C" int gsx_spherical_harmonics_fwd(uint32_t degrees_to_use, uint32_t n, uint32_t K, const float* dirs,
+                                           const float* coeffs, const uint8_t* masks, float* colors, void* stream) {
+    if (n == 0) return GSX_OK;  // upstream skips the launch (SphericalHarmonicsCUDA.cu:418-421)
+    if (!dirs || !coeffs || !colors) { set_error("spherical_harmonics_fwd: null pointer"); return GSX_ERR_INVALID_ARGUMENT; }
+    if (degrees_to_use > 4 || (degrees_to_use + 1) * (degrees_to_use + 1) > K) {
+        set_error("spherical_harmonics_fwd: degrees_to_use needs (deg+1)^2 <= K and deg <= 4");
+        return GSX_ERR_INVALID_ARGUMENT;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    switch (degrees_to_use) {
+    case 0: launch_sh_fwd<0>(n, K, dirs, coeffs, masks, colors, st); break;
+    case 1: launch_sh_fwd<1>(n, K, dirs, coeffs, masks, colors, st); break;
+    case 2: launch_sh_fwd<2>(n, K, dirs, coeffs, masks, colors, st); break;
+    case 3: launch_sh_fwd<3>(n, K, dirs, coeffs, masks, colors, st); break;
+    default: launch_sh_fwd<4>(n, K, dirs, coeffs, masks, colors, st); break;
+    }
+    return check_launch("spherical_harmonics_fwd");
+}
+
+extern "C" int gsx_spherical_harmonics_bwd(uint32_t K, uint32_t degrees_to_use, uint32_t n, const float* dirs,
+                                           const float* coeffs, const uint8_t* masks, const float* v_colors,
+                                           float* v_coeffs, float* v_dirs, void* stream) {
+    if (n == 0) return GSX_OK;
+    if (!dirs || !coeffs || !v_colors || !v_coeffs) { set_error("spherical_harmonics_bwd: null pointer"); return GSX_ERR_INVALID_ARGUMENT; }
+    if (degrees_to_use > 4 || (degrees_to_use + 1) * (degrees_to_use + 1) > K) {
+        set_error("spherical_harmonics_bwd: degrees_to_use needs (deg+1)^2 <= K and deg <= 4");
+        return GSX_ERR_INVALID_ARGUMENT;
+    }
+    if ((size_t)SH_BLOCK * ((K * 3u) | 1u) * sizeof(float) > 160u * 1024u) {
+        set_error("spherical_harmonics_bwd: K too large for the LDS row tile (K <= 53)");
+        return GSX_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    switch (degrees_to_use) {
+    case 0: launch_sh_bwd<0>(n, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, st); break;
+    case 1: launch_sh_bwd<1>(n, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, st); break;
+    case 2: launch_sh_bwd<2>(n, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, st); break;
+    case 3: launch_sh_bwd<3>(n, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, st); break;
+    default: launch_sh_bwd<4>(n, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, st); break;
+    }
+    return check_launch("spherical_harmonics_bwd");
+}

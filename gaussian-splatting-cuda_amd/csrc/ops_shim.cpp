@@ -1,0 +1,309 @@
+// ops_shim.cpp — `namespace gsplat` on at::Tensor over the C ABI of libgsx.so.
+//
+// Mirrors the reference's host wrappers (gsplat/SphericalHarmonics.cpp, Intersect.cpp, Projection.cpp,
+// Rasterization.cpp): same checks (device + contiguity, like CHECK_INPUT in gsplat/Common.h:12-17),
+// same output allocation on the input's device, same error type (c10::Error via TORCH_CHECK), launches on
+// the current HIP stream.  The only blocking point is, as upstream (Intersect.cpp:76), the read of
+// n_isects inside intersect_tile — the op's return type needs the exact length.
+// Also exports the ops to Python (pybind11 module `_gsx_ops`) for the tests and the bench.
+#include <ATen/ATen.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/extension.h>
+
+#include "../../include/gsx.h"
+#include "../../include/gsx_ops.h"
+
+namespace {
+
+#define GSX_CHECK_INPUT(x)                                         \
+    TORCH_CHECK((x).is_cuda(), #x " must be a CUDA tensor");       \
+    TORCH_CHECK((x).is_contiguous(), #x " must be contiguous")
+
+inline void* cur_stream() { return (void*)c10::hip::getCurrentHIPStream().stream(); }
+inline void check(int rc, const char* op) { TORCH_CHECK(rc == GSX_OK, op, " failed (", rc, "): ", gsx_last_error()); }
+
+inline const float* fptr(const at::optional<at::Tensor>& t) {
+    return (t.has_value() && t->defined() && t->numel() > 0) ? t->data_ptr<float>() : nullptr;
+}
+inline const uint8_t* bptr(const at::optional<at::Tensor>& t) {
+    return (t.has_value() && t->defined() && t->numel() > 0) ? reinterpret_cast<const uint8_t*>(t->data_ptr<bool>()) : nullptr;
+}
+
+gsx_cameras make_cams(const at::Tensor& viewmats0, const at::optional<at::Tensor>& viewmats1, const at::Tensor& Ks,
+                      gsplat::CameraModelType model, ShutterType rs, const at::optional<at::Tensor>& radial,
+                      const at::optional<at::Tensor>& tangential, const at::optional<at::Tensor>& thin_prism, uint32_t C) {
+    GSX_CHECK_INPUT(viewmats0);
+    GSX_CHECK_INPUT(Ks);
+    TORCH_CHECK(viewmats0.scalar_type() == at::kFloat && Ks.scalar_type() == at::kFloat, "camera tensors must be float32");
+    if (viewmats1.has_value()) { GSX_CHECK_INPUT(viewmats1.value()); }
+    if (radial.has_value()) { GSX_CHECK_INPUT(radial.value()); }
+    if (tangential.has_value()) { GSX_CHECK_INPUT(tangential.value()); }
+    if (thin_prism.has_value()) { GSX_CHECK_INPUT(thin_prism.value()); }
+    gsx_cameras c;
+    c.C = C;
+    c.viewmats0 = viewmats0.data_ptr<float>();
+    c.viewmats1 = fptr(viewmats1);
+    c.Ks = Ks.data_ptr<float>();
+    c.camera_model = (int32_t)model;
+    c.shutter = (int32_t)rs;
+    c.radial = fptr(radial);
+    c.tangential = fptr(tangential);
+    c.thin_prism = fptr(thin_prism);
+    return c;
+}
+gsx_ut_params make_ut(const UnscentedTransformParameters& u) {
+    return gsx_ut_params{u.alpha, u.beta, u.kappa, u.in_image_margin_factor, u.require_all_sigma_points_valid ? 1 : 0};
+}
+
+}  // namespace
+
+namespace gsplat {
+
+at::Tensor spherical_harmonics_fwd(const uint32_t degrees_to_use, const at::Tensor dirs, const at::Tensor coeffs,
+                                   const at::optional<at::Tensor> masks) {
+    const c10::hip::OptionalHIPGuard guard(at::device_of(dirs));
+    GSX_CHECK_INPUT(dirs);
+    GSX_CHECK_INPUT(coeffs);
+    if (masks.has_value()) { GSX_CHECK_INPUT(masks.value()); }
+    TORCH_CHECK(coeffs.size(-1) == 3, "coeffs must have last dimension 3");
+    TORCH_CHECK(dirs.size(-1) == 3, "dirs must have last dimension 3");
+    TORCH_CHECK(dirs.scalar_type() == at::kFloat && coeffs.scalar_type() == at::kFloat, "float32 only");
+    at::Tensor colors = at::empty_like(dirs);
+    const uint32_t K = coeffs.size(-2), N = dirs.numel() / 3;
+    check(gsx_spherical_harmonics_fwd(degrees_to_use, N, K, dirs.data_ptr<float>(), coeffs.data_ptr<float>(), bptr(masks),
+                                      colors.data_ptr<float>(), cur_stream()),
+          "spherical_harmonics_fwd");
+    return colors;
+}
+
+std::tuple<at::Tensor, at::Tensor> spherical_harmonics_bwd(const uint32_t K, const uint32_t degrees_to_use,
+                                                           const at::Tensor dirs, const at::Tensor coeffs,
+                                                           const at::optional<at::Tensor> masks,
+                                                           const at::Tensor v_colors, bool compute_v_dirs) {
+    const c10::hip::OptionalHIPGuard guard(at::device_of(dirs));
+    GSX_CHECK_INPUT(dirs);
+    GSX_CHECK_INPUT(coeffs);
+    GSX_CHECK_INPUT(v_colors);
+    if (masks.has_value()) { GSX_CHECK_INPUT(masks.value()); }
+    TORCH_CHECK(v_colors.size(-1) == 3, "v_colors must have last dimension 3");
+    TORCH_CHECK(coeffs.size(-1) == 3, "coeffs must have last dimension 3");
+    TORCH_CHECK(dirs.size(-1) == 3, "dirs must have last dimension 3");
+    TORCH_CHECK((int64_t)K == coeffs.size(-2), "K must equal coeffs.size(-2)");
+    const uint32_t N = dirs.numel() / 3;
+    at::Tensor v_coeffs = at::empty_like(coeffs);  // fully written by the kernel (incl. zeros)
+    at::Tensor v_dirs;
+    if (compute_v_dirs) v_dirs = at::empty_like(dirs);
+    check(gsx_spherical_harmonics_bwd(K, degrees_to_use, N, dirs.data_ptr<float>(), coeffs.data_ptr<float>(), bptr(masks),
+                                      v_colors.data_ptr<float>(), v_coeffs.data_ptr<float>(),
+                                      compute_v_dirs ? v_dirs.data_ptr<float>() : nullptr, cur_stream()),
+          "spherical_harmonics_bwd");
+    return std::make_tuple(v_coeffs, v_dirs);
+}
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile(const at::Tensor means2d, const at::Tensor radii,
+                                                              const at::Tensor depths,
+                                                              const at::optional<at::Tensor> camera_ids,
+                                                              const at::optional<at::Tensor> gaussian_ids,
+                                                              const uint32_t C, const uint32_t tile_size,
+                                                              const uint32_t tile_width, const uint32_t tile_height,
+                                                              const bool sort) {
+    const c10::hip::OptionalHIPGuard guard(at::device_of(means2d));
+    GSX_CHECK_INPUT(means2d);
+    GSX_CHECK_INPUT(radii);
+    GSX_CHECK_INPUT(depths);
+    const bool packed = means2d.dim() == 2;
+    TORCH_CHECK(!packed, "packed mode is not supported (the reference's world-space path asserts packed == false, "
+                         "RasterizeToPixelsFromWorld3DGSFwd.cu:316-317)");
+    (void)camera_ids; (void)gaussian_ids;
+    TORCH_CHECK(means2d.scalar_type() == at::kFloat && depths.scalar_type() == at::kFloat, "float32 only");
+    TORCH_CHECK(radii.scalar_type() == at::kInt, "radii must be int32");
+    const uint32_t n_elements = means2d.numel() / 2;
+    const uint32_t N = C ? n_elements / C : 0;
+    void* st = cur_stream();
+    at::Tensor tiles_per_gauss = at::empty_like(depths, depths.options().dtype(at::kInt));
+    int64_t n_isects = 0;
+    at::Tensor cum;
+    if (n_elements) {
+        cum = at::empty({(int64_t)n_elements}, depths.options().dtype(at::kLong));
+        const size_t wsb = gsx_intersect_count_workspace_bytes(C, N);
+        at::Tensor ws = at::empty({(int64_t)wsb}, depths.options().dtype(at::kByte));
+        at::Tensor n_host = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+        check(gsx_intersect_tile_count(C, N, means2d.data_ptr<float>(), radii.data_ptr<int32_t>(), tile_size, tile_width,
+                                       tile_height, tiles_per_gauss.data_ptr<int32_t>(), cum.data_ptr<int64_t>(), nullptr,
+                                       n_host.data_ptr<int64_t>(), ws.data_ptr(), wsb, st),
+              "intersect_tile(count)");
+        c10::hip::getCurrentHIPStream().synchronize();  // the one host sync, as upstream (Intersect.cpp:76)
+        n_isects = n_host.data_ptr<int64_t>()[0];
+    }
+    at::Tensor isect_ids = at::empty({n_isects}, depths.options().dtype(at::kLong));
+    at::Tensor flatten_ids = at::empty({n_isects}, depths.options().dtype(at::kInt));
+    if (n_isects) {
+        const size_t wsb = gsx_intersect_fill_workspace_bytes(C, N, n_isects, sort ? 1 : 0);
+        at::Tensor ws = at::empty({(int64_t)wsb}, depths.options().dtype(at::kByte));
+        check(gsx_intersect_tile_fill(C, N, means2d.data_ptr<float>(), radii.data_ptr<int32_t>(), depths.data_ptr<float>(),
+                                      cum.data_ptr<int64_t>(), tile_size, tile_width, tile_height, sort ? 1 : 0, n_isects,
+                                      isect_ids.data_ptr<int64_t>(), flatten_ids.data_ptr<int32_t>(), ws.data_ptr(), wsb, st),
+              "intersect_tile(fill)");
+    }
+    return std::make_tuple(tiles_per_gauss, isect_ids, flatten_ids);
+}
+
+at::Tensor intersect_offset(const at::Tensor isect_ids, const uint32_t C, const uint32_t tile_width,
+                            const uint32_t tile_height) {
+    const c10::hip::OptionalHIPGuard guard(at::device_of(isect_ids));
+    GSX_CHECK_INPUT(isect_ids);
+    TORCH_CHECK(isect_ids.scalar_type() == at::kLong, "isect_ids must be int64");
+    at::Tensor offsets = at::empty({(int64_t)C, (int64_t)tile_height, (int64_t)tile_width}, isect_ids.options().dtype(at::kInt));
+    check(gsx_intersect_offset(isect_ids.size(0), isect_ids.numel() ? isect_ids.data_ptr<int64_t>() : nullptr, C, tile_width,
+                               tile_height, offsets.data_ptr<int32_t>(), cur_stream()),
+          "intersect_offset");
+    return offsets;
+}
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> projection_ut_3dgs_fused(
+    const at::Tensor means, const at::Tensor quats, const at::Tensor scales, const at::optional<at::Tensor> opacities,
+    const at::Tensor viewmats0, const at::optional<at::Tensor> viewmats1, const at::Tensor Ks,
+    const uint32_t image_width, const uint32_t image_height, const float eps2d, const float near_plane,
+    const float far_plane, const float radius_clip, const bool calc_compensations, const CameraModelType camera_model,
+    const UnscentedTransformParameters ut_params, ShutterType rs_type, const at::optional<at::Tensor> radial_coeffs,
+    const at::optional<at::Tensor> tangential_coeffs, const at::optional<at::Tensor> thin_prism_coeffs) {
+    const c10::hip::OptionalHIPGuard guard(at::device_of(means));
+    GSX_CHECK_INPUT(means);
+    GSX_CHECK_INPUT(quats);
+    GSX_CHECK_INPUT(scales);
+    if (opacities.has_value()) { GSX_CHECK_INPUT(opacities.value()); }
+    TORCH_CHECK(means.scalar_type() == at::kFloat, "float32 only");
+    const uint32_t N = means.size(0), C = Ks.size(0);
+    const gsx_cameras cams = make_cams(viewmats0, viewmats1, Ks, camera_model, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, C);
+    const gsx_ut_params ut = make_ut(ut_params);
+    at::Tensor radii = at::empty({C, N, 2}, means.options().dtype(at::kInt));
+    at::Tensor means2d = at::empty({C, N, 2}, means.options());
+    at::Tensor depths = at::empty({C, N}, means.options());
+    at::Tensor conics = at::empty({C, N, 3}, means.options());
+    at::Tensor compensations;
+    if (calc_compensations) compensations = at::zeros({C, N}, means.options());
+    check(gsx_projection_ut_3dgs_fused(N, means.data_ptr<float>(), quats.data_ptr<float>(), scales.data_ptr<float>(),
+                                       fptr(opacities), &cams, image_width, image_height, eps2d, near_plane, far_plane,
+                                       radius_clip, &ut, radii.data_ptr<int32_t>(), means2d.data_ptr<float>(),
+                                       depths.data_ptr<float>(), conics.data_ptr<float>(),
+                                       calc_compensations ? compensations.data_ptr<float>() : nullptr, cur_stream()),
+          "projection_ut_3dgs_fused");
+    return std::make_tuple(radii, means2d, depths, conics, compensations);
+}
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor> rasterize_to_pixels_from_world_3dgs_fwd(
+    const at::Tensor means, const at::Tensor quats, const at::Tensor scales, const at::Tensor colors,
+    const at::Tensor opacities, const at::optional<at::Tensor> backgrounds, const at::optional<at::Tensor> masks,
+    const uint32_t image_width, const uint32_t image_height, const uint32_t tile_size, const at::Tensor viewmats0,
+    const at::optional<at::Tensor> viewmats1, const at::Tensor Ks, const CameraModelType camera_model,
+    const UnscentedTransformParameters ut_params, ShutterType rs_type, const at::optional<at::Tensor> radial_coeffs,
+    const at::optional<at::Tensor> tangential_coeffs, const at::optional<at::Tensor> thin_prism_coeffs,
+    const at::Tensor tile_offsets, const at::Tensor flatten_ids) {
+    const c10::hip::OptionalHIPGuard guard(at::device_of(means));
+    GSX_CHECK_INPUT(means);
+    GSX_CHECK_INPUT(quats);
+    GSX_CHECK_INPUT(scales);
+    GSX_CHECK_INPUT(colors);
+    GSX_CHECK_INPUT(opacities);
+    GSX_CHECK_INPUT(tile_offsets);
+    GSX_CHECK_INPUT(flatten_ids);
+    if (backgrounds.has_value()) { GSX_CHECK_INPUT(backgrounds.value()); }
+    if (masks.has_value()) { GSX_CHECK_INPUT(masks.value()); }
+    TORCH_CHECK(means.scalar_type() == at::kFloat && colors.scalar_type() == at::kFloat, "float32 only");
+    const uint32_t C = tile_offsets.size(0), N = means.size(0);
+    const uint32_t channels = colors.size(-1);
+    TORCH_CHECK(channels == 3, "Unsupported number of channels: ", channels);
+    const gsx_cameras cams = make_cams(viewmats0, viewmats1, Ks, camera_model, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, C);
+    const gsx_ut_params ut = make_ut(ut_params);
+    at::Tensor renders = at::empty({C, image_height, image_width, channels}, means.options());
+    at::Tensor alphas = at::empty({C, image_height, image_width, 1}, means.options());
+    at::Tensor last_ids = at::empty({C, image_height, image_width}, means.options().dtype(at::kInt));
+    check(gsx_rasterize_to_pixels_from_world_3dgs_fwd(
+              N, flatten_ids.size(0), means.data_ptr<float>(), quats.data_ptr<float>(), scales.data_ptr<float>(),
+              colors.data_ptr<float>(), channels, opacities.data_ptr<float>(), fptr(backgrounds), bptr(masks), image_width,
+              image_height, tile_size, &cams, &ut, tile_offsets.data_ptr<int32_t>(),
+              flatten_ids.numel() ? flatten_ids.data_ptr<int32_t>() : nullptr, renders.data_ptr<float>(),
+              alphas.data_ptr<float>(), last_ids.data_ptr<int32_t>(), cur_stream()),
+          "rasterize_to_pixels_from_world_3dgs_fwd");
+    return std::make_tuple(renders, alphas, last_ids);
+}
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize_to_pixels_from_world_3dgs_bwd(
+    const at::Tensor means, const at::Tensor quats, const at::Tensor scales, const at::Tensor colors,
+    const at::Tensor opacities, const at::optional<at::Tensor> backgrounds, const at::optional<at::Tensor> masks,
+    const uint32_t image_width, const uint32_t image_height, const uint32_t tile_size, const at::Tensor viewmats0,
+    const at::optional<at::Tensor> viewmats1, const at::Tensor Ks, const CameraModelType camera_model,
+    const UnscentedTransformParameters ut_params, ShutterType rs_type, const at::optional<at::Tensor> radial_coeffs,
+    const at::optional<at::Tensor> tangential_coeffs, const at::optional<at::Tensor> thin_prism_coeffs,
+    const at::Tensor tile_offsets, const at::Tensor flatten_ids, const at::Tensor render_alphas,
+    const at::Tensor last_ids, const at::Tensor v_render_colors, const at::Tensor v_render_alphas) {
+    const c10::hip::OptionalHIPGuard guard(at::device_of(means));
+    GSX_CHECK_INPUT(means);
+    GSX_CHECK_INPUT(quats);
+    GSX_CHECK_INPUT(scales);
+    GSX_CHECK_INPUT(colors);
+    GSX_CHECK_INPUT(opacities);
+    GSX_CHECK_INPUT(tile_offsets);
+    GSX_CHECK_INPUT(flatten_ids);
+    GSX_CHECK_INPUT(render_alphas);
+    GSX_CHECK_INPUT(last_ids);
+    GSX_CHECK_INPUT(v_render_colors);
+    GSX_CHECK_INPUT(v_render_alphas);
+    if (backgrounds.has_value()) { GSX_CHECK_INPUT(backgrounds.value()); }
+    if (masks.has_value()) { GSX_CHECK_INPUT(masks.value()); }
+    const uint32_t C = tile_offsets.size(0), N = means.size(0);
+    const uint32_t channels = colors.size(-1);
+    TORCH_CHECK(channels == 3, "Unsupported number of channels: ", channels);
+    const gsx_cameras cams = make_cams(viewmats0, viewmats1, Ks, camera_model, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, C);
+    const gsx_ut_params ut = make_ut(ut_params);
+    at::Tensor v_means = at::zeros_like(means);
+    at::Tensor v_quats = at::zeros_like(quats);
+    at::Tensor v_scales = at::zeros_like(scales);
+    at::Tensor v_colors = at::zeros_like(colors);
+    at::Tensor v_opacities = at::zeros_like(opacities);
+    check(gsx_rasterize_to_pixels_from_world_3dgs_bwd(
+              N, flatten_ids.size(0), means.data_ptr<float>(), quats.data_ptr<float>(), scales.data_ptr<float>(),
+              colors.data_ptr<float>(), channels, opacities.data_ptr<float>(), fptr(backgrounds), bptr(masks), image_width,
+              image_height, tile_size, &cams, &ut, tile_offsets.data_ptr<int32_t>(),
+              flatten_ids.numel() ? flatten_ids.data_ptr<int32_t>() : nullptr, render_alphas.data_ptr<float>(),
+              last_ids.data_ptr<int32_t>(), v_render_colors.data_ptr<float>(), v_render_alphas.data_ptr<float>(),
+              v_means.data_ptr<float>(), v_quats.data_ptr<float>(), v_scales.data_ptr<float>(), v_colors.data_ptr<float>(),
+              v_opacities.data_ptr<float>(), cur_stream()),
+          "rasterize_to_pixels_from_world_3dgs_bwd");
+    return std::make_tuple(v_means, v_quats, v_scales, v_colors, v_opacities);
+}
+
+}  // namespace gsplat
+
+// ---------------------------------------------------------------------------------------------
+// Python bindings (names as in gsplat/Ops.h)
+// ---------------------------------------------------------------------------------------------
+namespace py = pybind11;
+
+PYBIND11_MODULE(_gsx_ops, m) {
+    m.doc() = "gsplat operator surface on the MI355X HIP backend (libgsx.so)";
+    py::class_<UnscentedTransformParameters>(m, "UnscentedTransformParameters")
+        .def(py::init<>())
+        .def_readwrite("alpha", &UnscentedTransformParameters::alpha)
+        .def_readwrite("beta", &UnscentedTransformParameters::beta)
+        .def_readwrite("kappa", &UnscentedTransformParameters::kappa)
+        .def_readwrite("in_image_margin_factor", &UnscentedTransformParameters::in_image_margin_factor)
+        .def_readwrite("require_all_sigma_points_valid", &UnscentedTransformParameters::require_all_sigma_points_valid);
+    py::enum_<gsplat::CameraModelType>(m, "CameraModelType")
+        .value("PINHOLE", gsplat::PINHOLE).value("ORTHO", gsplat::ORTHO).value("FISHEYE", gsplat::FISHEYE);
+    py::enum_<ShutterType>(m, "ShutterType")
+        .value("ROLLING_TOP_TO_BOTTOM", ShutterType::ROLLING_TOP_TO_BOTTOM)
+        .value("ROLLING_LEFT_TO_RIGHT", ShutterType::ROLLING_LEFT_TO_RIGHT)
+        .value("ROLLING_BOTTOM_TO_TOP", ShutterType::ROLLING_BOTTOM_TO_TOP)
+        .value("ROLLING_RIGHT_TO_LEFT", ShutterType::ROLLING_RIGHT_TO_LEFT)
+        .value("GLOBAL", ShutterType::GLOBAL);
+    m.def("spherical_harmonics_fwd", &gsplat::spherical_harmonics_fwd);
+    m.def("spherical_harmonics_bwd", &gsplat::spherical_harmonics_bwd);
+    m.def("intersect_tile", &gsplat::intersect_tile);
+    m.def("intersect_offset", &gsplat::intersect_offset);
+    m.def("projection_ut_3dgs_fused", &gsplat::projection_ut_3dgs_fused);
+    m.def("rasterize_to_pixels_from_world_3dgs_fwd", &gsplat::rasterize_to_pixels_from_world_3dgs_fwd);
+    m.def("rasterize_to_pixels_from_world_3dgs_bwd", &gsplat::rasterize_to_pixels_from_world_3dgs_bwd);
+    m.def("abi_version", []() { return gsx_abi_version(); });
+}

@@ -1,0 +1,32 @@
+"""The gsplat operator surface (gsplat/Ops.h:12-43,69-166 of the reference) on the HIP backend.
+
+Everything here is the C++ shim `_gsx_ops` (csrc/ops_shim.cpp) over the C ABI of libgsx.so.  There is NO
+fallback: if the native module is missing or cannot be loaded this import fails loudly.
+"""
+import os
+import sys
+
+import torch  # noqa: F401  (loads libamdhip64 / libtorch before the extension)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+if _HERE not in sys.path:
+    sys.path.insert(0, _HERE)
+try:
+    import _gsx_ops as _C
+except ImportError as e:  # pragma: no cover
+    raise ImportError(
+        "gsx: the native HIP extension (_gsx_ops / libgsx.so) is not built or failed to load; run "
+        "`python __graft_entry__.py` (build()) first. There is no CPU or PyTorch fallback. Cause: %s" % e)
+
+CameraModelType = _C.CameraModelType
+ShutterType = _C.ShutterType
+UnscentedTransformParameters = _C.UnscentedTransformParameters
+
+spherical_harmonics_fwd = _C.spherical_harmonics_fwd
+spherical_harmonics_bwd = _C.spherical_harmonics_bwd
+intersect_tile = _C.intersect_tile
+intersect_offset = _C.intersect_offset
+projection_ut_3dgs_fused = _C.projection_ut_3dgs_fused
+rasterize_to_pixels_from_world_3dgs_fwd = _C.rasterize_to_pixels_from_world_3dgs_fwd
+rasterize_to_pixels_from_world_3dgs_bwd = _C.rasterize_to_pixels_from_world_3dgs_bwd
+abi_version = _C.abi_version

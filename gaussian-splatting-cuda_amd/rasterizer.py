@@ -1,0 +1,228 @@
+"""Render glue + autograd wrappers around the gsplat operators: the Python mirror of the reference's
+`gs::training::rasterize` (src/training/rasterization/rasterizer.cpp:46-437) and of the three wrappers in
+src/training/rasterization/rasterizer_autograd.cpp (SphericalHarmonicsFunction :12-132,
+fully_fused_projection_with_ut :135-265, GUTRasterizationFunction :267-391).
+
+Data contracts mirrored from the reference:
+  * Camera: row-major world->camera `viewmat` [1,4,4] (src/core/camera.cpp:15-22), K [1,3,3] (:80-89)
+  * SplatData activations (src/core/splat_data.cpp:267-286): opacity = sigmoid(raw).squeeze(-1),
+    rotation = normalize(raw), scaling = exp(raw), shs = cat(sh0, shN)
+Hot-path constants hard-coded upstream (rasterizer.cpp:176-181): eps2d 0.3, near 0.01, far 1e4,
+radius_clip 0, tile 16, calc_compensations = antialiased, GLOBAL shutter, default UT parameters.
+"""
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+
+from . import ops
+
+TILE_SIZE = 16
+EPS2D, NEAR_PLANE, FAR_PLANE, RADIUS_CLIP = 0.3, 0.01, 10000.0, 0.0
+
+
+@dataclass
+class Camera:
+    viewmat: torch.Tensor                  # [4,4] row-major world->camera
+    K: torch.Tensor                        # [3,3]
+    width: int
+    height: int
+    camera_model: object = None            # ops.CameraModelType, default PINHOLE
+    radial: Optional[torch.Tensor] = None  # 1-D, padded to >=4 like rasterizer.cpp:183-195
+    tangential: Optional[torch.Tensor] = None
+
+    def world_view_transform(self):
+        return self.viewmat.reshape(1, 4, 4)
+
+    def K_batched(self):
+        return self.K.reshape(1, 3, 3)
+
+
+@dataclass
+class SplatData:
+    means: torch.Tensor       # [N,3]
+    sh0: torch.Tensor         # [N,1,3]
+    shN: torch.Tensor         # [N,K-1,3]
+    scaling_raw: torch.Tensor  # [N,3] log-scales
+    rotation_raw: torch.Tensor  # [N,4] wxyz
+    opacity_raw: torch.Tensor   # [N,1] logits
+    active_sh_degree: int = 3
+
+    def params(self):
+        return [self.means, self.sh0, self.shN, self.scaling_raw, self.rotation_raw, self.opacity_raw]
+
+    def get_means(self): return self.means
+    def get_opacity(self): return torch.sigmoid(self.opacity_raw).squeeze(-1)
+    def get_rotation(self): return torch.nn.functional.normalize(self.rotation_raw, dim=-1)
+    def get_scaling(self): return torch.exp(self.scaling_raw)
+    def get_shs(self): return torch.cat([self.sh0, self.shN], 1)
+
+
+@dataclass
+class RenderOutput:
+    image: torch.Tensor = None
+    alpha: torch.Tensor = None
+    depth: torch.Tensor = None
+    means2d: torch.Tensor = None
+    depths: torch.Tensor = None
+    radii: torch.Tensor = None
+    visibility: torch.Tensor = None
+    width: int = 0
+    height: int = 0
+    n_isects: int = 0
+    aux: dict = field(default_factory=dict)
+
+
+class SphericalHarmonicsFunction(torch.autograd.Function):
+    """rasterizer_autograd.cpp:12-132 (the degree is passed as a plain int: upstream round-trips it through a
+    1-element device tensor and .item()s it back, a per-frame H2D+D2H with no effect on results)."""
+
+    @staticmethod
+    def forward(ctx, sh_degree, dirs, coeffs, masks):
+        num = (sh_degree + 1) ** 2
+        assert dirs.shape[-1] == 3 and coeffs.shape[-1] == 3 and coeffs.shape[-2] >= num
+        assert dirs.shape[:-1] == coeffs.shape[:-2], "dirs and coeffs batch dimensions must match"
+        dirs = dirs.contiguous()
+        coeffs = coeffs.contiguous()
+        if masks is None:
+            masks = torch.ones(dirs.shape[:-1], dtype=torch.bool, device=dirs.device)
+        masks = masks.contiguous()
+        colors = ops.spherical_harmonics_fwd(sh_degree, dirs.reshape(-1, 3), coeffs.reshape(-1, coeffs.shape[-2], 3),
+                                             masks.reshape(-1))
+        ctx.save_for_backward(dirs, coeffs, masks)
+        ctx.sh_degree = sh_degree
+        return colors.reshape(dirs.shape)
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        dirs, coeffs, masks = ctx.saved_tensors
+        K = coeffs.shape[-2]
+        compute_v_dirs = ctx.needs_input_grad[1]
+        v_coeffs, v_dirs = ops.spherical_harmonics_bwd(K, ctx.sh_degree, dirs.reshape(-1, 3), coeffs.reshape(-1, K, 3),
+                                                       masks.reshape(-1), v_colors.contiguous().reshape(-1, 3),
+                                                       compute_v_dirs)
+        v_dirs = v_dirs.reshape(dirs.shape) if (compute_v_dirs and v_dirs is not None) else None
+        v_coeffs = v_coeffs.reshape(coeffs.shape) if ctx.needs_input_grad[2] else None
+        return None, v_dirs, v_coeffs, None
+
+
+def spherical_harmonics(sh_degree, dirs, coeffs, masks=None):
+    if coeffs.shape[:-2] != dirs.shape[:-1]:  # broadcast [1,N,K,3] -> [C,N,K,3] (rasterizer.cpp:260)
+        coeffs = coeffs.expand(*dirs.shape[:-1], *coeffs.shape[-2:])
+    return SphericalHarmonicsFunction.apply(sh_degree, dirs, coeffs, masks)
+
+
+def fully_fused_projection_with_ut(means, quats, scales, opacities, viewmat, K, radial, tangential, thin_prism,
+                                   width, height, scaling_modifier=1.0, camera_model=None, ut_params=None,
+                                   eps2d=EPS2D, near_plane=NEAR_PLANE, far_plane=FAR_PLANE, radius_clip=RADIUS_CLIP):
+    """rasterizer_autograd.cpp:135-265 — non-differentiable (no autograd node upstream either)."""
+    camera_model = camera_model if camera_model is not None else ops.CameraModelType.PINHOLE
+    ut_params = ut_params or ops.UnscentedTransformParameters()
+    with torch.no_grad():
+        scaled = (scales * scaling_modifier).contiguous()
+        return ops.projection_ut_3dgs_fused(means.contiguous(), quats.contiguous(), scaled,
+                                            opacities.contiguous() if opacities is not None else None,
+                                            viewmat.contiguous(), None, K.contiguous(), width, height, eps2d, near_plane,
+                                            far_plane, radius_clip, False, camera_model, ut_params,
+                                            ops.ShutterType.GLOBAL, radial, tangential, thin_prism)
+
+
+class GUTRasterizationFunction(torch.autograd.Function):
+    """rasterizer_autograd.cpp:267-391."""
+
+    @staticmethod
+    def forward(ctx, means, quats, scales, colors, opacities, bg_color, masks, viewmat, K, radial, tangential,
+                thin_prism, isect_offsets, flatten_ids, width, height, tile_size, scaling_modifier, camera_model,
+                ut_params):
+        assert colors.shape[-1] == 3, "only RGB (3 channels) is supported on this path (rasterizer_autograd.cpp:285)"
+        scales = (scales * scaling_modifier).contiguous()
+        means, quats, colors, opacities = means.contiguous(), quats.contiguous(), colors.contiguous(), opacities.contiguous()
+        bg = bg_color.contiguous() if (bg_color is not None and bg_color.numel() > 0) else None
+        renders, alphas, last_ids = ops.rasterize_to_pixels_from_world_3dgs_fwd(
+            means, quats, scales, colors, opacities, bg, masks, width, height, tile_size, viewmat.contiguous(), None,
+            K.contiguous(), camera_model, ut_params, ops.ShutterType.GLOBAL, radial, tangential, thin_prism,
+            isect_offsets.contiguous(), flatten_ids.contiguous())
+        ctx.save_for_backward(means, quats, scales, colors, opacities, viewmat, K, isect_offsets, flatten_ids, alphas,
+                              last_ids)
+        ctx.extra = (bg, masks, radial, tangential, thin_prism, width, height, tile_size, camera_model, ut_params,
+                     scaling_modifier)
+        return renders, alphas
+
+    @staticmethod
+    def backward(ctx, v_render_colors, v_render_alpha):
+        means, quats, scales, colors, opacities, viewmat, K, isect_offsets, flatten_ids, alphas, last_ids = ctx.saved_tensors
+        bg, masks, radial, tangential, thin_prism, width, height, tile_size, camera_model, ut_params, _ = ctx.extra
+        v_render_colors = v_render_colors.contiguous()
+        v_render_alpha = v_render_alpha.contiguous()
+        v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_to_pixels_from_world_3dgs_bwd(
+            means, quats, scales, colors, opacities, bg, masks, width, height, tile_size, viewmat.contiguous(), None,
+            K.contiguous(), camera_model, ut_params, ops.ShutterType.GLOBAL, radial, tangential, thin_prism,
+            isect_offsets.contiguous(), flatten_ids.contiguous(), alphas, last_ids, v_render_colors, v_render_alpha)
+        v_bg = None
+        if bg is not None and ctx.needs_input_grad[5]:
+            v_bg = (v_render_colors * (1.0 - alphas)).float().sum(dim=(-3, -2))
+        # NB: v_scales is w.r.t. the scaled scales and is returned as is (upstream does not multiply by
+        # scaling_modifier either: rasterizer_autograd.cpp:291,377).
+        return (v_means, v_quats, v_scales, v_colors, v_opac, v_bg) + (None,) * 14
+
+
+def rasterize(camera: Camera, model: SplatData, bg_color: Optional[torch.Tensor], scaling_modifier: float = 1.0,
+              packed: bool = False, antialiased: bool = False, sh_degree: Optional[int] = None) -> RenderOutput:
+    """gs::training::rasterize, RGB render mode (the only one that works on this path upstream)."""
+    assert not packed, "Packed mode is not supported in this implementation"
+    W, H = int(camera.width), int(camera.height)
+    viewmat = camera.world_view_transform()
+    K = camera.K_batched()
+    means = model.get_means()
+    opacities = model.get_opacity()
+    scales = model.get_scaling()
+    rotations = model.get_rotation()
+    sh_coeffs = model.get_shs()
+    sh_degree = model.active_sh_degree if sh_degree is None else sh_degree
+    assert sh_coeffs.shape[1] >= (sh_degree + 1) ** 2, "Not enough SH coefficients"
+    cam_model = camera.camera_model if camera.camera_model is not None else ops.CameraModelType.PINHOLE
+    ut = ops.UnscentedTransformParameters()
+
+    def _pad(t, n):
+        if t is None or t.numel() == 0:
+            return None
+        t = t.reshape(-1).to(means.device, torch.float32)
+        if t.numel() < n:
+            t = torch.nn.functional.pad(t, (0, n - t.numel()))
+        return t.contiguous()
+    radial, tangential = _pad(camera.radial, 4), _pad(camera.tangential, 2)
+    if radial is not None and cam_model == ops.CameraModelType.PINHOLE and radial.numel() < 6:
+        radial = torch.nn.functional.pad(radial, (0, 6 - radial.numel()))  # the pinhole kernel reads 6 (Cameras.cuh:483)
+
+    # 1. projection (no grad)
+    radii, means2d, depths, conics, _ = fully_fused_projection_with_ut(
+        means, rotations, scales, opacities, viewmat, K, radial, tangential, None, W, H, scaling_modifier, cam_model, ut)
+    # 2. colours from SH
+    campos = torch.inverse(viewmat)[:, :3, 3]
+    dirs = means.unsqueeze(0) - campos.unsqueeze(1)
+    masks = (radii > 0).all(-1)
+    colors = spherical_harmonics(sh_degree, dirs, sh_coeffs.unsqueeze(0), masks)
+    colors = torch.clamp_min(colors + 0.5, 0.0)
+    # 3. background / opacities
+    bg = bg_color.reshape(1, -1).to(means.device) if (bg_color is not None and bg_color.numel() > 0) else None
+    final_opacities = opacities.unsqueeze(0)
+    # 4. tile intersection
+    tw, th = (W + TILE_SIZE - 1) // TILE_SIZE, (H + TILE_SIZE - 1) // TILE_SIZE
+    with torch.no_grad():
+        _, isect_ids, flatten_ids = ops.intersect_tile(means2d, radii, depths, None, None, 1, TILE_SIZE, tw, th, True)
+        isect_offsets = ops.intersect_offset(isect_ids, 1, tw, th).reshape(1, th, tw)
+    # 5. blend
+    renders, alphas = GUTRasterizationFunction.apply(means, rotations, scales, colors, final_opacities, bg, None, viewmat, K,
+                                                     radial, tangential, None, isect_offsets, flatten_ids, W, H, TILE_SIZE,
+                                                     scaling_modifier, cam_model, ut)
+    out = RenderOutput()
+    out.image = torch.clamp(renders.squeeze(0).permute(2, 0, 1), 0.0, 1.0)
+    out.alpha = alphas.squeeze(0).permute(2, 0, 1)
+    out.means2d = means2d
+    out.depths = depths.squeeze(0)
+    out.radii = radii.squeeze(0).max(-1).values
+    out.visibility = out.radii > 0
+    out.width, out.height = W, H
+    out.n_isects = int(flatten_ids.shape[0])
+    out.aux = dict(isect_offsets=isect_offsets, flatten_ids=flatten_ids, colors=colors, radii_full=radii)
+    return out

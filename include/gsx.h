@@ -1,0 +1,144 @@
+/* gsx.h — C ABI of libgsx.so: the MI355X (gfx950) implementation of the differentiable 3DGS
+ * rasterizer hot path of MrNeRF/gaussian-splatting-cuda (`--gut` path, gsplat/Ops.h operator surface).
+ *
+ * This is the drop-in boundary: plain pointers (device memory unless stated), sizes, scalars and a
+ * HIP stream.  No torch types, no allocation inside the library (callers pass outputs and, where
+ * needed, a workspace sized by the matching *_workspace_bytes query).  Every entry point returns
+ * GSX_OK (0) or a negative gsx_status; gsx_last_error() gives a thread-local message.
+ * All launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ * The library is stateless and re-entrant, like the reference.
+ *
+ * Each function cites the reference interface it replaces (paths relative to /root/reference).
+ * The C++ shim that re-creates `namespace gsplat` on at::Tensor over this ABI is
+ * gaussian-splatting-cuda_amd/csrc/ops_shim.cpp; the binding a reference maintainer would add is
+ * shown in INTEGRATION.md.
+ */
+#ifndef GSX_H
+#define GSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSX_ABI_VERSION 1
+
+typedef enum gsx_status {
+    GSX_OK = 0,
+    GSX_ERR_INVALID_ARGUMENT = -1, /* null pointer, bad size, unsupported channel count ... */
+    GSX_ERR_UNSUPPORTED = -2,      /* e.g. ORTHO camera (rejected upstream too: Fwd.cu:128-132), packed mode */
+    GSX_ERR_WORKSPACE_TOO_SMALL = -3,
+    GSX_ERR_LAUNCH_FAILED = -4     /* hipGetLastError() != hipSuccess after a launch */
+} gsx_status;
+
+/* gsplat/Common.h:46-50 */
+typedef enum gsx_camera_model { GSX_CAMERA_PINHOLE = 0, GSX_CAMERA_ORTHO = 1, GSX_CAMERA_FISHEYE = 2 } gsx_camera_model;
+
+/* gsplat/Cameras.h:16-22 */
+typedef enum gsx_shutter {
+    GSX_SHUTTER_ROLLING_TOP_TO_BOTTOM = 0,
+    GSX_SHUTTER_ROLLING_LEFT_TO_RIGHT = 1,
+    GSX_SHUTTER_ROLLING_BOTTOM_TO_TOP = 2,
+    GSX_SHUTTER_ROLLING_RIGHT_TO_LEFT = 3,
+    GSX_SHUTTER_GLOBAL = 4
+} gsx_shutter;
+
+/* gsplat/Cameras.h:27-44 (UnscentedTransformParameters) */
+typedef struct gsx_ut_params {
+    float alpha;                             /* 0.1 */
+    float beta;                              /* 2   */
+    float kappa;                             /* 0   */
+    float in_image_margin_factor;            /* 0.1 */
+    int32_t require_all_sigma_points_valid;  /* 1   */
+} gsx_ut_params;
+
+/* The camera block shared by projection and rasterization (the `viewmats0 … thin_prism_coeffs`
+ * argument run of gsplat/Ops.h:75-97, 113-125, 146-158).  All pointers are device pointers. */
+typedef struct gsx_cameras {
+    uint32_t C;               /* number of cameras */
+    const float* viewmats0;   /* [C,4,4] row-major world->camera */
+    const float* viewmats1;   /* [C,4,4] or NULL (rolling shutter end pose) */
+    const float* Ks;          /* [C,3,3] */
+    int32_t camera_model;     /* gsx_camera_model */
+    int32_t shutter;          /* gsx_shutter */
+    const float* radial;      /* [C,6] (pinhole) / [C,4] (fisheye) or NULL */
+    const float* tangential;  /* [C,2] or NULL */
+    const float* thin_prism;  /* [C,4] or NULL */
+} gsx_cameras;
+
+const char* gsx_last_error(void);
+int gsx_abi_version(void);
+
+/* ---- spherical harmonics: gsplat/Ops.h:12-25, SphericalHarmonics.cpp:15-75 ------------------ */
+/* dirs [n,3], coeffs [n,K,3], masks [n] bool(uint8) or NULL -> colors [n,3].
+ * Masked-out elements are left untouched (as upstream, SphericalHarmonicsCUDA.cu:390-392). */
+int gsx_spherical_harmonics_fwd(uint32_t degrees_to_use, uint32_t n, uint32_t K, const float* dirs,
+                                const float* coeffs, const uint8_t* masks, float* colors, void* stream);
+/* v_coeffs [n,K,3] is fully written (zeros for bases above the active degree and for masked
+ * elements: replaces upstream's at::zeros_like + partial write); v_dirs [n,3] or NULL, fully written. */
+int gsx_spherical_harmonics_bwd(uint32_t K, uint32_t degrees_to_use, uint32_t n, const float* dirs,
+                                const float* coeffs, const uint8_t* masks, const float* v_colors, float* v_coeffs,
+                                float* v_dirs, void* stream);
+
+/* ---- projection: gsplat/Ops.h:69-98, Projection.cpp:22-110, ProjectionUT3DGSFused.cu ------- */
+/* means [N,3], quats [N,4] wxyz, scales [N,3], opacities [N] or NULL ->
+ * radii int32 [C,N,2], means2d [C,N,2], depths [C,N], conics [C,N,3], compensations [C,N] or NULL.
+ * As upstream, only radii is written for culled Gaussians. */
+int gsx_projection_ut_3dgs_fused(uint32_t N, const float* means, const float* quats, const float* scales,
+                                 const float* opacities, const gsx_cameras* cams, uint32_t image_width,
+                                 uint32_t image_height, float eps2d, float near_plane, float far_plane,
+                                 float radius_clip, const gsx_ut_params* ut, int32_t* radii, float* means2d,
+                                 float* depths, float* conics, float* compensations, void* stream);
+
+/* ---- tile intersection: gsplat/Ops.h:28-43, Intersect.cpp:15-137, IntersectTile.cu --------- */
+/* Phase 1 (Intersect.cpp:54-76): tiles_per_gauss int32 [C*N], cum_tiles_per_gauss int64 [C*N]
+ * (inclusive scan), *n_isects_dev (device int64) = total.  If n_isects_host_pinned != NULL the total is
+ * also copied there asynchronously (caller synchronises the stream before reading it). */
+size_t gsx_intersect_count_workspace_bytes(uint32_t C, uint32_t N);
+int gsx_intersect_tile_count(uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, uint32_t tile_size,
+                             uint32_t tile_width, uint32_t tile_height, int32_t* tiles_per_gauss,
+                             int64_t* cum_tiles_per_gauss, int64_t* n_isects_dev, int64_t* n_isects_host_pinned,
+                             void* workspace, size_t workspace_bytes, void* stream);
+/* Phase 2 (Intersect.cpp:79-118, IntersectTile.cu:95-111,290-342): emit (key,value) pairs and
+ * stable-sort them by the low 32+tile_n_bits+cam_n_bits key bits.  Outputs isect_ids int64 [n_isects],
+ * flatten_ids int32 [n_isects]. */
+size_t gsx_intersect_fill_workspace_bytes(uint32_t C, uint32_t N, int64_t n_isects, int sort);
+int gsx_intersect_tile_fill(uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, const float* depths,
+                            const int64_t* cum_tiles_per_gauss, uint32_t tile_size, uint32_t tile_width,
+                            uint32_t tile_height, int sort, int64_t n_isects, int64_t* isect_ids,
+                            int32_t* flatten_ids, void* workspace, size_t workspace_bytes, void* stream);
+/* Intersect.cpp:124-137: offsets int32 [C,tile_height,tile_width]. */
+int gsx_intersect_offset(int64_t n_isects, const int64_t* isect_ids, uint32_t C, uint32_t tile_width,
+                         uint32_t tile_height, int32_t* offsets, void* stream);
+
+/* ---- world-space blend: gsplat/Ops.h:100-166, Rasterization.cpp:20-261 ---------------------- */
+/* colors [C,N,3], opacities [C,N], backgrounds [C,3] or NULL, masks [C,th,tw] bool or NULL,
+ * tile_offsets int32 [C,th,tw], flatten_ids int32 [n_isects] ->
+ * renders [C,H,W,3], alphas [C,H,W,1], last_ids int32 [C,H,W].  channels must be 3. */
+int gsx_rasterize_to_pixels_from_world_3dgs_fwd(uint32_t N, int64_t n_isects, const float* means,
+                                                const float* quats, const float* scales, const float* colors,
+                                                uint32_t channels, const float* opacities, const float* backgrounds,
+                                                const uint8_t* masks, uint32_t image_width, uint32_t image_height,
+                                                uint32_t tile_size, const gsx_cameras* cams, const gsx_ut_params* ut,
+                                                const int32_t* tile_offsets, const int32_t* flatten_ids,
+                                                float* renders, float* alphas, int32_t* last_ids, void* stream);
+/* Gradient outputs v_means [N,3], v_quats [N,4], v_scales [N,3], v_colors [C,N,3], v_opacities [C,N]
+ * must be zero-initialised by the caller (upstream: at::zeros_like, Rasterization.cpp:190-194);
+ * the kernel accumulates into them with float atomics. */
+int gsx_rasterize_to_pixels_from_world_3dgs_bwd(uint32_t N, int64_t n_isects, const float* means,
+                                                const float* quats, const float* scales, const float* colors,
+                                                uint32_t channels, const float* opacities, const float* backgrounds,
+                                                const uint8_t* masks, uint32_t image_width, uint32_t image_height,
+                                                uint32_t tile_size, const gsx_cameras* cams, const gsx_ut_params* ut,
+                                                const int32_t* tile_offsets, const int32_t* flatten_ids,
+                                                const float* render_alphas, const int32_t* last_ids,
+                                                const float* v_render_colors, const float* v_render_alphas,
+                                                float* v_means, float* v_quats, float* v_scales, float* v_colors,
+                                                float* v_opacities, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSX_H */
