@@ -7,8 +7,8 @@
 // n_isects inside intersect_tile — the op's return type needs the exact length.
 // Also exports the ops to Python (pybind11 module `_gsx_ops`) for the tests and the bench.
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/extension.h>
 
 #include "../../include/gsx.h"
@@ -20,7 +20,7 @@ namespace {
     TORCH_CHECK((x).is_cuda(), #x " must be a CUDA tensor");       \
     TORCH_CHECK((x).is_contiguous(), #x " must be contiguous")
 
-inline void* cur_stream() { return (void*)c10::hip::getCurrentHIPStream().stream(); }
+inline void* cur_stream() { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream(); }
 inline void check(int rc, const char* op) { TORCH_CHECK(rc == GSX_OK, op, " failed (", rc, "): ", gsx_last_error()); }
 
 inline const float* fptr(const at::optional<at::Tensor>& t) {
@@ -62,7 +62,7 @@ namespace gsplat {
 
 at::Tensor spherical_harmonics_fwd(const uint32_t degrees_to_use, const at::Tensor dirs, const at::Tensor coeffs,
                                    const at::optional<at::Tensor> masks) {
-    const c10::hip::OptionalHIPGuard guard(at::device_of(dirs));
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(dirs));
     GSX_CHECK_INPUT(dirs);
     GSX_CHECK_INPUT(coeffs);
     if (masks.has_value()) { GSX_CHECK_INPUT(masks.value()); }
@@ -81,7 +81,7 @@ std::tuple<at::Tensor, at::Tensor> spherical_harmonics_bwd(const uint32_t K, con
                                                            const at::Tensor dirs, const at::Tensor coeffs,
                                                            const at::optional<at::Tensor> masks,
                                                            const at::Tensor v_colors, bool compute_v_dirs) {
-    const c10::hip::OptionalHIPGuard guard(at::device_of(dirs));
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(dirs));
     GSX_CHECK_INPUT(dirs);
     GSX_CHECK_INPUT(coeffs);
     GSX_CHECK_INPUT(v_colors);
@@ -108,7 +108,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile(const at::Tensor m
                                                               const uint32_t C, const uint32_t tile_size,
                                                               const uint32_t tile_width, const uint32_t tile_height,
                                                               const bool sort) {
-    const c10::hip::OptionalHIPGuard guard(at::device_of(means2d));
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(means2d));
     GSX_CHECK_INPUT(means2d);
     GSX_CHECK_INPUT(radii);
     GSX_CHECK_INPUT(depths);
@@ -133,7 +133,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile(const at::Tensor m
                                        tile_height, tiles_per_gauss.data_ptr<int32_t>(), cum.data_ptr<int64_t>(), nullptr,
                                        n_host.data_ptr<int64_t>(), ws.data_ptr(), wsb, st),
               "intersect_tile(count)");
-        c10::hip::getCurrentHIPStream().synchronize();  // the one host sync, as upstream (Intersect.cpp:76)
+        c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().synchronize();  // the one host sync, as upstream (Intersect.cpp:76)
         n_isects = n_host.data_ptr<int64_t>()[0];
     }
     at::Tensor isect_ids = at::empty({n_isects}, depths.options().dtype(at::kLong));
@@ -151,7 +151,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile(const at::Tensor m
 
 at::Tensor intersect_offset(const at::Tensor isect_ids, const uint32_t C, const uint32_t tile_width,
                             const uint32_t tile_height) {
-    const c10::hip::OptionalHIPGuard guard(at::device_of(isect_ids));
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(isect_ids));
     GSX_CHECK_INPUT(isect_ids);
     TORCH_CHECK(isect_ids.scalar_type() == at::kLong, "isect_ids must be int64");
     at::Tensor offsets = at::empty({(int64_t)C, (int64_t)tile_height, (int64_t)tile_width}, isect_ids.options().dtype(at::kInt));
@@ -168,7 +168,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> projectio
     const float far_plane, const float radius_clip, const bool calc_compensations, const CameraModelType camera_model,
     const UnscentedTransformParameters ut_params, ShutterType rs_type, const at::optional<at::Tensor> radial_coeffs,
     const at::optional<at::Tensor> tangential_coeffs, const at::optional<at::Tensor> thin_prism_coeffs) {
-    const c10::hip::OptionalHIPGuard guard(at::device_of(means));
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(means));
     GSX_CHECK_INPUT(means);
     GSX_CHECK_INPUT(quats);
     GSX_CHECK_INPUT(scales);
@@ -200,7 +200,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> rasterize_to_pixels_from_world_3d
     const UnscentedTransformParameters ut_params, ShutterType rs_type, const at::optional<at::Tensor> radial_coeffs,
     const at::optional<at::Tensor> tangential_coeffs, const at::optional<at::Tensor> thin_prism_coeffs,
     const at::Tensor tile_offsets, const at::Tensor flatten_ids) {
-    const c10::hip::OptionalHIPGuard guard(at::device_of(means));
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(means));
     GSX_CHECK_INPUT(means);
     GSX_CHECK_INPUT(quats);
     GSX_CHECK_INPUT(scales);
@@ -238,7 +238,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
     const at::optional<at::Tensor> tangential_coeffs, const at::optional<at::Tensor> thin_prism_coeffs,
     const at::Tensor tile_offsets, const at::Tensor flatten_ids, const at::Tensor render_alphas,
     const at::Tensor last_ids, const at::Tensor v_render_colors, const at::Tensor v_render_alphas) {
-    const c10::hip::OptionalHIPGuard guard(at::device_of(means));
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(means));
     GSX_CHECK_INPUT(means);
     GSX_CHECK_INPUT(quats);
     GSX_CHECK_INPUT(scales);
