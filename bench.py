@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""bench.py — the hot path's headline benchmark (BASELINE.json): forward + backward of the `--gut`
+rasterizer at 1 M Gaussians / SH degree 3 / 1920x1080 (configs[1], "S-1M"), on N GPUs of one node.
+
+A step = one pass of the hot path over one camera per rank:
+    projection_ut -> SH fwd -> (+0.5, clamp) -> intersect_tile (+sort) -> intersect_offset -> blend fwd
+    -> L1 loss -> blend bwd -> SH bwd -> activation Jacobians (torch) [-> gradient all-reduce when N > 1]
+Inputs are resident in HBM before the timed region.  N > 1: launched by torch.distributed.run, one rank per
+GPU over RCCL; every rank renders its own camera of the step's batch (cameras on a small orbit around the
+cfg2 pose so per-GPU work stays fixed: weak scaling) and the per-Gaussian gradients (59 fp32 / Gaussian, one
+flat bucket) are all-reduced after backward.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, live HIP-event
+timing) and `cpu_baseline` (the CPU oracle timed on one full frame of the same workload, ~10 s on 8 cores).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
+
+
+def algorithmic_bytes(N, C, I, P, tiles, deg, K):  # noqa: E741  
+    nb = (deg + 1) ** 2
+    return {
+        "projection_ut_3dgs_fused": 76 * N * C,
+        "spherical_harmonics_fwd": N * C * (12 + 12 * nb + 1 + 12),
+        "spherical_harmonics_bwd": N * C * (12 + 12 * nb + 1 + 12 + 12 * K + 12),
+        "intersect_tile": 20 * N * C + 12 * N * C + (28 * N * C + 12 * I) + 144 * I,
+        "intersect_offset": 8 * I + 4 * tiles,
+        "rasterize_to_pixels_from_world_3dgs_fwd": 60 * I + 20 * P + 4 * tiles,
+        "rasterize_to_pixels_from_world_3dgs_bwd": 172 * I + 24 * P,
+    }
+
+
+class OpTimer:
+    """Brackets every gsplat op with HIP events on the stream the kernels are launched on (torch's current
+    stream: the shim launches on c10's current HIP stream)."""
+
+    def __init__(self, ops_mod):
+        self.ops = ops_mod
+        self.names = ["projection_ut_3dgs_fused", "spherical_harmonics_fwd", "spherical_harmonics_bwd", "intersect_tile",
+                      "intersect_offset", "rasterize_to_pixels_from_world_3dgs_fwd", "rasterize_to_pixels_from_world_3dgs_bwd"]
+        self.orig = {n: getattr(ops_mod, n) for n in self.names}
+        self.events = {n: [] for n in self.names}
+        self.enabled = False
+        for n in self.names:
+            setattr(ops_mod, n, self._wrap(n))
+
+    def _wrap(self, name):
+        fn = self.orig[name]
+
+        def wrapped(*a, **k):
+            if not self.enabled:
+                return fn(*a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = fn(*a, **k)
+            e.record()
+            self.events[name].append((s, e))
+            return r
+        return wrapped
+
+    def mean_ms(self):
+        out = {}
+        for n, evs in self.events.items():
+            if evs:
+                out[n] = sum(s.elapsed_time(e) for s, e in evs) / len(evs)
+        return out
+
+
+def cpu_baseline(scene, threads):
+    """The CPU oracle (a restatement of the reference kernels: kind "port", OpenMP over tiles / Gaussians) timed
+    on ONE full step of the same workload (the whole S-1M frame, forward + backward)."""
+    import numpy as np
+    from oracle import oracle
+    from tests.helpers import oracle_pipeline
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    H, W, deg = scene["height"], scene["width"], scene["sh_degree"]
+    rng = np.random.default_rng(0)
+    v_rc = rng.standard_normal((1, H, W, 3)).astype(np.float32)
+    v_ra = np.zeros((1, H, W, 1), np.float32)
+    t0 = time.perf_counter()
+    o = oracle_pipeline(scene, v_render_colors=v_rc, v_render_alphas=v_ra)
+    oracle.sh_bwd(deg, o["dirs"].reshape(-1, 3), scene["sh"].numpy(), o["masks"].reshape(-1), o["v_colors"].reshape(-1, 3), True)
+    dt = time.perf_counter() - t0
+    return dt, int(o["flatten_ids"].shape[0])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scene", default="1m", choices=["small", "1m", "5m"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import gsx  # noqa: F401
+    from gsx import distributed as gdist
+    from gsx import ops, rasterizer, scenes
+
+    rank, local_rank, world = gdist.init_from_env()
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    assert world == max(1, args.gpus), "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    scene = {"small": scenes.scene_small, "1m": scenes.scene_1m, "5m": scenes.scene_5m}[args.scene]()
+    N, W, H, deg = scene["means"].shape[0], scene["width"], scene["height"], scene["sh_degree"]
+    model = scenes.to_splat_data(scene, dev)
+    for p in model.params():
+        p.requires_grad_(True)
+    bucket = gdist.GradBucket(model.params())
+    # camera of this rank: cfg2 pose on a 5 cm orbit (rank 0 of a 1-GPU run = exactly the cfg2 camera)
+    vm = scene["viewmat"].clone()
+    if world > 1:
+        a = 2 * math.pi * rank / world
+        vm[0, 3], vm[1, 3] = 0.05 * math.cos(a), 0.05 * math.sin(a)
+    cam = rasterizer.Camera(viewmat=vm.to(dev), K=scene["K"].to(dev), width=W, height=H)
+    bg = scene["background"].to(dev)
+    g = torch.Generator().manual_seed(1234 + rank)
+    target = torch.rand(3, H, W, generator=g).to(dev)
+
+    timer = OpTimer(ops)
+    state = {}
+
+    def step():
+        bucket.zero_()
+        out = rasterizer.rasterize(cam, model, bg)
+        loss = (out.image - target).abs().mean()
+        loss.backward()
+        bucket.all_reduce_mean()
+        state["n_isects"] = out.n_isects
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        I = state["n_isects"]  # noqa: E741
+        P = W * H
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        K = (deg + 1) ** 2
+        ab = algorithmic_bytes(N, 1, I, P, tiles, deg, K)
+        op_ms = timer.mean_ms()
+        kernels = {}
+        for n, ms in op_ms.items():
+            gbs = ab[n] / (ms * 1e-3) / 1e9
+            kernels[n] = {"ms": round(ms, 4), "algorithmic_bytes": int(ab[n]), "GBps": round(gbs, 1),
+                          "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
+        blend = [n for n in op_ms if n.startswith("rasterize_to_pixels")]
+        dom = max(blend or list(op_ms), key=lambda n: op_ms[n])
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": kernels[dom]["frac_hbm"], "traffic": traffic,
+                    "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"], "avg_launch_ms": kernels[dom]["ms"]}
+        result = {
+            "metric": "train iters/s: fwd+bwd frames/s through the gut rasterizer, 1M Gaussians @1080p SH3",
+            "value": round(world * args.steps / elapsed, 4),
+            "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "S-1M (BASELINE configs[1]): 1M random Gaussians, SH deg 3, 1920x1080, fwd+bwd, "
+                                   "one camera per GPU" if args.scene == "1m" else args.scene,
+                       "n_gaussians": N, "width": W, "height": H, "sh_degree": deg, "n_isects": I,
+                       "cameras_per_step": world, "grad_allreduce_bytes": bucket.nbytes() if world > 1 else 0},
+            "gaussians_x_pixels_per_s": round(world * N * P / (elapsed / args.steps), 1),
+            "pairs_per_s_fwd": round(256.0 * I / (op_ms.get("rasterize_to_pixels_from_world_3dgs_fwd", float("nan")) * 1e-3), 1),
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = os.cpu_count() or 1
+            dt, i_cpu = cpu_baseline(scene, threads)
+            result["cpu_baseline"] = {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": threads, "kind": "port",
+                                      "sample": "oracle (CPU restatement, OpenMP) forward+backward of ONE full frame of the "
+                                                "same workload (%d isects): %.2f s" % (i_cpu, dt)}
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,60 @@
+"""Camera-sharded data parallelism for the hot path (new functionality: the reference is single-GPU,
+SURVEY.md §0.4 / §8e).  One process per GPU, full parameter replica per rank, rank r renders camera r of the
+step's batch; ONE collective per step: an all-reduce (sum, then 1/world) of the per-Gaussian gradients.
+
+All six parameter gradients live in ONE flat fp32 bucket (59 floats per Gaussian at SH degree 3: means 3,
+sh0 3, shN 45, scaling 3, rotation 4, opacity 1) allocated once; `.grad` of every parameter is a view into it,
+so autograd accumulates straight into the bucket and the step issues a single large all-reduce — on MI355X's
+point-to-point xGMI mesh one big message lets RCCL spread the reduce-scatter/all-gather over all 7 links."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """torch.distributed.run contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+class GradBucket:
+    """Flat gradient bucket over a list of parameters; .grad of each parameter is a view into it."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        n = sum(p.numel() for p in self.params)
+        p0 = self.params[0]
+        self.flat = torch.zeros(n, dtype=p0.dtype, device=p0.device)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero_(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self, async_op=False):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return None
+        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+        if async_op:
+            return work
+        self.flat.mul_(1.0 / dist.get_world_size())
+        return None
+
+    def nbytes(self):
+        return self.flat.numel() * self.flat.element_size()
+
+
+def shard_cameras(cameras, rank, world):
+    """Camera i of the step's batch goes to rank i % world (one camera per GPU when len == world)."""
+    return [c for i, c in enumerate(cameras) if i % world == rank]
