@@ -19,26 +19,12 @@
 // over the wave with DPP row operations, added into a per-chunk LDS accumulator (ds_add_f32), and
 // after the chunk ONE thread per Gaussian applies the mean / quaternion / scale chain rule
 // (Utils.cuh:104-158) and issues the 14 global atomics: 14 per (tile, Gaussian), 8x fewer.
-#include "gsx_device.hpp"
+#include <stdlib.h>
+#include <string.h>
+
+#include "gsx_raster_common.hpp"
 
 namespace gsx {
-
-void set_error(const char* msg);
-int check_launch(const char* what);
-
-constexpr int TILE = 16;
-constexpr int RB = 256;  // threads per workgroup == Gaussians per chunk
-constexpr float ALPHA_MIN = 1.f / 255.f;
-
-struct RasterArgs {
-    uint32_t C, N;
-    int64_t n_isects;
-    const float* means; const float* quats; const float* scales; const float* colors; const float* opacities;
-    const float* backgrounds; const uint8_t* masks;
-    uint32_t W, H, tw, th;
-    gsx_cameras cams;
-    const int32_t* tile_offsets; const int32_t* flatten_ids;
-};
 
 // One staged Gaussian: 4 x float4 = 64 B.
 //  r0 = (M00 M01 M02 gro.x)  r1 = (M10 M11 M12 gro.y)  r2 = (M20 M21 M22 gro.z)  r3 = (opac, r, g, b)
@@ -66,13 +52,6 @@ GSX_DEV void stage_gaussian(const RasterArgs& a, int32_t g, f3 org, Staged& s) {
         s.r0.w = mu.x; s.r1.w = mu.y; s.r2.w = mu.z;
     }
     s.r3 = make_float4(a.opacities[g], a.colors[(size_t)g * 3], a.colors[(size_t)g * 3 + 1], a.colors[(size_t)g * 3 + 2]);
-}
-
-// pixel owned by this thread
-GSX_DEV void thread_pixel(uint32_t tid, uint32_t tile_x, uint32_t tile_y, uint32_t& i, uint32_t& j) {
-    const uint32_t wave = tid >> 6, lane = tid & 63u;
-    j = tile_x * TILE + (wave & 1u) * 8u + (lane & 7u);
-    i = tile_y * TILE + (wave >> 1) * 8u + (lane >> 3);
 }
 
 // alpha of one (pixel, Gaussian) pair, reference order (Fwd.cu:227-239)
@@ -398,6 +377,12 @@ static int fill_args(RasterArgs& a, uint32_t N, int64_t n_isects, const float* m
     return GSX_OK;
 }
 
+// GSX_RASTER_PATH=generic forces the reference-order kernels (used by the tests to cover both paths)
+static bool force_generic() {
+    const char* e = getenv("GSX_RASTER_PATH");
+    return e != nullptr && strcmp(e, "generic") == 0;
+}
+
 static int cam_kind(const gsx_cameras& c) {
     if (c.camera_model == GSX_CAMERA_FISHEYE) return CAM_OPENCV_FISHEYE;
     return (c.radial || c.tangential || c.thin_prism) ? CAM_OPENCV_PINHOLE : CAM_PERFECT_PINHOLE;
@@ -423,6 +408,10 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_fwd(
     const dim3 grid(a.tw, a.th, a.C), block(RB);
     hipStream_t st = (hipStream_t)stream;
     const bool hoist = cams->shutter == GSX_SHUTTER_GLOBAL;
+    if (hoist && cam_kind(*cams) != CAM_OPENCV_FISHEYE && !force_generic()) {
+        launch_raster_fwd_fast(cam_kind(*cams), a, renders, alphas, last_ids, st);
+        return check_launch("rasterize_to_pixels_from_world_3dgs_fwd(fast)");
+    }
 #define GSX_FWD(KIND)                                                                                                  \
     do {                                                                                                               \
         if (hoist) hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_fwd_kernel<KIND, true>), grid, block, 0, st, a, renders, alphas, last_ids); \
@@ -458,6 +447,11 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd(
     const dim3 grid(a.tw, a.th, a.C), block(RB);
     hipStream_t st = (hipStream_t)stream;
     const bool hoist = cams->shutter == GSX_SHUTTER_GLOBAL;
+    if (hoist && cam_kind(*cams) != CAM_OPENCV_FISHEYE && !force_generic()) {
+        launch_raster_bwd_fast(cam_kind(*cams), a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats,
+                               v_scales, v_colors, v_opacities, st);
+        return check_launch("rasterize_to_pixels_from_world_3dgs_bwd(fast)");
+    }
 #define GSX_BWD(KIND)                                                                                                  \
     do {                                                                                                               \
         if (hoist) hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_kernel<KIND, true>), grid, block, 0, st, a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors, v_opacities); \

@@ -1,0 +1,590 @@
+// gsx_raster_fast.hip — the MI355X fast path of the world-space blend (global shutter, pinhole cameras
+// with or without OpenCV distortion).  Same operator semantics as gsx_raster.hip (reference:
+// gsplat/RasterizeToPixelsFromWorld3DGSFwd.cu:19-279, ...Bwd.cu:16-373), different arithmetic route.
+//
+// 1. Algebra.  For a global shutter every pixel ray starts at the camera centre c, so with
+//    A = M Rc (M = diag(1/s) R^T, Rc = camera->world rotation), m = Rc^T (mu - c) the camera-space centre,
+//    p = (u, v, 1) the pixel's undistorted normalised coordinates and g = M (c - mu) = -A m:
+//        grayDist = |(A p) x g|^2 / |A p|^2                       (scale of the ray direction cancels)
+//        (A p) x g = -(A p) x (A m) = -cof(A) (p x m)             (cof(A) columns = a_i x a_j)
+//        p x m     = m_z (dv, -du, du v0 - dv u0),   (u0,v0) = (m_x,m_y)/m_z,  (du,dv) = (u-u0, v-v0)
+//    => (A p) x g = du B0 + dv B1 with two per-Gaussian 3-vectors.  The reference evaluates the cross
+//    product of a unit vector with g whose norm is depth/scale ~ 1e2..1e4 and loses that many digits to
+//    cancellation; here the only subtraction is u - u0.  |du B0 + dv B1|^2 is evaluated through the 2x2
+//    triangular factor L of [B0 B1] (two squares, no cancellation); |A p|^2 is a convex quadratic in
+//    (du,dv) normalised to 1 at the centre.  16 VALU per (pixel, Gaussian) instead of ~35, and closer to
+//    the float64 truth than the reference's own fp32 order (tests/test_gpu_ops.py measures both).
+// 2. Sub-tile culling.  Each wave owns an 8x8 quadrant.  alpha >= 1/255 needs
+//    |L d|^2 <= log2(255 o) * den(d); den is convex, so its maximum over the tile is at a corner and the
+//    bounding box of that ellipse in (u,v) is a conservative footprint.  Every wave tests 64 staged
+//    Gaussians at a time (one per lane) against its quadrant, __ballot()s the survivors and walks only
+//    the set bits, front to back.  A skipped Gaussian has alpha < 1/255 on all 64 pixels, so results are
+//    unchanged (the reference `continue`s on exactly those pairs, Fwd.cu:240).
+// 3. Staging.  Chunks of 256 Gaussians, records in LDS as four float4 SoA planes (conflict-free per-lane
+//    cull reads, broadcast reads in the pixel loop), double buffered: the gathers of chunk b+1 are in
+//    flight while chunk b is composited; one barrier per chunk.
+// 4. Dispatch.  1-D grid, XCD-aware: block b runs on XCD b % 8, so each XCD is given a contiguous band of
+//    tiles and neighbouring tiles (which share Gaussians) hit the same 4 MiB L2.
+#include "gsx_raster_common.hpp"
+
+namespace gsx {
+
+#ifdef GSX_STATS
+// debug build only (tools/fwd_stats.py): counters for tuning the culling / early-exit behaviour
+__device__ unsigned long long g_stats[8];
+#define GSX_STAT_ADD(i, v) do { if (lane == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define GSX_STAT_ADD(i, v) do { } while (0)
+#endif
+
+constexpr float LOG2_255 = 7.994353436858858f;
+constexpr float HALF_LOG2E = 0.7213475204444817f;  // 0.5 * log2(e)
+
+struct CamFrame {
+    float Rc[3][3];  // camera -> world rotation (== reference's R_inv, Cameras.cuh:262)
+    f3 c;            // camera centre in world space
+};
+
+GSX_DEV CamFrame make_cam_frame(const ShutterPoses& sp) {
+    CamFrame f;
+    const m33 Rinv = quat_to_mat_raw(quat_conj_over_norm2(sp.q0));
+    for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 3; ++k) f.Rc[r][k] = Rinv.a[r][k];
+    const f3 rt = mul(Rinv, sp.t0);
+    f.c = {-rt.x, -rt.y, -rt.z};
+    return f;
+}
+
+// raw per-Gaussian parameters in flight between the gather and the record computation
+struct RawG {
+    f3 mu; float4 q; f3 sc; float opac; f3 rgb; int32_t g;
+};
+
+GSX_DEV void load_raw(const RasterArgs& a, int32_t idx, RawG& r) {
+    const int32_t g = a.flatten_ids[idx];
+    const int32_t gi = (a.C == 1) ? g : (int32_t)((uint32_t)g % a.N);
+    r.g = g;
+    r.mu = {a.means[(size_t)gi * 3], a.means[(size_t)gi * 3 + 1], a.means[(size_t)gi * 3 + 2]};
+    r.q = reinterpret_cast<const float4*>(a.quats)[gi];
+    r.sc = {a.scales[(size_t)gi * 3], a.scales[(size_t)gi * 3 + 1], a.scales[(size_t)gi * 3 + 2]};
+    r.opac = a.opacities[g];
+    r.rgb = {a.colors[(size_t)g * 3], a.colors[(size_t)g * 3 + 1], a.colors[(size_t)g * 3 + 2]};
+}
+
+// Everything the pixel loop needs for one Gaussian (see header comment).  tb = tile bounds in (u,v).
+struct FastRec {
+    float u0, v0, hx, hy;        // footprint centre and conservative half extents in (u,v)
+    float l00, l01, l11, lo;     // triangular factor (pre-scaled by sqrt(0.5 log2 e / d0)), log2(opacity)
+    float d1, d2, d3, d4, d5;    // |A p|^2 / |A p_mu|^2 = 1 + d1 du + d2 dv + d3 du^2 + d4 du dv + d5 dv^2
+    // backward finishing only: columns of A, h = A p_mu, B0, B1, the cofactor columns, camera-space centre, 1/d0
+    f3 a0, a1, a2, h, B0, B1, c01, c12, c20, m;
+    float inv_d0;
+    float Mt[3][3];  // M(r,c) = (1/s_r) R(c,r)
+};
+
+template <bool BWD>
+GSX_DEV void make_record(const RawG& r, const CamFrame& cf, const float tb[4], FastRec& o) {
+    const m33 R = quat_to_rotmat(r.q.x, r.q.y, r.q.z, r.q.w);
+    const float is[3] = {1.f / r.sc.x, 1.f / r.sc.y, 1.f / r.sc.z};
+    float M[3][3], A[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) M[i][k] = is[i] * R.a[k][i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) A[i][j] = M[i][0] * cf.Rc[0][j] + M[i][1] * cf.Rc[1][j] + M[i][2] * cf.Rc[2][j];
+    const f3 dm = r.mu - cf.c;
+    const float mx = cf.Rc[0][0] * dm.x + cf.Rc[1][0] * dm.y + cf.Rc[2][0] * dm.z;
+    const float my = cf.Rc[0][1] * dm.x + cf.Rc[1][1] * dm.y + cf.Rc[2][1] * dm.z;
+    const float mz = cf.Rc[0][2] * dm.x + cf.Rc[1][2] * dm.y + cf.Rc[2][2] * dm.z;
+    const float imz = 1.f / mz;
+    o.u0 = mx * imz; o.v0 = my * imz;
+    const f3 a0{A[0][0], A[1][0], A[2][0]}, a1{A[0][1], A[1][1], A[2][1]}, a2{A[0][2], A[1][2], A[2][2]};
+    const f3 c01 = cross3(a0, a1), c12 = cross3(a1, a2), c20 = cross3(a2, a0);
+    const f3 B0 = (c20 - c01 * o.v0) * mz;
+    const f3 B1 = (c01 * o.u0 - c12) * mz;
+    const f3 h = a0 * o.u0 + a1 * o.v0 + a2;
+    const float d0 = dot3(h, h);
+    const float inv_d0 = 1.f / d0;
+    o.d1 = 2.f * dot3(h, a0) * inv_d0; o.d2 = 2.f * dot3(h, a1) * inv_d0;
+    o.d3 = dot3(a0, a0) * inv_d0; o.d4 = 2.f * dot3(a0, a1) * inv_d0; o.d5 = dot3(a1, a1) * inv_d0;
+    const float sL = sqrtf(HALF_LOG2E * inv_d0);
+    const float n0 = sqrtf(dot3(B0, B0));
+    const float l01r = dot3(B0, B1) / n0;
+    const f3 rr = B1 - B0 * (l01r / n0);
+    o.l00 = n0 * sL; o.l01 = l01r * sL; o.l11 = sqrtf(dot3(rr, rr)) * sL;
+    o.lo = __log2f(r.opac);
+    // conservative footprint: |L d|^2 <= tau2 * max_tile den'
+    const float tau2 = o.lo + LOG2_255;
+    float hx = -INFINITY, hy = -INFINITY;
+    if (tau2 > 0.f && fabsf(mz) > 1e-12f) {
+        float dmax = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float du = ((k & 1) ? tb[1] : tb[0]) - o.u0, dv = ((k & 2) ? tb[3] : tb[2]) - o.v0;
+            dmax = fmaxf(dmax, 1.f + du * (o.d1 + o.d3 * du + o.d4 * dv) + dv * (o.d2 + o.d5 * dv));
+        }
+        const float rad = sqrtf(tau2 * dmax) * 1.001f + 1e-7f;
+        hy = rad / o.l11;
+        hx = rad * sqrtf(o.l01 * o.l01 + o.l11 * o.l11) / (o.l00 * o.l11);
+        if (!(hx == hx) || !(hy == hy)) { hx = INFINITY; hy = INFINITY; }  // degenerate factor: never cull
+    }
+    o.hx = hx; o.hy = hy;
+    if (BWD) {
+        o.a0 = a0; o.a1 = a1; o.a2 = a2; o.h = h; o.B0 = B0; o.B1 = B1; o.c01 = c01; o.c12 = c12; o.c20 = c20;
+        o.m = {mx, my, mz}; o.inv_d0 = inv_d0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o.Mt[i][k] = M[i][k];
+    }
+}
+
+// alpha of one (pixel, Gaussian) pair: 16 VALU.  Returns alpha; num2 = 0.5 log2(e) * grayDist * den' (scaled numerator),
+// rden = 1/den'.
+GSX_DEV float fast_alpha(float u, float v, float4 q0, float4 q1, float4 q2, float d5, float& du, float& dv, float& num2,
+                         float& rden) {
+    du = u - q0.x; dv = v - q0.y;
+    const float t0 = fmaf(q1.y, dv, q1.x * du);
+    const float t1 = q1.z * dv;
+    num2 = fmaf(t0, t0, t1 * t1);
+    const float den = fmaf(du, fmaf(q2.z, du, fmaf(q2.w, dv, q2.x)), fmaf(dv, fmaf(d5, dv, q2.y), 1.f));
+    rden = __builtin_amdgcn_rcpf(den);
+    return fminf(0.999f, __builtin_amdgcn_exp2f(fmaf(-num2, rden, q1.w)));
+}
+
+// per-thread pixel set-up shared by forward and backward: undistorted normalised coordinates (u,v)
+template <int KIND>
+GSX_DEV bool pixel_uv(const Camera<KIND>& cam, uint32_t i, uint32_t j, float& u, float& v) {
+    const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+    if (KIND == CAM_PERFECT_PINHOLE) {
+        u = (px - cam.cx) / cam.fx;
+        v = (py - cam.cy) / cam.fy;
+        return true;
+    }
+    f3 d;
+    const bool ok = cam.unproject(f2{px, py}, d);
+    u = d.x / d.z; v = d.y / d.z;
+    return ok;
+}
+
+// tile bounds in (u,v): min/max over the valid pixels of each wave -> LDS -> whole tile
+GSX_DEV void uv_bounds(bool valid, float u, float v, uint32_t wave, uint32_t lane, float (*s_bounds)[4], float wb[4],
+                       float tb[4]) {
+    float umin = valid ? u : INFINITY, umax = valid ? u : -INFINITY;
+    float vmin = valid ? v : INFINITY, vmax = valid ? v : -INFINITY;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        umin = fminf(umin, __shfl_xor(umin, o)); umax = fmaxf(umax, __shfl_xor(umax, o));
+        vmin = fminf(vmin, __shfl_xor(vmin, o)); vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    }
+    wb[0] = umin; wb[1] = umax; wb[2] = vmin; wb[3] = vmax;
+    if (lane == 0) { s_bounds[wave][0] = umin; s_bounds[wave][1] = umax; s_bounds[wave][2] = vmin; s_bounds[wave][3] = vmax; }
+    __syncthreads();
+    tb[0] = fminf(fminf(s_bounds[0][0], s_bounds[1][0]), fminf(s_bounds[2][0], s_bounds[3][0]));
+    tb[1] = fmaxf(fmaxf(s_bounds[0][1], s_bounds[1][1]), fmaxf(s_bounds[2][1], s_bounds[3][1]));
+    tb[2] = fminf(fminf(s_bounds[0][2], s_bounds[1][2]), fminf(s_bounds[2][2], s_bounds[3][2]));
+    tb[3] = fmaxf(fmaxf(s_bounds[0][3], s_bounds[1][3]), fmaxf(s_bounds[2][3], s_bounds[3][3]));
+}
+
+// XCD-aware 1-D grid -> tile id (block b is dispatched to XCD b % 8)
+GSX_DEV bool swizzled_tile(uint32_t b, uint32_t n_tiles, uint32_t& tile_id) {
+    const uint32_t per = (n_tiles + 7u) / 8u;
+    tile_id = (b & 7u) * per + (b >> 3);
+    return (b >> 3) < per && tile_id < n_tiles;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(RB) void raster_fwd_fast_kernel(RasterArgs a, float* __restrict__ render_colors,
+                                                             float* __restrict__ render_alphas,
+                                                             int32_t* __restrict__ last_ids) {
+    __shared__ float4 s_q0[2][RB], s_q1[2][RB], s_q2[2][RB], s_q3[2][RB];
+    __shared__ float s_bounds[4][4];
+    __shared__ int s_wdone[2][4];
+    const uint32_t cid = blockIdx.y;
+    uint32_t tile_id;
+    if (!swizzled_tile(blockIdx.x, a.tw * a.th, tile_id)) return;
+    const uint32_t tile_y = tile_id / a.tw, tile_x = tile_id - tile_y * a.tw;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t i, j;
+    thread_pixel(tid, tile_x, tile_y, i, j);
+    const bool inside = i < a.H && j < a.W;
+    const size_t pix = (size_t)cid * a.H * a.W + (size_t)i * a.W + j;
+    const float* bg = a.backgrounds ? a.backgrounds + cid * 3 : nullptr;
+    if (a.masks != nullptr && !a.masks[(size_t)cid * a.th * a.tw + tile_id]) {  // Fwd.cu:143-150
+        if (inside)
+            for (int k = 0; k < 3; ++k) render_colors[pix * 3 + k] = bg ? bg[k] : 0.f;
+        return;
+    }
+    const Camera<KIND> cam(a.cams, cid, a.W, a.H);
+    const ShutterPoses sp(a.cams.viewmats0 + cid * 16, nullptr);
+    const CamFrame cf = make_cam_frame(sp);
+    float u, v;
+    const bool ray_ok = pixel_uv(cam, i, j, u, v);
+    bool done = !inside || !ray_ok;
+    float wb[4], tb[4];
+    uv_bounds(!done, u, v, wave, lane, s_bounds, wb, tb);
+
+    const int32_t* toff = a.tile_offsets + (size_t)cid * a.th * a.tw;
+    const int32_t range_start = toff[tile_id];
+    const int32_t range_end = (cid == a.C - 1 && tile_id == a.tw * a.th - 1) ? (int32_t)a.n_isects : toff[tile_id + 1];
+    const int32_t n_chunks = (range_end - range_start + RB - 1) / RB;
+
+    float T = 1.f;
+    uint32_t cur_idx = 0;
+    float out_r = 0.f, out_g = 0.f, out_b = 0.f;
+    bool wave_done = __ballot(!done) == 0ull;
+    RawG raw;
+    bool have = range_start + (int32_t)tid < range_end;
+    if (have) load_raw(a, range_start + (int32_t)tid, raw);
+    for (int32_t b = 0; b < n_chunks; ++b) {
+        const int buf = b & 1;
+        const int32_t chunk_start = range_start + RB * b;
+        if (have) {
+            FastRec r;
+            make_record<false>(raw, cf, tb, r);
+            s_q0[buf][tid] = make_float4(r.u0, r.v0, r.hx, r.hy);
+            s_q1[buf][tid] = make_float4(r.l00, r.l01, r.l11, r.lo);
+            s_q2[buf][tid] = make_float4(r.d1, r.d2, r.d3, r.d4);
+            s_q3[buf][tid] = make_float4(r.d5, raw.rgb.x, raw.rgb.y, raw.rgb.z);
+        }
+        if (lane == 0) s_wdone[buf][wave] = wave_done ? 1 : 0;
+        __syncthreads();
+        if (s_wdone[buf][0] & s_wdone[buf][1] & s_wdone[buf][2] & s_wdone[buf][3]) break;  // Fwd.cu:188-190
+        have = (b + 1 < n_chunks) && (chunk_start + RB + (int32_t)tid < range_end);
+        if (have) load_raw(a, chunk_start + RB + (int32_t)tid, raw);  // in flight during the pixel loop
+        if (wave_done) continue;
+        const int32_t chunk_size = min(RB, range_end - chunk_start);
+        for (int32_t sub = 0; sub < chunk_size && !wave_done; sub += 64) {
+            // one candidate Gaussian per lane: does its footprint touch this wave's quadrant?
+            bool hit = false;
+            if (sub + (int32_t)lane < chunk_size) {
+                const float4 c = s_q0[buf][sub + lane];
+                hit = (c.x + c.z >= wb[0]) && (c.x - c.z <= wb[1]) && (c.y + c.w >= wb[2]) && (c.y - c.w <= wb[3]);
+            }
+            unsigned long long todo = __ballot(hit);
+            GSX_STAT_ADD(1, min(64, chunk_size - sub));
+            GSX_STAT_ADD(0, __popcll(todo));
+            while (todo) {
+                const int t = sub + __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const float4 q0 = s_q0[buf][t], q1 = s_q1[buf][t], q2 = s_q2[buf][t], q3 = s_q3[buf][t];
+                float du, dv, num2, rden;
+                const float alpha = fast_alpha(u, v, q0, q1, q2, q3.x, du, dv, num2, rden);
+                if (!done && alpha >= ALPHA_MIN) {
+                    const float next_T = T * (1.f - alpha);
+                    if (next_T <= 1e-4f) {
+                        done = true;
+                    } else {
+                        const float w = alpha * T;
+                        out_r = fmaf(q3.y, w, out_r); out_g = fmaf(q3.z, w, out_g); out_b = fmaf(q3.w, w, out_b);
+                        cur_idx = (uint32_t)(chunk_start + t);
+                        T = next_T;
+                    }
+                }
+#ifdef GSX_STATS
+                { const unsigned long long c = __ballot(!done && alpha >= ALPHA_MIN); GSX_STAT_ADD(2, c != 0ull); GSX_STAT_ADD(3, __popcll(c)); }
+#endif
+                if (__ballot(!done) == 0ull) { wave_done = true; GSX_STAT_ADD(4, __popcll(todo)); break; }
+            }
+        }
+    }
+    if (inside) {
+        render_alphas[pix] = 1.f - T;
+        render_colors[pix * 3] = bg ? out_r + T * bg[0] : out_r;
+        render_colors[pix * 3 + 1] = bg ? out_g + T * bg[1] : out_g;
+        render_colors[pix * 3 + 2] = bg ? out_b + T * bg[2] : out_b;
+        last_ids[pix] = (int32_t)cur_idx;
+    }
+}
+
+void launch_raster_fwd_fast(int kind, const RasterArgs& a, float* renders, float* alphas, int32_t* last_ids, hipStream_t st) {
+    const uint32_t n_tiles = a.tw * a.th;
+    const dim3 grid(((n_tiles + 7u) / 8u) * 8u, a.C), block(RB);
+    if (kind == CAM_PERFECT_PINHOLE)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_fwd_fast_kernel<CAM_PERFECT_PINHOLE>), grid, block, 0, st, a, renders, alphas, last_ids);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_fwd_fast_kernel<CAM_OPENCV_PINHOLE>), grid, block, 0, st, a, renders, alphas, last_ids);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+// With D = N/Dn, N = |du B0 + dv B1|^2, Dn = |h + a0 du + a1 dv|^2 every parameter gradient is a linear
+// combination of 11 per-(tile, Gaussian) pixel moments
+//     Ma = sum a {du^2, du dv, dv^2, du, dv},   Mb = sum b {1, du, dv, du^2, du dv, dv^2},
+//     a = (dL/dD) / den',  b = a D
+// plus v_rgb[3] and the opacity term: 15 sums (+1 lane count) per evaluated (wave, Gaussian), instead of the
+// reference's 14 per-pixel chain-ruled floats.  The sums are reduced over the wave by a multi-value butterfly
+// (v_permlane32_swap / v_permlane16_swap halve the register count at each level; 40 VALU for 16 values
+// instead of 96 for 16 independent 6-step reductions), added into an LDS accumulator, and one thread per
+// Gaussian turns the moments into (v_mean, v_quat, v_scale) and issues the 14 global atomics.
+constexpr int NMOM = 16;
+
+// reduce x[0..15] over the 64 lanes; on return lane 16*r+15 holds in z[j] the total of value 4*j + {0,2,1,3}[r].
+// The swaps are issued through inline asm: with hipcc/ROCm 7.2 `r[0] + r[1]` on the result of
+// __builtin_amdgcn_permlane{32,16}_swap compiles to `v_add v, vdst, vdst` (the second result is lost; see
+// tools/butterfly_probe.hip).  `s_nop 1` = the two wait states a VALU write needs before v_permlane*_swap reads it.
+GSX_DEV void butterfly_reduce16(float (&x)[16], float (&z)[4]) {
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\t"
+                 "v_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7\n\t"
+                 "v_permlane32_swap_b32 %8, %9\n\tv_permlane32_swap_b32 %10, %11\n\t"
+                 "v_permlane32_swap_b32 %12, %13\n\tv_permlane32_swap_b32 %14, %15\n\t"
+                 "s_nop 1"
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]),
+                   "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+    float y[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[j] = x[2 * j] + x[2 * j + 1];
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+                 "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\t"
+                 "s_nop 1"
+                 : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v = y[2 * j] + y[2 * j + 1];
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));  // row_shr:1
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));  // row_shr:2
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));  // row_shr:4
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));  // row_shr:8
+        z[j] = v;
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(RB) void raster_bwd_fast_kernel(RasterArgs a, const float* __restrict__ render_alphas,
+                                                             const int32_t* __restrict__ last_ids,
+                                                             const float* __restrict__ v_render_colors,
+                                                             const float* __restrict__ v_render_alphas,
+                                                             float* __restrict__ v_means, float* __restrict__ v_quats,
+                                                             float* __restrict__ v_scales, float* __restrict__ v_colors,
+                                                             float* __restrict__ v_opacities) {
+    __shared__ float4 s_q0[RB], s_q1[RB], s_q2[RB], s_q3[RB];
+    __shared__ float s_acc[NMOM][RB];
+    __shared__ float s_bounds[4][4];
+    __shared__ int32_t s_blockmax;
+    const uint32_t cid = blockIdx.y;
+    uint32_t tile_id;
+    if (!swizzled_tile(blockIdx.x, a.tw * a.th, tile_id)) return;
+    if (a.masks != nullptr && !a.masks[(size_t)cid * a.th * a.tw + tile_id]) return;  // Bwd.cu:84-86
+    const uint32_t tile_y = tile_id / a.tw, tile_x = tile_id - tile_y * a.tw;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t i, j;
+    thread_pixel(tid, tile_x, tile_y, i, j);
+    const bool inside = i < a.H && j < a.W;
+    const size_t pix = (size_t)cid * a.H * a.W + (size_t)min(i, a.H - 1) * a.W + min(j, a.W - 1);
+    const float* bg = a.backgrounds ? a.backgrounds + cid * 3 : nullptr;
+    const Camera<KIND> cam(a.cams, cid, a.W, a.H);
+    const ShutterPoses sp(a.cams.viewmats0 + cid * 16, nullptr);
+    const CamFrame cf = make_cam_frame(sp);
+    float u, v;
+    const bool ray_ok = pixel_uv(cam, i, j, u, v);
+    const bool active = inside && ray_ok;
+    if (tid == 0) s_blockmax = -1;
+    float wb[4], tb[4];
+    uv_bounds(active, u, v, wave, lane, s_bounds, wb, tb);   // contains a barrier
+
+    const int32_t* toff = a.tile_offsets + (size_t)cid * a.th * a.tw;
+    const int32_t range_start = toff[tile_id];
+    const int32_t range_end = (cid == a.C - 1 && tile_id == a.tw * a.th - 1) ? (int32_t)a.n_isects : toff[tile_id + 1];
+
+    const float T_final = 1.f - render_alphas[pix];
+    float T = T_final;
+    float buf_r = 0.f, buf_g = 0.f, buf_b = 0.f;
+    const int32_t bin_final = active ? last_ids[pix] : -1;
+    const float vr = v_render_colors[pix * 3], vg = v_render_colors[pix * 3 + 1], vb = v_render_colors[pix * 3 + 2];
+    const float va = v_render_alphas[pix];
+    float tail = va;  // T_final * ra * (v_alpha_out - bg . v_out)   (Bwd.cu:307-316)
+    if (bg) tail -= bg[0] * vr + bg[1] * vg + bg[2] * vb;
+    tail *= T_final;
+
+    int32_t wave_last = bin_final;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, o));
+    if (lane == 0) atomicMax(&s_blockmax, wave_last);
+    __syncthreads();
+    const int32_t block_last = min(s_blockmax, range_end - 1);
+    if (block_last < range_start) return;
+    const int32_t n_chunks = (block_last - range_start + RB) / RB;
+
+    for (int32_t b = 0; b < n_chunks; ++b) {
+        __syncthreads();  // previous chunk's finishing step is done with the LDS planes
+        const int32_t chunk_end = block_last - RB * b;  // inclusive; slot t holds sorted index chunk_end - t
+        const int32_t chunk_size = min(RB, chunk_end + 1 - range_start);
+        RawG raw;
+        const bool have = (int32_t)tid < chunk_size;
+        if (have) {
+            load_raw(a, chunk_end - (int32_t)tid, raw);
+            FastRec r;
+            make_record<false>(raw, cf, tb, r);
+            s_q0[tid] = make_float4(r.u0, r.v0, r.hx, r.hy);
+            s_q1[tid] = make_float4(r.l00, r.l01, r.l11, r.lo);
+            s_q2[tid] = make_float4(r.d1, r.d2, r.d3, r.d4);
+            s_q3[tid] = make_float4(r.d5, raw.rgb.x, raw.rgb.y, raw.rgb.z);
+        }
+#pragma unroll
+        for (int k = 0; k < NMOM; ++k) s_acc[k][tid] = 0.f;
+        __syncthreads();
+
+        for (int32_t sub = 0; sub < chunk_size; sub += 64) {
+            bool hit = false;
+            if (sub + (int32_t)lane < chunk_size && chunk_end - (sub + (int32_t)lane) <= wave_last) {
+                const float4 c = s_q0[sub + lane];
+                hit = (c.x + c.z >= wb[0]) && (c.x - c.z <= wb[1]) && (c.y + c.w >= wb[2]) && (c.y - c.w <= wb[3]);
+            }
+            unsigned long long todo = __ballot(hit);
+            while (todo) {
+                const int t = sub + __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const float4 q0 = s_q0[t], q1 = s_q1[t], q2 = s_q2[t], q3 = s_q3[t];
+                float du, dv, num2, rden;
+                const float alpha = fast_alpha(u, v, q0, q1, q2, q3.x, du, dv, num2, rden);
+                const bool valid = (chunk_end - t <= bin_final) && alpha >= ALPHA_MIN;
+                if (__ballot(valid) == 0ull) continue;
+                float x[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) x[k] = 0.f;
+                if (valid) {
+                    const float ra = 1.f / (1.f - alpha);
+                    T *= ra;
+                    const float fac = alpha * T;
+                    x[0] = fac * vr; x[1] = fac * vg; x[2] = fac * vb;
+                    float v_alpha = (q3.y * T - buf_r * ra) * vr + (q3.z * T - buf_g * ra) * vg + (q3.w * T - buf_b * ra) * vb;
+                    v_alpha = fmaf(tail, ra, v_alpha);
+                    buf_r = fmaf(q3.y, fac, buf_r); buf_g = fmaf(q3.z, fac, buf_g); buf_b = fmaf(q3.w, fac, buf_b);
+                    x[15] = 1.f;
+                    if (alpha < 0.999f) {  // not clamped (Bwd.cu:318): alpha = o * exp(-D/2), dalpha/dD = -alpha/2
+                        const float av = alpha * v_alpha;
+                        x[3] = av;                               // o * v_opacity
+                        const float aw = -0.5f * av * rden;      // a = (dL/dD) / den'
+                        const float bw = aw * (num2 * rden);     // b = a * D * (0.5 log2 e)
+                        const float uu = du * du, uv = du * dv, vv = dv * dv;
+                        x[4] = aw * uu; x[5] = aw * uv; x[6] = aw * vv; x[7] = aw * du; x[8] = aw * dv;
+                        x[9] = bw; x[10] = bw * du; x[11] = bw * dv; x[12] = bw * uu; x[13] = bw * uv; x[14] = bw * vv;
+                    }
+                }
+                float z[4];
+                butterfly_reduce16(x, z);
+                if ((lane & 15u) == 15u) {
+                    const uint32_t row = lane >> 4;
+                    const uint32_t k0 = (row == 1u) ? 2u : (row == 2u ? 1u : row);  // {0,2,1,3}
+                    atomicAdd(&s_acc[k0][t], z[0]);
+                    atomicAdd(&s_acc[4 + k0][t], z[1]);
+                    atomicAdd(&s_acc[8 + k0][t], z[2]);
+                    atomicAdd(&s_acc[12 + k0][t], z[3]);
+                }
+            }
+        }
+        __syncthreads();
+
+        // one thread per Gaussian of the chunk: moments -> (v_mean, v_quat, v_scale), 14 global atomics
+        if (have && s_acc[15][tid] > 0.f) {
+            float Mo[NMOM];
+#pragma unroll
+            for (int k = 0; k < NMOM; ++k) Mo[k] = s_acc[k][tid];
+            const int32_t g = raw.g;
+            const int32_t gi = (a.C == 1) ? g : (int32_t)((uint32_t)g % a.N);
+            atomicAdd(&v_colors[(size_t)g * 3], Mo[0]);
+            atomicAdd(&v_colors[(size_t)g * 3 + 1], Mo[1]);
+            atomicAdd(&v_colors[(size_t)g * 3 + 2], Mo[2]);
+            atomicAdd(&v_opacities[g], Mo[3] / raw.opac);
+            FastRec r;
+            make_record<true>(raw, cf, tb, r);
+            const float kap = 2.f * r.inv_d0;
+            const float Mauu = Mo[4] * kap, Mauv = Mo[5] * kap, Mavv = Mo[6] * kap, Mau = Mo[7] * kap, Mav = Mo[8] * kap;
+            const float kb = kap / HALF_LOG2E;  // b was accumulated with D scaled by 0.5 log2 e
+            const float Mb1 = Mo[9] * kb, Mbu = Mo[10] * kb, Mbv = Mo[11] * kb, Mbuu = Mo[12] * kb, Mbuv = Mo[13] * kb, Mbvv = Mo[14] * kb;
+            // direct gradients
+            const f3 G_B0 = r.B0 * Mauu + r.B1 * Mauv;
+            const f3 G_B1 = r.B0 * Mauv + r.B1 * Mavv;
+            float G_u0 = -(dot3(r.B0, r.B0) * Mau + dot3(r.B0, r.B1) * Mav);
+            float G_v0 = -(dot3(r.B0, r.B1) * Mau + dot3(r.B1, r.B1) * Mav);
+            const f3 G_h = (r.h * Mb1 + r.a0 * Mbu + r.a1 * Mbv) * -1.f;
+            f3 G_a0 = (r.h * Mbu + r.a0 * Mbuu + r.a1 * Mbuv) * -1.f;
+            f3 G_a1 = (r.h * Mbv + r.a0 * Mbuv + r.a1 * Mbvv) * -1.f;
+            // v = a0 u + a1 v + a2 does not depend on (u0,v0): fold h = a0 u0 + a1 v0 + a2 into the columns
+            G_a0 = G_a0 + G_h * r.u0;
+            G_a1 = G_a1 + G_h * r.v0;
+            f3 G_a2 = G_h;
+            // B0 = mz (c20 - v0 c01), B1 = mz (u0 c01 - c12)
+            const float mz = r.m.z, imz = 1.f / mz;
+            f3 G_c20 = G_B0 * mz;
+            f3 G_c01 = G_B1 * (mz * r.u0) - G_B0 * (mz * r.v0);
+            f3 G_c12 = G_B1 * -mz;
+            G_v0 += -mz * dot3(r.c01, G_B0);
+            G_u0 += mz * dot3(r.c01, G_B1);
+            float G_mz = (dot3(r.B0, G_B0) + dot3(r.B1, G_B1)) * imz;
+            // c01 = a0 x a1, c12 = a1 x a2, c20 = a2 x a0   (c = a x b: G_a += b x G_c, G_b += G_c x a)
+            G_a0 = G_a0 + cross3(r.a1, G_c01); G_a1 = G_a1 + cross3(G_c01, r.a0);
+            G_a1 = G_a1 + cross3(r.a2, G_c12); G_a2 = G_a2 + cross3(G_c12, r.a1);
+            G_a2 = G_a2 + cross3(r.a0, G_c20); G_a0 = G_a0 + cross3(G_c20, r.a2);
+            // u0 = mx / mz, v0 = my / mz
+            const float G_mx = G_u0 * imz, G_my = G_v0 * imz;
+            G_mz += -(r.u0 * G_u0 + r.v0 * G_v0) * imz;
+            // m = Rc^T (mu - c)  ->  v_mean = Rc G_m
+            atomicAdd(&v_means[(size_t)gi * 3], cf.Rc[0][0] * G_mx + cf.Rc[0][1] * G_my + cf.Rc[0][2] * G_mz);
+            atomicAdd(&v_means[(size_t)gi * 3 + 1], cf.Rc[1][0] * G_mx + cf.Rc[1][1] * G_my + cf.Rc[1][2] * G_mz);
+            atomicAdd(&v_means[(size_t)gi * 3 + 2], cf.Rc[2][0] * G_mx + cf.Rc[2][1] * G_my + cf.Rc[2][2] * G_mz);
+            // A = M Rc  ->  G_M(i,k) = sum_j G_A(i,j) Rc(k,j)   (G_A(i,j) = component i of G_aj)
+            const float GA[3][3] = {{G_a0.x, G_a1.x, G_a2.x}, {G_a0.y, G_a1.y, G_a2.y}, {G_a0.z, G_a1.z, G_a2.z}};
+            float vMt[3][3];
+#pragma unroll
+            for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) vMt[ii][k] = GA[ii][0] * cf.Rc[k][0] + GA[ii][1] * cf.Rc[k][1] + GA[ii][2] * cf.Rc[k][2];
+            // quat_scale_to_preci_half_vjp (Utils.cuh:104-158) with v_M = vMt^T  (M here is the reference's Mt)
+            const float isv[3] = {1.f / raw.sc.x, 1.f / raw.sc.y, 1.f / raw.sc.z};
+            float w = raw.q.x, x_ = raw.q.y, y_ = raw.q.z, z_ = raw.q.w;
+            const float inv_norm = rsqrtf(x_ * x_ + y_ * y_ + z_ * z_ + w * w);
+            w *= inv_norm; x_ *= inv_norm; y_ *= inv_norm; z_ *= inv_norm;
+#define GSX_G(i, j) (vMt[i][j] * isv[i])
+            float vq[4];
+            vq[0] = 2.f * (x_ * (GSX_G(1, 2) - GSX_G(2, 1)) + y_ * (GSX_G(2, 0) - GSX_G(0, 2)) + z_ * (GSX_G(0, 1) - GSX_G(1, 0)));
+            vq[1] = 2.f * (-2.f * x_ * (GSX_G(1, 1) + GSX_G(2, 2)) + y_ * (GSX_G(0, 1) + GSX_G(1, 0)) + z_ * (GSX_G(0, 2) + GSX_G(2, 0)) + w * (GSX_G(1, 2) - GSX_G(2, 1)));
+            vq[2] = 2.f * (x_ * (GSX_G(0, 1) + GSX_G(1, 0)) - 2.f * y_ * (GSX_G(0, 0) + GSX_G(2, 2)) + z_ * (GSX_G(1, 2) + GSX_G(2, 1)) + w * (GSX_G(2, 0) - GSX_G(0, 2)));
+            vq[3] = 2.f * (x_ * (GSX_G(0, 2) + GSX_G(2, 0)) + y_ * (GSX_G(1, 2) + GSX_G(2, 1)) - 2.f * z_ * (GSX_G(0, 0) + GSX_G(1, 1)) + w * (GSX_G(0, 1) - GSX_G(1, 0)));
+#undef GSX_G
+            const float qn[4] = {w, x_, y_, z_};
+            const float dq = vq[0] * qn[0] + vq[1] * qn[1] + vq[2] * qn[2] + vq[3] * qn[3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) atomicAdd(&v_quats[(size_t)gi * 4 + k], (vq[k] - dq * qn[k]) * inv_norm);
+            // v_scale[k] = -(1/s_k)^2 sum_r R(r,k) vMt[k][r],  R(r,k) = Mt[k][r] * s_k
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float sum = r.Mt[k][0] * vMt[k][0] + r.Mt[k][1] * vMt[k][1] + r.Mt[k][2] * vMt[k][2];
+                atomicAdd(&v_scales[(size_t)gi * 3 + k], -isv[k] * sum);
+            }
+        }
+    }
+}
+
+void launch_raster_bwd_fast(int kind, const RasterArgs& a, const float* render_alphas, const int32_t* last_ids,
+                            const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats,
+                            float* v_scales, float* v_colors, float* v_opacities, hipStream_t st) {
+    const uint32_t n_tiles = a.tw * a.th;
+    const dim3 grid(((n_tiles + 7u) / 8u) * 8u, a.C), block(RB);
+    if (kind == CAM_PERFECT_PINHOLE)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_fast_kernel<CAM_PERFECT_PINHOLE>), grid, block, 0, st, a, render_alphas,
+                           last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors, v_opacities);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_fast_kernel<CAM_OPENCV_PINHOLE>), grid, block, 0, st, a, render_alphas,
+                           last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors, v_opacities);
+}
+
+}  // namespace gsx
+
+#ifdef GSX_STATS
+extern "C" void gsx_debug_read_stats(unsigned long long* out, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(gsx::g_stats), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(gsx::g_stats), z, sizeof(z)); }
+}
+#endif

@@ -1,0 +1,30 @@
+"""Run the S-1M hot path a few times (for rocprofv3 --pmc / --kernel-trace runs): python tools/run_fwd_bwd.py [n] [fwd|all]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import gsx  # noqa: E402,F401
+from gsx import rasterizer, scenes  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+mode = sys.argv[2] if len(sys.argv) > 2 else "all"
+dev = "cuda:0"
+scene = {"1m": scenes.scene_1m, "5m": scenes.scene_5m}[os.environ.get("GSX_SCENE", "1m")]()
+model = scenes.to_splat_data(scene, dev)
+cam = rasterizer.Camera(viewmat=scene["viewmat"].to(dev), K=scene["K"].to(dev), width=scene["width"], height=scene["height"])
+bg = scene["background"].to(dev)
+if mode == "all":
+    for p in model.params():
+        p.requires_grad_(True)
+for _ in range(n):
+    if mode == "all":
+        out = rasterizer.rasterize(cam, model, bg)
+        out.image.sum().backward()
+    else:
+        with torch.no_grad():
+            out = rasterizer.rasterize(cam, model, bg)
+torch.cuda.synchronize()
+print("n_isects", out.n_isects)
