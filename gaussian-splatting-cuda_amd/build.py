@@ -48,7 +48,9 @@ def build_libgsx(force=False, verbose=False):
     for s in srcs:  # compile the translation units in parallel
         o = os.path.join(CSRC, os.path.basename(s) + ".o")
         objs.append(o)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
+        # -fno-slp-vectorize: v_pk_fma_f32 / v_pk_mul_f32 issue at ~7.5 cycles per wave64 instruction on gfx950 vs ~2.9 for the
+        # scalar forms (tools/valu_probe.hip), so SLP-packed fp32 math is a net loss in the VALU-bound blend loops
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-c", s, "-o", o]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for cmd, p in procs:
         out, _ = p.communicate()

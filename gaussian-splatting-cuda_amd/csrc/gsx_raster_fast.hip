@@ -369,6 +369,7 @@ __global__ __launch_bounds__(RB) void raster_bwd_fast_kernel(RasterArgs a, const
                                                              float* __restrict__ v_opacities) {
     __shared__ float4 s_q0[RB], s_q1[RB], s_q2[RB], s_q3[RB];
     __shared__ float s_acc[NMOM][RB];
+    __shared__ unsigned long long s_touched[RB / 64];
     __shared__ float s_bounds[4][4];
     __shared__ int32_t s_blockmax;
     const uint32_t cid = blockIdx.y;
@@ -432,6 +433,7 @@ __global__ __launch_bounds__(RB) void raster_bwd_fast_kernel(RasterArgs a, const
         }
 #pragma unroll
         for (int k = 0; k < NMOM; ++k) s_acc[k][tid] = 0.f;
+        if (tid < RB / 64) s_touched[tid] = 0ull;
         __syncthreads();
 
         for (int32_t sub = 0; sub < chunk_size; sub += 64) {
@@ -441,6 +443,7 @@ __global__ __launch_bounds__(RB) void raster_bwd_fast_kernel(RasterArgs a, const
                 hit = (c.x + c.z >= wb[0]) && (c.x - c.z <= wb[1]) && (c.y + c.w >= wb[2]) && (c.y - c.w <= wb[3]);
             }
             unsigned long long todo = __ballot(hit);
+            unsigned long long touched = 0ull;
             while (todo) {
                 const int t = sub + __builtin_ctzll(todo);
                 todo &= todo - 1ull;
@@ -449,28 +452,27 @@ __global__ __launch_bounds__(RB) void raster_bwd_fast_kernel(RasterArgs a, const
                 const float alpha = fast_alpha(u, v, q0, q1, q2, q3.x, du, dv, num2, rden);
                 const bool valid = (chunk_end - t <= bin_final) && alpha >= ALPHA_MIN;
                 if (__ballot(valid) == 0ull) continue;
+                touched |= 1ull << (t - sub);
+                // branch-free: lanes that do not take this Gaussian run with alpha = 0, which makes every
+                // update below the identity (ra = 1, fac = 0) and every moment weight zero.
+                const float al = valid ? alpha : 0.f;
+                const float ra = __builtin_amdgcn_rcpf(1.f - al);
+                T *= ra;
+                const float fac = al * T;
                 float x[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) x[k] = 0.f;
-                if (valid) {
-                    const float ra = 1.f / (1.f - alpha);
-                    T *= ra;
-                    const float fac = alpha * T;
-                    x[0] = fac * vr; x[1] = fac * vg; x[2] = fac * vb;
-                    float v_alpha = (q3.y * T - buf_r * ra) * vr + (q3.z * T - buf_g * ra) * vg + (q3.w * T - buf_b * ra) * vb;
-                    v_alpha = fmaf(tail, ra, v_alpha);
-                    buf_r = fmaf(q3.y, fac, buf_r); buf_g = fmaf(q3.z, fac, buf_g); buf_b = fmaf(q3.w, fac, buf_b);
-                    x[15] = 1.f;
-                    if (alpha < 0.999f) {  // not clamped (Bwd.cu:318): alpha = o * exp(-D/2), dalpha/dD = -alpha/2
-                        const float av = alpha * v_alpha;
-                        x[3] = av;                               // o * v_opacity
-                        const float aw = -0.5f * av * rden;      // a = (dL/dD) / den'
-                        const float bw = aw * (num2 * rden);     // b = a * D * (0.5 log2 e)
-                        const float uu = du * du, uv = du * dv, vv = dv * dv;
-                        x[4] = aw * uu; x[5] = aw * uv; x[6] = aw * vv; x[7] = aw * du; x[8] = aw * dv;
-                        x[9] = bw; x[10] = bw * du; x[11] = bw * dv; x[12] = bw * uu; x[13] = bw * uv; x[14] = bw * vv;
-                    }
-                }
+                x[0] = fac * vr; x[1] = fac * vg; x[2] = fac * vb;
+                float v_alpha = (q3.y * T - buf_r * ra) * vr + (q3.z * T - buf_g * ra) * vg + (q3.w * T - buf_b * ra) * vb;
+                v_alpha = fmaf(tail, ra, v_alpha);
+                buf_r = fmaf(q3.y, fac, buf_r); buf_g = fmaf(q3.z, fac, buf_g); buf_b = fmaf(q3.w, fac, buf_b);
+                // clamped alpha (>= 0.999) carries no gradient to opacity / geometry (Bwd.cu:318)
+                const float av = (al < 0.999f) ? al * v_alpha : 0.f;   // o * v_opacity;  dalpha/dD = -alpha/2
+                const float aw = -0.5f * av * rden;                    // a = (dL/dD) / den'
+                const float bw = aw * (num2 * rden);                   // b = a * D * (0.5 log2 e)
+                const float uu = du * du, uv = du * dv, vv = dv * dv;
+                x[3] = av;
+                x[4] = aw * uu; x[5] = aw * uv; x[6] = aw * vv; x[7] = aw * du; x[8] = aw * dv;
+                x[9] = bw; x[10] = bw * du; x[11] = bw * dv; x[12] = bw * uu; x[13] = bw * uv; x[14] = bw * vv;
+                x[15] = 0.f;
                 float z[4];
                 butterfly_reduce16(x, z);
                 if ((lane & 15u) == 15u) {
@@ -482,11 +484,12 @@ __global__ __launch_bounds__(RB) void raster_bwd_fast_kernel(RasterArgs a, const
                     atomicAdd(&s_acc[12 + k0][t], z[3]);
                 }
             }
+            if (lane == 0 && touched) atomicOr(&s_touched[sub >> 6], touched);
         }
         __syncthreads();
 
         // one thread per Gaussian of the chunk: moments -> (v_mean, v_quat, v_scale), 14 global atomics
-        if (have && s_acc[15][tid] > 0.f) {
+        if (have && ((s_touched[tid >> 6] >> (tid & 63u)) & 1ull)) {
             float Mo[NMOM];
 #pragma unroll
             for (int k = 0; k < NMOM; ++k) Mo[k] = s_acc[k][tid];
