@@ -9,7 +9,9 @@
 #include <ATen/ATen.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#ifndef GSX_NO_PYBIND
 #include <torch/extension.h>
+#endif
 
 #include "../../include/gsx.h"
 #include "../../include/gsx_ops.h"
@@ -279,6 +281,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
 // ---------------------------------------------------------------------------------------------
 // Python bindings (names as in gsplat/Ops.h)
 // ---------------------------------------------------------------------------------------------
+#ifndef GSX_NO_PYBIND
 namespace py = pybind11;
 
 PYBIND11_MODULE(_gsx_ops, m) {
@@ -307,3 +310,4 @@ PYBIND11_MODULE(_gsx_ops, m) {
     m.def("rasterize_to_pixels_from_world_3dgs_bwd", &gsplat::rasterize_to_pixels_from_world_3dgs_bwd);
     m.def("abi_version", []() { return gsx_abi_version(); });
 }
+#endif  // GSX_NO_PYBIND

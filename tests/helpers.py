@@ -11,7 +11,7 @@ def np32(t):
 
 
 def oracle_pipeline(scene, dtype=np.float32, frag_rel=None, v_render_colors=None, v_render_alphas=None,
-                    isect_override=None, colors_override=None):
+                    isect_override=None, colors_override=None, cam=None):
     """projection -> SH (+0.5, clamp_min 0) -> intersect -> offsets -> blend fwd (-> blend bwd) with the oracle.
     `isect_override=(tile_offsets, flatten_ids)` lets the blend be tested on identical binning."""
     f = lambda k: np.ascontiguousarray(scene[k].numpy(), dtype=dtype)  # noqa: E731
@@ -20,7 +20,11 @@ def oracle_pipeline(scene, dtype=np.float32, frag_rel=None, v_render_colors=None
     W, H = scene["width"], scene["height"]
     sh, deg = f("sh"), scene["sh_degree"]
     bg = None if scene.get("background") is None else f("background")[None]
-    radii, means2d, depths, conics, _ = oracle.projection_ut(means, quats, scales, opac, viewmat, K, W, H)
+    cam = dict(cam or {})   # optional: camera_model, shutter, viewmats1, radial, tangential, thin_prism
+    for k in ("viewmats1", "radial", "tangential", "thin_prism"):
+        if cam.get(k) is not None:
+            cam[k] = np.ascontiguousarray(np.asarray(cam[k]), dtype=dtype)
+    radii, means2d, depths, conics, _ = oracle.projection_ut(means, quats, scales, opac, viewmat, K, W, H, **cam)
     campos = np.linalg.inv(viewmat.astype(np.float64))[:, :3, 3].astype(dtype)
     dirs = means[None] - campos[:, None]
     masks = (radii > 0).all(-1)
@@ -37,13 +41,13 @@ def oracle_pipeline(scene, dtype=np.float32, frag_rel=None, v_render_colors=None
         offsets, fl = isect_override
         tpg, ids = None, None
     res = oracle.rasterize_fwd(means, quats, scales, colors, opac[None], bg, None, W, H, TILE, viewmat, K, offsets, fl,
-                               frag_rel=frag_rel)
+                               frag_rel=frag_rel, **cam)
     out = dict(radii=radii, means2d=means2d, depths=depths, conics=conics, dirs=dirs, masks=masks, colors=colors,
                tiles_per_gauss=tpg, isect_ids=ids, flatten_ids=fl, tile_offsets=offsets, renders=res[0], alphas=res[1],
                last_ids=res[2], fragile=res[3] if frag_rel is not None else None)
     if v_render_colors is not None:
         g = oracle.rasterize_bwd(means, quats, scales, colors, opac[None], bg, None, W, H, TILE, viewmat, K, offsets, fl,
-                                 res[1], res[2], v_render_colors.astype(dtype), v_render_alphas.astype(dtype))
+                                 res[1], res[2], v_render_colors.astype(dtype), v_render_alphas.astype(dtype), **cam)
         out.update(v_means=g[0], v_quats=g[1], v_scales=g[2], v_colors=g[3], v_opacities=g[4])
     return out
 

@@ -1,0 +1,80 @@
+"""N>1 path on CPU: two processes over gloo exercise the camera sharding + the flat gradient bucket all-reduce
+(gaussian-splatting-cuda_amd/distributed.py).  Per-rank gradients come from the CPU oracle (tests may use it),
+one camera per rank; after the collective every rank must hold the mean of both cameras' gradients."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _camera_grads(rank):
+    """Oracle gradients of sum(image * w) for camera `rank` of a 2-camera orbit around a small scene."""
+    from gsx import scenes
+    from tests.helpers import oracle_pipeline
+    sc = scenes.scene_small(seed=5, N=300)
+    sc["width"] = sc["height"] = 48
+    sc["K"] = scenes.intrinsics(40.0, 40.0, 24.0, 24.0)
+    vm = torch.eye(4)
+    vm[0, 3] = 0.05 if rank == 0 else -0.05
+    sc["viewmat"] = vm
+    rng = np.random.default_rng(7)
+    v_rc = rng.standard_normal((1, 48, 48, 3)).astype(np.float32)
+    v_ra = rng.standard_normal((1, 48, 48, 1)).astype(np.float32)
+    o = oracle_pipeline(sc, v_render_colors=v_rc, v_render_alphas=v_ra)
+    return [o["v_means"], o["v_quats"], o["v_scales"], o["v_opacities"].reshape(-1, 1)]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import gsx  # noqa: F401
+    from gsx import distributed as gdist
+    r, lr, w = gdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    grads = _camera_grads(rank)
+    params = [torch.zeros(g.shape, dtype=torch.float32, requires_grad=True) for g in grads]
+    bucket = gdist.GradBucket(params)
+    assert bucket.flat.numel() == sum(g.size for g in grads)
+    for p, g in zip(params, grads):
+        assert p.grad.data_ptr() >= bucket.flat.data_ptr()          # .grad is a view into the bucket
+        p.grad.add_(torch.from_numpy(g))
+    bucket.all_reduce_mean()
+    cams = list(range(5))
+    assert gdist.shard_cameras(cams, rank, world) == [c for c in cams if c % world == rank]
+    np.save(os.path.join(out_dir, "bucket_%d.npy" % rank), bucket.flat.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_bucket_all_reduce_two_ranks(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    b0 = np.load(tmp_path / "bucket_0.npy")
+    b1 = np.load(tmp_path / "bucket_1.npy")
+    assert np.array_equal(b0, b1)                                    # replicas stay identical
+    expect = 0.5 * (np.concatenate([g.reshape(-1) for g in _camera_grads(0)]) +
+                    np.concatenate([g.reshape(-1) for g in _camera_grads(1)]))
+    np.testing.assert_allclose(b0, expect, rtol=1e-6, atol=1e-7)
+
+
+def test_single_process_is_a_noop():
+    import gsx  # noqa: F401
+    from gsx import distributed as gdist
+    p = torch.ones(4, 3, requires_grad=True)
+    b = gdist.GradBucket([p])
+    p.grad.fill_(2.0)
+    assert b.all_reduce_mean() is None and torch.all(b.flat == 2.0)
+    b.zero_()
+    assert torch.all(p.grad == 0)
