@@ -37,6 +37,15 @@ __device__ unsigned long long g_stats[8];
 #define GSX_STAT_ADD(i, v) do { } while (0)
 #endif
 
+// minimum waves per SIMD requested from the register allocator (__launch_bounds__ 2nd argument)
+#ifndef GSX_FWD_WAVES
+#define GSX_FWD_WAVES 8
+#endif
+#ifndef GSX_BWD_WAVES
+#define GSX_BWD_WAVES 4
+#endif
+
+constexpr int FCH = 128;  // Gaussians per forward chunk (double buffered: 2 x 64 B x FCH of LDS)
 constexpr float LOG2_255 = 7.994353436858858f;
 constexpr float HALF_LOG2E = 0.7213475204444817f;  // 0.5 * log2(e)
 
@@ -200,10 +209,10 @@ GSX_DEV bool swizzled_tile(uint32_t b, uint32_t n_tiles, uint32_t& tile_id) {
 // forward
 // ------------------------------------------------------------------------------------------------
 template <int KIND>
-__global__ __launch_bounds__(RB) void raster_fwd_fast_kernel(RasterArgs a, float* __restrict__ render_colors,
+__global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(RasterArgs a, float* __restrict__ render_colors,
                                                              float* __restrict__ render_alphas,
                                                              int32_t* __restrict__ last_ids) {
-    __shared__ float4 s_q0[2][RB], s_q1[2][RB], s_q2[2][RB], s_q3[2][RB];
+    __shared__ float4 s_q0[2][FCH], s_q1[2][FCH], s_q2[2][FCH], s_q3[2][FCH];
     __shared__ float s_bounds[4][4];
     __shared__ int s_wdone[2][4];
     const uint32_t cid = blockIdx.y;
@@ -233,18 +242,18 @@ __global__ __launch_bounds__(RB) void raster_fwd_fast_kernel(RasterArgs a, float
     const int32_t* toff = a.tile_offsets + (size_t)cid * a.th * a.tw;
     const int32_t range_start = toff[tile_id];
     const int32_t range_end = (cid == a.C - 1 && tile_id == a.tw * a.th - 1) ? (int32_t)a.n_isects : toff[tile_id + 1];
-    const int32_t n_chunks = (range_end - range_start + RB - 1) / RB;
+    const int32_t n_chunks = (range_end - range_start + FCH - 1) / FCH;
 
     float T = 1.f;
     uint32_t cur_idx = 0;
     float out_r = 0.f, out_g = 0.f, out_b = 0.f;
     bool wave_done = __ballot(!done) == 0ull;
     RawG raw;
-    bool have = range_start + (int32_t)tid < range_end;
+    bool have = (int32_t)tid < FCH && range_start + (int32_t)tid < range_end;
     if (have) load_raw(a, range_start + (int32_t)tid, raw);
     for (int32_t b = 0; b < n_chunks; ++b) {
         const int buf = b & 1;
-        const int32_t chunk_start = range_start + RB * b;
+        const int32_t chunk_start = range_start + FCH * b;
         if (have) {
             FastRec r;
             make_record<false>(raw, cf, tb, r);
@@ -256,10 +265,10 @@ __global__ __launch_bounds__(RB) void raster_fwd_fast_kernel(RasterArgs a, float
         if (lane == 0) s_wdone[buf][wave] = wave_done ? 1 : 0;
         __syncthreads();
         if (s_wdone[buf][0] & s_wdone[buf][1] & s_wdone[buf][2] & s_wdone[buf][3]) break;  // Fwd.cu:188-190
-        have = (b + 1 < n_chunks) && (chunk_start + RB + (int32_t)tid < range_end);
-        if (have) load_raw(a, chunk_start + RB + (int32_t)tid, raw);  // in flight during the pixel loop
+        have = (b + 1 < n_chunks) && (int32_t)tid < FCH && (chunk_start + FCH + (int32_t)tid < range_end);
+        if (have) load_raw(a, chunk_start + FCH + (int32_t)tid, raw);  // in flight during the pixel loop
         if (wave_done) continue;
-        const int32_t chunk_size = min(RB, range_end - chunk_start);
+        const int32_t chunk_size = min(FCH, range_end - chunk_start);
         for (int32_t sub = 0; sub < chunk_size && !wave_done; sub += 64) {
             // one candidate Gaussian per lane: does its footprint touch this wave's quadrant?
             bool hit = false;
@@ -326,6 +335,7 @@ void launch_raster_fwd_fast(int kind, const RasterArgs& a, float* renders, float
 // instead of 96 for 16 independent 6-step reductions), added into an LDS accumulator, and one thread per
 // Gaussian turns the moments into (v_mean, v_quat, v_scale) and issues the 14 global atomics.
 constexpr int NMOM = 16;
+constexpr int BCH = 128;  // Gaussians per backward chunk (LDS: 16 B*4 planes + 64 B accumulators per Gaussian)
 
 // reduce x[0..15] over the 64 lanes; on return lane 16*r+15 holds in z[j] the total of value 4*j + {0,2,1,3}[r].
 // The swaps are issued through inline asm: with hipcc/ROCm 7.2 `r[0] + r[1]` on the result of
@@ -360,16 +370,16 @@ GSX_DEV void butterfly_reduce16(float (&x)[16], float (&z)[4]) {
 }
 
 template <int KIND>
-__global__ __launch_bounds__(RB) void raster_bwd_fast_kernel(RasterArgs a, const float* __restrict__ render_alphas,
+__global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(RasterArgs a, const float* __restrict__ render_alphas,
                                                              const int32_t* __restrict__ last_ids,
                                                              const float* __restrict__ v_render_colors,
                                                              const float* __restrict__ v_render_alphas,
                                                              float* __restrict__ v_means, float* __restrict__ v_quats,
                                                              float* __restrict__ v_scales, float* __restrict__ v_colors,
                                                              float* __restrict__ v_opacities) {
-    __shared__ float4 s_q0[RB], s_q1[RB], s_q2[RB], s_q3[RB];
-    __shared__ float s_acc[NMOM][RB];
-    __shared__ unsigned long long s_touched[RB / 64];
+    __shared__ float4 s_q0[BCH], s_q1[BCH], s_q2[BCH], s_q3[BCH];
+    __shared__ float s_acc[NMOM][BCH];
+    __shared__ unsigned long long s_touched[BCH / 64];
     __shared__ float s_bounds[4][4];
     __shared__ int32_t s_blockmax;
     const uint32_t cid = blockIdx.y;
@@ -414,12 +424,12 @@ __global__ __launch_bounds__(RB) void raster_bwd_fast_kernel(RasterArgs a, const
     __syncthreads();
     const int32_t block_last = min(s_blockmax, range_end - 1);
     if (block_last < range_start) return;
-    const int32_t n_chunks = (block_last - range_start + RB) / RB;
+    const int32_t n_chunks = (block_last - range_start + BCH) / BCH;
 
     for (int32_t b = 0; b < n_chunks; ++b) {
         __syncthreads();  // previous chunk's finishing step is done with the LDS planes
-        const int32_t chunk_end = block_last - RB * b;  // inclusive; slot t holds sorted index chunk_end - t
-        const int32_t chunk_size = min(RB, chunk_end + 1 - range_start);
+        const int32_t chunk_end = block_last - BCH * b;  // inclusive; slot t holds sorted index chunk_end - t
+        const int32_t chunk_size = min(BCH, chunk_end + 1 - range_start);
         RawG raw;
         const bool have = (int32_t)tid < chunk_size;
         if (have) {
@@ -431,9 +441,11 @@ __global__ __launch_bounds__(RB) void raster_bwd_fast_kernel(RasterArgs a, const
             s_q2[tid] = make_float4(r.d1, r.d2, r.d3, r.d4);
             s_q3[tid] = make_float4(r.d5, raw.rgb.x, raw.rgb.y, raw.rgb.z);
         }
+        if (tid < BCH) {
 #pragma unroll
-        for (int k = 0; k < NMOM; ++k) s_acc[k][tid] = 0.f;
-        if (tid < RB / 64) s_touched[tid] = 0ull;
+            for (int k = 0; k < NMOM; ++k) s_acc[k][tid] = 0.f;
+        }
+        if (tid < BCH / 64) s_touched[tid] = 0ull;
         __syncthreads();
 
         for (int32_t sub = 0; sub < chunk_size; sub += 64) {

@@ -40,22 +40,30 @@ class Camera:
 
 @dataclass
 class SplatData:
-    means: torch.Tensor       # [N,3]
-    sh0: torch.Tensor         # [N,1,3]
-    shN: torch.Tensor         # [N,K-1,3]
-    scaling_raw: torch.Tensor  # [N,3] log-scales
+    """Raw (pre-activation) parameters.  The reference keeps SH as two tensors `sh0 [N,1,3]` / `shN [N,K-1,3]` and
+    concatenates them every frame (`get_shs`, splat_data.cpp:284-286: a 192 MB copy per frame at 1M/deg 3, plus the
+    split in backward).  Here they are views of ONE `sh [N,K,3]` leaf, so `get_shs()` is free; a per-group learning
+    rate can still address `sh[:, :1]` and `sh[:, 1:]`."""
+    means: torch.Tensor         # [N,3]
+    sh: torch.Tensor            # [N,K,3]  (sh0 = sh[:, :1], shN = sh[:, 1:])
+    scaling_raw: torch.Tensor   # [N,3] log-scales
     rotation_raw: torch.Tensor  # [N,4] wxyz
     opacity_raw: torch.Tensor   # [N,1] logits
     active_sh_degree: int = 3
 
     def params(self):
-        return [self.means, self.sh0, self.shN, self.scaling_raw, self.rotation_raw, self.opacity_raw]
+        return [self.means, self.sh, self.scaling_raw, self.rotation_raw, self.opacity_raw]
+
+    @property
+    def sh0(self): return self.sh[:, :1]
+    @property
+    def shN(self): return self.sh[:, 1:]
 
     def get_means(self): return self.means
     def get_opacity(self): return torch.sigmoid(self.opacity_raw).squeeze(-1)
     def get_rotation(self): return torch.nn.functional.normalize(self.rotation_raw, dim=-1)
     def get_scaling(self): return torch.exp(self.scaling_raw)
-    def get_shs(self): return torch.cat([self.sh0, self.shN], 1)
+    def get_shs(self): return self.sh
 
 
 @dataclass

@@ -95,7 +95,7 @@ def to_splat_data(scene, device):
     from .rasterizer import SplatData
     sh = scene["sh"].to(device)
     op = scene["opacities"].to(device).clamp(1e-6, 1 - 1e-6)
-    return SplatData(means=scene["means"].to(device).clone(), sh0=sh[:, :1].contiguous().clone(),
-                     shN=sh[:, 1:].contiguous().clone(), scaling_raw=torch.log(scene["scales"].to(device)),
+    return SplatData(means=scene["means"].to(device).clone(), sh=sh.contiguous().clone(),
+                     scaling_raw=torch.log(scene["scales"].to(device)),
                      rotation_raw=scene["quats"].to(device).clone(), opacity_raw=torch.logit(op).unsqueeze(-1),
                      active_sh_degree=scene["sh_degree"])
