@@ -432,7 +432,7 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd(
     uint32_t image_height, uint32_t tile_size, const gsx_cameras* cams, const gsx_ut_params* ut,
     const int32_t* tile_offsets, const int32_t* flatten_ids, const float* render_alphas, const int32_t* last_ids,
     const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats, float* v_scales,
-    float* v_colors, float* v_opacities, void* stream) {
+    float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes, void* stream) {
     (void)ut;
     RasterArgs a;
     int rc = fill_args(a, N, n_isects, means, quats, scales, colors, channels, opacities, backgrounds, masks, image_width,
@@ -449,7 +449,7 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd(
     const bool hoist = cams->shutter == GSX_SHUTTER_GLOBAL;
     if (hoist && cam_kind(*cams) != CAM_OPENCV_FISHEYE && !force_generic()) {
         launch_raster_bwd_fast(cam_kind(*cams), a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats,
-                               v_scales, v_colors, v_opacities, st);
+                               v_scales, v_colors, v_opacities, workspace, workspace_bytes, st);
         return check_launch("rasterize_to_pixels_from_world_3dgs_bwd(fast)");
     }
 #define GSX_BWD(KIND)                                                                                                  \
@@ -464,4 +464,8 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd(
     }
 #undef GSX_BWD
     return check_launch("rasterize_to_pixels_from_world_3dgs_bwd");
+}
+
+extern "C" size_t gsx_rasterize_bwd_workspace_bytes(uint32_t C, uint32_t N, int64_t n_isects) {
+    return raster_bwd_fast_workspace_bytes(C, N, n_isects);
 }

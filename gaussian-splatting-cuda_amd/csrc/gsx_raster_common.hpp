@@ -34,6 +34,8 @@ GSX_DEV void thread_pixel(uint32_t tid, uint32_t tile_x, uint32_t tile_y, uint32
 void launch_raster_fwd_fast(int kind, const RasterArgs& a, float* renders, float* alphas, int32_t* last_ids, hipStream_t st);
 void launch_raster_bwd_fast(int kind, const RasterArgs& a, const float* render_alphas, const int32_t* last_ids,
                             const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats,
-                            float* v_scales, float* v_colors, float* v_opacities, hipStream_t st);
+                            float* v_scales, float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes,
+                            hipStream_t st);
+size_t raster_bwd_fast_workspace_bytes(uint32_t C, uint32_t N, int64_t n_isects);
 
 }  // namespace gsx

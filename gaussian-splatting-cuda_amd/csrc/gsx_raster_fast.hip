@@ -334,6 +334,11 @@ void launch_raster_fwd_fast(int kind, const RasterArgs& a, float* renders, float
 // (v_permlane32_swap / v_permlane16_swap halve the register count at each level; 40 VALU for 16 values
 // instead of 96 for 16 independent 6-step reductions), added into an LDS accumulator, and one thread per
 // Gaussian turns the moments into (v_mean, v_quat, v_scale) and issues the 14 global atomics.
+#if defined(GSX_ABLATE) && GSX_ABLATE == 4   // finishing math without the global atomics
+#define GSX_GATOMIC(p, v) do { if ((v) == 123.456f) *(p) = (v); } while (0)
+#else
+#define GSX_GATOMIC(p, v) atomicAdd((p), (v))
+#endif
 constexpr int NMOM = 16;
 constexpr int BCH = 128;  // Gaussians per backward chunk (LDS: 16 B*4 planes + 64 B accumulators per Gaussian)
 
@@ -376,7 +381,8 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
                                                              const float* __restrict__ v_render_alphas,
                                                              float* __restrict__ v_means, float* __restrict__ v_quats,
                                                              float* __restrict__ v_scales, float* __restrict__ v_colors,
-                                                             float* __restrict__ v_opacities) {
+                                                             float* __restrict__ v_opacities, float4* __restrict__ ws_rec,
+                                                             int32_t* __restrict__ ws_head) {
     __shared__ float4 s_q0[BCH], s_q1[BCH], s_q2[BCH], s_q3[BCH];
     __shared__ float s_acc[NMOM][BCH];
     __shared__ unsigned long long s_touched[BCH / 64];
@@ -485,8 +491,19 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
                 x[4] = aw * uu; x[5] = aw * uv; x[6] = aw * vv; x[7] = aw * du; x[8] = aw * dv;
                 x[9] = bw; x[10] = bw * du; x[11] = bw * dv; x[12] = bw * uu; x[13] = bw * uv; x[14] = bw * vv;
                 x[15] = 0.f;
+#if defined(GSX_ABLATE) && GSX_ABLATE == 1   // no cross-lane reduction: keep the values alive, skip butterfly + LDS atomics
+                { float sacc = 0.f;
+#pragma unroll
+                  for (int k = 0; k < 16; ++k) sacc += x[k];
+                  if (sacc == 123.456f) s_acc[0][t] = sacc; }
+                continue;
+#endif
                 float z[4];
                 butterfly_reduce16(x, z);
+#if defined(GSX_ABLATE) && GSX_ABLATE == 2   // butterfly but no LDS atomics
+                if (z[0] + z[1] + z[2] + z[3] == 123.456f) s_acc[0][t] = z[0];
+                continue;
+#endif
                 if ((lane & 15u) == 15u) {
                     const uint32_t row = lane >> 4;
                     const uint32_t k0 = (row == 1u) ? 2u : (row == 2u ? 1u : row);  // {0,2,1,3}
@@ -500,17 +517,21 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
         }
         __syncthreads();
 
-        // one thread per Gaussian of the chunk: moments -> (v_mean, v_quat, v_scale), 14 global atomics
+        // one thread per Gaussian of the chunk: moments -> (v_mean, v_quat, v_scale)
+#if defined(GSX_ABLATE) && GSX_ABLATE == 3   // no finishing step
+        if (false) {
+#else
         if (have && ((s_touched[tid >> 6] >> (tid & 63u)) & 1ull)) {
+#endif
             float Mo[NMOM];
 #pragma unroll
             for (int k = 0; k < NMOM; ++k) Mo[k] = s_acc[k][tid];
             const int32_t g = raw.g;
             const int32_t gi = (a.C == 1) ? g : (int32_t)((uint32_t)g % a.N);
-            atomicAdd(&v_colors[(size_t)g * 3], Mo[0]);
-            atomicAdd(&v_colors[(size_t)g * 3 + 1], Mo[1]);
-            atomicAdd(&v_colors[(size_t)g * 3 + 2], Mo[2]);
-            atomicAdd(&v_opacities[g], Mo[3] / raw.opac);
+            // out[]: v_colors 0-2, v_opacity 3, v_mean 4-6, v_quat 7-10, v_scale 11-13
+            float out[14];
+            out[0] = Mo[0]; out[1] = Mo[1]; out[2] = Mo[2];
+            out[3] = Mo[3] / raw.opac;
             FastRec r;
             make_record<true>(raw, cf, tb, r);
             const float kap = 2.f * r.inv_d0;
@@ -545,9 +566,9 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
             const float G_mx = G_u0 * imz, G_my = G_v0 * imz;
             G_mz += -(r.u0 * G_u0 + r.v0 * G_v0) * imz;
             // m = Rc^T (mu - c)  ->  v_mean = Rc G_m
-            atomicAdd(&v_means[(size_t)gi * 3], cf.Rc[0][0] * G_mx + cf.Rc[0][1] * G_my + cf.Rc[0][2] * G_mz);
-            atomicAdd(&v_means[(size_t)gi * 3 + 1], cf.Rc[1][0] * G_mx + cf.Rc[1][1] * G_my + cf.Rc[1][2] * G_mz);
-            atomicAdd(&v_means[(size_t)gi * 3 + 2], cf.Rc[2][0] * G_mx + cf.Rc[2][1] * G_my + cf.Rc[2][2] * G_mz);
+            out[4] = cf.Rc[0][0] * G_mx + cf.Rc[0][1] * G_my + cf.Rc[0][2] * G_mz;
+            out[5] = cf.Rc[1][0] * G_mx + cf.Rc[1][1] * G_my + cf.Rc[1][2] * G_mz;
+            out[6] = cf.Rc[2][0] * G_mx + cf.Rc[2][1] * G_my + cf.Rc[2][2] * G_mz;
             // A = M Rc  ->  G_M(i,k) = sum_j G_A(i,j) Rc(k,j)   (G_A(i,j) = component i of G_aj)
             const float GA[3][3] = {{G_a0.x, G_a1.x, G_a2.x}, {G_a0.y, G_a1.y, G_a2.y}, {G_a0.z, G_a1.z, G_a2.z}};
             float vMt[3][3];
@@ -570,28 +591,106 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
             const float qn[4] = {w, x_, y_, z_};
             const float dq = vq[0] * qn[0] + vq[1] * qn[1] + vq[2] * qn[2] + vq[3] * qn[3];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) atomicAdd(&v_quats[(size_t)gi * 4 + k], (vq[k] - dq * qn[k]) * inv_norm);
+            for (int k = 0; k < 4; ++k) out[7 + k] = (vq[k] - dq * qn[k]) * inv_norm;
             // v_scale[k] = -(1/s_k)^2 sum_r R(r,k) vMt[k][r],  R(r,k) = Mt[k][r] * s_k
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float sum = r.Mt[k][0] * vMt[k][0] + r.Mt[k][1] * vMt[k][1] + r.Mt[k][2] * vMt[k][2];
-                atomicAdd(&v_scales[(size_t)gi * 3 + k], -isv[k] * sum);
+                out[11 + k] = -isv[k] * sum;
+            }
+            if (ws_rec != nullptr) {
+                // atomic-free scatter: one 64 B record per (tile, Gaussian) at its sorted index, chained into a
+                // per-Gaussian list with ONE returning exchange; gsx_bwd_gather_kernel sums the lists afterwards
+                const int32_t isect = chunk_end - (int32_t)tid;
+                const int32_t prev = atomicExch(&ws_head[g], isect);
+                float4* rec = ws_rec + (size_t)isect * 4;
+                rec[0] = make_float4(out[0], out[1], out[2], out[3]);
+                rec[1] = make_float4(out[4], out[5], out[6], out[7]);
+                rec[2] = make_float4(out[8], out[9], out[10], out[11]);
+                rec[3] = make_float4(out[12], out[13], 0.f, __int_as_float(prev));
+            } else {
+                GSX_GATOMIC(&v_colors[(size_t)g * 3], out[0]);
+                GSX_GATOMIC(&v_colors[(size_t)g * 3 + 1], out[1]);
+                GSX_GATOMIC(&v_colors[(size_t)g * 3 + 2], out[2]);
+                GSX_GATOMIC(&v_opacities[g], out[3]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) GSX_GATOMIC(&v_means[(size_t)gi * 3 + k], out[4 + k]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) GSX_GATOMIC(&v_quats[(size_t)gi * 4 + k], out[7 + k]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) GSX_GATOMIC(&v_scales[(size_t)gi * 3 + k], out[11 + k]);
             }
         }
     }
 }
 
+// Sum the per-(tile, Gaussian) records of every Gaussian (lists built by raster_bwd_fast_kernel).  One thread per
+// Gaussian; colours / opacities are per camera, means / quats / scales are shared by the C cameras.
+__global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(uint32_t C, uint32_t N, const float4* __restrict__ ws_rec,
+                                                             const int32_t* __restrict__ ws_head, float* __restrict__ v_means,
+                                                             float* __restrict__ v_quats, float* __restrict__ v_scales,
+                                                             float* __restrict__ v_colors, float* __restrict__ v_opacities) {
+    const uint32_t gi = blockIdx.x * 256u + threadIdx.x;
+    if (gi >= N) return;
+    float geo[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) geo[k] = 0.f;
+    bool any_geo = false;
+    for (uint32_t c = 0; c < C; ++c) {
+        const size_t g = (size_t)c * N + gi;
+        int32_t i = ws_head[g];
+        if (i < 0) continue;
+        float col[4] = {0.f, 0.f, 0.f, 0.f};
+        while (i >= 0) {
+            const float4* rec = ws_rec + (size_t)i * 4;
+            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+            col[0] += r0.x; col[1] += r0.y; col[2] += r0.z; col[3] += r0.w;
+            geo[0] += r1.x; geo[1] += r1.y; geo[2] += r1.z; geo[3] += r1.w;
+            geo[4] += r2.x; geo[5] += r2.y; geo[6] += r2.z; geo[7] += r2.w;
+            geo[8] += r3.x; geo[9] += r3.y;
+            i = __float_as_int(r3.w);
+        }
+        any_geo = true;
+        v_colors[g * 3] += col[0]; v_colors[g * 3 + 1] += col[1]; v_colors[g * 3 + 2] += col[2];
+        v_opacities[g] += col[3];
+    }
+    if (any_geo) {
+        v_means[(size_t)gi * 3] += geo[0]; v_means[(size_t)gi * 3 + 1] += geo[1]; v_means[(size_t)gi * 3 + 2] += geo[2];
+        v_quats[(size_t)gi * 4] += geo[3]; v_quats[(size_t)gi * 4 + 1] += geo[4]; v_quats[(size_t)gi * 4 + 2] += geo[5];
+        v_quats[(size_t)gi * 4 + 3] += geo[6];
+        v_scales[(size_t)gi * 3] += geo[7]; v_scales[(size_t)gi * 3 + 1] += geo[8]; v_scales[(size_t)gi * 3 + 2] += geo[9];
+    }
+}
+
+size_t raster_bwd_fast_workspace_bytes(uint32_t C, uint32_t N, int64_t n_isects) {
+    // records (64 B per intersection) + list heads (4 B per (camera, Gaussian)), 256 B aligned
+    return (((size_t)n_isects * 64 + 255) / 256) * 256 + (((size_t)C * N * 4 + 255) / 256) * 256;
+}
+
 void launch_raster_bwd_fast(int kind, const RasterArgs& a, const float* render_alphas, const int32_t* last_ids,
                             const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats,
-                            float* v_scales, float* v_colors, float* v_opacities, hipStream_t st) {
+                            float* v_scales, float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes,
+                            hipStream_t st) {
     const uint32_t n_tiles = a.tw * a.th;
     const dim3 grid(((n_tiles + 7u) / 8u) * 8u, a.C), block(RB);
+    float4* ws_rec = nullptr;
+    int32_t* ws_head = nullptr;
+    if (workspace != nullptr && workspace_bytes >= raster_bwd_fast_workspace_bytes(a.C, a.N, a.n_isects)) {
+        ws_rec = (float4*)workspace;
+        ws_head = (int32_t*)((char*)workspace + (((size_t)a.n_isects * 64 + 255) / 256) * 256);
+        (void)hipMemsetAsync(ws_head, 0xFF, (size_t)a.C * a.N * 4, st);  // -1 = empty list
+    }
     if (kind == CAM_PERFECT_PINHOLE)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_fast_kernel<CAM_PERFECT_PINHOLE>), grid, block, 0, st, a, render_alphas,
-                           last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors, v_opacities);
+                           last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors, v_opacities, ws_rec,
+                           ws_head);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_fast_kernel<CAM_OPENCV_PINHOLE>), grid, block, 0, st, a, render_alphas,
-                           last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors, v_opacities);
+                           last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors, v_opacities, ws_rec,
+                           ws_head);
+    if (ws_rec != nullptr)
+        hipLaunchKernelGGL(gsx_bwd_gather_kernel, dim3((a.N + 255u) / 256u), dim3(256), 0, st, a.C, a.N, ws_rec, ws_head, v_means,
+                           v_quats, v_scales, v_colors, v_opacities);
 }
 
 }  // namespace gsx

@@ -264,6 +264,8 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
     at::Tensor v_scales = at::zeros_like(scales);
     at::Tensor v_colors = at::zeros_like(colors);
     at::Tensor v_opacities = at::zeros_like(opacities);
+    const size_t wsb = gsx_rasterize_bwd_workspace_bytes(C, N, flatten_ids.size(0));
+    at::Tensor ws = at::empty({(int64_t)wsb}, means.options().dtype(at::kByte));  // caching allocator, like CUB temp storage upstream
     check(gsx_rasterize_to_pixels_from_world_3dgs_bwd(
               N, flatten_ids.size(0), means.data_ptr<float>(), quats.data_ptr<float>(), scales.data_ptr<float>(),
               colors.data_ptr<float>(), channels, opacities.data_ptr<float>(), fptr(backgrounds), bptr(masks), image_width,
@@ -271,7 +273,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
               flatten_ids.numel() ? flatten_ids.data_ptr<int32_t>() : nullptr, render_alphas.data_ptr<float>(),
               last_ids.data_ptr<int32_t>(), v_render_colors.data_ptr<float>(), v_render_alphas.data_ptr<float>(),
               v_means.data_ptr<float>(), v_quats.data_ptr<float>(), v_scales.data_ptr<float>(), v_colors.data_ptr<float>(),
-              v_opacities.data_ptr<float>(), cur_stream()),
+              v_opacities.data_ptr<float>(), ws.data_ptr(), wsb, cur_stream()),
           "rasterize_to_pixels_from_world_3dgs_bwd");
     return std::make_tuple(v_means, v_quats, v_scales, v_colors, v_opacities);
 }

@@ -125,8 +125,13 @@ int gsx_rasterize_to_pixels_from_world_3dgs_fwd(uint32_t N, int64_t n_isects, co
                                                 const int32_t* tile_offsets, const int32_t* flatten_ids,
                                                 float* renders, float* alphas, int32_t* last_ids, void* stream);
 /* Gradient outputs v_means [N,3], v_quats [N,4], v_scales [N,3], v_colors [C,N,3], v_opacities [C,N]
- * must be zero-initialised by the caller (upstream: at::zeros_like, Rasterization.cpp:190-194);
- * the kernel accumulates into them with float atomics. */
+ * must be zero-initialised by the caller (upstream: at::zeros_like, Rasterization.cpp:190-194); the
+ * gradients are accumulated into them.
+ * `workspace` (optional; size from gsx_rasterize_bwd_workspace_bytes): with it the fast path writes one 64 B
+ * record per (tile, Gaussian) and sums them per Gaussian in a second kernel instead of issuing 14 device-scope
+ * float atomics per (tile, Gaussian) — on MI355X those atomics are served memory-side (the 8 XCD L2s are not
+ * coherent) and cost more than the whole rest of the kernel.  NULL / too small = accumulate with atomics. */
+size_t gsx_rasterize_bwd_workspace_bytes(uint32_t C, uint32_t N, int64_t n_isects);
 int gsx_rasterize_to_pixels_from_world_3dgs_bwd(uint32_t N, int64_t n_isects, const float* means,
                                                 const float* quats, const float* scales, const float* colors,
                                                 uint32_t channels, const float* opacities, const float* backgrounds,
@@ -136,7 +141,8 @@ int gsx_rasterize_to_pixels_from_world_3dgs_bwd(uint32_t N, int64_t n_isects, co
                                                 const float* render_alphas, const int32_t* last_ids,
                                                 const float* v_render_colors, const float* v_render_alphas,
                                                 float* v_means, float* v_quats, float* v_scales, float* v_colors,
-                                                float* v_opacities, void* stream);
+                                                float* v_opacities, void* workspace, size_t workspace_bytes,
+                                                void* stream);
 
 #ifdef __cplusplus
 }
