@@ -3,8 +3,10 @@
 rasterizer at 1 M Gaussians / SH degree 3 / 1920x1080 (configs[1], "S-1M"), on N GPUs of one node.
 
 A step = one pass of the hot path over one camera per rank:
-    projection_ut -> SH fwd -> (+0.5, clamp) -> intersect_tile (+sort) -> intersect_offset -> blend fwd
-    -> L1 loss -> blend bwd -> SH bwd -> activation Jacobians (torch) [-> gradient all-reduce when N > 1]
+    activations -> projection_ut -> SH colours (+0.5, clamp) -> intersect_tile (+sort) -> intersect_offset -> blend fwd
+    -> L1 loss -> blend bwd -> SH bwd -> activation Jacobians [-> gradient all-reduce when N > 1]
+Default: the fused glue kernels of rasterize_fused (gradients written straight into the flat all-reduce bucket);
+--unfused runs the reference-style chain of torch ops around the seven gsplat operators.
 Inputs are resident in HBM before the timed region.  N > 1: launched by torch.distributed.run, one rank per
 GPU over RCCL; every rank renders its own camera of the step's batch (cameras on a small orbit around the
 cfg2 pose so per-GPU work stays fixed: weak scaling) and the per-Gaussian gradients (59 fp32 / Gaussian, one
@@ -36,6 +38,11 @@ def algorithmic_bytes(N, C, I, P, tiles, deg, K):  # noqa: E741  (SURVEY.md §8d
         "projection_ut_3dgs_fused": 76 * N * C,
         "spherical_harmonics_fwd": N * C * (12 + 12 * nb + 1 + 12),
         "spherical_harmonics_bwd": N * C * (12 + 12 * nb + 1 + 12 + 12 * K + 12),
+        # fused variants: means instead of dirs, radii (8 B) instead of the mask; bwd also reads colours and v_means
+        "sh_colors_fwd": N * C * (12 + 12 * nb + 8 + 12),
+        "sh_colors_bwd": N * C * (12 + 12 * nb + 8 + 12 + 12 + 12 * K + 24),
+        "splat_activations_fwd": N * (40 + 44),
+        "splat_activations_bwd": N * (40 + 44 + 40),
         "intersect_tile": 20 * N * C + 12 * N * C + (28 * N * C + 12 * I) + 144 * I,
         "intersect_offset": 8 * I + 4 * tiles,
         "rasterize_to_pixels_from_world_3dgs_fwd": 60 * I + 20 * P + 4 * tiles,
@@ -50,7 +57,8 @@ class OpTimer:
     def __init__(self, ops_mod):
         self.ops = ops_mod
         self.names = ["projection_ut_3dgs_fused", "spherical_harmonics_fwd", "spherical_harmonics_bwd", "intersect_tile",
-                      "intersect_offset", "rasterize_to_pixels_from_world_3dgs_fwd", "rasterize_to_pixels_from_world_3dgs_bwd"]
+                      "intersect_offset", "rasterize_to_pixels_from_world_3dgs_fwd", "rasterize_to_pixels_from_world_3dgs_bwd",
+                      "sh_colors_fwd", "sh_colors_bwd", "splat_activations_fwd", "splat_activations_bwd"]
         self.orig = {n: getattr(ops_mod, n) for n in self.names}
         self.events = {n: [] for n in self.names}
         self.enabled = False
@@ -104,6 +112,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scene", default="1m", choices=["small", "1m", "5m"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="reference-style glue (one torch op per activation / SH pre-post step)")
     args = ap.parse_args()
 
     import gsx  # noqa: F401
@@ -135,9 +144,14 @@ def main():
     timer = OpTimer(ops)
     state = {}
 
+    sinks = bucket.sinks()
+
     def step():
-        bucket.zero_()
-        out = rasterizer.rasterize(cam, model, bg)
+        # fused glue: gradients are written straight into the flat bucket (no zero fill, no AccumulateGrad adds)
+        out = rasterizer.rasterize_fused(cam, model, bg, grad_sinks=sinks) if not args.unfused else None
+        if args.unfused:
+            bucket.zero_()
+            out = rasterizer.rasterize(cam, model, bg)
         loss = (out.image - target).abs().mean()
         loss.backward()
         bucket.all_reduce_mean()

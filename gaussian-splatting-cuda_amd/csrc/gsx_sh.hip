@@ -254,6 +254,218 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(uint32_t n, uint32_t K
 
 void set_error(const char* msg);
 
+// ------------------------------------------------------------------------------------------------
+// Fused glue kernels (extensions, not part of gsplat/Ops.h): they replace the chains of small torch ops the
+// reference's glue runs around the SH op every frame (src/training/rasterization/rasterizer.cpp:250-266):
+//   campos = inverse(viewmat)[:3,3]; dirs = means - campos; masks = (radii > 0).all(-1);
+//   colors = clamp_min(SH(dirs, coeffs, masks) + 0.5, 0)
+// and their autograd backward (clamp mask, SH backward, dirs -> means, sum over cameras of the broadcast coeffs).
+// One lane per Gaussian, all C cameras in a loop so the coefficient rows are staged through LDS once.
+// campos is computed as -R^T t (exact for a rigid world->camera transform; upstream uses torch::inverse).
+// ------------------------------------------------------------------------------------------------
+GSX_DEV f3 cam_position(const float* __restrict__ vm) {
+    const f3 t{vm[3], vm[7], vm[11]};
+    return {-(vm[0] * t.x + vm[4] * t.y + vm[8] * t.z), -(vm[1] * t.x + vm[5] * t.y + vm[9] * t.z),
+            -(vm[2] * t.x + vm[6] * t.y + vm[10] * t.z)};
+}
+
+template <int DEG>
+__global__ __launch_bounds__(SH_BLOCK) void sh_colors_fwd_kernel(uint32_t C, uint32_t N, uint32_t K,
+                                                                 const float* __restrict__ means,
+                                                                 const float* __restrict__ viewmats,
+                                                                 const float* __restrict__ coeffs,
+                                                                 const int32_t* __restrict__ radii,
+                                                                 float* __restrict__ colors) {
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    constexpr uint32_t NB3 = NB * 3;
+    constexpr uint32_t LS = NB3 | 1u;
+    extern __shared__ __attribute__((aligned(16))) float sh_lds[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t e0 = blockIdx.x * SH_BLOCK + wave * 64u;
+    const uint32_t e = e0 + lane;
+    bool any_live = false;
+    if (e < N)
+        for (uint32_t c = 0; c < C; ++c) {
+            const int2 r = reinterpret_cast<const int2*>(radii)[(size_t)c * N + e];
+            any_live |= (r.x > 0 && r.y > 0);
+        }
+    const unsigned long long live_mask = __ballot(any_live);
+    float* tile = sh_lds + wave * 64u * LS;
+    if (e0 < N) sh_stage_rows(coeffs, N, e0, K * 3u, NB3, live_mask, tile, LS, lane);
+    __syncthreads();
+    if (!any_live) return;
+    const f3 mu{means[(size_t)e * 3], means[(size_t)e * 3 + 1], means[(size_t)e * 3 + 2]};
+    const float* row = tile + lane * LS;
+    for (uint32_t c = 0; c < C; ++c) {
+        const int2 r = reinterpret_cast<const int2*>(radii)[(size_t)c * N + e];
+        if (!(r.x > 0 && r.y > 0)) continue;  // masked: output untouched, as the unfused op
+        const f3 cp = cam_position(viewmats + c * 16);
+        float x = mu.x - cp.x, y = mu.y - cp.y, z = mu.z - cp.z;
+        if (DEG >= 1) {
+            const float inorm = rsqrtf(x * x + y * y + z * z);
+            x *= inorm; y *= inorm; z *= inorm;
+        }
+        float Y[NB];
+        ShBasis<DEG>::template eval<false>(x, y, z, Y, nullptr, nullptr, nullptr);
+        float cr = 0.f, cg = 0.f, cb = 0.f;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            cr += Y[k] * row[k * 3];
+            cg += Y[k] * row[k * 3 + 1];
+            cb += Y[k] * row[k * 3 + 2];
+        }
+        float* o = colors + ((size_t)c * N + e) * 3;
+        o[0] = fmaxf(cr + 0.5f, 0.f); o[1] = fmaxf(cg + 0.5f, 0.f); o[2] = fmaxf(cb + 0.5f, 0.f);
+    }
+}
+
+// v_coeffs [N,K,3] is fully written (sum over cameras); v_means_inout [N,3] += d(colors)/d(means).
+template <int DEG>
+__global__ __launch_bounds__(SH_BLOCK) void sh_colors_bwd_kernel(uint32_t C, uint32_t N, uint32_t K,
+                                                                 const float* __restrict__ means,
+                                                                 const float* __restrict__ viewmats,
+                                                                 const float* __restrict__ coeffs,
+                                                                 const int32_t* __restrict__ radii,
+                                                                 const float* __restrict__ colors,
+                                                                 const float* __restrict__ v_colors,
+                                                                 float* __restrict__ v_coeffs,
+                                                                 const float* __restrict__ v_means_in,
+                                                                 float* __restrict__ v_means_out) {
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    constexpr uint32_t NB3 = NB * 3;
+    extern __shared__ __attribute__((aligned(16))) float sh_lds[];
+    const uint32_t K3 = K * 3u;
+    const uint32_t LS = K3 | 1u;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t e0 = blockIdx.x * SH_BLOCK + wave * 64u;
+    const uint32_t e = e0 + lane;
+    bool any_live = false;
+    if (e < N)
+        for (uint32_t c = 0; c < C; ++c) {
+            const int2 r = reinterpret_cast<const int2*>(radii)[(size_t)c * N + e];
+            any_live |= (r.x > 0 && r.y > 0);
+        }
+    float* tile = sh_lds + wave * 64u * LS;
+    float* row = tile + lane * LS;
+    if (DEG >= 1 && e0 < N) {
+        const unsigned long long live_mask = __ballot(any_live);
+        sh_stage_rows(coeffs, N, e0, K3, NB3, live_mask, tile, LS, lane);
+    }
+    __syncthreads();
+    float vc[NB3];
+#pragma unroll
+    for (int k = 0; k < (int)NB3; ++k) vc[k] = 0.f;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    if (any_live) {
+        const f3 mu{means[(size_t)e * 3], means[(size_t)e * 3 + 1], means[(size_t)e * 3 + 2]};
+        for (uint32_t c = 0; c < C; ++c) {
+            const size_t ce = (size_t)c * N + e;
+            const int2 r = reinterpret_cast<const int2*>(radii)[ce];
+            if (!(r.x > 0 && r.y > 0)) continue;
+            // clamp_min(x + 0.5, 0) passes the gradient where the output is positive
+            const float vr = colors[ce * 3] > 0.f ? v_colors[ce * 3] : 0.f;
+            const float vg = colors[ce * 3 + 1] > 0.f ? v_colors[ce * 3 + 1] : 0.f;
+            const float vb = colors[ce * 3 + 2] > 0.f ? v_colors[ce * 3 + 2] : 0.f;
+            const f3 cp = cam_position(viewmats + c * 16);
+            float x = mu.x - cp.x, y = mu.y - cp.y, z = mu.z - cp.z, inorm = 1.f;
+            if (DEG >= 1) {
+                inorm = rsqrtf(x * x + y * y + z * z);
+                x *= inorm; y *= inorm; z *= inorm;
+            }
+            float Y[NB], Yx[NB], Yy[NB], Yz[NB];
+            ShBasis<DEG>::template eval<(DEG >= 1)>(x, y, z, Y, Yx, Yy, Yz);
+            float vx = 0.f, vy = 0.f, vz = 0.f;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                vc[k * 3] += Y[k] * vr; vc[k * 3 + 1] += Y[k] * vg; vc[k * 3 + 2] += Y[k] * vb;
+                if (DEG >= 1 && k >= 1) {
+                    const float gk = row[k * 3] * vr + row[k * 3 + 1] * vg + row[k * 3 + 2] * vb;
+                    vx += Yx[k] * gk; vy += Yy[k] * gk; vz += Yz[k] * gk;
+                }
+            }
+            if (DEG >= 1) {
+                const float d = vx * x + vy * y + vz * z;
+                gx += (vx - d * x) * inorm; gy += (vy - d * y) * inorm; gz += (vz - d * z) * inorm;
+            }
+        }
+    }
+    __syncthreads();  // staged coefficients fully consumed: reuse the tile for the output rows
+    if (e < N) {
+#pragma unroll
+        for (int k = 0; k < (int)NB3; ++k) row[k] = vc[k];
+        for (uint32_t j = NB3; j < K3; ++j) row[j] = 0.f;
+    }
+    __syncthreads();
+    if (e0 < N) {
+        const uint32_t rows = min(64u, N - e0);
+        float* dst = v_coeffs + (size_t)e0 * K3;
+        if ((K3 & 3u) == 0u) {
+            const uint32_t q_per_row = K3 >> 2, total = rows * q_per_row;
+            for (uint32_t j = lane; j < total; j += 64) {
+                const uint32_t er = j / q_per_row, rr = (j - er * q_per_row) << 2;
+                const float* sp = tile + er * LS + rr;
+                reinterpret_cast<float4*>(dst)[j] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+            }
+        } else {
+            const uint32_t total = rows * K3;
+            for (uint32_t j = lane; j < total; j += 64) {
+                const uint32_t er = j / K3, rr = j - er * K3;
+                dst[j] = tile[er * LS + rr];
+            }
+        }
+    }
+    if (e < N) {
+        const float bx = v_means_in ? v_means_in[(size_t)e * 3] : 0.f, by = v_means_in ? v_means_in[(size_t)e * 3 + 1] : 0.f,
+                    bz = v_means_in ? v_means_in[(size_t)e * 3 + 2] : 0.f;
+        v_means_out[(size_t)e * 3] = bx + gx; v_means_out[(size_t)e * 3 + 1] = by + gy; v_means_out[(size_t)e * 3 + 2] = bz + gz;
+    }
+}
+
+// SplatData activations (reference: src/core/splat_data.cpp:267-286): scales = exp(raw) * modifier,
+// quats = raw / max(|raw|, 1e-12) (torch normalize), opacities = sigmoid(raw); and their backward.
+__global__ __launch_bounds__(256) void splat_activations_fwd_kernel(uint32_t N, const float* __restrict__ scaling_raw,
+                                                                    const float* __restrict__ rotation_raw,
+                                                                    const float* __restrict__ opacity_raw, float* __restrict__ scales,
+                                                                    float* __restrict__ quats, float* __restrict__ opacities) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= N) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) scales[(size_t)i * 3 + k] = expf(scaling_raw[(size_t)i * 3 + k]);
+    const float4 q = reinterpret_cast<const float4*>(rotation_raw)[i];
+    const float inv = 1.f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+    reinterpret_cast<float4*>(quats)[i] = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+    opacities[i] = 1.f / (1.f + expf(-opacity_raw[i]));
+}
+
+__global__ __launch_bounds__(256) void splat_activations_bwd_kernel(uint32_t N, const float* __restrict__ scaling_raw,
+                                                                    const float* __restrict__ rotation_raw,
+                                                                    const float* __restrict__ opacity_raw,
+                                                                    const float* __restrict__ v_scales, const float* __restrict__ v_quats,
+                                                                    const float* __restrict__ v_opacities,
+                                                                    float* __restrict__ v_scaling_raw, float* __restrict__ v_rotation_raw,
+                                                                    float* __restrict__ v_opacity_raw) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= N) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v_scaling_raw[(size_t)i * 3 + k] = v_scales[(size_t)i * 3 + k] * expf(scaling_raw[(size_t)i * 3 + k]);
+    const float4 q = reinterpret_cast<const float4*>(rotation_raw)[i];
+    const float4 g = reinterpret_cast<const float4*>(v_quats)[i];
+    const float nrm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    float4 o;
+    if (nrm > 1e-12f) {
+        const float inv = 1.f / nrm;
+        const float4 qn = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+        const float d = g.x * qn.x + g.y * qn.y + g.z * qn.z + g.w * qn.w;
+        o = make_float4((g.x - d * qn.x) * inv, (g.y - d * qn.y) * inv, (g.z - d * qn.z) * inv, (g.w - d * qn.w) * inv);
+    } else {
+        o = make_float4(g.x * 1e12f, g.y * 1e12f, g.z * 1e12f, g.w * 1e12f);
+    }
+    reinterpret_cast<float4*>(v_rotation_raw)[i] = o;
+    const float sg = 1.f / (1.f + expf(-opacity_raw[i]));
+    v_opacity_raw[i] = v_opacities[i] * sg * (1.f - sg);
+}
+
+
 template <int DEG> static int launch_sh_fwd(uint32_t n, uint32_t K, const float* dirs, const float* coeffs,
                                             const uint8_t* masks, float* colors, hipStream_t st) {
     constexpr uint32_t LS = ((DEG + 1) * (DEG + 1) * 3) | 1;
@@ -324,4 +536,56 @@ extern "C" int gsx_spherical_harmonics_bwd(uint32_t K, uint32_t degrees_to_use, 
     default: launch_sh_bwd<4>(n, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, st); break;
     }
     return check_launch("spherical_harmonics_bwd");
+}
+
+// ---- fused glue entry points (extensions; see include/gsx.h) ----------------------------------------------
+extern "C" int gsx_sh_colors_fwd(uint32_t degrees_to_use, uint32_t C, uint32_t N, uint32_t K, const float* means,
+                                 const float* viewmats, const float* coeffs, const int32_t* radii, float* colors, void* stream) {
+    if (N == 0 || C == 0) return GSX_OK;
+    if (!means || !viewmats || !coeffs || !radii || !colors) { set_error("sh_colors_fwd: null pointer"); return GSX_ERR_INVALID_ARGUMENT; }
+    if (degrees_to_use > 4 || (degrees_to_use + 1) * (degrees_to_use + 1) > K) { set_error("sh_colors_fwd: bad degree"); return GSX_ERR_INVALID_ARGUMENT; }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((N + SH_BLOCK - 1) / SH_BLOCK), block(SH_BLOCK);
+#define GSX_L(D) hipLaunchKernelGGL(HIP_KERNEL_NAME(sh_colors_fwd_kernel<D>), grid, block, (size_t)SH_BLOCK * ((((D + 1) * (D + 1) * 3) | 1)) * 4, st, C, N, K, means, viewmats, coeffs, radii, colors)
+    switch (degrees_to_use) { case 0: GSX_L(0); break; case 1: GSX_L(1); break; case 2: GSX_L(2); break; case 3: GSX_L(3); break; default: GSX_L(4); break; }
+#undef GSX_L
+    return check_launch("sh_colors_fwd");
+}
+
+extern "C" int gsx_sh_colors_bwd(uint32_t degrees_to_use, uint32_t C, uint32_t N, uint32_t K, const float* means,
+                                 const float* viewmats, const float* coeffs, const int32_t* radii, const float* colors,
+                                 const float* v_colors, float* v_coeffs, const float* v_means_in, float* v_means_out, void* stream) {
+    if (N == 0 || C == 0) return GSX_OK;
+    if (!means || !viewmats || !coeffs || !radii || !colors || !v_colors || !v_coeffs || !v_means_out) { set_error("sh_colors_bwd: null pointer"); return GSX_ERR_INVALID_ARGUMENT; }
+    if (degrees_to_use > 4 || (degrees_to_use + 1) * (degrees_to_use + 1) > K) { set_error("sh_colors_bwd: bad degree"); return GSX_ERR_INVALID_ARGUMENT; }
+    const size_t lds = (size_t)SH_BLOCK * ((K * 3u) | 1u) * sizeof(float);
+    if (lds > 160u * 1024u) { set_error("sh_colors_bwd: K too large for the LDS row tile (K <= 53)"); return GSX_ERR_UNSUPPORTED; }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((N + SH_BLOCK - 1) / SH_BLOCK), block(SH_BLOCK);
+#define GSX_L(D) hipLaunchKernelGGL(HIP_KERNEL_NAME(sh_colors_bwd_kernel<D>), grid, block, lds, st, C, N, K, means, viewmats, coeffs, radii, colors, v_colors, v_coeffs, v_means_in, v_means_out)
+    switch (degrees_to_use) { case 0: GSX_L(0); break; case 1: GSX_L(1); break; case 2: GSX_L(2); break; case 3: GSX_L(3); break; default: GSX_L(4); break; }
+#undef GSX_L
+    return check_launch("sh_colors_bwd");
+}
+
+extern "C" int gsx_splat_activations_fwd(uint32_t N, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                                         float* scales, float* quats, float* opacities, void* stream) {
+    if (N == 0) return GSX_OK;
+    if (!scaling_raw || !rotation_raw || !opacity_raw || !scales || !quats || !opacities) { set_error("splat_activations_fwd: null pointer"); return GSX_ERR_INVALID_ARGUMENT; }
+    hipLaunchKernelGGL(splat_activations_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, scaling_raw, rotation_raw,
+                       opacity_raw, scales, quats, opacities);
+    return check_launch("splat_activations_fwd");
+}
+
+extern "C" int gsx_splat_activations_bwd(uint32_t N, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                                         const float* v_scales, const float* v_quats, const float* v_opacities, float* v_scaling_raw,
+                                         float* v_rotation_raw, float* v_opacity_raw, void* stream) {
+    if (N == 0) return GSX_OK;
+    if (!scaling_raw || !rotation_raw || !opacity_raw || !v_scales || !v_quats || !v_opacities || !v_scaling_raw || !v_rotation_raw || !v_opacity_raw) {
+        set_error("splat_activations_bwd: null pointer");
+        return GSX_ERR_INVALID_ARGUMENT;
+    }
+    hipLaunchKernelGGL(splat_activations_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, scaling_raw, rotation_raw,
+                       opacity_raw, v_scales, v_quats, v_opacities, v_scaling_raw, v_rotation_raw, v_opacity_raw);
+    return check_launch("splat_activations_bwd");
 }

@@ -280,6 +280,79 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
 
 }  // namespace gsplat
 
+
+// ---------------------------------------------------------------------------------------------
+// Fused glue ops (extensions beyond gsplat/Ops.h; see include/gsx.h "fused glue")
+// ---------------------------------------------------------------------------------------------
+namespace gsx_ext {
+
+// colors [C,N,3] = clamp_min(SH(means - campos, coeffs | radii > 0) + 0.5, 0); masked rows are zero
+at::Tensor sh_colors_fwd(const uint32_t degrees_to_use, const at::Tensor means, const at::Tensor viewmats,
+                         const at::Tensor coeffs, const at::Tensor radii) {
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(means));
+    GSX_CHECK_INPUT(means); GSX_CHECK_INPUT(viewmats); GSX_CHECK_INPUT(coeffs); GSX_CHECK_INPUT(radii);
+    TORCH_CHECK(means.scalar_type() == at::kFloat && coeffs.scalar_type() == at::kFloat && radii.scalar_type() == at::kInt, "dtype");
+    const uint32_t C = viewmats.size(0), N = means.size(0), K = coeffs.size(-2);
+    at::Tensor colors = at::zeros({C, N, 3}, means.options());
+    check(gsx_sh_colors_fwd(degrees_to_use, C, N, K, means.data_ptr<float>(), viewmats.data_ptr<float>(), coeffs.data_ptr<float>(),
+                            radii.data_ptr<int32_t>(), colors.data_ptr<float>(), cur_stream()), "sh_colors_fwd");
+    return colors;
+}
+
+// writes v_coeffs (into `v_coeffs_out` if given) and v_means_out = v_means_in + d colors/d means (into `v_means_out` if given)
+std::tuple<at::Tensor, at::Tensor> sh_colors_bwd(const uint32_t degrees_to_use, const at::Tensor means, const at::Tensor viewmats,
+                                                 const at::Tensor coeffs, const at::Tensor radii, const at::Tensor colors,
+                                                 const at::Tensor v_colors, const at::optional<at::Tensor> v_means_in,
+                                                 const at::optional<at::Tensor> v_coeffs_out, const at::optional<at::Tensor> v_means_out) {
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(means));
+    GSX_CHECK_INPUT(means); GSX_CHECK_INPUT(viewmats); GSX_CHECK_INPUT(coeffs); GSX_CHECK_INPUT(radii); GSX_CHECK_INPUT(colors); GSX_CHECK_INPUT(v_colors);
+    const uint32_t C = viewmats.size(0), N = means.size(0), K = coeffs.size(-2);
+    at::Tensor vc = (v_coeffs_out.has_value() && v_coeffs_out->defined()) ? v_coeffs_out.value() : at::empty_like(coeffs);
+    at::Tensor vm = (v_means_out.has_value() && v_means_out->defined()) ? v_means_out.value() : at::empty_like(means);
+    GSX_CHECK_INPUT(vc); GSX_CHECK_INPUT(vm);
+    TORCH_CHECK(vc.numel() == coeffs.numel() && vm.numel() == means.numel(), "gradient sink has the wrong size");
+    const float* vmi = nullptr;
+    if (v_means_in.has_value() && v_means_in->defined()) { GSX_CHECK_INPUT(v_means_in.value()); vmi = v_means_in->data_ptr<float>(); }
+    check(gsx_sh_colors_bwd(degrees_to_use, C, N, K, means.data_ptr<float>(), viewmats.data_ptr<float>(), coeffs.data_ptr<float>(),
+                            radii.data_ptr<int32_t>(), colors.data_ptr<float>(), v_colors.data_ptr<float>(), vc.data_ptr<float>(), vmi,
+                            vm.data_ptr<float>(), cur_stream()), "sh_colors_bwd");
+    return std::make_tuple(vc, vm);
+}
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor> splat_activations_fwd(const at::Tensor scaling_raw, const at::Tensor rotation_raw,
+                                                                     const at::Tensor opacity_raw) {
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(scaling_raw));
+    GSX_CHECK_INPUT(scaling_raw); GSX_CHECK_INPUT(rotation_raw); GSX_CHECK_INPUT(opacity_raw);
+    const uint32_t N = scaling_raw.size(0);
+    at::Tensor scales = at::empty_like(scaling_raw), quats = at::empty_like(rotation_raw);
+    at::Tensor opac = at::empty({(int64_t)N}, scaling_raw.options());
+    check(gsx_splat_activations_fwd(N, scaling_raw.data_ptr<float>(), rotation_raw.data_ptr<float>(), opacity_raw.data_ptr<float>(),
+                                    scales.data_ptr<float>(), quats.data_ptr<float>(), opac.data_ptr<float>(), cur_stream()), "splat_activations_fwd");
+    return std::make_tuple(scales, quats, opac);
+}
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor> splat_activations_bwd(const at::Tensor scaling_raw, const at::Tensor rotation_raw,
+                                                                     const at::Tensor opacity_raw, const at::Tensor v_scales,
+                                                                     const at::Tensor v_quats, const at::Tensor v_opacities,
+                                                                     const at::optional<at::Tensor> out_scaling,
+                                                                     const at::optional<at::Tensor> out_rotation,
+                                                                     const at::optional<at::Tensor> out_opacity) {
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(scaling_raw));
+    GSX_CHECK_INPUT(scaling_raw); GSX_CHECK_INPUT(rotation_raw); GSX_CHECK_INPUT(opacity_raw);
+    GSX_CHECK_INPUT(v_scales); GSX_CHECK_INPUT(v_quats); GSX_CHECK_INPUT(v_opacities);
+    const uint32_t N = scaling_raw.size(0);
+    at::Tensor gs = (out_scaling.has_value() && out_scaling->defined()) ? out_scaling.value() : at::empty_like(scaling_raw);
+    at::Tensor gr = (out_rotation.has_value() && out_rotation->defined()) ? out_rotation.value() : at::empty_like(rotation_raw);
+    at::Tensor go = (out_opacity.has_value() && out_opacity->defined()) ? out_opacity.value() : at::empty_like(opacity_raw);
+    GSX_CHECK_INPUT(gs); GSX_CHECK_INPUT(gr); GSX_CHECK_INPUT(go);
+    check(gsx_splat_activations_bwd(N, scaling_raw.data_ptr<float>(), rotation_raw.data_ptr<float>(), opacity_raw.data_ptr<float>(),
+                                    v_scales.data_ptr<float>(), v_quats.data_ptr<float>(), v_opacities.data_ptr<float>(),
+                                    gs.data_ptr<float>(), gr.data_ptr<float>(), go.data_ptr<float>(), cur_stream()), "splat_activations_bwd");
+    return std::make_tuple(gs, gr, go);
+}
+
+}  // namespace gsx_ext
+
 // ---------------------------------------------------------------------------------------------
 // Python bindings (names as in gsplat/Ops.h)
 // ---------------------------------------------------------------------------------------------
@@ -311,5 +384,9 @@ PYBIND11_MODULE(_gsx_ops, m) {
     m.def("rasterize_to_pixels_from_world_3dgs_fwd", &gsplat::rasterize_to_pixels_from_world_3dgs_fwd);
     m.def("rasterize_to_pixels_from_world_3dgs_bwd", &gsplat::rasterize_to_pixels_from_world_3dgs_bwd);
     m.def("abi_version", []() { return gsx_abi_version(); });
+    m.def("sh_colors_fwd", &gsx_ext::sh_colors_fwd);
+    m.def("sh_colors_bwd", &gsx_ext::sh_colors_bwd);
+    m.def("splat_activations_fwd", &gsx_ext::splat_activations_fwd);
+    m.def("splat_activations_bwd", &gsx_ext::splat_activations_bwd);
 }
 #endif  // GSX_NO_PYBIND

@@ -39,6 +39,11 @@ class GradBucket:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
 
+    def sinks(self, names=("means", "sh", "scaling_raw", "rotation_raw", "opacity_raw")):
+        """name -> gradient view, for rasterize_fused(grad_sinks=...): backward overwrites the bucket in place."""
+        assert len(names) == len(self.params)
+        return {n: p.grad for n, p in zip(names, self.params)}
+
     def zero_(self):
         self.flat.zero_()
 

@@ -30,3 +30,9 @@ projection_ut_3dgs_fused = _C.projection_ut_3dgs_fused
 rasterize_to_pixels_from_world_3dgs_fwd = _C.rasterize_to_pixels_from_world_3dgs_fwd
 rasterize_to_pixels_from_world_3dgs_bwd = _C.rasterize_to_pixels_from_world_3dgs_bwd
 abi_version = _C.abi_version
+
+# fused glue ops (extensions beyond Ops.h; include/gsx.h "fused glue")
+sh_colors_fwd = _C.sh_colors_fwd
+sh_colors_bwd = _C.sh_colors_bwd
+splat_activations_fwd = _C.splat_activations_fwd
+splat_activations_bwd = _C.splat_activations_bwd

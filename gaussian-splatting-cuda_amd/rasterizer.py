@@ -234,3 +234,86 @@ def rasterize(camera: Camera, model: SplatData, bg_color: Optional[torch.Tensor]
     out.n_isects = int(flatten_ids.shape[0])
     out.aux = dict(isect_offsets=isect_offsets, flatten_ids=flatten_ids, colors=colors, radii_full=radii)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Fused render: the same pipeline as rasterize(), RGB mode, with the chains of small torch ops replaced by the
+# fused glue kernels (activations, campos/dirs/masks/SH/+0.5/clamp) and ONE autograd node for the whole render.
+# Gradients can be written straight into caller-provided buffers (`grad_sinks`, e.g. the views of a flat
+# all-reduce bucket): no zero fill and no AccumulateGrad add pass over the 192 MB SH gradient.
+# ---------------------------------------------------------------------------------------------------------
+class GutRenderFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, sh, scaling_raw, rotation_raw, opacity_raw, viewmat, K, bg, width, height, sh_degree, scaling_modifier,
+                camera_model, radial, tangential, grad_sinks):
+        ut = ops.UnscentedTransformParameters()
+        means_c, sh_c = means.contiguous(), sh.contiguous()
+        sr, rr, orw = scaling_raw.contiguous(), rotation_raw.contiguous(), opacity_raw.reshape(-1).contiguous()
+        scales, quats, opac = ops.splat_activations_fwd(sr, rr, orw)
+        if scaling_modifier != 1.0:
+            scales = scales * scaling_modifier
+        radii, means2d, depths, conics, _ = ops.projection_ut_3dgs_fused(
+            means_c, quats, scales, opac, viewmat, None, K, width, height, EPS2D, NEAR_PLANE, FAR_PLANE, RADIUS_CLIP, False,
+            camera_model, ut, ops.ShutterType.GLOBAL, radial, tangential, None)
+        colors = ops.sh_colors_fwd(sh_degree, means_c, viewmat, sh_c, radii)
+        tw, th = (width + TILE_SIZE - 1) // TILE_SIZE, (height + TILE_SIZE - 1) // TILE_SIZE
+        _, isect_ids, flatten_ids = ops.intersect_tile(means2d, radii, depths, None, None, 1, TILE_SIZE, tw, th, True)
+        isect_offsets = ops.intersect_offset(isect_ids, 1, tw, th)
+        opac2 = opac.unsqueeze(0)
+        renders, alphas, last_ids = ops.rasterize_to_pixels_from_world_3dgs_fwd(
+            means_c, quats, scales, colors, opac2, bg, None, width, height, TILE_SIZE, viewmat, None, K, camera_model, ut,
+            ops.ShutterType.GLOBAL, radial, tangential, None, isect_offsets, flatten_ids)
+        ctx.save_for_backward(means_c, sh_c, sr, rr, orw, scales, quats, opac2, colors, radii, viewmat, K, isect_offsets,
+                              flatten_ids, alphas, last_ids)
+        ctx.extra = (bg, width, height, sh_degree, scaling_modifier, camera_model, radial, tangential, grad_sinks, ut)
+        ctx.mark_non_differentiable(radii, means2d, depths, flatten_ids, isect_offsets)
+        return renders, alphas, radii, means2d, depths, flatten_ids, isect_offsets
+
+    @staticmethod
+    def backward(ctx, v_renders, v_alphas, *unused):
+        (means, sh, sr, rr, orw, scales, quats, opac2, colors, radii, viewmat, K, isect_offsets, flatten_ids, alphas,
+         last_ids) = ctx.saved_tensors
+        bg, width, height, sh_degree, scaling_modifier, camera_model, radial, tangential, sinks, ut = ctx.extra
+        v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_to_pixels_from_world_3dgs_bwd(
+            means, quats, scales, colors, opac2, bg, None, width, height, TILE_SIZE, viewmat, None, K, camera_model, ut,
+            ops.ShutterType.GLOBAL, radial, tangential, None, isect_offsets, flatten_ids, alphas, last_ids,
+            v_renders.contiguous(), v_alphas.contiguous())
+        if scaling_modifier != 1.0:
+            v_scales = v_scales * scaling_modifier
+        s = sinks or {}
+        v_sh, v_means = ops.sh_colors_bwd(sh_degree, means, viewmat, sh, radii, colors, v_colors, v_means, s.get("sh"), s.get("means"))
+        g_s, g_r, g_o = ops.splat_activations_bwd(sr, rr, orw, v_scales, v_quats, v_opac.reshape(-1), s.get("scaling_raw"),
+                                                 s.get("rotation_raw"), s.get("opacity_raw"))
+        v_bg = None
+        if bg is not None and ctx.needs_input_grad[7]:
+            v_bg = (v_renders * (1.0 - alphas)).float().sum(dim=(-3, -2))
+        if sinks:  # gradients already sit in the caller's buffers
+            return (None,) * 7 + (v_bg,) + (None,) * 8
+        return (v_means, v_sh, g_s, g_r, g_o.reshape(-1, 1), None, None, v_bg) + (None,) * 8
+
+
+def rasterize_fused(camera: Camera, model: SplatData, bg_color: Optional[torch.Tensor], scaling_modifier: float = 1.0,
+                    sh_degree: Optional[int] = None, grad_sinks: Optional[dict] = None,
+                    with_visibility: bool = False) -> RenderOutput:
+    """Same result as rasterize() (RGB mode) through the fused glue kernels.  `grad_sinks` maps
+    {"means","sh","scaling_raw","rotation_raw","opacity_raw"} to preallocated gradient buffers that backward
+    overwrites (autograd then sees no gradient for the parameters: use the sinks as `.grad`)."""
+    W, H = int(camera.width), int(camera.height)
+    viewmat, K = camera.world_view_transform().contiguous(), camera.K_batched().contiguous()
+    sh_degree = model.active_sh_degree if sh_degree is None else sh_degree
+    cam_model = camera.camera_model if camera.camera_model is not None else ops.CameraModelType.PINHOLE
+    bg = bg_color.reshape(1, -1).to(model.means.device).contiguous() if (bg_color is not None and bg_color.numel() > 0) else None
+    renders, alphas, radii, means2d, depths, flatten_ids, isect_offsets = GutRenderFunction.apply(
+        model.means, model.sh, model.scaling_raw, model.rotation_raw, model.opacity_raw, viewmat, K, bg, W, H, sh_degree,
+        scaling_modifier, cam_model, None, None, grad_sinks)
+    out = RenderOutput()
+    out.image = torch.clamp(renders.squeeze(0).permute(2, 0, 1), 0.0, 1.0)
+    out.alpha = alphas.squeeze(0).permute(2, 0, 1)
+    out.means2d, out.depths = means2d, depths.squeeze(0)
+    if with_visibility:  # only the densification strategies read these (three more N-sized kernels)
+        out.radii = radii.squeeze(0).max(-1).values
+        out.visibility = out.radii > 0
+    out.width, out.height = W, H
+    out.n_isects = int(flatten_ids.shape[0])
+    out.aux = dict(isect_offsets=isect_offsets, flatten_ids=flatten_ids, radii_full=radii)
+    return out

@@ -144,6 +144,25 @@ int gsx_rasterize_to_pixels_from_world_3dgs_bwd(uint32_t N, int64_t n_isects, co
                                                 float* v_opacities, void* workspace, size_t workspace_bytes,
                                                 void* stream);
 
+/* ---- fused glue (extensions beyond gsplat/Ops.h) --------------------------------------------------
+ * The reference's render glue wraps the operators in chains of small torch ops every frame; on MI355X those
+ * ~40 launches cost as much as a blend kernel.  These entry points fuse them; results are identical to the
+ * unfused sequence (tests/test_gpu_fused.py).
+ *   gsx_sh_colors_*:        rasterizer.cpp:250-266  campos/dirs/masks/SH/+0.5/clamp_min (and their backward,
+ *                           incl. the dirs->means gradient and the sum over cameras of the broadcast coeffs)
+ *   gsx_splat_activations_*: splat_data.cpp:267-286  exp / normalize / sigmoid (and their backward) */
+int gsx_sh_colors_fwd(uint32_t degrees_to_use, uint32_t C, uint32_t N, uint32_t K, const float* means,
+                      const float* viewmats, const float* coeffs, const int32_t* radii, float* colors, void* stream);
+/* v_coeffs [N,K,3] fully written; v_means_out [N,3] = (v_means_in or 0) + d colors / d means */
+int gsx_sh_colors_bwd(uint32_t degrees_to_use, uint32_t C, uint32_t N, uint32_t K, const float* means,
+                      const float* viewmats, const float* coeffs, const int32_t* radii, const float* colors,
+                      const float* v_colors, float* v_coeffs, const float* v_means_in, float* v_means_out, void* stream);
+int gsx_splat_activations_fwd(uint32_t N, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                              float* scales, float* quats, float* opacities, void* stream);
+int gsx_splat_activations_bwd(uint32_t N, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                              const float* v_scales, const float* v_quats, const float* v_opacities, float* v_scaling_raw,
+                              float* v_rotation_raw, float* v_opacity_raw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

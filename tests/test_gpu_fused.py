@@ -1,0 +1,85 @@
+"""The fused render (rasterize_fused: fused activation / SH-colour glue kernels, one autograd node, optional gradient
+sinks) must give the same image and the same parameter gradients as the reference-style chain (rasterize)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import gsx  # noqa: F401
+    from gsx import distributed, ops, rasterizer, scenes
+    return distributed, ops, rasterizer, scenes
+
+
+def _setup(scenes, rasterizer, deg):
+    sc = scenes.scene_small(seed=17, N=6000)
+    sc["width"], sc["height"] = 160, 112
+    sc["K"] = scenes.intrinsics(120.0, 120.0, 80.0, 56.0)
+    g = torch.Generator().manual_seed(3)
+    sc["sh"] = (torch.rand(6000, 16, 3, generator=g) - 0.5) * 0.6
+    sc["sh_degree"] = deg
+    vm = scenes.look_at_viewmat((0.3, -0.2, -0.5), (0.0, 0.0, 2.5))
+    sc["viewmat"] = vm
+    cam = rasterizer.Camera(viewmat=vm.to(DEV), K=sc["K"].to(DEV), width=160, height=112)
+    return sc, cam
+
+
+@pytest.mark.parametrize("deg", [0, 2, 3])
+def test_fused_equals_unfused(mods, deg):
+    distributed, ops, rasterizer, scenes = mods
+    sc, cam = _setup(scenes, rasterizer, deg)
+    bg = sc["background"].to(DEV) + 0.2
+    w = torch.linspace(0.5, 1.5, 160, device=DEV)
+
+    def run(fn, **kw):
+        model = scenes.to_splat_data(sc, DEV)
+        for p in model.params():
+            p.requires_grad_(True)
+        out = fn(cam, model, bg, **kw)
+        ((out.image * w).sum() + 0.3 * out.alpha.sum()).backward()
+        return model, out
+
+    m_ref, o_ref = run(rasterizer.rasterize)
+    m_fus, o_fus = run(rasterizer.rasterize_fused)
+    assert o_ref.n_isects == o_fus.n_isects
+    assert float((o_ref.image - o_fus.image).abs().max()) < 2e-5
+    assert float((o_ref.alpha - o_fus.alpha).abs().max()) < 2e-5
+    for a, b, n in zip(m_ref.params(), m_fus.params(), ["means", "sh", "scaling_raw", "rotation_raw", "opacity_raw"]):
+        e = rel_l2(b.grad.cpu().numpy(), a.grad.cpu().numpy())
+        assert e < 1e-3, (n, e)
+    # gradient sinks: backward writes into the flat bucket, autograd sees no gradient
+    model = scenes.to_splat_data(sc, DEV)
+    for p in model.params():
+        p.requires_grad_(True)
+    bucket = distributed.GradBucket(model.params())
+    bucket.flat.fill_(float("nan"))       # every element must be overwritten
+    out = rasterizer.rasterize_fused(cam, model, bg, grad_sinks=bucket.sinks())
+    ((out.image * w).sum() + 0.3 * out.alpha.sum()).backward()
+    assert bool(torch.isfinite(bucket.flat).all())
+    for a, b, n in zip(m_fus.params(), model.params(), ["means", "sh", "scaling_raw", "rotation_raw", "opacity_raw"]):
+        assert rel_l2(b.grad.cpu().numpy(), a.grad.cpu().numpy()) < 1e-4, n
+
+
+def test_fused_ops_vs_torch(mods):
+    """The two fused glue ops against the torch expressions they replace."""
+    _, ops, _, _ = mods
+    g = torch.Generator(device=DEV).manual_seed(0)
+    N = 5000
+    sr = torch.randn(N, 3, device=DEV, generator=g) * 0.5 - 3
+    rr = torch.randn(N, 4, device=DEV, generator=g)
+    orw = torch.randn(N, device=DEV, generator=g)
+    s, q, o = ops.splat_activations_fwd(sr, rr, orw)
+    assert torch.allclose(s, torch.exp(sr), rtol=1e-6, atol=0) and torch.allclose(o, torch.sigmoid(orw), rtol=1e-6, atol=1e-7)
+    assert torch.allclose(q, torch.nn.functional.normalize(rr, dim=-1), rtol=1e-6, atol=1e-7)
+    sr2, rr2, or2 = (t.clone().requires_grad_(True) for t in (sr, rr, orw))
+    vs, vq, vo = torch.randn_like(sr), torch.randn_like(rr), torch.randn_like(orw)
+    (torch.exp(sr2) * vs).sum().backward(); (torch.nn.functional.normalize(rr2, dim=-1) * vq).sum().backward(); (torch.sigmoid(or2) * vo).sum().backward()
+    gs, gr, go = ops.splat_activations_bwd(sr, rr, orw, vs, vq, vo, None, None, None)
+    assert torch.allclose(gs, sr2.grad, rtol=1e-5, atol=1e-7) and torch.allclose(gr, rr2.grad, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(go, or2.grad, rtol=1e-5, atol=1e-7)
