@@ -448,9 +448,9 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd(
     hipStream_t st = (hipStream_t)stream;
     const bool hoist = cams->shutter == GSX_SHUTTER_GLOBAL;
     if (hoist && cam_kind(*cams) != CAM_OPENCV_FISHEYE && !force_generic()) {
-        launch_raster_bwd_fast(cam_kind(*cams), a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats,
-                               v_scales, v_colors, v_opacities, workspace, workspace_bytes, st);
-        return check_launch("rasterize_to_pixels_from_world_3dgs_bwd(fast)");
+        if (launch_raster_bwd_fast(cam_kind(*cams), a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats,
+                                   v_scales, v_colors, v_opacities, workspace, workspace_bytes, st))
+            return check_launch("rasterize_to_pixels_from_world_3dgs_bwd(fast)");
     }
 #define GSX_BWD(KIND)                                                                                                  \
     do {                                                                                                               \

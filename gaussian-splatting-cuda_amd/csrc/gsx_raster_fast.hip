@@ -325,22 +325,29 @@ void launch_raster_fwd_fast(int kind, const RasterArgs& a, float* renders, float
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
-// With D = N/Dn, N = |du B0 + dv B1|^2, Dn = |h + a0 du + a1 dv|^2 every parameter gradient is a linear
-// combination of 11 per-(tile, Gaussian) pixel moments
+// With D = N/Dn, N = |du B0 + dv B1|^2, Dn = |h + a0 du + a1 dv|^2 every parameter gradient is LINEAR in 11
+// pixel moments of each (camera, Gaussian)
 //     Ma = sum a {du^2, du dv, dv^2, du, dv},   Mb = sum b {1, du, dv, du^2, du dv, dv^2},
-//     a = (dL/dD) / den',  b = a D
-// plus v_rgb[3] and the opacity term: 15 sums (+1 lane count) per evaluated (wave, Gaussian), instead of the
-// reference's 14 per-pixel chain-ruled floats.  The sums are reduced over the wave by a multi-value butterfly
-// (v_permlane32_swap / v_permlane16_swap halve the register count at each level; 40 VALU for 16 values
-// instead of 96 for 16 independent 6-step reductions), added into an LDS accumulator, and one thread per
-// Gaussian turns the moments into (v_mean, v_quat, v_scale) and issues the 14 global atomics.
-#if defined(GSX_ABLATE) && GSX_ABLATE == 4   // finishing math without the global atomics
-#define GSX_GATOMIC(p, v) do { if ((v) == 123.456f) *(p) = (v); } while (0)
-#else
+//     a = (dL/dD) / den',  b = a D,
+// plus v_rgb[3] and the opacity term: 15 sums.  The coefficients of that linear map depend on the Gaussian and
+// the camera only — not on the tile — so the kernel accumulates moments and the chain rule runs ONCE per
+// (camera, Gaussian) afterwards (gsx_bwd_gather_kernel), not once per (tile, Gaussian).
+//
+// Per evaluated (wave, Gaussian) every lane produces its pixel's 15 terms; they are reduced over the wave by a
+// multi-value butterfly (v_permlane32_swap / v_permlane16_swap halve the register count at each level: 40 VALU for
+// 16 values instead of 96 for 16 independent 6-step reductions) and added to the chunk's LDS accumulator.
+// (A two-phase variant — park per-pair weights in LDS, then fold pixels per Gaussian with lanes = Gaussians —
+// was measured too: 26 % fewer VALU instructions but twice the LDS traffic, 1.35 ms vs 1.24 ms; not kept.)
+// At the end of a chunk one thread per touched Gaussian writes its 64 B moment record to the workspace and chains
+// it into the Gaussian's list with one returning exchange: no float atomics reach memory (on MI355X the 8 XCD L2s
+// are not coherent, device-scope float atomics are served memory-side and 14 of them per (tile, Gaussian) cost
+// more than all the arithmetic of the kernel).
+constexpr int NMOM = 16;
+constexpr int BCH = 128;  // Gaussians per backward chunk
+
+#if defined(GSX_ABLATE)
 #define GSX_GATOMIC(p, v) atomicAdd((p), (v))
 #endif
-constexpr int NMOM = 16;
-constexpr int BCH = 128;  // Gaussians per backward chunk (LDS: 16 B*4 planes + 64 B accumulators per Gaussian)
 
 // reduce x[0..15] over the 64 lanes; on return lane 16*r+15 holds in z[j] the total of value 4*j + {0,2,1,3}[r].
 // The swaps are issued through inline asm: with hipcc/ROCm 7.2 `r[0] + r[1]` on the result of
@@ -376,16 +383,14 @@ GSX_DEV void butterfly_reduce16(float (&x)[16], float (&z)[4]) {
 
 template <int KIND>
 __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(RasterArgs a, const float* __restrict__ render_alphas,
-                                                             const int32_t* __restrict__ last_ids,
-                                                             const float* __restrict__ v_render_colors,
-                                                             const float* __restrict__ v_render_alphas,
-                                                             float* __restrict__ v_means, float* __restrict__ v_quats,
-                                                             float* __restrict__ v_scales, float* __restrict__ v_colors,
-                                                             float* __restrict__ v_opacities, float4* __restrict__ ws_rec,
-                                                             int32_t* __restrict__ ws_head) {
+                                                                            const int32_t* __restrict__ last_ids,
+                                                                            const float* __restrict__ v_render_colors,
+                                                                            const float* __restrict__ v_render_alphas,
+                                                                            float4* __restrict__ ws_rec, int32_t* __restrict__ ws_head) {
     __shared__ float4 s_q0[BCH], s_q1[BCH], s_q2[BCH], s_q3[BCH];
     __shared__ float s_acc[NMOM][BCH];
-    __shared__ unsigned long long s_touched[BCH / 64];
+    __shared__ int32_t s_gid[BCH];
+    __shared__ unsigned long long s_touched[(BCH + 63) / 64];
     __shared__ float s_bounds[4][4];
     __shared__ int32_t s_blockmax;
     const uint32_t cid = blockIdx.y;
@@ -433,12 +438,11 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
     const int32_t n_chunks = (block_last - range_start + BCH) / BCH;
 
     for (int32_t b = 0; b < n_chunks; ++b) {
-        __syncthreads();  // previous chunk's finishing step is done with the LDS planes
+        __syncthreads();  // previous chunk's records are written, LDS planes are free
         const int32_t chunk_end = block_last - BCH * b;  // inclusive; slot t holds sorted index chunk_end - t
         const int32_t chunk_size = min(BCH, chunk_end + 1 - range_start);
-        RawG raw;
-        const bool have = (int32_t)tid < chunk_size;
-        if (have) {
+        if ((int32_t)tid < chunk_size) {
+            RawG raw;
             load_raw(a, chunk_end - (int32_t)tid, raw);
             FastRec r;
             make_record<false>(raw, cf, tb, r);
@@ -446,12 +450,13 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
             s_q1[tid] = make_float4(r.l00, r.l01, r.l11, r.lo);
             s_q2[tid] = make_float4(r.d1, r.d2, r.d3, r.d4);
             s_q3[tid] = make_float4(r.d5, raw.rgb.x, raw.rgb.y, raw.rgb.z);
+            s_gid[tid] = raw.g;
         }
         if (tid < BCH) {
 #pragma unroll
             for (int k = 0; k < NMOM; ++k) s_acc[k][tid] = 0.f;
         }
-        if (tid < BCH / 64) s_touched[tid] = 0ull;
+        if (tid < (BCH + 63) / 64) s_touched[tid] = 0ull;
         __syncthreads();
 
         for (int32_t sub = 0; sub < chunk_size; sub += 64) {
@@ -491,19 +496,8 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
                 x[4] = aw * uu; x[5] = aw * uv; x[6] = aw * vv; x[7] = aw * du; x[8] = aw * dv;
                 x[9] = bw; x[10] = bw * du; x[11] = bw * dv; x[12] = bw * uu; x[13] = bw * uv; x[14] = bw * vv;
                 x[15] = 0.f;
-#if defined(GSX_ABLATE) && GSX_ABLATE == 1   // no cross-lane reduction: keep the values alive, skip butterfly + LDS atomics
-                { float sacc = 0.f;
-#pragma unroll
-                  for (int k = 0; k < 16; ++k) sacc += x[k];
-                  if (sacc == 123.456f) s_acc[0][t] = sacc; }
-                continue;
-#endif
                 float z[4];
                 butterfly_reduce16(x, z);
-#if defined(GSX_ABLATE) && GSX_ABLATE == 2   // butterfly but no LDS atomics
-                if (z[0] + z[1] + z[2] + z[3] == 123.456f) s_acc[0][t] = z[0];
-                continue;
-#endif
                 if ((lane & 15u) == 15u) {
                     const uint32_t row = lane >> 4;
                     const uint32_t k0 = (row == 1u) ? 2u : (row == 2u ? 1u : row);  // {0,2,1,3}
@@ -517,144 +511,128 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
         }
         __syncthreads();
 
-        // one thread per Gaussian of the chunk: moments -> (v_mean, v_quat, v_scale)
-#if defined(GSX_ABLATE) && GSX_ABLATE == 3   // no finishing step
-        if (false) {
-#else
-        if (have && ((s_touched[tid >> 6] >> (tid & 63u)) & 1ull)) {
-#endif
-            float Mo[NMOM];
-#pragma unroll
-            for (int k = 0; k < NMOM; ++k) Mo[k] = s_acc[k][tid];
-            const int32_t g = raw.g;
-            const int32_t gi = (a.C == 1) ? g : (int32_t)((uint32_t)g % a.N);
-            // out[]: v_colors 0-2, v_opacity 3, v_mean 4-6, v_quat 7-10, v_scale 11-13
-            float out[14];
-            out[0] = Mo[0]; out[1] = Mo[1]; out[2] = Mo[2];
-            out[3] = Mo[3] / raw.opac;
-            FastRec r;
-            make_record<true>(raw, cf, tb, r);
-            const float kap = 2.f * r.inv_d0;
-            const float Mauu = Mo[4] * kap, Mauv = Mo[5] * kap, Mavv = Mo[6] * kap, Mau = Mo[7] * kap, Mav = Mo[8] * kap;
-            const float kb = kap / HALF_LOG2E;  // b was accumulated with D scaled by 0.5 log2 e
-            const float Mb1 = Mo[9] * kb, Mbu = Mo[10] * kb, Mbv = Mo[11] * kb, Mbuu = Mo[12] * kb, Mbuv = Mo[13] * kb, Mbvv = Mo[14] * kb;
-            // direct gradients
-            const f3 G_B0 = r.B0 * Mauu + r.B1 * Mauv;
-            const f3 G_B1 = r.B0 * Mauv + r.B1 * Mavv;
-            float G_u0 = -(dot3(r.B0, r.B0) * Mau + dot3(r.B0, r.B1) * Mav);
-            float G_v0 = -(dot3(r.B0, r.B1) * Mau + dot3(r.B1, r.B1) * Mav);
-            const f3 G_h = (r.h * Mb1 + r.a0 * Mbu + r.a1 * Mbv) * -1.f;
-            f3 G_a0 = (r.h * Mbu + r.a0 * Mbuu + r.a1 * Mbuv) * -1.f;
-            f3 G_a1 = (r.h * Mbv + r.a0 * Mbuv + r.a1 * Mbvv) * -1.f;
-            // v = a0 u + a1 v + a2 does not depend on (u0,v0): fold h = a0 u0 + a1 v0 + a2 into the columns
-            G_a0 = G_a0 + G_h * r.u0;
-            G_a1 = G_a1 + G_h * r.v0;
-            f3 G_a2 = G_h;
-            // B0 = mz (c20 - v0 c01), B1 = mz (u0 c01 - c12)
-            const float mz = r.m.z, imz = 1.f / mz;
-            f3 G_c20 = G_B0 * mz;
-            f3 G_c01 = G_B1 * (mz * r.u0) - G_B0 * (mz * r.v0);
-            f3 G_c12 = G_B1 * -mz;
-            G_v0 += -mz * dot3(r.c01, G_B0);
-            G_u0 += mz * dot3(r.c01, G_B1);
-            float G_mz = (dot3(r.B0, G_B0) + dot3(r.B1, G_B1)) * imz;
-            // c01 = a0 x a1, c12 = a1 x a2, c20 = a2 x a0   (c = a x b: G_a += b x G_c, G_b += G_c x a)
-            G_a0 = G_a0 + cross3(r.a1, G_c01); G_a1 = G_a1 + cross3(G_c01, r.a0);
-            G_a1 = G_a1 + cross3(r.a2, G_c12); G_a2 = G_a2 + cross3(G_c12, r.a1);
-            G_a2 = G_a2 + cross3(r.a0, G_c20); G_a0 = G_a0 + cross3(G_c20, r.a2);
-            // u0 = mx / mz, v0 = my / mz
-            const float G_mx = G_u0 * imz, G_my = G_v0 * imz;
-            G_mz += -(r.u0 * G_u0 + r.v0 * G_v0) * imz;
-            // m = Rc^T (mu - c)  ->  v_mean = Rc G_m
-            out[4] = cf.Rc[0][0] * G_mx + cf.Rc[0][1] * G_my + cf.Rc[0][2] * G_mz;
-            out[5] = cf.Rc[1][0] * G_mx + cf.Rc[1][1] * G_my + cf.Rc[1][2] * G_mz;
-            out[6] = cf.Rc[2][0] * G_mx + cf.Rc[2][1] * G_my + cf.Rc[2][2] * G_mz;
-            // A = M Rc  ->  G_M(i,k) = sum_j G_A(i,j) Rc(k,j)   (G_A(i,j) = component i of G_aj)
-            const float GA[3][3] = {{G_a0.x, G_a1.x, G_a2.x}, {G_a0.y, G_a1.y, G_a2.y}, {G_a0.z, G_a1.z, G_a2.z}};
-            float vMt[3][3];
-#pragma unroll
-            for (int ii = 0; ii < 3; ++ii)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) vMt[ii][k] = GA[ii][0] * cf.Rc[k][0] + GA[ii][1] * cf.Rc[k][1] + GA[ii][2] * cf.Rc[k][2];
-            // quat_scale_to_preci_half_vjp (Utils.cuh:104-158) with v_M = vMt^T  (M here is the reference's Mt)
-            const float isv[3] = {1.f / raw.sc.x, 1.f / raw.sc.y, 1.f / raw.sc.z};
-            float w = raw.q.x, x_ = raw.q.y, y_ = raw.q.z, z_ = raw.q.w;
-            const float inv_norm = rsqrtf(x_ * x_ + y_ * y_ + z_ * z_ + w * w);
-            w *= inv_norm; x_ *= inv_norm; y_ *= inv_norm; z_ *= inv_norm;
-#define GSX_G(i, j) (vMt[i][j] * isv[i])
-            float vq[4];
-            vq[0] = 2.f * (x_ * (GSX_G(1, 2) - GSX_G(2, 1)) + y_ * (GSX_G(2, 0) - GSX_G(0, 2)) + z_ * (GSX_G(0, 1) - GSX_G(1, 0)));
-            vq[1] = 2.f * (-2.f * x_ * (GSX_G(1, 1) + GSX_G(2, 2)) + y_ * (GSX_G(0, 1) + GSX_G(1, 0)) + z_ * (GSX_G(0, 2) + GSX_G(2, 0)) + w * (GSX_G(1, 2) - GSX_G(2, 1)));
-            vq[2] = 2.f * (x_ * (GSX_G(0, 1) + GSX_G(1, 0)) - 2.f * y_ * (GSX_G(0, 0) + GSX_G(2, 2)) + z_ * (GSX_G(1, 2) + GSX_G(2, 1)) + w * (GSX_G(2, 0) - GSX_G(0, 2)));
-            vq[3] = 2.f * (x_ * (GSX_G(0, 2) + GSX_G(2, 0)) + y_ * (GSX_G(1, 2) + GSX_G(2, 1)) - 2.f * z_ * (GSX_G(0, 0) + GSX_G(1, 1)) + w * (GSX_G(0, 1) - GSX_G(1, 0)));
-#undef GSX_G
-            const float qn[4] = {w, x_, y_, z_};
-            const float dq = vq[0] * qn[0] + vq[1] * qn[1] + vq[2] * qn[2] + vq[3] * qn[3];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) out[7 + k] = (vq[k] - dq * qn[k]) * inv_norm;
-            // v_scale[k] = -(1/s_k)^2 sum_r R(r,k) vMt[k][r],  R(r,k) = Mt[k][r] * s_k
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float sum = r.Mt[k][0] * vMt[k][0] + r.Mt[k][1] * vMt[k][1] + r.Mt[k][2] * vMt[k][2];
-                out[11 + k] = -isv[k] * sum;
-            }
-            if (ws_rec != nullptr) {
-                // atomic-free scatter: one 64 B record per (tile, Gaussian) at its sorted index, chained into a
-                // per-Gaussian list with ONE returning exchange; gsx_bwd_gather_kernel sums the lists afterwards
-                const int32_t isect = chunk_end - (int32_t)tid;
-                const int32_t prev = atomicExch(&ws_head[g], isect);
-                float4* rec = ws_rec + (size_t)isect * 4;
-                rec[0] = make_float4(out[0], out[1], out[2], out[3]);
-                rec[1] = make_float4(out[4], out[5], out[6], out[7]);
-                rec[2] = make_float4(out[8], out[9], out[10], out[11]);
-                rec[3] = make_float4(out[12], out[13], 0.f, __int_as_float(prev));
-            } else {
-                GSX_GATOMIC(&v_colors[(size_t)g * 3], out[0]);
-                GSX_GATOMIC(&v_colors[(size_t)g * 3 + 1], out[1]);
-                GSX_GATOMIC(&v_colors[(size_t)g * 3 + 2], out[2]);
-                GSX_GATOMIC(&v_opacities[g], out[3]);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) GSX_GATOMIC(&v_means[(size_t)gi * 3 + k], out[4 + k]);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) GSX_GATOMIC(&v_quats[(size_t)gi * 4 + k], out[7 + k]);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) GSX_GATOMIC(&v_scales[(size_t)gi * 3 + k], out[11 + k]);
-            }
+        // one thread per touched Gaussian of the chunk: 64 B moment record at its sorted index, chained per Gaussian
+        if ((int32_t)tid < chunk_size && ((s_touched[tid >> 6] >> (tid & 63u)) & 1ull)) {
+            const int32_t isect = chunk_end - (int32_t)tid;
+            const int32_t prev = atomicExch(&ws_head[s_gid[tid]], isect);
+            float4* rec = ws_rec + (size_t)isect * 4;
+            rec[0] = make_float4(s_acc[0][tid], s_acc[1][tid], s_acc[2][tid], s_acc[3][tid]);
+            rec[1] = make_float4(s_acc[4][tid], s_acc[5][tid], s_acc[6][tid], s_acc[7][tid]);
+            rec[2] = make_float4(s_acc[8][tid], s_acc[9][tid], s_acc[10][tid], s_acc[11][tid]);
+            rec[3] = make_float4(s_acc[12][tid], s_acc[13][tid], s_acc[14][tid], __int_as_float(prev));
         }
     }
 }
 
-// Sum the per-(tile, Gaussian) records of every Gaussian (lists built by raster_bwd_fast_kernel).  One thread per
-// Gaussian; colours / opacities are per camera, means / quats / scales are shared by the C cameras.
-__global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(uint32_t C, uint32_t N, const float4* __restrict__ ws_rec,
+// Sum the moment records of every (camera, Gaussian) (lists built by raster_bwd_fast_kernel) and apply the chain
+// rule once: moments -> (B0, B1, h, a_i, u0, v0, m_z) -> (A, m) -> (M, mu) -> (quat, scale) (Utils.cuh:104-158).
+// One thread per Gaussian; colours / opacities are per camera, means / quats / scales are shared by the cameras.
+template <int KIND>
+__global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const float4* __restrict__ ws_rec,
                                                              const int32_t* __restrict__ ws_head, float* __restrict__ v_means,
                                                              float* __restrict__ v_quats, float* __restrict__ v_scales,
                                                              float* __restrict__ v_colors, float* __restrict__ v_opacities) {
     const uint32_t gi = blockIdx.x * 256u + threadIdx.x;
-    if (gi >= N) return;
+    if (gi >= a.N) return;
     float geo[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) geo[k] = 0.f;
-    bool any_geo = false;
-    for (uint32_t c = 0; c < C; ++c) {
-        const size_t g = (size_t)c * N + gi;
-        int32_t i = ws_head[g];
-        if (i < 0) continue;
-        float col[4] = {0.f, 0.f, 0.f, 0.f};
-        while (i >= 0) {
-            const float4* rec = ws_rec + (size_t)i * 4;
+    bool any = false;
+    RawG raw;
+    raw.g = (int32_t)gi;
+    for (uint32_t c = 0; c < a.C; ++c) {
+        const size_t g = (size_t)c * a.N + gi;
+        int32_t it = ws_head[g];
+        if (it < 0) continue;
+        float Mo[15];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) Mo[k] = 0.f;
+        while (it >= 0) {
+            const float4* rec = ws_rec + (size_t)it * 4;
             const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-            col[0] += r0.x; col[1] += r0.y; col[2] += r0.z; col[3] += r0.w;
-            geo[0] += r1.x; geo[1] += r1.y; geo[2] += r1.z; geo[3] += r1.w;
-            geo[4] += r2.x; geo[5] += r2.y; geo[6] += r2.z; geo[7] += r2.w;
-            geo[8] += r3.x; geo[9] += r3.y;
-            i = __float_as_int(r3.w);
+            Mo[0] += r0.x; Mo[1] += r0.y; Mo[2] += r0.z; Mo[3] += r0.w;
+            Mo[4] += r1.x; Mo[5] += r1.y; Mo[6] += r1.z; Mo[7] += r1.w;
+            Mo[8] += r2.x; Mo[9] += r2.y; Mo[10] += r2.z; Mo[11] += r2.w;
+            Mo[12] += r3.x; Mo[13] += r3.y; Mo[14] += r3.z;
+            it = __float_as_int(r3.w);
         }
-        any_geo = true;
-        v_colors[g * 3] += col[0]; v_colors[g * 3 + 1] += col[1]; v_colors[g * 3 + 2] += col[2];
-        v_opacities[g] += col[3];
+        if (!any) {
+            raw.mu = {a.means[(size_t)gi * 3], a.means[(size_t)gi * 3 + 1], a.means[(size_t)gi * 3 + 2]};
+            raw.q = reinterpret_cast<const float4*>(a.quats)[gi];
+            raw.sc = {a.scales[(size_t)gi * 3], a.scales[(size_t)gi * 3 + 1], a.scales[(size_t)gi * 3 + 2]};
+            any = true;
+        }
+        raw.opac = a.opacities[g];
+        v_colors[g * 3] += Mo[0]; v_colors[g * 3 + 1] += Mo[1]; v_colors[g * 3 + 2] += Mo[2];
+        v_opacities[g] += Mo[3] / raw.opac;
+        const ShutterPoses sp(a.cams.viewmats0 + c * 16, nullptr);
+        const CamFrame cf = make_cam_frame(sp);
+        const float tb0[4] = {0.f, 0.f, 0.f, 0.f};
+        FastRec r;
+        make_record<true>(raw, cf, tb0, r);
+        const float kap = 2.f * r.inv_d0;
+        const float Mauu = Mo[4] * kap, Mauv = Mo[5] * kap, Mavv = Mo[6] * kap, Mau = Mo[7] * kap, Mav = Mo[8] * kap;
+        const float kb = kap / HALF_LOG2E;  // b was accumulated with D scaled by 0.5 log2 e
+        const float Mb1 = Mo[9] * kb, Mbu = Mo[10] * kb, Mbv = Mo[11] * kb, Mbuu = Mo[12] * kb, Mbuv = Mo[13] * kb, Mbvv = Mo[14] * kb;
+        // direct gradients
+        const f3 G_B0 = r.B0 * Mauu + r.B1 * Mauv;
+        const f3 G_B1 = r.B0 * Mauv + r.B1 * Mavv;
+        float G_u0 = -(dot3(r.B0, r.B0) * Mau + dot3(r.B0, r.B1) * Mav);
+        float G_v0 = -(dot3(r.B0, r.B1) * Mau + dot3(r.B1, r.B1) * Mav);
+        const f3 G_h = (r.h * Mb1 + r.a0 * Mbu + r.a1 * Mbv) * -1.f;
+        f3 G_a0 = (r.h * Mbu + r.a0 * Mbuu + r.a1 * Mbuv) * -1.f;
+        f3 G_a1 = (r.h * Mbv + r.a0 * Mbuv + r.a1 * Mbvv) * -1.f;
+        // v = a0 u + a1 v + a2 does not depend on (u0,v0): fold h = a0 u0 + a1 v0 + a2 into the columns
+        G_a0 = G_a0 + G_h * r.u0;
+        G_a1 = G_a1 + G_h * r.v0;
+        f3 G_a2 = G_h;
+        // B0 = mz (c20 - v0 c01), B1 = mz (u0 c01 - c12)
+        const float mz = r.m.z, imz = 1.f / mz;
+        const f3 G_c20 = G_B0 * mz;
+        const f3 G_c01 = G_B1 * (mz * r.u0) - G_B0 * (mz * r.v0);
+        const f3 G_c12 = G_B1 * -mz;
+        G_v0 += -mz * dot3(r.c01, G_B0);
+        G_u0 += mz * dot3(r.c01, G_B1);
+        float G_mz = (dot3(r.B0, G_B0) + dot3(r.B1, G_B1)) * imz;
+        // c01 = a0 x a1, c12 = a1 x a2, c20 = a2 x a0   (c = a x b: G_a += b x G_c, G_b += G_c x a)
+        G_a0 = G_a0 + cross3(r.a1, G_c01); G_a1 = G_a1 + cross3(G_c01, r.a0);
+        G_a1 = G_a1 + cross3(r.a2, G_c12); G_a2 = G_a2 + cross3(G_c12, r.a1);
+        G_a2 = G_a2 + cross3(r.a0, G_c20); G_a0 = G_a0 + cross3(G_c20, r.a2);
+        // u0 = mx / mz, v0 = my / mz
+        const float G_mx = G_u0 * imz, G_my = G_v0 * imz;
+        G_mz += -(r.u0 * G_u0 + r.v0 * G_v0) * imz;
+        // m = Rc^T (mu - c)  ->  v_mean = Rc G_m
+        geo[0] += cf.Rc[0][0] * G_mx + cf.Rc[0][1] * G_my + cf.Rc[0][2] * G_mz;
+        geo[1] += cf.Rc[1][0] * G_mx + cf.Rc[1][1] * G_my + cf.Rc[1][2] * G_mz;
+        geo[2] += cf.Rc[2][0] * G_mx + cf.Rc[2][1] * G_my + cf.Rc[2][2] * G_mz;
+        // A = M Rc  ->  G_M(i,k) = sum_j G_A(i,j) Rc(k,j)   (G_A(i,j) = component i of G_aj)
+        const float GA[3][3] = {{G_a0.x, G_a1.x, G_a2.x}, {G_a0.y, G_a1.y, G_a2.y}, {G_a0.z, G_a1.z, G_a2.z}};
+        float vMt[3][3];
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) vMt[ii][k] = GA[ii][0] * cf.Rc[k][0] + GA[ii][1] * cf.Rc[k][1] + GA[ii][2] * cf.Rc[k][2];
+        // quat_scale_to_preci_half_vjp (Utils.cuh:104-158) with v_M = vMt^T  (M here is the reference's Mt)
+        const float isv[3] = {1.f / raw.sc.x, 1.f / raw.sc.y, 1.f / raw.sc.z};
+        float w = raw.q.x, x_ = raw.q.y, y_ = raw.q.z, z_ = raw.q.w;
+        const float inv_norm = rsqrtf(x_ * x_ + y_ * y_ + z_ * z_ + w * w);
+        w *= inv_norm; x_ *= inv_norm; y_ *= inv_norm; z_ *= inv_norm;
+#define GSX_G(i, j) (vMt[i][j] * isv[i])
+        float vq[4];
+        vq[0] = 2.f * (x_ * (GSX_G(1, 2) - GSX_G(2, 1)) + y_ * (GSX_G(2, 0) - GSX_G(0, 2)) + z_ * (GSX_G(0, 1) - GSX_G(1, 0)));
+        vq[1] = 2.f * (-2.f * x_ * (GSX_G(1, 1) + GSX_G(2, 2)) + y_ * (GSX_G(0, 1) + GSX_G(1, 0)) + z_ * (GSX_G(0, 2) + GSX_G(2, 0)) + w * (GSX_G(1, 2) - GSX_G(2, 1)));
+        vq[2] = 2.f * (x_ * (GSX_G(0, 1) + GSX_G(1, 0)) - 2.f * y_ * (GSX_G(0, 0) + GSX_G(2, 2)) + z_ * (GSX_G(1, 2) + GSX_G(2, 1)) + w * (GSX_G(2, 0) - GSX_G(0, 2)));
+        vq[3] = 2.f * (x_ * (GSX_G(0, 2) + GSX_G(2, 0)) + y_ * (GSX_G(1, 2) + GSX_G(2, 1)) - 2.f * z_ * (GSX_G(0, 0) + GSX_G(1, 1)) + w * (GSX_G(0, 1) - GSX_G(1, 0)));
+#undef GSX_G
+        const float qn[4] = {w, x_, y_, z_};
+        const float dq = vq[0] * qn[0] + vq[1] * qn[1] + vq[2] * qn[2] + vq[3] * qn[3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) geo[3 + k] += (vq[k] - dq * qn[k]) * inv_norm;
+        // v_scale[k] = -(1/s_k)^2 sum_r R(r,k) vMt[k][r],  R(r,k) = Mt[k][r] * s_k
+#pragma unroll
+        for (int k = 0; k < 3; ++k) geo[7 + k] += -isv[k] * (r.Mt[k][0] * vMt[k][0] + r.Mt[k][1] * vMt[k][1] + r.Mt[k][2] * vMt[k][2]);
     }
-    if (any_geo) {
+    if (any) {
         v_means[(size_t)gi * 3] += geo[0]; v_means[(size_t)gi * 3 + 1] += geo[1]; v_means[(size_t)gi * 3 + 2] += geo[2];
         v_quats[(size_t)gi * 4] += geo[3]; v_quats[(size_t)gi * 4 + 1] += geo[4]; v_quats[(size_t)gi * 4 + 2] += geo[5];
         v_quats[(size_t)gi * 4 + 3] += geo[6];
@@ -663,34 +641,33 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(uint32_t C, uint32_
 }
 
 size_t raster_bwd_fast_workspace_bytes(uint32_t C, uint32_t N, int64_t n_isects) {
-    // records (64 B per intersection) + list heads (4 B per (camera, Gaussian)), 256 B aligned
+    // moment records (64 B per intersection) + list heads (4 B per (camera, Gaussian)), 256 B aligned
     return (((size_t)n_isects * 64 + 255) / 256) * 256 + (((size_t)C * N * 4 + 255) / 256) * 256;
 }
 
-void launch_raster_bwd_fast(int kind, const RasterArgs& a, const float* render_alphas, const int32_t* last_ids,
+bool launch_raster_bwd_fast(int kind, const RasterArgs& a, const float* render_alphas, const int32_t* last_ids,
                             const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats,
                             float* v_scales, float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes,
                             hipStream_t st) {
+    if (workspace == nullptr || workspace_bytes < raster_bwd_fast_workspace_bytes(a.C, a.N, a.n_isects)) return false;
     const uint32_t n_tiles = a.tw * a.th;
     const dim3 grid(((n_tiles + 7u) / 8u) * 8u, a.C), block(RB);
-    float4* ws_rec = nullptr;
-    int32_t* ws_head = nullptr;
-    if (workspace != nullptr && workspace_bytes >= raster_bwd_fast_workspace_bytes(a.C, a.N, a.n_isects)) {
-        ws_rec = (float4*)workspace;
-        ws_head = (int32_t*)((char*)workspace + (((size_t)a.n_isects * 64 + 255) / 256) * 256);
-        (void)hipMemsetAsync(ws_head, 0xFF, (size_t)a.C * a.N * 4, st);  // -1 = empty list
-    }
-    if (kind == CAM_PERFECT_PINHOLE)
+    float4* ws_rec = (float4*)workspace;
+    int32_t* ws_head = (int32_t*)((char*)workspace + (((size_t)a.n_isects * 64 + 255) / 256) * 256);
+    (void)hipMemsetAsync(ws_head, 0xFF, (size_t)a.C * a.N * 4, st);  // -1 = empty list
+    const dim3 ggrid((a.N + 255u) / 256u), gblock(256);
+    if (kind == CAM_PERFECT_PINHOLE) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_fast_kernel<CAM_PERFECT_PINHOLE>), grid, block, 0, st, a, render_alphas,
-                           last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors, v_opacities, ws_rec,
-                           ws_head);
-    else
+                           last_ids, v_render_colors, v_render_alphas, ws_rec, ws_head);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_bwd_gather_kernel<CAM_PERFECT_PINHOLE>), ggrid, gblock, 0, st, a, ws_rec, ws_head,
+                           v_means, v_quats, v_scales, v_colors, v_opacities);
+    } else {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_fast_kernel<CAM_OPENCV_PINHOLE>), grid, block, 0, st, a, render_alphas,
-                           last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors, v_opacities, ws_rec,
-                           ws_head);
-    if (ws_rec != nullptr)
-        hipLaunchKernelGGL(gsx_bwd_gather_kernel, dim3((a.N + 255u) / 256u), dim3(256), 0, st, a.C, a.N, ws_rec, ws_head, v_means,
-                           v_quats, v_scales, v_colors, v_opacities);
+                           last_ids, v_render_colors, v_render_alphas, ws_rec, ws_head);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_bwd_gather_kernel<CAM_OPENCV_PINHOLE>), ggrid, gblock, 0, st, a, ws_rec, ws_head,
+                           v_means, v_quats, v_scales, v_colors, v_opacities);
+    }
+    return true;
 }
 
 }  // namespace gsx

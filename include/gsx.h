@@ -128,9 +128,10 @@ int gsx_rasterize_to_pixels_from_world_3dgs_fwd(uint32_t N, int64_t n_isects, co
  * must be zero-initialised by the caller (upstream: at::zeros_like, Rasterization.cpp:190-194); the
  * gradients are accumulated into them.
  * `workspace` (optional; size from gsx_rasterize_bwd_workspace_bytes): with it the fast path writes one 64 B
- * record per (tile, Gaussian) and sums them per Gaussian in a second kernel instead of issuing 14 device-scope
- * float atomics per (tile, Gaussian) — on MI355X those atomics are served memory-side (the 8 XCD L2s are not
- * coherent) and cost more than the whole rest of the kernel.  NULL / too small = accumulate with atomics. */
+ * moment record per (tile, Gaussian), and a second kernel sums them and applies the chain rule once per
+ * (camera, Gaussian), instead of issuing 14 device-scope float atomics per (tile, Gaussian) — on MI355X those
+ * atomics are served memory-side (the 8 XCD L2s are not coherent) and cost more than the rest of the kernel.
+ * NULL / too small = the reference-order kernels with float atomics. */
 size_t gsx_rasterize_bwd_workspace_bytes(uint32_t C, uint32_t N, int64_t n_isects);
 int gsx_rasterize_to_pixels_from_world_3dgs_bwd(uint32_t N, int64_t n_isects, const float* means,
                                                 const float* quats, const float* scales, const float* colors,
