@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scene", default="1m", choices=["small", "1m", "5m"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL)")
     ap.add_argument("--unfused", action="store_true", help="reference-style glue (one torch op per activation / SH pre-post step)")
     args = ap.parse_args()
 
@@ -119,8 +120,10 @@ def main():
     from gsx import distributed as gdist
     from gsx import ops, rasterizer, scenes
 
-    rank, local_rank, world = gdist.init_from_env()
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    if os.environ.get("GSX_BENCH_ALL_RANKS_ON_DEVICE0"):  # functional test of the N>1 code path on a 1-GPU box (gloo)
+        os.environ["LOCAL_RANK"] = "0"
+    rank, local_rank, world = gdist.init_from_env(args.backend)
     assert world == max(1, args.gpus), "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
