@@ -374,6 +374,7 @@ static int fill_args(RasterArgs& a, uint32_t N, int64_t n_isects, const float* m
     a.W = W; a.H = H; a.tw = (W + TILE - 1) / TILE; a.th = (H + TILE - 1) / TILE;
     a.cams = *cams;
     a.tile_offsets = tile_offsets; a.flatten_ids = flatten_ids;
+    a.packed = nullptr;
     return GSX_OK;
 }
 
@@ -397,7 +398,7 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_fwd(
     uint32_t channels, const float* opacities, const float* backgrounds, const uint8_t* masks, uint32_t image_width,
     uint32_t image_height, uint32_t tile_size, const gsx_cameras* cams, const gsx_ut_params* ut,
     const int32_t* tile_offsets, const int32_t* flatten_ids, float* renders, float* alphas, int32_t* last_ids,
-    void* stream) {
+    void* workspace, size_t workspace_bytes, void* stream) {
     (void)ut;
     RasterArgs a;
     int rc = fill_args(a, N, n_isects, means, quats, scales, colors, channels, opacities, backgrounds, masks, image_width,
@@ -409,7 +410,7 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_fwd(
     hipStream_t st = (hipStream_t)stream;
     const bool hoist = cams->shutter == GSX_SHUTTER_GLOBAL;
     if (hoist && cam_kind(*cams) != CAM_OPENCV_FISHEYE && !force_generic()) {
-        launch_raster_fwd_fast(cam_kind(*cams), a, renders, alphas, last_ids, st);
+        launch_raster_fwd_fast(cam_kind(*cams), a, renders, alphas, last_ids, workspace, workspace_bytes, st);
         return check_launch("rasterize_to_pixels_from_world_3dgs_fwd(fast)");
     }
 #define GSX_FWD(KIND)                                                                                                  \
@@ -465,6 +466,8 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd(
 #undef GSX_BWD
     return check_launch("rasterize_to_pixels_from_world_3dgs_bwd");
 }
+
+extern "C" size_t gsx_rasterize_fwd_workspace_bytes(uint32_t C, uint32_t N) { return raster_fwd_fast_workspace_bytes(C, N); }
 
 extern "C" size_t gsx_rasterize_bwd_workspace_bytes(uint32_t C, uint32_t N, int64_t n_isects) {
     return raster_bwd_fast_workspace_bytes(C, N, n_isects);

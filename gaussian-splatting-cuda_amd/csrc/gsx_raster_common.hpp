@@ -20,6 +20,7 @@ struct RasterArgs {
     uint32_t W, H, tw, th;
     gsx_cameras cams;
     const int32_t* tile_offsets; const int32_t* flatten_ids;
+    const float4* packed;  // optional [C*N] x 64 B camera-space records (gsx_raster_fast.hip: pack_records_kernel), else nullptr
 };
 
 
@@ -31,9 +32,11 @@ GSX_DEV void thread_pixel(uint32_t tid, uint32_t tile_x, uint32_t tile_y, uint32
 }
 
 // fast-path launchers (gsx_raster_fast.hip); kind is CAM_PERFECT_PINHOLE or CAM_OPENCV_PINHOLE, global shutter
-void launch_raster_fwd_fast(int kind, const RasterArgs& a, float* renders, float* alphas, int32_t* last_ids, hipStream_t st);
+void launch_raster_fwd_fast(int kind, RasterArgs a, float* renders, float* alphas, int32_t* last_ids, void* workspace,
+                            size_t workspace_bytes, hipStream_t st);
+size_t raster_fwd_fast_workspace_bytes(uint32_t C, uint32_t N);
 // returns false (nothing launched) when no sufficient workspace was supplied: the caller falls back to the generic kernels
-bool launch_raster_bwd_fast(int kind, const RasterArgs& a, const float* render_alphas, const int32_t* last_ids,
+bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, const int32_t* last_ids,
                             const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats,
                             float* v_scales, float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes,
                             hipStream_t st);

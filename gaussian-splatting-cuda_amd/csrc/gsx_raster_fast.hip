@@ -151,6 +151,65 @@ GSX_DEV void make_record(const RawG& r, const CamFrame& cf, const float tb[4], F
     }
 }
 
+// ---- packed per-(camera, Gaussian) records ---------------------------------------------------------------
+// The tile kernels need, per (tile, Gaussian), data that lives in five separate arrays (means 12 B, quats 16 B,
+// scales 12 B, opacities 4 B, colours 12 B): five cache lines gathered for 60 useful bytes, and ~300 VALU to turn
+// them into the 15 camera-space coefficients — all of which depend on (camera, Gaussian) only, not on the tile.
+// pack_records_kernel does that once per (camera, Gaussian) into ONE 64 B line; staging a tile then gathers a
+// single line per Gaussian and only adds the tile-dependent footprint (hx, hy).
+//   p0 = (u0, v0, l00, l01)  p1 = (l11, lo, d1, d2)  p2 = (d3, d4, d5, -)  p3 = (r, g, b, -)
+__global__ __launch_bounds__(256) void pack_records_kernel(RasterArgs a, float4* __restrict__ packed) {
+    const uint32_t n = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
+    if (n >= a.N) return;
+    const size_t g = (size_t)c * a.N + n;
+    RawG raw;
+    raw.g = (int32_t)g;
+    raw.mu = {a.means[(size_t)n * 3], a.means[(size_t)n * 3 + 1], a.means[(size_t)n * 3 + 2]};
+    raw.q = reinterpret_cast<const float4*>(a.quats)[n];
+    raw.sc = {a.scales[(size_t)n * 3], a.scales[(size_t)n * 3 + 1], a.scales[(size_t)n * 3 + 2]};
+    raw.opac = a.opacities[g];
+    raw.rgb = {a.colors[g * 3], a.colors[g * 3 + 1], a.colors[g * 3 + 2]};
+    const ShutterPoses sp(a.cams.viewmats0 + c * 16, nullptr);
+    const CamFrame cf = make_cam_frame(sp);
+    const float tb0[4] = {0.f, 0.f, 0.f, 0.f};
+    FastRec r;
+    make_record<false>(raw, cf, tb0, r);
+    if (!(r.hx > -INFINITY) && !(r.lo + LOG2_255 > 0.f)) r.lo = -INFINITY;  // never visible (opacity <= 1/255)
+    if (!(fabsf(r.l00) < INFINITY)) r.lo = -INFINITY;                       // camera-space z == 0: skipped
+    float4* o = packed + g * 4;
+    o[0] = make_float4(r.u0, r.v0, r.l00, r.l01);
+    o[1] = make_float4(r.l11, r.lo, r.d1, r.d2);
+    o[2] = make_float4(r.d3, r.d4, r.d5, 0.f);
+    o[3] = make_float4(raw.rgb.x, raw.rgb.y, raw.rgb.z, 0.f);
+}
+
+// packed record -> the four LDS planes of one staged Gaussian (adds the tile-dependent conservative footprint)
+GSX_DEV void stage_packed(const float4* __restrict__ packed, int32_t g, const float tb[4], float4& q0, float4& q1, float4& q2,
+                          float4& q3) {
+    const float4* p = packed + (size_t)g * 4;
+    const float4 p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
+    const float u0 = p0.x, v0 = p0.y, l00 = p0.z, l01 = p0.w, l11 = p1.x, lo = p1.y;
+    const float d1 = p1.z, d2 = p1.w, d3 = p2.x, d4 = p2.y, d5 = p2.z;
+    const float tau2 = lo + LOG2_255;
+    float hx = -INFINITY, hy = -INFINITY;
+    if (tau2 > 0.f) {
+        float dmax = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float du = ((k & 1) ? tb[1] : tb[0]) - u0, dv = ((k & 2) ? tb[3] : tb[2]) - v0;
+            dmax = fmaxf(dmax, 1.f + du * (d1 + d3 * du + d4 * dv) + dv * (d2 + d5 * dv));
+        }
+        const float rad = sqrtf(tau2 * dmax) * 1.001f + 1e-7f;
+        hy = rad / l11;
+        hx = rad * sqrtf(l01 * l01 + l11 * l11) / (l00 * l11);
+        if (!(hx == hx) || !(hy == hy)) { hx = INFINITY; hy = INFINITY; }
+    }
+    q0 = make_float4(u0, v0, hx, hy);
+    q1 = make_float4(l00, l01, l11, lo);
+    q2 = make_float4(d1, d2, d3, d4);
+    q3 = make_float4(d5, p3.x, p3.y, p3.z);
+}
+
 // alpha of one (pixel, Gaussian) pair: 16 VALU.  Returns alpha; num2 = 0.5 log2(e) * grayDist * den' (scaled numerator),
 // rden = 1/den'.
 GSX_DEV float fast_alpha(float u, float v, float4 q0, float4 q1, float4 q2, float d5, float& du, float& dv, float& num2,
@@ -249,24 +308,34 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
     float out_r = 0.f, out_g = 0.f, out_b = 0.f;
     bool wave_done = __ballot(!done) == 0ull;
     RawG raw;
+    int32_t g_pre = 0;  // packed path: only the flatten id is prefetched, the 64 B record is gathered at staging time
     bool have = (int32_t)tid < FCH && range_start + (int32_t)tid < range_end;
-    if (have) load_raw(a, range_start + (int32_t)tid, raw);
+    if (have) { if (a.packed) g_pre = a.flatten_ids[range_start + (int32_t)tid]; else load_raw(a, range_start + (int32_t)tid, raw); }
     for (int32_t b = 0; b < n_chunks; ++b) {
         const int buf = b & 1;
         const int32_t chunk_start = range_start + FCH * b;
         if (have) {
-            FastRec r;
-            make_record<false>(raw, cf, tb, r);
-            s_q0[buf][tid] = make_float4(r.u0, r.v0, r.hx, r.hy);
-            s_q1[buf][tid] = make_float4(r.l00, r.l01, r.l11, r.lo);
-            s_q2[buf][tid] = make_float4(r.d1, r.d2, r.d3, r.d4);
-            s_q3[buf][tid] = make_float4(r.d5, raw.rgb.x, raw.rgb.y, raw.rgb.z);
+            if (a.packed) {
+                float4 q0, q1, q2, q3;
+                stage_packed(a.packed, g_pre, tb, q0, q1, q2, q3);
+                s_q0[buf][tid] = q0; s_q1[buf][tid] = q1; s_q2[buf][tid] = q2; s_q3[buf][tid] = q3;
+            } else {
+                FastRec r;
+                make_record<false>(raw, cf, tb, r);
+                s_q0[buf][tid] = make_float4(r.u0, r.v0, r.hx, r.hy);
+                s_q1[buf][tid] = make_float4(r.l00, r.l01, r.l11, r.lo);
+                s_q2[buf][tid] = make_float4(r.d1, r.d2, r.d3, r.d4);
+                s_q3[buf][tid] = make_float4(r.d5, raw.rgb.x, raw.rgb.y, raw.rgb.z);
+            }
         }
         if (lane == 0) s_wdone[buf][wave] = wave_done ? 1 : 0;
         __syncthreads();
         if (s_wdone[buf][0] & s_wdone[buf][1] & s_wdone[buf][2] & s_wdone[buf][3]) break;  // Fwd.cu:188-190
         have = (b + 1 < n_chunks) && (int32_t)tid < FCH && (chunk_start + FCH + (int32_t)tid < range_end);
-        if (have) load_raw(a, chunk_start + FCH + (int32_t)tid, raw);  // in flight during the pixel loop
+        if (have) {  // in flight during the pixel loop
+            if (a.packed) g_pre = a.flatten_ids[chunk_start + FCH + (int32_t)tid];
+            else load_raw(a, chunk_start + FCH + (int32_t)tid, raw);
+        }
         if (wave_done) continue;
         const int32_t chunk_size = min(FCH, range_end - chunk_start);
         for (int32_t sub = 0; sub < chunk_size && !wave_done; sub += 64) {
@@ -312,15 +381,26 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
     }
 }
 
-void launch_raster_fwd_fast(int kind, const RasterArgs& a, float* renders, float* alphas, int32_t* last_ids, hipStream_t st) {
+size_t raster_fwd_fast_workspace_bytes(uint32_t C, uint32_t N) { return (size_t)C * N * 64 + 256; }
+
+static const float4* pack_into(RasterArgs& a, void* base, hipStream_t st) {
+    float4* packed = (float4*)(((uintptr_t)base + 255) & ~(uintptr_t)255);
+    hipLaunchKernelGGL(pack_records_kernel, dim3((a.N + 255u) / 256u, a.C), dim3(256), 0, st, a, packed);
+    a.packed = packed;
+    return packed;
+}
+
+void launch_raster_fwd_fast(int kind, RasterArgs a, float* renders, float* alphas, int32_t* last_ids, void* workspace,
+                            size_t workspace_bytes, hipStream_t st) {
     const uint32_t n_tiles = a.tw * a.th;
     const dim3 grid(((n_tiles + 7u) / 8u) * 8u, a.C), block(RB);
+    a.packed = nullptr;
+    if (workspace != nullptr && workspace_bytes >= raster_fwd_fast_workspace_bytes(a.C, a.N)) pack_into(a, workspace, st);
     if (kind == CAM_PERFECT_PINHOLE)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_fwd_fast_kernel<CAM_PERFECT_PINHOLE>), grid, block, 0, st, a, renders, alphas, last_ids);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_fwd_fast_kernel<CAM_OPENCV_PINHOLE>), grid, block, 0, st, a, renders, alphas, last_ids);
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // backward
@@ -442,15 +522,23 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
         const int32_t chunk_end = block_last - BCH * b;  // inclusive; slot t holds sorted index chunk_end - t
         const int32_t chunk_size = min(BCH, chunk_end + 1 - range_start);
         if ((int32_t)tid < chunk_size) {
-            RawG raw;
-            load_raw(a, chunk_end - (int32_t)tid, raw);
-            FastRec r;
-            make_record<false>(raw, cf, tb, r);
-            s_q0[tid] = make_float4(r.u0, r.v0, r.hx, r.hy);
-            s_q1[tid] = make_float4(r.l00, r.l01, r.l11, r.lo);
-            s_q2[tid] = make_float4(r.d1, r.d2, r.d3, r.d4);
-            s_q3[tid] = make_float4(r.d5, raw.rgb.x, raw.rgb.y, raw.rgb.z);
-            s_gid[tid] = raw.g;
+            if (a.packed) {
+                const int32_t g = a.flatten_ids[chunk_end - (int32_t)tid];
+                float4 q0, q1, q2, q3;
+                stage_packed(a.packed, g, tb, q0, q1, q2, q3);
+                s_q0[tid] = q0; s_q1[tid] = q1; s_q2[tid] = q2; s_q3[tid] = q3;
+                s_gid[tid] = g;
+            } else {
+                RawG raw;
+                load_raw(a, chunk_end - (int32_t)tid, raw);
+                FastRec r;
+                make_record<false>(raw, cf, tb, r);
+                s_q0[tid] = make_float4(r.u0, r.v0, r.hx, r.hy);
+                s_q1[tid] = make_float4(r.l00, r.l01, r.l11, r.lo);
+                s_q2[tid] = make_float4(r.d1, r.d2, r.d3, r.d4);
+                s_q3[tid] = make_float4(r.d5, raw.rgb.x, raw.rgb.y, raw.rgb.z);
+                s_gid[tid] = raw.g;
+            }
         }
         if (tid < BCH) {
 #pragma unroll
@@ -641,11 +729,11 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
 }
 
 size_t raster_bwd_fast_workspace_bytes(uint32_t C, uint32_t N, int64_t n_isects) {
-    // moment records (64 B per intersection) + list heads (4 B per (camera, Gaussian)), 256 B aligned
-    return (((size_t)n_isects * 64 + 255) / 256) * 256 + (((size_t)C * N * 4 + 255) / 256) * 256;
+    // moment records (64 B per intersection) + list heads (4 B per (camera, Gaussian)) + packed records, 256 B aligned
+    return (((size_t)n_isects * 64 + 255) / 256) * 256 + (((size_t)C * N * 4 + 255) / 256) * 256 + raster_fwd_fast_workspace_bytes(C, N);
 }
 
-bool launch_raster_bwd_fast(int kind, const RasterArgs& a, const float* render_alphas, const int32_t* last_ids,
+bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, const int32_t* last_ids,
                             const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats,
                             float* v_scales, float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes,
                             hipStream_t st) {
@@ -655,6 +743,7 @@ bool launch_raster_bwd_fast(int kind, const RasterArgs& a, const float* render_a
     float4* ws_rec = (float4*)workspace;
     int32_t* ws_head = (int32_t*)((char*)workspace + (((size_t)a.n_isects * 64 + 255) / 256) * 256);
     (void)hipMemsetAsync(ws_head, 0xFF, (size_t)a.C * a.N * 4, st);  // -1 = empty list
+    pack_into(a, (char*)ws_head + (((size_t)a.C * a.N * 4 + 255) / 256) * 256, st);
     const dim3 ggrid((a.N + 255u) / 256u), gblock(256);
     if (kind == CAM_PERFECT_PINHOLE) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_fast_kernel<CAM_PERFECT_PINHOLE>), grid, block, 0, st, a, render_alphas,

@@ -221,12 +221,14 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> rasterize_to_pixels_from_world_3d
     at::Tensor renders = at::empty({C, image_height, image_width, channels}, means.options());
     at::Tensor alphas = at::empty({C, image_height, image_width, 1}, means.options());
     at::Tensor last_ids = at::empty({C, image_height, image_width}, means.options().dtype(at::kInt));
+    const size_t fwsb = gsx_rasterize_fwd_workspace_bytes(C, N);
+    at::Tensor fws = at::empty({(int64_t)fwsb}, means.options().dtype(at::kByte));
     check(gsx_rasterize_to_pixels_from_world_3dgs_fwd(
               N, flatten_ids.size(0), means.data_ptr<float>(), quats.data_ptr<float>(), scales.data_ptr<float>(),
               colors.data_ptr<float>(), channels, opacities.data_ptr<float>(), fptr(backgrounds), bptr(masks), image_width,
               image_height, tile_size, &cams, &ut, tile_offsets.data_ptr<int32_t>(),
               flatten_ids.numel() ? flatten_ids.data_ptr<int32_t>() : nullptr, renders.data_ptr<float>(),
-              alphas.data_ptr<float>(), last_ids.data_ptr<int32_t>(), cur_stream()),
+              alphas.data_ptr<float>(), last_ids.data_ptr<int32_t>(), fws.data_ptr(), fwsb, cur_stream()),
           "rasterize_to_pixels_from_world_3dgs_fwd");
     return std::make_tuple(renders, alphas, last_ids);
 }

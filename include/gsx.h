@@ -123,7 +123,12 @@ int gsx_rasterize_to_pixels_from_world_3dgs_fwd(uint32_t N, int64_t n_isects, co
                                                 const uint8_t* masks, uint32_t image_width, uint32_t image_height,
                                                 uint32_t tile_size, const gsx_cameras* cams, const gsx_ut_params* ut,
                                                 const int32_t* tile_offsets, const int32_t* flatten_ids,
-                                                float* renders, float* alphas, int32_t* last_ids, void* stream);
+                                                float* renders, float* alphas, int32_t* last_ids, void* workspace,
+                                                size_t workspace_bytes, void* stream);
+/* `workspace` (optional; gsx_rasterize_fwd_workspace_bytes): room for one packed 64 B camera-space record per
+ * (camera, Gaussian), so that staging a tile gathers ONE cache line per Gaussian instead of five (means, quats,
+ * scales, opacities, colours live in five arrays).  NULL / too small = records are built from the raw arrays. */
+size_t gsx_rasterize_fwd_workspace_bytes(uint32_t C, uint32_t N);
 /* Gradient outputs v_means [N,3], v_quats [N,4], v_scales [N,3], v_colors [C,N,3], v_opacities [C,N]
  * must be zero-initialised by the caller (upstream: at::zeros_like, Rasterization.cpp:190-194); the
  * gradients are accumulated into them.
