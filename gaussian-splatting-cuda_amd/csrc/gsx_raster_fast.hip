@@ -157,7 +157,7 @@ GSX_DEV void make_record(const RawG& r, const CamFrame& cf, const float tb[4], F
 // them into the 15 camera-space coefficients — all of which depend on (camera, Gaussian) only, not on the tile.
 // pack_records_kernel does that once per (camera, Gaussian) into ONE 64 B line; staging a tile then gathers a
 // single line per Gaussian and only adds the tile-dependent footprint (hx, hy).
-//   p0 = (u0, v0, l00, l01)  p1 = (l11, lo, d1, d2)  p2 = (d3, d4, d5, -)  p3 = (r, g, b, -)
+//   p0 = (u0, v0, l00, l01)  p1 = (l11, lo, d1, d2)  p2 = (d3, d4, d5, red)  p3 = (green, blue, -, -)
 __global__ __launch_bounds__(256) void pack_records_kernel(RasterArgs a, float4* __restrict__ packed) {
     const uint32_t n = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
     if (n >= a.N) return;
@@ -179,48 +179,60 @@ __global__ __launch_bounds__(256) void pack_records_kernel(RasterArgs a, float4*
     float4* o = packed + g * 4;
     o[0] = make_float4(r.u0, r.v0, r.l00, r.l01);
     o[1] = make_float4(r.l11, r.lo, r.d1, r.d2);
-    o[2] = make_float4(r.d3, r.d4, r.d5, 0.f);
-    o[3] = make_float4(raw.rgb.x, raw.rgb.y, raw.rgb.z, 0.f);
+    o[2] = make_float4(r.d3, r.d4, r.d5, raw.rgb.x);
+    o[3] = make_float4(raw.rgb.y, raw.rgb.z, 0.f, 0.f);
 }
 
-// packed record -> the four LDS planes of one staged Gaussian (adds the tile-dependent conservative footprint)
-GSX_DEV void stage_packed(const float4* __restrict__ packed, int32_t g, const float tb[4], float4& q0, float4& q1, float4& q2,
-                          float4& q3) {
-    const float4* p = packed + (size_t)g * 4;
-    const float4 p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
-    const float u0 = p0.x, v0 = p0.y, l00 = p0.z, l01 = p0.w, l11 = p1.x, lo = p1.y;
-    const float d1 = p1.z, d2 = p1.w, d3 = p2.x, d4 = p2.y, d5 = p2.z;
-    const float tau2 = lo + LOG2_255;
-    float hx = -INFINITY, hy = -INFINITY;
+// alpha of one (pixel, Gaussian) pair: 16 VALU.  Record layout (== the packed 64 B record):
+//   r0 = (u0, v0, l00, l01)  r1 = (l11, lo, d1, d2)  r2 = (d3, d4, d5, red)  r3 = (green, blue, -, -)
+// Returns alpha; num2 = 0.5 log2(e) * grayDist * den' (scaled numerator), rden = 1/den'.
+GSX_DEV float fast_alpha(float u, float v, float4 r0, float4 r1, float4 r2, float& du, float& dv, float& num2, float& rden) {
+    du = u - r0.x; dv = v - r0.y;
+    const float t0 = fmaf(r0.w, dv, r0.z * du);
+    const float t1 = r1.x * dv;
+    num2 = fmaf(t0, t0, t1 * t1);
+    const float den = fmaf(du, fmaf(r2.x, du, fmaf(r2.y, dv, r1.z)), fmaf(dv, fmaf(r2.z, dv, r1.w), 1.f));
+    rden = __builtin_amdgcn_rcpf(den);
+    return fminf(0.999f, __builtin_amdgcn_exp2f(fmaf(-num2, rden, r1.y)));
+}
+
+// conservative (u,v) footprint half extents of a record for the tile bounds tb (see header comment, item 2)
+GSX_DEV void footprint(float4 r0, float4 r1, float4 r2, const float tb[4], float& hx, float& hy) {
+    const float tau2 = r1.y + LOG2_255;
+    hx = -INFINITY; hy = -INFINITY;
     if (tau2 > 0.f) {
         float dmax = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float du = ((k & 1) ? tb[1] : tb[0]) - u0, dv = ((k & 2) ? tb[3] : tb[2]) - v0;
-            dmax = fmaxf(dmax, 1.f + du * (d1 + d3 * du + d4 * dv) + dv * (d2 + d5 * dv));
+            const float du = ((k & 1) ? tb[1] : tb[0]) - r0.x, dv = ((k & 2) ? tb[3] : tb[2]) - r0.y;
+            dmax = fmaxf(dmax, 1.f + du * (r1.z + r2.x * du + r2.y * dv) + dv * (r1.w + r2.z * dv));
         }
         const float rad = sqrtf(tau2 * dmax) * 1.001f + 1e-7f;
-        hy = rad / l11;
-        hx = rad * sqrtf(l01 * l01 + l11 * l11) / (l00 * l11);
-        if (!(hx == hx) || !(hy == hy)) { hx = INFINITY; hy = INFINITY; }
+        hy = rad / r1.x;
+        hx = rad * sqrtf(r0.w * r0.w + r1.x * r1.x) / (r0.z * r1.x);
+        if (!(hx == hx) || !(hy == hy)) { hx = INFINITY; hy = INFINITY; }  // degenerate factor: never cull
     }
-    q0 = make_float4(u0, v0, hx, hy);
-    q1 = make_float4(l00, l01, l11, lo);
-    q2 = make_float4(d1, d2, d3, d4);
-    q3 = make_float4(d5, p3.x, p3.y, p3.z);
 }
 
-// alpha of one (pixel, Gaussian) pair: 16 VALU.  Returns alpha; num2 = 0.5 log2(e) * grayDist * den' (scaled numerator),
-// rden = 1/den'.
-GSX_DEV float fast_alpha(float u, float v, float4 q0, float4 q1, float4 q2, float d5, float& du, float& dv, float& num2,
-                         float& rden) {
-    du = u - q0.x; dv = v - q0.y;
-    const float t0 = fmaf(q1.y, dv, q1.x * du);
-    const float t1 = q1.z * dv;
-    num2 = fmaf(t0, t0, t1 * t1);
-    const float den = fmaf(du, fmaf(q2.z, du, fmaf(q2.w, dv, q2.x)), fmaf(dv, fmaf(d5, dv, q2.y), 1.f));
-    rden = __builtin_amdgcn_rcpf(den);
-    return fminf(0.999f, __builtin_amdgcn_exp2f(fmaf(-num2, rden, q1.w)));
+// one staged Gaussian: the 64 B record (AoS, read at a wave-uniform index with one base address) + the cull plane entry
+struct StagedRec { float4 r0, r1, r2, r3, cull; };
+
+GSX_DEV void stage_one(const RasterArgs& a, const CamFrame& cf, const float tb[4], int32_t g, const RawG& raw, StagedRec& o) {
+    if (a.packed) {
+        const float4* p = a.packed + (size_t)g * 4;
+        o.r0 = p[0]; o.r1 = p[1]; o.r2 = p[2]; o.r3 = p[3];
+    } else {
+        FastRec r;
+        make_record<false>(raw, cf, tb, r);
+        const bool never = !(r.lo + LOG2_255 > 0.f) || !(fabsf(r.l00) < INFINITY);
+        o.r0 = make_float4(r.u0, r.v0, r.l00, r.l01);
+        o.r1 = make_float4(r.l11, never ? -INFINITY : r.lo, r.d1, r.d2);
+        o.r2 = make_float4(r.d3, r.d4, r.d5, raw.rgb.x);
+        o.r3 = make_float4(raw.rgb.y, raw.rgb.z, 0.f, 0.f);
+    }
+    float hx, hy;
+    footprint(o.r0, o.r1, o.r2, tb, hx, hy);
+    o.cull = make_float4(o.r0.x, o.r0.y, hx, hy);
 }
 
 // per-thread pixel set-up shared by forward and backward: undistorted normalised coordinates (u,v)
@@ -271,7 +283,8 @@ template <int KIND>
 __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(RasterArgs a, float* __restrict__ render_colors,
                                                              float* __restrict__ render_alphas,
                                                              int32_t* __restrict__ last_ids) {
-    __shared__ float4 s_q0[2][FCH], s_q1[2][FCH], s_q2[2][FCH], s_q3[2][FCH];
+    __shared__ float4 s_rec[2][FCH][4];   // AoS records, double buffered
+    __shared__ float4 s_cull[2][FCH];     // (u0, v0, hx, hy): per-lane cull reads are conflict-free on this plane
     __shared__ float s_bounds[4][4];
     __shared__ int s_wdone[2][4];
     const uint32_t cid = blockIdx.y;
@@ -315,18 +328,10 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
         const int buf = b & 1;
         const int32_t chunk_start = range_start + FCH * b;
         if (have) {
-            if (a.packed) {
-                float4 q0, q1, q2, q3;
-                stage_packed(a.packed, g_pre, tb, q0, q1, q2, q3);
-                s_q0[buf][tid] = q0; s_q1[buf][tid] = q1; s_q2[buf][tid] = q2; s_q3[buf][tid] = q3;
-            } else {
-                FastRec r;
-                make_record<false>(raw, cf, tb, r);
-                s_q0[buf][tid] = make_float4(r.u0, r.v0, r.hx, r.hy);
-                s_q1[buf][tid] = make_float4(r.l00, r.l01, r.l11, r.lo);
-                s_q2[buf][tid] = make_float4(r.d1, r.d2, r.d3, r.d4);
-                s_q3[buf][tid] = make_float4(r.d5, raw.rgb.x, raw.rgb.y, raw.rgb.z);
-            }
+            StagedRec sr;
+            stage_one(a, cf, tb, g_pre, raw, sr);
+            s_rec[buf][tid][0] = sr.r0; s_rec[buf][tid][1] = sr.r1; s_rec[buf][tid][2] = sr.r2; s_rec[buf][tid][3] = sr.r3;
+            s_cull[buf][tid] = sr.cull;
         }
         if (lane == 0) s_wdone[buf][wave] = wave_done ? 1 : 0;
         __syncthreads();
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
             // one candidate Gaussian per lane: does its footprint touch this wave's quadrant?
             bool hit = false;
             if (sub + (int32_t)lane < chunk_size) {
-                const float4 c = s_q0[buf][sub + lane];
+                const float4 c = s_cull[buf][sub + lane];
                 hit = (c.x + c.z >= wb[0]) && (c.x - c.z <= wb[1]) && (c.y + c.w >= wb[2]) && (c.y - c.w <= wb[3]);
             }
             unsigned long long todo = __ballot(hit);
@@ -351,22 +356,22 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
             while (todo) {
                 const int t = sub + __builtin_ctzll(todo);
                 todo &= todo - 1ull;
-                const float4 q0 = s_q0[buf][t], q1 = s_q1[buf][t], q2 = s_q2[buf][t], q3 = s_q3[buf][t];
+                const float4* rp = s_rec[buf][t];
+                const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
                 float du, dv, num2, rden;
-                const float alpha = fast_alpha(u, v, q0, q1, q2, q3.x, du, dv, num2, rden);
-                if (!done && alpha >= ALPHA_MIN) {
-                    const float next_T = T * (1.f - alpha);
-                    if (next_T <= 1e-4f) {
-                        done = true;
-                    } else {
-                        const float w = alpha * T;
-                        out_r = fmaf(q3.y, w, out_r); out_g = fmaf(q3.z, w, out_g); out_b = fmaf(q3.w, w, out_b);
-                        cur_idx = (uint32_t)(chunk_start + t);
-                        T = next_T;
-                    }
-                }
+                const float alpha = fast_alpha(u, v, r0, r1, r2, du, dv, num2, rden);
+                // branch-free compositing step (Fwd.cu:240-259): lanes that skip this Gaussian run with weight 0
+                const bool contrib = !done && alpha >= ALPHA_MIN;
+                const float next_T = T * (1.f - alpha);
+                const bool stop = contrib && next_T <= 1e-4f;
+                const bool take = contrib && !stop;
+                const float w = take ? alpha * T : 0.f;
+                out_r = fmaf(r2.w, w, out_r); out_g = fmaf(r3.x, w, out_g); out_b = fmaf(r3.y, w, out_b);
+                T = take ? next_T : T;
+                cur_idx = take ? (uint32_t)(chunk_start + t) : cur_idx;
+                done = done || stop;
 #ifdef GSX_STATS
-                { const unsigned long long c = __ballot(!done && alpha >= ALPHA_MIN); GSX_STAT_ADD(2, c != 0ull); GSX_STAT_ADD(3, __popcll(c)); }
+                { const unsigned long long c = __ballot(take); GSX_STAT_ADD(2, c != 0ull); GSX_STAT_ADD(3, __popcll(c)); }
 #endif
                 if (__ballot(!done) == 0ull) { wave_done = true; GSX_STAT_ADD(4, __popcll(todo)); break; }
             }
@@ -467,7 +472,8 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
                                                                             const float* __restrict__ v_render_colors,
                                                                             const float* __restrict__ v_render_alphas,
                                                                             float4* __restrict__ ws_rec, int32_t* __restrict__ ws_head) {
-    __shared__ float4 s_q0[BCH], s_q1[BCH], s_q2[BCH], s_q3[BCH];
+    __shared__ float4 s_rec[BCH][4];
+    __shared__ float4 s_cull[BCH];
     __shared__ float s_acc[NMOM][BCH];
     __shared__ int32_t s_gid[BCH];
     __shared__ unsigned long long s_touched[(BCH + 63) / 64];
@@ -522,23 +528,15 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
         const int32_t chunk_end = block_last - BCH * b;  // inclusive; slot t holds sorted index chunk_end - t
         const int32_t chunk_size = min(BCH, chunk_end + 1 - range_start);
         if ((int32_t)tid < chunk_size) {
-            if (a.packed) {
-                const int32_t g = a.flatten_ids[chunk_end - (int32_t)tid];
-                float4 q0, q1, q2, q3;
-                stage_packed(a.packed, g, tb, q0, q1, q2, q3);
-                s_q0[tid] = q0; s_q1[tid] = q1; s_q2[tid] = q2; s_q3[tid] = q3;
-                s_gid[tid] = g;
-            } else {
-                RawG raw;
-                load_raw(a, chunk_end - (int32_t)tid, raw);
-                FastRec r;
-                make_record<false>(raw, cf, tb, r);
-                s_q0[tid] = make_float4(r.u0, r.v0, r.hx, r.hy);
-                s_q1[tid] = make_float4(r.l00, r.l01, r.l11, r.lo);
-                s_q2[tid] = make_float4(r.d1, r.d2, r.d3, r.d4);
-                s_q3[tid] = make_float4(r.d5, raw.rgb.x, raw.rgb.y, raw.rgb.z);
-                s_gid[tid] = raw.g;
-            }
+            RawG raw;
+            int32_t g;
+            if (a.packed) g = a.flatten_ids[chunk_end - (int32_t)tid];
+            else { load_raw(a, chunk_end - (int32_t)tid, raw); g = raw.g; }
+            StagedRec sr;
+            stage_one(a, cf, tb, g, raw, sr);
+            s_rec[tid][0] = sr.r0; s_rec[tid][1] = sr.r1; s_rec[tid][2] = sr.r2; s_rec[tid][3] = sr.r3;
+            s_cull[tid] = sr.cull;
+            s_gid[tid] = g;
         }
         if (tid < BCH) {
 #pragma unroll
@@ -550,7 +548,7 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
         for (int32_t sub = 0; sub < chunk_size; sub += 64) {
             bool hit = false;
             if (sub + (int32_t)lane < chunk_size && chunk_end - (sub + (int32_t)lane) <= wave_last) {
-                const float4 c = s_q0[sub + lane];
+                const float4 c = s_cull[sub + lane];
                 hit = (c.x + c.z >= wb[0]) && (c.x - c.z <= wb[1]) && (c.y + c.w >= wb[2]) && (c.y - c.w <= wb[3]);
             }
             unsigned long long todo = __ballot(hit);
@@ -558,9 +556,10 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
             while (todo) {
                 const int t = sub + __builtin_ctzll(todo);
                 todo &= todo - 1ull;
-                const float4 q0 = s_q0[t], q1 = s_q1[t], q2 = s_q2[t], q3 = s_q3[t];
+                const float4* rp = s_rec[t];
+                const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
                 float du, dv, num2, rden;
-                const float alpha = fast_alpha(u, v, q0, q1, q2, q3.x, du, dv, num2, rden);
+                const float alpha = fast_alpha(u, v, r0, r1, r2, du, dv, num2, rden);
                 const bool valid = (chunk_end - t <= bin_final) && alpha >= ALPHA_MIN;
                 if (__ballot(valid) == 0ull) continue;
                 touched |= 1ull << (t - sub);
@@ -572,9 +571,9 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
                 const float fac = al * T;
                 float x[16];
                 x[0] = fac * vr; x[1] = fac * vg; x[2] = fac * vb;
-                float v_alpha = (q3.y * T - buf_r * ra) * vr + (q3.z * T - buf_g * ra) * vg + (q3.w * T - buf_b * ra) * vb;
+                float v_alpha = (r2.w * T - buf_r * ra) * vr + (r3.x * T - buf_g * ra) * vg + (r3.y * T - buf_b * ra) * vb;
                 v_alpha = fmaf(tail, ra, v_alpha);
-                buf_r = fmaf(q3.y, fac, buf_r); buf_g = fmaf(q3.z, fac, buf_g); buf_b = fmaf(q3.w, fac, buf_b);
+                buf_r = fmaf(r2.w, fac, buf_r); buf_g = fmaf(r3.x, fac, buf_g); buf_b = fmaf(r3.y, fac, buf_b);
                 // clamped alpha (>= 0.999) carries no gradient to opacity / geometry (Bwd.cu:318)
                 const float av = (al < 0.999f) ? al * v_alpha : 0.f;   // o * v_opacity;  dalpha/dD = -alpha/2
                 const float aw = -0.5f * av * rden;                    // a = (dL/dD) / den'
