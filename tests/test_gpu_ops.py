@@ -253,3 +253,22 @@ def test_error_behaviour(gsx_mod):
         ops.spherical_harmonics_fwd(0, torch.zeros(3, 8, device=DEV).t(), torch.zeros(8, 1, 3, device=DEV), None)
     with pytest.raises(RuntimeError):  # degree needs (deg+1)^2 <= K
         ops.spherical_harmonics_fwd(3, torch.zeros(8, 3, device=DEV), torch.zeros(8, 4, 3, device=DEV), None)
+
+
+def test_blend_with_no_intersections(gsx_mod, raster_path):
+    """All Gaussians culled: n_isects == 0 -> background image, zero alpha, zero gradients (Bwd.cu:434-437)."""
+    _, ops, _, scenes = gsx_mod
+    sc = _scene(scenes, N=64, size=48, seed=1)
+    N = 64
+    off = torch.zeros(1, 3, 3, dtype=torch.int32, device=DEV)
+    fl = torch.zeros(0, dtype=torch.int32, device=DEV)
+    colors = torch.rand(1, N, 3, device=DEV)
+    ut = ops.UnscentedTransformParameters()
+    args = (sc["means"].to(DEV), sc["quats"].to(DEV), sc["scales"].to(DEV), colors, sc["opacities"][None].to(DEV),
+            sc["background"][None].to(DEV), None, 48, 48, 16, sc["viewmat"][None].to(DEV), None, sc["K"][None].to(DEV),
+            ops.CameraModelType.PINHOLE, ut, ops.ShutterType.GLOBAL, None, None, None, off, fl)
+    ren, alp, last = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args)
+    assert torch.allclose(ren, sc["background"].to(DEV).expand(1, 48, 48, 3)) and torch.all(alp == 0) and torch.all(last == 0)
+    grads = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, alp, last, torch.randn(1, 48, 48, 3, device=DEV),
+                                                        torch.randn(1, 48, 48, 1, device=DEV))
+    assert all(float(g.abs().max()) == 0.0 for g in grads)
