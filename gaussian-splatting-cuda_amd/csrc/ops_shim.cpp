@@ -280,6 +280,43 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
     return std::make_tuple(v_means, v_quats, v_scales, v_colors, v_opacities);
 }
 
+at::Tensor quats_to_rotmats(const at::Tensor quats) {
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(quats));
+    GSX_CHECK_INPUT(quats);
+    const uint32_t N = quats.size(0);
+    at::Tensor rotmats = at::empty({N, 3, 3}, quats.options());
+    check(gsx_quats_to_rotmats(N, quats.data_ptr<float>(), rotmats.data_ptr<float>(), cur_stream()), "quats_to_rotmats");
+    return rotmats;
+}
+
+std::tuple<at::Tensor, at::Tensor> relocation(at::Tensor opacities, at::Tensor scales, at::Tensor ratios, at::Tensor binoms,
+                                              const int n_max) {
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(opacities));
+    GSX_CHECK_INPUT(opacities);
+    GSX_CHECK_INPUT(scales);
+    GSX_CHECK_INPUT(ratios);
+    GSX_CHECK_INPUT(binoms);
+    TORCH_CHECK(ratios.scalar_type() == at::kInt, "ratios must be int32");
+    at::Tensor new_opacities = at::empty_like(opacities);
+    at::Tensor new_scales = at::empty_like(scales);
+    check(gsx_relocation(opacities.size(0), opacities.data_ptr<float>(), scales.data_ptr<float>(), ratios.data_ptr<int32_t>(),
+                         binoms.data_ptr<float>(), n_max, new_opacities.data_ptr<float>(), new_scales.data_ptr<float>(), cur_stream()),
+          "relocation");
+    return std::make_tuple(new_opacities, new_scales);
+}
+
+void add_noise(at::Tensor raw_opacities, at::Tensor raw_scales, at::Tensor raw_quats, at::Tensor noise, at::Tensor means,
+               const float current_lr) {
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(raw_opacities));
+    GSX_CHECK_INPUT(raw_opacities);
+    GSX_CHECK_INPUT(raw_scales);
+    GSX_CHECK_INPUT(raw_quats);
+    GSX_CHECK_INPUT(noise);
+    GSX_CHECK_INPUT(means);
+    check(gsx_add_noise(raw_opacities.size(0), raw_opacities.data_ptr<float>(), raw_scales.data_ptr<float>(), raw_quats.data_ptr<float>(),
+                        noise.data_ptr<float>(), means.data_ptr<float>(), current_lr, cur_stream()), "add_noise");
+}
+
 }  // namespace gsplat
 
 
@@ -385,6 +422,9 @@ PYBIND11_MODULE(_gsx_ops, m) {
     m.def("projection_ut_3dgs_fused", &gsplat::projection_ut_3dgs_fused);
     m.def("rasterize_to_pixels_from_world_3dgs_fwd", &gsplat::rasterize_to_pixels_from_world_3dgs_fwd);
     m.def("rasterize_to_pixels_from_world_3dgs_bwd", &gsplat::rasterize_to_pixels_from_world_3dgs_bwd);
+    m.def("quats_to_rotmats", &gsplat::quats_to_rotmats);
+    m.def("relocation", &gsplat::relocation);
+    m.def("add_noise", &gsplat::add_noise);
     m.def("abi_version", []() { return gsx_abi_version(); });
     m.def("sh_colors_fwd", &gsx_ext::sh_colors_fwd);
     m.def("sh_colors_bwd", &gsx_ext::sh_colors_bwd);

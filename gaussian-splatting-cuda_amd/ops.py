@@ -29,6 +29,9 @@ intersect_offset = _C.intersect_offset
 projection_ut_3dgs_fused = _C.projection_ut_3dgs_fused
 rasterize_to_pixels_from_world_3dgs_fwd = _C.rasterize_to_pixels_from_world_3dgs_fwd
 rasterize_to_pixels_from_world_3dgs_bwd = _C.rasterize_to_pixels_from_world_3dgs_bwd
+quats_to_rotmats = _C.quats_to_rotmats
+relocation = _C.relocation
+add_noise = _C.add_noise
 abi_version = _C.abi_version
 
 # fused glue ops (extensions beyond Ops.h; include/gsx.h "fused glue")

@@ -150,6 +150,16 @@ int gsx_rasterize_to_pixels_from_world_3dgs_bwd(uint32_t N, int64_t n_isects, co
                                                 float* v_opacities, void* workspace, size_t workspace_bytes,
                                                 void* stream);
 
+/* ---- the remaining gsplat/Ops.h functions (Ops.h:45-65), so libgsx can stand in for the whole gsplat_backend --- */
+/* gsplat::quats_to_rotmats, QuatToRotmatCUDA.cu:13-39: quats [N,4] wxyz -> rotmats [N,3,3] row-major */
+int gsx_quats_to_rotmats(uint32_t N, const float* quats, float* rotmats, void* stream);
+/* gsplat::relocation, Relocation.cpp:15-33 / RelocationCUDA.cu:11-43: ratios int32 [N], binoms [n_max,n_max] */
+int gsx_relocation(uint32_t N, const float* opacities, const float* scales, const int32_t* ratios, const float* binoms,
+                   int n_max, float* new_opacities, float* new_scales, void* stream);
+/* gsplat::add_noise, Relocation.cpp:35-50 / RelocationCUDA.cu:112-141: means updated IN PLACE */
+int gsx_add_noise(uint32_t N, const float* raw_opacities, const float* raw_scales, const float* raw_quats, const float* noise,
+                  float* means, float current_lr, void* stream);
+
 /* ---- fused glue (extensions beyond gsplat/Ops.h) --------------------------------------------------
  * The reference's render glue wraps the operators in chains of small torch ops every frame; on MI355X those
  * ~40 launches cost as much as a blend kernel.  These entry points fuse them; results are identical to the

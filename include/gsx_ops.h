@@ -1,4 +1,4 @@
-// gsx_ops.h — C++ operator surface of the MI355X backend: the same seven free functions, in the same
+// gsx_ops.h — C++ operator surface of the MI355X backend: the same free functions (all ten of gsplat/Ops.h), in the same
 // namespace and with the same signatures, as the reference's gsplat/Ops.h:12-43,69-166, implemented in
 // gaussian-splatting-cuda_amd/csrc/ops_shim.cpp on top of the C ABI (include/gsx.h).
 // A reference build links this instead of its `gsplat_backend` static library.
@@ -41,6 +41,12 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile(const at::Tensor m
                                                               const bool sort);
 at::Tensor intersect_offset(const at::Tensor isect_ids, const uint32_t C, const uint32_t tile_width,
                             const uint32_t tile_height);
+// gsplat/Ops.h:45-65
+at::Tensor quats_to_rotmats(const at::Tensor quats);
+std::tuple<at::Tensor, at::Tensor> relocation(at::Tensor opacities, at::Tensor scales, at::Tensor ratios, at::Tensor binoms,
+                                              const int n_max);
+void add_noise(at::Tensor raw_opacities, at::Tensor raw_scales, at::Tensor raw_quats, at::Tensor noise, at::Tensor means,
+               const float current_lr);
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> projection_ut_3dgs_fused(
     const at::Tensor means, const at::Tensor quats, const at::Tensor scales, const at::optional<at::Tensor> opacities,
     const at::Tensor viewmats0, const at::optional<at::Tensor> viewmats1, const at::Tensor Ks,

@@ -1051,6 +1051,47 @@ void raster_bwd(uint32_t C, uint32_t N, int64_t n_isects, const T* means, const 
     for (size_t i = 0; i < a_opac.size(); ++i) v_opacities[i] = (T)a_opac[i];
 }
 
+// ------------------------------------------------------------------------------------------
+// next tier: relocation / add_noise — gsplat/RelocationCUDA.cu:11-43, 88-141
+// ------------------------------------------------------------------------------------------
+template <typename T>
+void relocation(int64_t N, const T* opacities, const T* scales, const int32_t* ratios, const T* binoms, int n_max,
+                T* new_opacities, T* new_scales) {
+    for (int64_t idx = 0; idx < N; ++idx) {
+        const int n_idx = ratios[idx];
+        T denom_sum = T(0);
+        new_opacities[idx] = T(1) - std::pow(T(1) - opacities[idx], T(1) / T(n_idx));
+        for (int i = 1; i <= n_idx; ++i)
+            for (int k = 0; k <= i - 1; ++k) {
+                T bin_coeff = binoms[(i - 1) * n_max + k];
+                T term = (std::pow(T(-1), T(k)) / std::sqrt(T(k + 1))) * std::pow(new_opacities[idx], T(k + 1));
+                denom_sum += bin_coeff * term;
+            }
+        T coeff = opacities[idx] / denom_sum;
+        for (int i = 0; i < 3; ++i) new_scales[idx * 3 + i] = coeff * scales[idx * 3 + i];
+    }
+}
+
+template <typename T>
+void add_noise(int64_t N, const T* raw_opacities, const T* raw_scales, const T* raw_quats, const T* noise, T* means, T lr) {
+    for (int64_t i = 0; i < N; ++i) {
+        T s2[3];
+        for (int k = 0; k < 3; ++k) s2[k] = std::exp(T(2) * raw_scales[i * 3 + k]);
+        T w = raw_quats[i * 4], x = raw_quats[i * 4 + 1], y = raw_quats[i * 4 + 2], z = raw_quats[i * 4 + 3];
+        T inv = std::min(T(1) / std::sqrt(x * x + y * y + z * z + w * w), T(1e12));
+        M3<T> R = mat3_cast(Q4<T>{w * inv, x * inv, y * inv, z * inv});
+        // covariance = R * S2 * R^T
+        M3<T> cov;
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) cov.a[r][c] = R.a[r][0] * s2[0] * R.a[c][0] + R.a[r][1] * s2[1] * R.a[c][1] + R.a[r][2] * s2[2] * R.a[c][2];
+        V3<T> tn = mv(cov, V3<T>{noise[i * 3], noise[i * 3 + 1], noise[i * 3 + 2]});
+        T opacity = T(1) / (T(1) + std::exp(-raw_opacities[i]));
+        T op_sigmoid = T(1) / (T(1) + std::exp(T(100) * opacity - T(0.5)));
+        T f = lr * op_sigmoid;
+        means[i * 3] += f * tn.x; means[i * 3 + 1] += f * tn.y; means[i * 3 + 2] += f * tn.z;
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -1116,6 +1157,18 @@ void raster_bwd(uint32_t C, uint32_t N, int64_t n_isects, const T* means, const 
 
 GSX_ORACLE_INSTANTIATE(f32, float)
 GSX_ORACLE_INSTANTIATE(f64, double)
+
+#define GSX_ORACLE_MCMC(SUF, T)                                                                                          \
+    extern "C" void gsx_oracle_relocation_##SUF(int64_t N, const T* opacities, const T* scales, const int32_t* ratios,   \
+                                                const T* binoms, int n_max, T* new_opacities, T* new_scales) {           \
+        relocation<T>(N, opacities, scales, ratios, binoms, n_max, new_opacities, new_scales);                           \
+    }                                                                                                                    \
+    extern "C" void gsx_oracle_add_noise_##SUF(int64_t N, const T* raw_opacities, const T* raw_scales, const T* raw_quats, \
+                                               const T* noise, T* means, T lr) {                                         \
+        add_noise<T>(N, raw_opacities, raw_scales, raw_quats, noise, means, lr);                                         \
+    }
+GSX_ORACLE_MCMC(f32, float)
+GSX_ORACLE_MCMC(f64, double)
 
 extern "C" void gsx_oracle_isect_offsets(int64_t n_isects, const int64_t* isect_ids, uint32_t C, uint32_t tw, uint32_t th,
                                          int32_t* offsets) {

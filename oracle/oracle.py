@@ -195,3 +195,21 @@ def rasterize_bwd(means, quats, scales, colors, opacities, backgrounds, masks, w
         _p(pri), _p(tile_offsets), _p(flatten_ids), _p(render_alphas), _p(last_ids), _p(v_render_colors),
         _p(v_render_alphas), _p(v_means), _p(v_quats), _p(v_scales), _p(v_colors), _p(v_opac))
     return v_means, v_quats, v_scales, v_colors, v_opac
+
+
+def relocation(opacities, scales, ratios, binoms, n_max):
+    dt = opacities.dtype
+    o, s, b = _c(opacities, dt), _c(scales, dt), _c(binoms, dt)
+    r = _c(ratios, np.int32)
+    new_o, new_s = np.zeros_like(o), np.zeros_like(s)
+    getattr(lib(), "gsx_oracle_relocation_" + _suf(dt))(ctypes.c_int64(o.shape[0]), _p(o), _p(s), _p(r), _p(b), ctypes.c_int(n_max),
+                                                        _p(new_o), _p(new_s))
+    return new_o, new_s
+
+
+def add_noise(raw_opacities, raw_scales, raw_quats, noise, means, lr):
+    dt = means.dtype
+    out = np.ascontiguousarray(means, dtype=dt).copy()
+    getattr(lib(), "gsx_oracle_add_noise_" + _suf(dt))(ctypes.c_int64(out.shape[0]), _p(_c(raw_opacities, dt)), _p(_c(raw_scales, dt)),
+                                                       _p(_c(raw_quats, dt)), _p(_c(noise, dt)), _p(out), _fl(dt, lr))
+    return out
