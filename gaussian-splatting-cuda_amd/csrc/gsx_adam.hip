@@ -1,0 +1,78 @@
+// gsx_adam.hip — fused Adam step.  Replaces fast_gs::optimizer::adam_step_wrapper
+// (reference: fastgs/optimizer/include/adam_kernels.cuh:13-38, host logic src/training/optimizers/fused_adam.cpp:20-96).
+// Pure streaming: 28 B per element (param r/w, exp_avg r/w, exp_avg_sq r/w, grad r) — HBM-bound.
+// `rows x cols` with leading dimensions lets one launch update a strided view (the sh0 / shN column blocks of the
+// single [N,K,3] SH tensor keep their own learning rate and state, like the reference's two parameter groups).
+#include <algorithm>
+
+#include "gsx_device.hpp"
+
+namespace gsx {
+
+void set_error(const char* msg);
+int check_launch(const char* what);
+
+__global__ __launch_bounds__(256) void adam_step_kernel(uint64_t rows, uint32_t cols, uint64_t ld_param, uint64_t ld_grad,
+                                                        float* __restrict__ param, float* __restrict__ exp_avg,
+                                                        float* __restrict__ exp_avg_sq, const float* __restrict__ grad, float lr,
+                                                        float beta1, float beta2, float eps, float bc1_rcp, float bc2_sqrt_rcp) {
+    const uint64_t total = rows * cols;
+    const float step_size = lr * bc1_rcp;
+    for (uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * 256u) {
+        const uint64_t r = idx / cols, c = idx - r * cols;
+        const float g = grad[r * ld_grad + c];
+        const float m1 = beta1 * exp_avg[idx] + (1.0f - beta1) * g;
+        const float m2 = beta2 * exp_avg_sq[idx] + (1.0f - beta2) * g * g;
+        const float denom = sqrtf(m2) * bc2_sqrt_rcp + eps;
+        param[r * ld_param + c] -= step_size * m1 / denom;
+        exp_avg[idx] = m1;
+        exp_avg_sq[idx] = m2;
+    }
+}
+
+// contiguous fast path: 16 B per lane per array
+__global__ __launch_bounds__(256) void adam_step_vec4_kernel(uint64_t n4, float4* __restrict__ param, float4* __restrict__ exp_avg,
+                                                             float4* __restrict__ exp_avg_sq, const float4* __restrict__ grad, float lr,
+                                                             float beta1, float beta2, float eps, float bc1_rcp, float bc2_sqrt_rcp) {
+    const float step_size = lr * bc1_rcp;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * 256u) {
+        const float4 g = grad[i];
+        float4 m = exp_avg[i], v = exp_avg_sq[i], p = param[i];
+#define GSX_ADAM1(F)                                                        \
+        m.F = beta1 * m.F + (1.0f - beta1) * g.F;                           \
+        v.F = beta2 * v.F + (1.0f - beta2) * g.F * g.F;                     \
+        p.F -= step_size * m.F / (sqrtf(v.F) * bc2_sqrt_rcp + eps);
+        GSX_ADAM1(x) GSX_ADAM1(y) GSX_ADAM1(z) GSX_ADAM1(w)
+#undef GSX_ADAM1
+        param[i] = p; exp_avg[i] = m; exp_avg_sq[i] = v;
+    }
+}
+
+}  // namespace gsx
+
+using namespace gsx;
+
+extern "C" int gsx_adam_step(uint64_t rows, uint32_t cols, uint64_t ld_param, uint64_t ld_grad, float* param, float* exp_avg,
+                             float* exp_avg_sq, const float* grad, float lr, float beta1, float beta2, float eps,
+                             float bias_correction1_rcp, float bias_correction2_sqrt_rcp, void* stream) {
+    if (rows == 0 || cols == 0) return GSX_OK;
+    if (!param || !exp_avg || !exp_avg_sq || !grad || ld_param < cols || ld_grad < cols) {
+        set_error("adam_step: null pointer / leading dimension smaller than cols");
+        return GSX_ERR_INVALID_ARGUMENT;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t total = rows * cols;
+    const bool contiguous = (ld_param == cols && ld_grad == cols) || rows == 1;
+    const bool aligned = ((((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)grad) & 15u) == 0) && (total % 4 == 0);
+    if (contiguous && aligned) {
+        const uint64_t n4 = total / 4;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((n4 + 255) / 256, 256u * 16u);
+        hipLaunchKernelGGL(adam_step_vec4_kernel, dim3(grid), dim3(256), 0, st, n4, (float4*)param, (float4*)exp_avg, (float4*)exp_avg_sq,
+                           (const float4*)grad, lr, beta1, beta2, eps, bias_correction1_rcp, bias_correction2_sqrt_rcp);
+    } else {
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256u * 32u);
+        hipLaunchKernelGGL(adam_step_kernel, dim3(grid), dim3(256), 0, st, rows, cols, ld_param, ld_grad, param, exp_avg, exp_avg_sq, grad,
+                           lr, beta1, beta2, eps, bias_correction1_rcp, bias_correction2_sqrt_rcp);
+    }
+    return check_launch("adam_step");
+}

@@ -390,6 +390,40 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> splat_activations_bwd(const at::T
     return std::make_tuple(gs, gr, go);
 }
 
+// fused Adam step on a parameter (or a row-strided view of one: dims after the first must be dense)
+void adam_step(at::Tensor param, at::Tensor exp_avg, at::Tensor exp_avg_sq, const at::Tensor grad, double lr, double beta1,
+               double beta2, double eps, double bias_correction1_rcp, double bias_correction2_sqrt_rcp) {
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(param));
+    TORCH_CHECK(param.is_cuda() && grad.is_cuda() && exp_avg.is_cuda() && exp_avg_sq.is_cuda(), "adam_step: CUDA tensors required");
+    TORCH_CHECK(exp_avg.is_contiguous() && exp_avg_sq.is_contiguous(), "adam_step: optimizer states must be contiguous");
+    TORCH_CHECK(param.sizes() == grad.sizes() && param.numel() == exp_avg.numel() && param.numel() == exp_avg_sq.numel(), "adam_step: shape mismatch");
+    if (param.numel() == 0) return;
+    auto rows_cols_ld = [](const at::Tensor& t, uint64_t& rows, uint32_t& cols, uint64_t& ld) {
+        if (t.is_contiguous()) { rows = 1; cols = 0; ld = 0; return true; }
+        if (t.dim() < 2) return false;
+        int64_t inner = 1;
+        for (int64_t d = t.dim() - 1; d >= 1; --d) { if (t.stride(d) != inner) return false; inner *= t.size(d); }
+        rows = t.size(0); cols = (uint32_t)inner; ld = t.stride(0);
+        return true;
+    };
+    uint64_t rp, rg, lp, lg; uint32_t cp, cg;
+    TORCH_CHECK(rows_cols_ld(param, rp, cp, lp) && rows_cols_ld(grad, rg, cg, lg), "adam_step: only dense or row-strided tensors are supported");
+    uint64_t rows; uint32_t cols;
+    if (cp == 0 && cg == 0) { rows = 1; cols = 0; }
+    else { rows = param.size(0); cols = (uint32_t)(param.numel() / param.size(0)); }
+    if (cols == 0) {  // both dense: treat as one long row, chunked to fit uint32 columns
+        const uint64_t n = param.numel();
+        TORCH_CHECK(n < (1ull << 32), "adam_step: dense tensors above 2^32 elements are not supported");
+        rows = 1; cols = (uint32_t)n; lp = lg = n;
+    } else {
+        if (cp == 0) lp = cols;
+        if (cg == 0) lg = cols;
+    }
+    check(gsx_adam_step(rows, cols, lp, lg, param.data_ptr<float>(), exp_avg.data_ptr<float>(), exp_avg_sq.data_ptr<float>(),
+                        grad.data_ptr<float>(), (float)lr, (float)beta1, (float)beta2, (float)eps, (float)bias_correction1_rcp,
+                        (float)bias_correction2_sqrt_rcp, cur_stream()), "adam_step");
+}
+
 }  // namespace gsx_ext
 
 // ---------------------------------------------------------------------------------------------
@@ -430,5 +464,6 @@ PYBIND11_MODULE(_gsx_ops, m) {
     m.def("sh_colors_bwd", &gsx_ext::sh_colors_bwd);
     m.def("splat_activations_fwd", &gsx_ext::splat_activations_fwd);
     m.def("splat_activations_bwd", &gsx_ext::splat_activations_bwd);
+    m.def("adam_step", &gsx_ext::adam_step);
 }
 #endif  // GSX_NO_PYBIND

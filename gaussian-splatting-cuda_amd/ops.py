@@ -39,3 +39,4 @@ sh_colors_fwd = _C.sh_colors_fwd
 sh_colors_bwd = _C.sh_colors_bwd
 splat_activations_fwd = _C.splat_activations_fwd
 splat_activations_bwd = _C.splat_activations_bwd
+adam_step = _C.adam_step

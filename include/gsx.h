@@ -160,6 +160,14 @@ int gsx_relocation(uint32_t N, const float* opacities, const float* scales, cons
 int gsx_add_noise(uint32_t N, const float* raw_opacities, const float* raw_scales, const float* raw_quats, const float* noise,
                   float* means, float current_lr, void* stream);
 
+/* ---- next tier: fused Adam step -------------------------------------------------------
+ * fast_gs::optimizer::adam_step_wrapper, fastgs/optimizer/include/adam_kernels.cuh:13-38:
+ *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr * bc1_rcp * m / (sqrt(v) * bc2_sqrt_rcp + eps)
+ * param / grad are [rows, cols] with leading dimensions (elements) ld_param / ld_grad, the states contiguous. */
+int gsx_adam_step(uint64_t rows, uint32_t cols, uint64_t ld_param, uint64_t ld_grad, float* param, float* exp_avg,
+                  float* exp_avg_sq, const float* grad, float lr, float beta1, float beta2, float eps,
+                  float bias_correction1_rcp, float bias_correction2_sqrt_rcp, void* stream);
+
 /* ---- fused glue (extensions beyond gsplat/Ops.h) --------------------------------------------------
  * The reference's render glue wraps the operators in chains of small torch ops every frame; on MI355X those
  * ~40 launches cost as much as a blend kernel.  These entry points fuse them; results are identical to the

@@ -1170,6 +1170,23 @@ GSX_ORACLE_INSTANTIATE(f64, double)
 GSX_ORACLE_MCMC(f32, float)
 GSX_ORACLE_MCMC(f64, double)
 
+// fastgs/optimizer/include/adam_kernels.cuh:13-38
+#define GSX_ORACLE_ADAM(SUF, T)                                                                                          \
+    extern "C" void gsx_oracle_adam_step_##SUF(int64_t n, T* param, T* exp_avg, T* exp_avg_sq, const T* grad, T lr, T beta1, \
+                                               T beta2, T eps, T bc1_rcp, T bc2_sqrt_rcp) {                              \
+        for (int64_t i = 0; i < n; ++i) {                                                                                \
+            const T g = grad[i];                                                                                         \
+            const T m1 = beta1 * exp_avg[i] + (T(1) - beta1) * g;                                                        \
+            const T m2 = beta2 * exp_avg_sq[i] + (T(1) - beta2) * g * g;                                                 \
+            const T denom = std::sqrt(m2) * bc2_sqrt_rcp + eps;                                                          \
+            param[i] -= lr * bc1_rcp * m1 / denom;                                                                       \
+            exp_avg[i] = m1;                                                                                             \
+            exp_avg_sq[i] = m2;                                                                                          \
+        }                                                                                                                \
+    }
+GSX_ORACLE_ADAM(f32, float)
+GSX_ORACLE_ADAM(f64, double)
+
 extern "C" void gsx_oracle_isect_offsets(int64_t n_isects, const int64_t* isect_ids, uint32_t C, uint32_t tw, uint32_t th,
                                          int32_t* offsets) {
     isect_offsets(n_isects, isect_ids, C, tw, th, offsets);

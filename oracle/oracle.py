@@ -213,3 +213,14 @@ def add_noise(raw_opacities, raw_scales, raw_quats, noise, means, lr):
     getattr(lib(), "gsx_oracle_add_noise_" + _suf(dt))(ctypes.c_int64(out.shape[0]), _p(_c(raw_opacities, dt)), _p(_c(raw_scales, dt)),
                                                        _p(_c(raw_quats, dt)), _p(_c(noise, dt)), _p(out), _fl(dt, lr))
     return out
+
+
+def adam_step(param, exp_avg, exp_avg_sq, grad, lr, beta1, beta2, eps, step_count):
+    """One reference Adam step (in place on copies; returns param, exp_avg, exp_avg_sq)."""
+    dt = param.dtype
+    p, m, v = (np.ascontiguousarray(a, dtype=dt).copy() for a in (param, exp_avg, exp_avg_sq))
+    bc1 = 1.0 / (1.0 - beta1 ** step_count)
+    bc2 = 1.0 / np.sqrt(1.0 - beta2 ** step_count)
+    getattr(lib(), "gsx_oracle_adam_step_" + _suf(dt))(ctypes.c_int64(p.size), _p(p), _p(m), _p(v), _p(_c(grad, dt)), _fl(dt, lr),
+                                                       _fl(dt, beta1), _fl(dt, beta2), _fl(dt, eps), _fl(dt, bc1), _fl(dt, bc2))
+    return p, m, v
