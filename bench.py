@@ -47,6 +47,10 @@ def algorithmic_bytes(N, C, I, P, tiles, deg, K):  # noqa: E741  (SURVEY.md §8d
         "intersect_offset": 8 * I + 4 * tiles,
         "rasterize_to_pixels_from_world_3dgs_fwd": 60 * I + 20 * P + 4 * tiles,
         "rasterize_to_pixels_from_world_3dgs_bwd": 172 * I + 24 * P,
+        # fused loss: fwd reads render + gt (24 B/px), writes 3 chained derivative maps x 3 channels (36 B/px);
+        # bwd reads those + render + gt, writes v_render (12 B/px)
+        "photometric_loss_fwd": 60 * P * C,
+        "photometric_loss_bwd": 72 * P * C,
     }
 
 
@@ -58,7 +62,8 @@ class OpTimer:
         self.ops = ops_mod
         self.names = ["projection_ut_3dgs_fused", "spherical_harmonics_fwd", "spherical_harmonics_bwd", "intersect_tile",
                       "intersect_offset", "rasterize_to_pixels_from_world_3dgs_fwd", "rasterize_to_pixels_from_world_3dgs_bwd",
-                      "sh_colors_fwd", "sh_colors_bwd", "splat_activations_fwd", "splat_activations_bwd"]
+                      "sh_colors_fwd", "sh_colors_bwd", "splat_activations_fwd", "splat_activations_bwd",
+                      "photometric_loss_fwd", "photometric_loss_bwd"]
         self.orig = {n: getattr(ops_mod, n) for n in self.names}
         self.events = {n: [] for n in self.names}
         self.enabled = False
@@ -114,11 +119,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL)")
     ap.add_argument("--unfused", action="store_true", help="reference-style glue (one torch op per activation / SH pre-post step)")
+    ap.add_argument("--l1-loss", action="store_true", help="plain torch L1 loss instead of the reference's fused L1 + SSIM loss")
+    ap.add_argument("--no-train-iter", action="store_true", help="skip the extra full-iteration timing (loss + backward + Adam)")
     args = ap.parse_args()
 
     import gsx  # noqa: F401
     from gsx import distributed as gdist
-    from gsx import ops, rasterizer, scenes
+    from gsx import loss as gloss
+    from gsx import ops, optim, rasterizer, scenes
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     if os.environ.get("GSX_BENCH_ALL_RANKS_ON_DEVICE0"):  # functional test of the N>1 code path on a 1-GPU box (gloo)
@@ -143,6 +151,7 @@ def main():
     bg = scene["background"].to(dev)
     g = torch.Generator().manual_seed(1234 + rank)
     target = torch.rand(3, H, W, generator=g).to(dev)
+    fused_loss = not (args.l1_loss or args.unfused)
 
     timer = OpTimer(ops)
     state = {}
@@ -155,7 +164,8 @@ def main():
         if args.unfused:
             bucket.zero_()
             out = rasterizer.rasterize(cam, model, bg)
-        loss = (out.image - target).abs().mean()
+        # the reference's photometric loss (trainer.cpp:103-127): 0.8 L1 + 0.2 (1 - SSIM), fused on the blend's own layout
+        loss = gloss.photometric_loss(out.render_hwc, target, 0.2) if fused_loss else (out.image - target).abs().mean()
         loss.backward()
         bucket.all_reduce_mean()
         state["n_isects"] = out.n_isects
@@ -180,6 +190,35 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    # second part of the BASELINE metric ("train iters/s"): the same step followed by the fused Adam update of all six
+    # parameter groups (optim.FusedAdam, reference lrs) — timed separately, after and outside the K contract steps.
+    train_iter_ms = None
+    if not args.no_train_iter and not args.unfused:
+        # (.grad of every parameter already is its view of the flat bucket the backward writes into)
+        opt = optim.FusedAdam.for_splat_data(model)
+        it = [1000]
+
+        def train_iter():
+            it[0] += 1
+            step()
+            opt.step(it[0])
+
+        for _ in range(2):
+            train_iter()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            train_iter()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        tt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        train_iter_ms = float(tt.item()) / args.steps * 1e3
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -222,7 +261,12 @@ def main():
             "pairs_per_s_fwd": round(256.0 * I / (op_ms.get("rasterize_to_pixels_from_world_3dgs_fwd", float("nan")) * 1e-3), 1),
             "roofline": roofline,
             "kernels": kernels,
+            "loss": "fused L1 + SSIM (lambda 0.2)" if fused_loss else "torch L1",
         }
+        if train_iter_ms is not None:
+            result["train_iter"] = {"ms": round(train_iter_ms, 4), "iters_per_s": round(1e3 / train_iter_ms, 3),
+                                    "frames_per_s": round(world * 1e3 / train_iter_ms, 3),
+                                    "what": "render + fused L1/SSIM loss + backward + grad all-reduce + fused Adam (6 groups)"}
         if world == 1 and not args.no_cpu_baseline:
             threads = os.cpu_count() or 1
             dt, i_cpu = cpu_baseline(scene, threads)

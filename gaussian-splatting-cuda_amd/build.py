@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIBGSX = os.path.join(HERE, "libgsx.so")
-HIP_SOURCES = ["gsx_capi.hip", "gsx_sh.hip", "gsx_projection.hip", "gsx_intersect.hip", "gsx_raster.hip", "gsx_raster_fast.hip", "gsx_mcmc.hip", "gsx_adam.hip"]
+HIP_SOURCES = ["gsx_capi.hip", "gsx_sh.hip", "gsx_projection.hip", "gsx_intersect.hip", "gsx_raster.hip", "gsx_raster_fast.hip", "gsx_mcmc.hip", "gsx_adam.hip", "gsx_ssim.hip"]
 HIP_HEADERS = ["gsx_device.hpp", "gsx_raster_common.hpp"]
 
 

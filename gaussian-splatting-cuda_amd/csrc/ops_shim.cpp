@@ -390,6 +390,85 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> splat_activations_bwd(const at::T
     return std::make_tuple(gs, gr, go);
 }
 
+void adam_step_split(at::Tensor param, at::Tensor exp_avg, at::Tensor exp_avg_sq, const at::Tensor grad, int64_t split, double lr_a, double lr_b,
+                     bool step_a, bool step_b, double beta1, double beta2, double eps, double bias_correction1_rcp, double bias_correction2_sqrt_rcp) {
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(param));
+    TORCH_CHECK(param.is_cuda() && grad.is_cuda() && exp_avg.is_cuda() && exp_avg_sq.is_cuda(), "adam_step_split: CUDA tensors required");
+    TORCH_CHECK(param.is_contiguous() && grad.is_contiguous() && exp_avg.is_contiguous() && exp_avg_sq.is_contiguous(), "adam_step_split: dense tensors required");
+    TORCH_CHECK(param.sizes() == grad.sizes() && param.sizes() == exp_avg.sizes() && param.sizes() == exp_avg_sq.sizes() && param.dim() >= 2,
+                "adam_step_split: shape mismatch");
+    if (param.numel() == 0) return;
+    const uint64_t rows = param.size(0);
+    const uint32_t cols = (uint32_t)(param.numel() / param.size(0));
+    check(gsx_adam_step_split(rows, cols, (uint32_t)split, param.data_ptr<float>(), exp_avg.data_ptr<float>(), exp_avg_sq.data_ptr<float>(),
+                              grad.data_ptr<float>(), (float)lr_a, (float)lr_b, step_a, step_b, (float)beta1, (float)beta2, (float)eps,
+                              (float)bias_correction1_rcp, (float)bias_correction2_sqrt_rcp, cur_stream()), "adam_step_split");
+}
+
+// fusedssim / fusedssim_backward (include/kernels/ssim.cuh:11-29): same tuple returns
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> fusedssim(double C1, double C2, const at::Tensor& img1_, const at::Tensor& img2_, bool train) {
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(img1_));
+    TORCH_CHECK(img1_.is_cuda() && img2_.is_cuda() && img1_.dim() == 4 && img1_.sizes() == img2_.sizes(), "fusedssim: two [B,CH,H,W] CUDA tensors required");
+    TORCH_CHECK(img1_.scalar_type() == at::kFloat && img2_.scalar_type() == at::kFloat, "fusedssim: float32 required");
+    const at::Tensor img1 = img1_.contiguous(), img2 = img2_.contiguous();
+    at::Tensor map = at::empty_like(img1);
+    at::Tensor d0 = train ? at::empty_like(img1) : at::empty({0}, img1.options());
+    at::Tensor d1 = train ? at::empty_like(img1) : at::empty({0}, img1.options());
+    at::Tensor d2 = train ? at::empty_like(img1) : at::empty({0}, img1.options());
+    check(gsx_fused_ssim_fwd((uint32_t)img1.size(0), (uint32_t)img1.size(1), (uint32_t)img1.size(2), (uint32_t)img1.size(3), (float)C1, (float)C2,
+                             img1.data_ptr<float>(), img2.data_ptr<float>(), map.data_ptr<float>(), train ? d0.data_ptr<float>() : nullptr,
+                             train ? d1.data_ptr<float>() : nullptr, train ? d2.data_ptr<float>() : nullptr, cur_stream()), "fusedssim");
+    return std::make_tuple(map, d0, d1, d2);
+}
+
+at::Tensor fusedssim_backward(double C1, double C2, const at::Tensor& img1_, const at::Tensor& img2_, const at::Tensor& dL_dmap_,
+                              const at::Tensor& dm_dmu1, const at::Tensor& dm_dsigma1_sq, const at::Tensor& dm_dsigma12) {
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(img1_));
+    TORCH_CHECK(img1_.is_cuda() && img1_.dim() == 4 && img1_.sizes() == img2_.sizes() && img1_.sizes() == dL_dmap_.sizes(), "fusedssim_backward: shape mismatch");
+    TORCH_CHECK(dm_dmu1.sizes() == img1_.sizes() && dm_dsigma1_sq.sizes() == img1_.sizes() && dm_dsigma12.sizes() == img1_.sizes(),
+                "fusedssim_backward: derivative maps of the forward (train = true) required");
+    const at::Tensor img1 = img1_.contiguous(), img2 = img2_.contiguous(), dL = dL_dmap_.contiguous();
+    const at::Tensor a = dm_dmu1.contiguous(), b = dm_dsigma1_sq.contiguous(), c = dm_dsigma12.contiguous();
+    at::Tensor out = at::empty_like(img1);
+    check(gsx_fused_ssim_bwd((uint32_t)img1.size(0), (uint32_t)img1.size(1), (uint32_t)img1.size(2), (uint32_t)img1.size(3), (float)C1, (float)C2,
+                             img1.data_ptr<float>(), img2.data_ptr<float>(), dL.data_ptr<float>(), out.data_ptr<float>(), a.data_ptr<float>(),
+                             b.data_ptr<float>(), c.data_ptr<float>(), cur_stream()), "fusedssim_backward");
+    return out;
+}
+
+// fused photometric loss on the blend's [C,H,W,3] output; returns (loss3 = {loss, l1, ssim}, workspace for the backward)
+std::tuple<at::Tensor, at::Tensor> photometric_loss_fwd(const at::Tensor& render, const at::Tensor& gt, double lambda_dssim) {
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(render));
+    TORCH_CHECK(render.is_cuda() && gt.is_cuda() && render.dim() == 4 && render.size(3) == 3 && render.is_contiguous(), "photometric_loss: render must be contiguous [C,H,W,3]");
+    TORCH_CHECK(gt.dim() == 4 && gt.size(0) == render.size(0) && gt.size(1) == 3 && gt.size(2) == render.size(1) && gt.size(3) == render.size(2) &&
+                    gt.is_contiguous(), "photometric_loss: gt must be contiguous [C,3,H,W]");
+    TORCH_CHECK(render.scalar_type() == at::kFloat && gt.scalar_type() == at::kFloat, "photometric_loss: float32 required");
+    const uint32_t C = (uint32_t)render.size(0), H = (uint32_t)render.size(1), W = (uint32_t)render.size(2);
+    const size_t bytes = gsx_photometric_loss_workspace_bytes(C, H, W);
+    at::Tensor ws = at::empty({(int64_t)bytes}, render.options().dtype(at::kByte));
+    at::Tensor loss3 = at::empty({3}, render.options());
+    check(gsx_photometric_loss_fwd(C, H, W, (float)lambda_dssim, render.data_ptr<float>(), gt.data_ptr<float>(), loss3.data_ptr<float>(),
+                                   ws.data_ptr(), bytes, cur_stream()), "photometric_loss_fwd");
+    return std::make_tuple(loss3, ws);
+}
+
+at::Tensor photometric_loss_bwd(const at::Tensor& render, const at::Tensor& gt, const at::Tensor& ws, double lambda_dssim,
+                                const c10::optional<at::Tensor>& grad_loss, double grad_scale) {
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(render));
+    const uint32_t C = (uint32_t)render.size(0), H = (uint32_t)render.size(1), W = (uint32_t)render.size(2);
+    at::Tensor v = at::empty_like(render);
+    const float* gl = nullptr;
+    at::Tensor glt;
+    if (grad_loss.has_value() && grad_loss->defined()) {
+        glt = grad_loss->to(at::kFloat).contiguous();
+        TORCH_CHECK(glt.is_cuda() && glt.numel() == 1, "photometric_loss_bwd: grad_loss must be a device scalar");
+        gl = glt.data_ptr<float>();
+    }
+    check(gsx_photometric_loss_bwd(C, H, W, (float)lambda_dssim, gl, (float)grad_scale, render.data_ptr<float>(), gt.data_ptr<float>(), ws.data_ptr(),
+                                   (size_t)ws.numel(), v.data_ptr<float>(), cur_stream()), "photometric_loss_bwd");
+    return v;
+}
+
 // fused Adam step on a parameter (or a row-strided view of one: dims after the first must be dense)
 void adam_step(at::Tensor param, at::Tensor exp_avg, at::Tensor exp_avg_sq, const at::Tensor grad, double lr, double beta1,
                double beta2, double eps, double bias_correction1_rcp, double bias_correction2_sqrt_rcp) {
@@ -465,5 +544,10 @@ PYBIND11_MODULE(_gsx_ops, m) {
     m.def("splat_activations_fwd", &gsx_ext::splat_activations_fwd);
     m.def("splat_activations_bwd", &gsx_ext::splat_activations_bwd);
     m.def("adam_step", &gsx_ext::adam_step);
+    m.def("adam_step_split", &gsx_ext::adam_step_split);
+    m.def("fusedssim", &gsx_ext::fusedssim);
+    m.def("fusedssim_backward", &gsx_ext::fusedssim_backward);
+    m.def("photometric_loss_fwd", &gsx_ext::photometric_loss_fwd);
+    m.def("photometric_loss_bwd", &gsx_ext::photometric_loss_bwd);
 }
 #endif  // GSX_NO_PYBIND

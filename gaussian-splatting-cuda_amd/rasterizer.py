@@ -69,6 +69,7 @@ class SplatData:
 @dataclass
 class RenderOutput:
     image: torch.Tensor = None
+    render_hwc: torch.Tensor = None
     alpha: torch.Tensor = None
     depth: torch.Tensor = None
     means2d: torch.Tensor = None
@@ -308,6 +309,7 @@ def rasterize_fused(camera: Camera, model: SplatData, bg_color: Optional[torch.T
         scaling_modifier, cam_model, None, None, grad_sinks)
     out = RenderOutput()
     out.image = torch.clamp(renders.squeeze(0).permute(2, 0, 1), 0.0, 1.0)
+    out.render_hwc = renders  # [1,H,W,3] unclamped: what loss.photometric_loss consumes
     out.alpha = alphas.squeeze(0).permute(2, 0, 1)
     out.means2d, out.depths = means2d, depths.squeeze(0)
     if with_visibility:  # only the densification strategies read these (three more N-sized kernels)

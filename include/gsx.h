@@ -167,6 +167,32 @@ int gsx_add_noise(uint32_t N, const float* raw_opacities, const float* raw_scale
 int gsx_adam_step(uint64_t rows, uint32_t cols, uint64_t ld_param, uint64_t ld_grad, float* param, float* exp_avg,
                   float* exp_avg_sq, const float* grad, float lr, float beta1, float beta2, float eps,
                   float bias_correction1_rcp, float bias_correction2_sqrt_rcp, void* stream);
+/* Same update on a dense [rows, cols] tensor (cols % 4 == 0) whose columns [0, split) and [split, cols) are two parameter
+ * groups sharing betas / eps / step count but not the learning rate (sh0 / shN of one [N,K,3] SH tensor:
+ * strategy_utils.cpp:36-37); step_a / step_b == 0 leaves that block and its state untouched (fused_adam.cpp:68-76). */
+int gsx_adam_step_split(uint64_t rows, uint32_t cols, uint32_t split, float* param, float* exp_avg, float* exp_avg_sq,
+                        const float* grad, float lr_a, float lr_b, int step_a, int step_b, float beta1, float beta2, float eps,
+                        float bias_correction1_rcp, float bias_correction2_sqrt_rcp, void* stream);
+
+/* ---- next tier: photometric loss ----------------------------------------------------------
+ * fusedssim / fusedssim_backward, src/training/kernels/ssim.cu:436-470 / 478-510 (kernels :64-275, :283-428): planar
+ * [B,CH,H,W] images, 11x11 Gaussian window (sigma 1.5), zero padding.  Pass dm_* = NULL for train == false. */
+int gsx_fused_ssim_fwd(uint32_t B, uint32_t CH, uint32_t H, uint32_t W, float C1, float C2, const float* img1, const float* img2,
+                       float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void* stream);
+int gsx_fused_ssim_bwd(uint32_t B, uint32_t CH, uint32_t H, uint32_t W, float C1, float C2, const float* img1, const float* img2,
+                       const float* dL_dmap, float* dL_dimg1, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                       const float* dm_dsigma12, void* stream);
+/* Trainer::compute_photometric_loss (src/training/trainer.cpp:103-127) fused with the image clamp / permute of
+ * rasterizer.cpp:401: loss = (1-lambda) * L1(clamp(render), gt) + lambda * (1 - mean(SSIM "valid" map)).
+ * render / v_render: the blend's [C,H,W,3] layout; gt: [C,3,H,W]; loss3 = {loss, l1, ssim} on the device.
+ * bwd multiplies by grad_scale and, when non-NULL, by the device scalar *grad_loss.  The same workspace must be passed
+ * to bwd after fwd. */
+size_t gsx_photometric_loss_workspace_bytes(uint32_t C, uint32_t H, uint32_t W);
+int gsx_photometric_loss_fwd(uint32_t C, uint32_t H, uint32_t W, float lambda_dssim, const float* render, const float* gt,
+                             float* loss3, void* workspace, size_t workspace_bytes, void* stream);
+int gsx_photometric_loss_bwd(uint32_t C, uint32_t H, uint32_t W, float lambda_dssim, const float* grad_loss, float grad_scale,
+                             const float* render, const float* gt, const void* workspace, size_t workspace_bytes, float* v_render,
+                             void* stream);
 
 /* ---- fused glue (extensions beyond gsplat/Ops.h) --------------------------------------------------
  * The reference's render glue wraps the operators in chains of small torch ops every frame; on MI355X those

@@ -1193,3 +1193,95 @@ extern "C" void gsx_oracle_isect_offsets(int64_t n_isects, const int64_t* isect_
 }
 
 extern "C" int gsx_oracle_abi_version(void) { return 1; }
+
+
+// ---- fused SSIM (src/training/kernels/ssim.cu) --------------------------------------------------------------------------
+// Window ssim.cu:16-27; zero padding :46-55; horizontal-then-vertical 11-tap passes in the reference's pairwise order
+// ((left + right) * w for d = 1..5, then the centre tap: :132-160, :222-245); SSIM and partials :247-270; backward :300-428.
+namespace {
+const float kSsimTaps[11] = {0.001028380123898387f, 0.0075987582094967365f, 0.036000773310661316f, 0.10936068743467331f,
+                             0.21300552785396576f,  0.26601171493530273f,   0.21300552785396576f,  0.10936068743467331f,
+                             0.036000773310661316f, 0.0075987582094967365f, 0.001028380123898387f};
+
+template <class T, class F>
+T ssim_conv11(F at) {  // at(d) for d = -5..5
+    T acc = T(0);
+    for (int d = 1; d <= 5; ++d) acc += (at(-d) + at(d)) * T(kSsimTaps[5 - d]);
+    acc += at(0) * T(kSsimTaps[5]);
+    return acc;
+}
+
+template <class T>
+void ssim_fwd_t(int64_t B, int64_t CH, int64_t H, int64_t W, T C1, T C2, const T* img1, const T* img2, T* map, T* dm1, T* ds1, T* ds12) {
+    std::vector<T> hx(5 * H * W);
+    for (int64_t bc = 0; bc < B * CH; ++bc) {
+        const T* X = img1 + bc * H * W;
+        const T* Y = img2 + bc * H * W;
+        for (int64_t y = 0; y < H; ++y)
+            for (int64_t x = 0; x < W; ++x) {
+                auto px = [&](const T* I, int64_t xx) { return (xx < 0 || xx >= W) ? T(0) : I[y * W + xx]; };
+                T* o = &hx[(y * W + x) * 5];
+                o[0] = ssim_conv11<T>([&](int d) { return px(X, x + d); });
+                o[1] = ssim_conv11<T>([&](int d) { const T v = px(X, x + d); return v * v; });
+                o[2] = ssim_conv11<T>([&](int d) { return px(Y, x + d); });
+                o[3] = ssim_conv11<T>([&](int d) { const T v = px(Y, x + d); return v * v; });
+                o[4] = ssim_conv11<T>([&](int d) { return px(X, x + d) * px(Y, x + d); });
+            }
+        for (int64_t y = 0; y < H; ++y)
+            for (int64_t x = 0; x < W; ++x) {
+                T o[5];
+                for (int q = 0; q < 5; ++q)
+                    o[q] = ssim_conv11<T>([&](int d) { const int64_t yy = y + d; return (yy < 0 || yy >= H) ? T(0) : hx[(yy * W + x) * 5 + q]; });
+                const T mu1 = o[0], mu2 = o[2], mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2;
+                const T s1 = o[1] - mu1_sq, s2 = o[3] - mu2_sq, s12 = o[4] - mu1 * mu2;
+                const T A = mu1_sq + mu2_sq + C1, Bq = s1 + s2 + C2, Cn = T(2) * mu1 * mu2 + C1, Dn = T(2) * s12 + C2;
+                const int64_t idx = bc * H * W + y * W + x;
+                map[idx] = (Cn * Dn) / (A * Bq);
+                if (dm1) {
+                    dm1[idx] = (mu2 * T(2) * Dn) / (A * Bq) - (mu2 * T(2) * Cn) / (A * Bq) - (mu1 * T(2) * Cn * Dn) / (A * A * Bq) +
+                               (mu1 * T(2) * Cn * Dn) / (A * Bq * Bq);
+                    ds1[idx] = (-Cn * Dn) / (A * Bq * Bq);
+                    ds12[idx] = (T(2) * Cn) / (A * Bq);
+                }
+            }
+    }
+}
+
+template <class T>
+void ssim_bwd_t(int64_t B, int64_t CH, int64_t H, int64_t W, const T* img1, const T* img2, const T* dL_dmap, T* dL_dimg1, const T* dm1,
+                const T* ds1, const T* ds12) {
+    std::vector<T> hx(3 * H * W);
+    for (int64_t bc = 0; bc < B * CH; ++bc) {
+        const int64_t base = bc * H * W;
+        for (int64_t y = 0; y < H; ++y)
+            for (int64_t x = 0; x < W; ++x) {
+                const T* src[3] = {dm1, ds1, ds12};
+                for (int q = 0; q < 3; ++q)
+                    hx[(y * W + x) * 3 + q] = ssim_conv11<T>([&](int d) {
+                        const int64_t xx = x + d;
+                        return (xx < 0 || xx >= W) ? T(0) : src[q][base + y * W + xx] * dL_dmap[base + y * W + xx];
+                    });
+            }
+        for (int64_t y = 0; y < H; ++y)
+            for (int64_t x = 0; x < W; ++x) {
+                T s[3];
+                for (int q = 0; q < 3; ++q)
+                    s[q] = ssim_conv11<T>([&](int d) { const int64_t yy = y + d; return (yy < 0 || yy >= H) ? T(0) : hx[(yy * W + x) * 3 + q]; });
+                const int64_t idx = base + y * W + x;
+                dL_dimg1[idx] = s[0] + (T(2) * img1[idx]) * s[1] + img2[idx] * s[2];
+            }
+    }
+}
+}  // namespace
+
+#define GSX_ORACLE_SSIM(SUF, T)                                                                                                     \
+    extern "C" void gsx_oracle_fused_ssim_fwd_##SUF(int64_t B, int64_t CH, int64_t H, int64_t W, T C1, T C2, const T* img1,         \
+                                                    const T* img2, T* map, T* dm1, T* ds1, T* ds12) {                               \
+        ssim_fwd_t<T>(B, CH, H, W, C1, C2, img1, img2, map, dm1, ds1, ds12);                                                        \
+    }                                                                                                                               \
+    extern "C" void gsx_oracle_fused_ssim_bwd_##SUF(int64_t B, int64_t CH, int64_t H, int64_t W, const T* img1, const T* img2,      \
+                                                    const T* dL_dmap, T* dL_dimg1, const T* dm1, const T* ds1, const T* ds12) {     \
+        ssim_bwd_t<T>(B, CH, H, W, img1, img2, dL_dmap, dL_dimg1, dm1, ds1, ds12);                                                  \
+    }
+GSX_ORACLE_SSIM(f32, float)
+GSX_ORACLE_SSIM(f64, double)

@@ -224,3 +224,51 @@ def adam_step(param, exp_avg, exp_avg_sq, grad, lr, beta1, beta2, eps, step_coun
     getattr(lib(), "gsx_oracle_adam_step_" + _suf(dt))(ctypes.c_int64(p.size), _p(p), _p(m), _p(v), _p(_c(grad, dt)), _fl(dt, lr),
                                                        _fl(dt, beta1), _fl(dt, beta2), _fl(dt, eps), _fl(dt, bc1), _fl(dt, bc2))
     return p, m, v
+
+
+SSIM_C1, SSIM_C2 = 0.01 * 0.01, 0.03 * 0.03
+
+
+def fused_ssim_fwd(img1, img2, train=True):
+    """fusedssim (ssim.cu:436-470) on [B,CH,H,W]: (map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12)."""
+    dt = img1.dtype
+    a, b = _c(img1, dt), _c(img2, dt)
+    B, CH, H, W = a.shape
+    outs = [np.zeros_like(a) for _ in range(4 if train else 1)]
+    getattr(lib(), "gsx_oracle_fused_ssim_fwd_" + _suf(dt))(
+        ctypes.c_int64(B), ctypes.c_int64(CH), ctypes.c_int64(H), ctypes.c_int64(W), _fl(dt, SSIM_C1), _fl(dt, SSIM_C2), _p(a), _p(b),
+        _p(outs[0]), *( [_p(o) for o in outs[1:]] if train else [None, None, None]))
+    return tuple(outs) if train else (outs[0], None, None, None)
+
+
+def fused_ssim_bwd(img1, img2, dL_dmap, dm1, ds1, ds12):
+    dt = img1.dtype
+    a, b = _c(img1, dt), _c(img2, dt)
+    B, CH, H, W = a.shape
+    out = np.zeros_like(a)
+    getattr(lib(), "gsx_oracle_fused_ssim_bwd_" + _suf(dt))(
+        ctypes.c_int64(B), ctypes.c_int64(CH), ctypes.c_int64(H), ctypes.c_int64(W), _p(a), _p(b), _p(_c(dL_dmap, dt)), _p(out),
+        _p(_c(dm1, dt)), _p(_c(ds1, dt)), _p(_c(ds12, dt)))
+    return out
+
+
+def photometric_loss(render_hwc, gt_chw, lambda_dssim=0.2):
+    """trainer.cpp:103-127 on the clamped image (rasterizer.cpp:401): returns (loss, l1, ssim_mean, d loss / d render_hwc).
+    render_hwc [C,H,W,3] unclamped blend output, gt_chw [C,3,H,W]."""
+    dt = render_hwc.dtype
+    raw = _c(render_hwc, dt)
+    img = np.clip(raw, 0, 1).transpose(0, 3, 1, 2).copy()
+    gt = _c(gt_chw, dt)
+    C, _, H, W = img.shape
+    m, dm1, ds1, ds12 = fused_ssim_fwd(img, gt, True)
+    crop = 5 if (H > 10 and W > 10) else 0
+    valid = m[:, :, crop:H - crop, crop:W - crop]
+    l1 = np.abs(img - gt).mean(dtype=np.float64)
+    ssim = valid.mean(dtype=np.float64)
+    loss = (1 - lambda_dssim) * l1 + lambda_dssim * (1 - ssim)
+    dmap = np.zeros_like(img)
+    if crop:  # fused_ssim.cuh:85-96: without a crop the scattered dL/dmap stays zero (upstream quirk, kept)
+        dmap[:, :, crop:H - crop, crop:W - crop] = -lambda_dssim / valid.size
+    g = fused_ssim_bwd(img, gt, dmap, dm1, ds1, ds12) + (1 - lambda_dssim) / img.size * np.sign(img - gt)
+    g = g.transpose(0, 2, 3, 1) * ((raw >= 0) & (raw <= 1))
+    return float(loss), float(l1), float(ssim), np.ascontiguousarray(g, dtype=dt)

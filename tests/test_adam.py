@@ -76,3 +76,61 @@ def test_fused_adam_reference_quirks():
     sched = optim.ExponentialLR(opt, 0.5, 0)
     sched.step()
     assert abs(opt.groups[0]["lr"] - 0.00008) < 1e-12 and opt.groups[1]["lr"] == 0.0025
+
+
+@pytest.mark.gpu
+def test_gpu_adam_split_blocks_vs_oracle():
+    import gsx  # noqa: F401
+    from gsx import ops
+    rng = np.random.default_rng(3)
+    sh, g = rng.standard_normal((777, 16, 3)).astype(np.float32), rng.standard_normal((777, 16, 3)).astype(np.float32)
+    m, v = (rng.random((777, 16, 3)) * 0.1).astype(np.float32), (rng.random((777, 16, 3)) * 0.01).astype(np.float32)
+    bc1, bc2 = 1.0 / (1 - 0.9 ** 5), 1.0 / np.sqrt(1 - 0.999 ** 5)
+    for do_b in (True, False):
+        P, M, V, G = (torch.from_numpy(a.copy()).cuda() for a in (sh, m, v, g))
+        ops.adam_step_split(P, M, V, G, 3, 2.5e-3, 1.25e-4, True, do_b, 0.9, 0.999, 1e-8, bc1, bc2)
+        p0, m0, v0 = oracle.adam_step(sh[:, :1], m[:, :1], v[:, :1], g[:, :1], 2.5e-3, 0.9, 0.999, 1e-8, 5)
+        np.testing.assert_allclose(P.cpu().numpy()[:, :1], p0, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(M.cpu().numpy()[:, :1], m0, rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(V.cpu().numpy()[:, :1], v0, rtol=1e-6, atol=1e-9)
+        if do_b:
+            p1, m1, v1 = oracle.adam_step(sh[:, 1:], m[:, 1:], v[:, 1:], g[:, 1:], 1.25e-4, 0.9, 0.999, 1e-8, 5)
+            np.testing.assert_allclose(P.cpu().numpy()[:, 1:], p1, rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(V.cpu().numpy()[:, 1:], v1, rtol=1e-6, atol=1e-9)
+        else:
+            assert np.array_equal(P.cpu().numpy()[:, 1:], sh[:, 1:]) and np.array_equal(M.cpu().numpy()[:, 1:], m[:, 1:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [16, 9])
+def test_fused_adam_matches_torch_adam_over_iterations(K):
+    """Whole-optimizer check incl. the split SH launch (K = 16) and the strided fallback (K = 9) against torch.optim.Adam."""
+    import gsx  # noqa: F401
+    from gsx import optim, scenes
+    sc = scenes.scene_small(seed=2, N=150)
+    gen = torch.Generator().manual_seed(1)
+    sc["sh"] = torch.rand(150, K, 3, generator=gen)
+    sc["sh_degree"] = {16: 3, 9: 2}[K]
+    model = scenes.to_splat_data(sc, "cuda:0")
+    params = model.params()
+    for p in params:
+        p.requires_grad_(True)
+    ref = [p.detach().cpu().double().requires_grad_(True) for p in params]
+    ref_sh0, ref_shN = ref[1][:, :1].detach().clone().requires_grad_(True), ref[1][:, 1:].detach().clone().requires_grad_(True)
+    lrs = [0.00016, 0.0025, 0.0025 / 20, 0.005, 0.001, 0.05]
+    topt = torch.optim.Adam([{"params": [t], "lr": lr} for t, lr in zip([ref[0], ref_sh0, ref_shN, ref[2], ref[3], ref[4]], lrs)],
+                            betas=(0.9, 0.999), eps=1e-8)
+    opt = optim.FusedAdam.for_splat_data(model)
+    for it in range(1001, 1006):                      # past the shN freeze
+        for p in params:
+            p.grad = torch.randn(p.shape, generator=gen).to(p.device)
+        for t, src in zip([ref[0], ref_sh0, ref_shN, ref[2], ref[3], ref[4]],
+                          [params[0].grad, params[1].grad[:, :1], params[1].grad[:, 1:], params[2].grad, params[3].grad, params[4].grad]):
+            t.grad = src.double().cpu()
+        opt.step(it)
+        topt.step()
+    got_sh = params[1].detach().cpu().double()
+    assert (params[0].detach().cpu().double() - ref[0].detach()).abs().max() < 1e-6
+    assert (got_sh[:, :1] - ref_sh0.detach()).abs().max() < 1e-5 and (got_sh[:, 1:] - ref_shN.detach()).abs().max() < 1e-6
+    for a, b in zip(params[2:], ref[2:]):
+        assert (a.detach().cpu().double() - b.detach()).abs().max() < 1e-4

@@ -1,0 +1,136 @@
+"""Photometric loss.  The reference has no test for its fused SSIM (parity unpinned by the reference's own
+tests): the oracle restates ssim.cu and is pinned here against an independent torch conv2d SSIM with autograd gradients (f64);
+the HIP kernels are compared with the oracle on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+
+
+def _window():
+    g = torch.tensor([0.001028380123898387, 0.0075987582094967365, 0.036000773310661316, 0.10936068743467331, 0.21300552785396576,
+                      0.26601171493530273, 0.21300552785396576, 0.10936068743467331, 0.036000773310661316, 0.0075987582094967365,
+                      0.001028380123898387], dtype=torch.float64)
+    return torch.outer(g, g)
+
+
+def _torch_ssim_map(a, b):
+    ch = a.shape[1]
+    w = _window().expand(ch, 1, 11, 11)
+    conv = lambda t: torch.nn.functional.conv2d(t, w, padding=5, groups=ch)  # noqa: E731
+    mu1, mu2 = conv(a), conv(b)
+    s1, s2, s12 = conv(a * a) - mu1 * mu1, conv(b * b) - mu2 * mu2, conv(a * b) - mu1 * mu2
+    return ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))
+
+
+def _torch_loss(render_hwc, gt, lam):
+    img = render_hwc.clamp(0, 1).permute(0, 3, 1, 2)
+    m = _torch_ssim_map(img, gt)
+    H, W = m.shape[2:]
+    if H > 10 and W > 10:
+        m = m[:, :, 5:H - 5, 5:W - 5]
+    else:
+        m = m.detach()   # upstream quirk (fused_ssim.cuh:85-96): no SSIM gradient for images of 10 px or less
+    l1 = (img - gt).abs().mean()
+    return (1 - lam) * l1 + lam * (1 - m.mean()), l1, m.mean()
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 37, 53), (2, 1, 16, 64), (1, 3, 9, 12)])
+def test_oracle_ssim_matches_torch_conv(shape):
+    torch.manual_seed(0)
+    a = torch.rand(shape, dtype=torch.float64, requires_grad=True)
+    b = torch.rand(shape, dtype=torch.float64)
+    ref = _torch_ssim_map(a, b)
+    m, dm1, ds1, ds12 = oracle.fused_ssim_fwd(a.detach().numpy(), b.numpy())
+    np.testing.assert_allclose(m, ref.detach().numpy(), rtol=1e-9, atol=1e-10)
+    up = torch.rand(shape, dtype=torch.float64)
+    (ref * up).sum().backward()
+    g = oracle.fused_ssim_bwd(a.detach().numpy(), b.numpy(), up.numpy(), dm1, ds1, ds12)
+    np.testing.assert_allclose(g, a.grad.numpy(), rtol=1e-8, atol=1e-10)
+
+
+def test_oracle_photometric_loss_matches_torch():
+    torch.manual_seed(1)
+    r = (torch.rand(2, 40, 33, 3, dtype=torch.float64) * 1.4 - 0.2).requires_grad_(True)   # some values outside [0,1]
+    gt = torch.rand(2, 3, 40, 33, dtype=torch.float64)
+    loss, l1, ssim = _torch_loss(r, gt, 0.2)
+    loss.backward()
+    ol, ol1, ossim, g = oracle.photometric_loss(r.detach().numpy(), gt.numpy(), 0.2)
+    assert abs(ol - loss.item()) < 1e-12 and abs(ol1 - l1.item()) < 1e-12 and abs(ossim - ssim.item()) < 1e-12
+    np.testing.assert_allclose(g, r.grad.numpy(), rtol=1e-8, atol=1e-12)
+    r2 = (torch.rand(1, 8, 30, 3, dtype=torch.float64)).requires_grad_(True)                # too small to crop
+    gt2 = torch.rand(1, 3, 8, 30, dtype=torch.float64)
+    loss2 = _torch_loss(r2, gt2, 0.2)[0]
+    loss2.backward()
+    o2 = oracle.photometric_loss(r2.detach().numpy(), gt2.numpy(), 0.2)
+    assert abs(o2[0] - loss2.item()) < 1e-12
+    np.testing.assert_allclose(o2[3], r2.grad.numpy(), rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 3, 37, 53), (2, 2, 16, 64), (1, 3, 130, 200), (1, 1, 9, 12)])
+def test_gpu_fused_ssim_vs_oracle(shape):
+    import gsx  # noqa: F401
+    from gsx import ops
+    rng = np.random.default_rng(0)
+    a, b = rng.random(shape, dtype=np.float32), rng.random(shape, dtype=np.float32)
+    up = rng.random(shape, dtype=np.float32)
+    A, B, UP = (torch.from_numpy(t).cuda() for t in (a, b, up))
+    m, d0, d1, d2 = ops.fusedssim(1e-4, 9e-4, A, B, True)
+    g = ops.fusedssim_backward(1e-4, 9e-4, A, B, UP, d0, d1, d2)
+    om, o0, o1, o2 = oracle.fused_ssim_fwd(a.astype(np.float64), b.astype(np.float64))
+    og = oracle.fused_ssim_bwd(a.astype(np.float64), b.astype(np.float64), up.astype(np.float64), o0, o1, o2)
+    np.testing.assert_allclose(m.cpu().numpy(), om, rtol=0, atol=2e-5)
+    for got, ref in ((d0, o0), (d1, o1), (d2, o2), (g, og)):
+        ref_scale = np.abs(ref).max()
+        assert np.abs(got.cpu().numpy() - ref).max() <= 1e-4 * ref_scale
+    m2 = ops.fusedssim(1e-4, 9e-4, A, B, False)
+    assert torch.equal(m2[0], m) and m2[1].numel() == 0
+
+
+@pytest.mark.gpu
+def test_gpu_fused_ssim_autograd_wrapper_and_padding():
+    import gsx  # noqa: F401
+    from gsx import loss
+    torch.manual_seed(0)
+    a = torch.rand(3, 48, 70, device="cuda", requires_grad=True)
+    b = torch.rand(3, 48, 70, device="cuda")
+    for padding in ("same", "valid"):
+        a.grad = None
+        v = loss.fused_ssim(a, b, padding)
+        v.backward()
+        a64 = a.detach().double().cpu().unsqueeze(0).requires_grad_(True)
+        m = _torch_ssim_map(a64, b.double().cpu().unsqueeze(0))
+        if padding == "valid":
+            m = m[:, :, 5:-5, 5:-5]
+        m.mean().backward()
+        assert abs(v.item() - m.mean().item()) < 1e-5
+        assert (a.grad.cpu().double() - a64.grad[0]).abs().max() <= 1e-4 * a64.grad.abs().max()
+    with pytest.raises(ValueError):
+        loss.fused_ssim(a, b, "reflect")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,H,W", [(1, 64, 96), (2, 37, 53), (1, 9, 20), (1, 270, 480)])
+def test_gpu_photometric_loss_vs_oracle(C, H, W):
+    import gsx  # noqa: F401
+    from gsx import loss
+    rng = np.random.default_rng(2)
+    r = (rng.random((C, H, W, 3), dtype=np.float32) * 1.4 - 0.2).astype(np.float32)
+    r[0, 0, :5] = [[0.0, 1.0, 0.5]] * 5                      # exact clamp bounds pass the gradient (inclusive)
+    gt = rng.random((C, 3, H, W), dtype=np.float32)
+    R = torch.from_numpy(r).cuda().requires_grad_(True)
+    G = torch.from_numpy(gt).cuda()
+    val, parts = loss.photometric_loss(R, G, 0.2, return_parts=True)
+    (val * 3.0).backward()
+    ol, ol1, ossim, og = oracle.photometric_loss(r.astype(np.float64), gt.astype(np.float64), 0.2)
+    assert abs(val.item() - ol) < 2e-6 and abs(parts[1].item() - ol1) < 2e-6 and abs(parts[2].item() - ossim) < 2e-6
+    got = R.grad.cpu().numpy() / 3.0
+    assert np.abs(got - og).max() <= 1e-4 * np.abs(og).max()
+    # the op-by-op composition of the reference gives the same loss and gradient
+    R2 = torch.from_numpy(r).cuda().requires_grad_(True)
+    ref = loss.photometric_loss_reference(R2.clamp(0, 1).permute(0, 3, 1, 2), G, 0.2)
+    ref.backward()
+    assert abs(ref.item() - val.item()) < 2e-6
+    assert (R2.grad - R.grad / 3.0).abs().max().item() <= 1e-4 * np.abs(og).max()
