@@ -198,7 +198,7 @@ __global__ __launch_bounds__(RB) void raster_bwd_kernel(RasterArgs a, const floa
     float buf_r = 0.f, buf_g = 0.f, buf_b = 0.f;
     const int32_t bin_final = active ? last_ids[pix] : -1;
     const float vr = v_render_colors[pix * 3], vg = v_render_colors[pix * 3 + 1], vb = v_render_colors[pix * 3 + 2];
-    const float va = v_render_alphas[pix];
+    const float va = v_render_alphas ? v_render_alphas[pix] : 0.f;
     float bg_dot = 0.f;
     if (bg) bg_dot = bg[0] * vr + bg[1] * vg + bg[2] * vb;
 
@@ -439,20 +439,32 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd(
     int rc = fill_args(a, N, n_isects, means, quats, scales, colors, channels, opacities, backgrounds, masks, image_width,
                        image_height, tile_size, cams, tile_offsets, flatten_ids, "bwd");
     if (rc != GSX_OK) return rc;
-    if (!render_alphas || !last_ids || !v_render_colors || !v_render_alphas || !v_means || !v_quats || !v_scales ||
-        !v_colors || !v_opacities) {
+    if (!render_alphas || !last_ids || !v_render_colors || !v_means || !v_quats || !v_scales || !v_colors || !v_opacities) {
         set_error("rasterize bwd: null pointer");
         return GSX_ERR_INVALID_ARGUMENT;
     }
-    if (n_isects == 0 || a.C == 0 || image_width == 0 || image_height == 0) return GSX_OK;  // Bwd.cu:434-437
-    const dim3 grid(a.tw, a.th, a.C), block(RB);
     hipStream_t st = (hipStream_t)stream;
+    // The five gradient outputs are OVERWRITTEN (upstream accumulates into caller-zeroed tensors: same result for its callers,
+    // Rasterization.cpp:196-200): the fast path writes every element, the other paths zero-fill here before their atomics.
+    auto zero_outputs = [&]() {
+        (void)hipMemsetAsync(v_means, 0, (size_t)N * 3 * 4, st);
+        (void)hipMemsetAsync(v_quats, 0, (size_t)N * 4 * 4, st);
+        (void)hipMemsetAsync(v_scales, 0, (size_t)N * 3 * 4, st);
+        (void)hipMemsetAsync(v_colors, 0, (size_t)a.C * N * 3 * 4, st);
+        (void)hipMemsetAsync(v_opacities, 0, (size_t)a.C * N * 4, st);
+    };
+    if (n_isects == 0 || a.C == 0 || image_width == 0 || image_height == 0) {  // Bwd.cu:434-437
+        if (N) zero_outputs();
+        return check_launch("rasterize_to_pixels_from_world_3dgs_bwd(empty)");
+    }
+    const dim3 grid(a.tw, a.th, a.C), block(RB);
     const bool hoist = cams->shutter == GSX_SHUTTER_GLOBAL;
     if (hoist && cam_kind(*cams) != CAM_OPENCV_FISHEYE && !force_generic()) {
         if (launch_raster_bwd_fast(cam_kind(*cams), a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats,
                                    v_scales, v_colors, v_opacities, workspace, workspace_bytes, st))
             return check_launch("rasterize_to_pixels_from_world_3dgs_bwd(fast)");
     }
+    zero_outputs();
 #define GSX_BWD(KIND)                                                                                                  \
     do {                                                                                                               \
         if (hoist) hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_kernel<KIND, true>), grid, block, 0, st, a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors, v_opacities); \

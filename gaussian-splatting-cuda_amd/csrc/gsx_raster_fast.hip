@@ -158,10 +158,11 @@ GSX_DEV void make_record(const RawG& r, const CamFrame& cf, const float tb[4], F
 // pack_records_kernel does that once per (camera, Gaussian) into ONE 64 B line; staging a tile then gathers a
 // single line per Gaussian and only adds the tile-dependent footprint (hx, hy).
 //   p0 = (u0, v0, l00, l01)  p1 = (l11, lo, d1, d2)  p2 = (d3, d4, d5, red)  p3 = (green, blue, -, -)
-__global__ __launch_bounds__(256) void pack_records_kernel(RasterArgs a, float4* __restrict__ packed) {
+__global__ __launch_bounds__(256) void pack_records_kernel(RasterArgs a, float4* __restrict__ packed, int32_t* __restrict__ heads) {
     const uint32_t n = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
     if (n >= a.N) return;
     const size_t g = (size_t)c * a.N + n;
+    if (heads) heads[g] = -1;  // backward: empty moment-record list
     RawG raw;
     raw.g = (int32_t)g;
     raw.mu = {a.means[(size_t)n * 3], a.means[(size_t)n * 3 + 1], a.means[(size_t)n * 3 + 2]};
@@ -353,6 +354,9 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
             unsigned long long todo = __ballot(hit);
             GSX_STAT_ADD(1, min(64, chunk_size - sub));
             GSX_STAT_ADD(0, __popcll(todo));
+#ifdef GSX_STATS
+            int st_b[4] = {0, 0, 0, 0}, st_s[4] = {0, 0, 0, 0};
+#endif
             while (todo) {
                 const int t = sub + __builtin_ctzll(todo);
                 todo &= todo - 1ull;
@@ -371,10 +375,18 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
                 cur_idx = take ? (uint32_t)(chunk_start + t) : cur_idx;
                 done = done || stop;
 #ifdef GSX_STATS
-                { const unsigned long long c = __ballot(take); GSX_STAT_ADD(2, c != 0ull); GSX_STAT_ADD(3, __popcll(c)); }
+                { const unsigned long long c = __ballot(take); GSX_STAT_ADD(2, c != 0ull); GSX_STAT_ADD(3, __popcll(c));
+                  const unsigned long long bm[4] = {0x0F0F0F0Full, 0xF0F0F0F0ull, 0x0F0F0F0Full << 32, 0xF0F0F0F0ull << 32};
+                  int nb = 0;
+                  for (int q = 0; q < 4; ++q) { const int hb = (c & bm[q]) != 0ull; st_b[q] += hb; nb += hb; st_s[q] += ((c >> (16 * q)) & 0xffffull) != 0ull; }
+                  GSX_STAT_ADD(5, nb); }
 #endif
                 if (__ballot(!done) == 0ull) { wave_done = true; GSX_STAT_ADD(4, __popcll(todo)); break; }
             }
+#ifdef GSX_STATS
+            GSX_STAT_ADD(6, max(max(st_b[0], st_b[1]), max(st_b[2], st_b[3])));
+            GSX_STAT_ADD(7, max(max(st_s[0], st_s[1]), max(st_s[2], st_s[3])));
+#endif
         }
     }
     if (inside) {
@@ -388,9 +400,9 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
 
 size_t raster_fwd_fast_workspace_bytes(uint32_t C, uint32_t N) { return (size_t)C * N * 64 + 256; }
 
-static const float4* pack_into(RasterArgs& a, void* base, hipStream_t st) {
+static const float4* pack_into(RasterArgs& a, void* base, hipStream_t st, int32_t* heads = nullptr) {
     float4* packed = (float4*)(((uintptr_t)base + 255) & ~(uintptr_t)255);
-    hipLaunchKernelGGL(pack_records_kernel, dim3((a.N + 255u) / 256u, a.C), dim3(256), 0, st, a, packed);
+    hipLaunchKernelGGL(pack_records_kernel, dim3((a.N + 255u) / 256u, a.C), dim3(256), 0, st, a, packed, heads);
     a.packed = packed;
     return packed;
 }
@@ -509,7 +521,7 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
     float buf_r = 0.f, buf_g = 0.f, buf_b = 0.f;
     const int32_t bin_final = active ? last_ids[pix] : -1;
     const float vr = v_render_colors[pix * 3], vg = v_render_colors[pix * 3 + 1], vb = v_render_colors[pix * 3 + 2];
-    const float va = v_render_alphas[pix];
+    const float va = v_render_alphas ? v_render_alphas[pix] : 0.f;
     float tail = va;  // T_final * ra * (v_alpha_out - bg . v_out)   (Bwd.cu:307-316)
     if (bg) tail -= bg[0] * vr + bg[1] * vg + bg[2] * vb;
     tail *= T_final;
@@ -630,7 +642,11 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
     for (uint32_t c = 0; c < a.C; ++c) {
         const size_t g = (size_t)c * a.N + gi;
         int32_t it = ws_head[g];
-        if (it < 0) continue;
+        if (it < 0) {  // no tile touched this (camera, Gaussian): every output element is written, none needs a pre-fill
+            v_colors[g * 3] = 0.f; v_colors[g * 3 + 1] = 0.f; v_colors[g * 3 + 2] = 0.f;
+            v_opacities[g] = 0.f;
+            continue;
+        }
         float Mo[15];
 #pragma unroll
         for (int k = 0; k < 15; ++k) Mo[k] = 0.f;
@@ -650,8 +666,8 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
             any = true;
         }
         raw.opac = a.opacities[g];
-        v_colors[g * 3] += Mo[0]; v_colors[g * 3 + 1] += Mo[1]; v_colors[g * 3 + 2] += Mo[2];
-        v_opacities[g] += Mo[3] / raw.opac;
+        v_colors[g * 3] = Mo[0]; v_colors[g * 3 + 1] = Mo[1]; v_colors[g * 3 + 2] = Mo[2];
+        v_opacities[g] = Mo[3] / raw.opac;
         const ShutterPoses sp(a.cams.viewmats0 + c * 16, nullptr);
         const CamFrame cf = make_cam_frame(sp);
         const float tb0[4] = {0.f, 0.f, 0.f, 0.f};
@@ -719,12 +735,9 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
 #pragma unroll
         for (int k = 0; k < 3; ++k) geo[7 + k] += -isv[k] * (r.Mt[k][0] * vMt[k][0] + r.Mt[k][1] * vMt[k][1] + r.Mt[k][2] * vMt[k][2]);
     }
-    if (any) {
-        v_means[(size_t)gi * 3] += geo[0]; v_means[(size_t)gi * 3 + 1] += geo[1]; v_means[(size_t)gi * 3 + 2] += geo[2];
-        v_quats[(size_t)gi * 4] += geo[3]; v_quats[(size_t)gi * 4 + 1] += geo[4]; v_quats[(size_t)gi * 4 + 2] += geo[5];
-        v_quats[(size_t)gi * 4 + 3] += geo[6];
-        v_scales[(size_t)gi * 3] += geo[7]; v_scales[(size_t)gi * 3 + 1] += geo[8]; v_scales[(size_t)gi * 3 + 2] += geo[9];
-    }
+    v_means[(size_t)gi * 3] = geo[0]; v_means[(size_t)gi * 3 + 1] = geo[1]; v_means[(size_t)gi * 3 + 2] = geo[2];
+    reinterpret_cast<float4*>(v_quats)[gi] = make_float4(geo[3], geo[4], geo[5], geo[6]);
+    v_scales[(size_t)gi * 3] = geo[7]; v_scales[(size_t)gi * 3 + 1] = geo[8]; v_scales[(size_t)gi * 3 + 2] = geo[9];
 }
 
 size_t raster_bwd_fast_workspace_bytes(uint32_t C, uint32_t N, int64_t n_isects) {
@@ -741,8 +754,7 @@ bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, 
     const dim3 grid(((n_tiles + 7u) / 8u) * 8u, a.C), block(RB);
     float4* ws_rec = (float4*)workspace;
     int32_t* ws_head = (int32_t*)((char*)workspace + (((size_t)a.n_isects * 64 + 255) / 256) * 256);
-    (void)hipMemsetAsync(ws_head, 0xFF, (size_t)a.C * a.N * 4, st);  // -1 = empty list
-    pack_into(a, (char*)ws_head + (((size_t)a.C * a.N * 4 + 255) / 256) * 256, st);
+    pack_into(a, (char*)ws_head + (((size_t)a.C * a.N * 4 + 255) / 256) * 256, st, ws_head);  // also sets every list head to -1
     const dim3 ggrid((a.N + 255u) / 256u), gblock(256);
     if (kind == CAM_PERFECT_PINHOLE) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_fast_kernel<CAM_PERFECT_PINHOLE>), grid, block, 0, st, a, render_alphas,

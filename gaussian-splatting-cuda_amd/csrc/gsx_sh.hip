@@ -293,12 +293,23 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_colors_fwd_kernel(uint32_t C, uin
     float* tile = sh_lds + wave * 64u * LS;
     if (e0 < N) sh_stage_rows(coeffs, N, e0, K * 3u, NB3, live_mask, tile, LS, lane);
     __syncthreads();
-    if (!any_live) return;
+    if (e >= N) return;
+    if (!any_live) {  // masked for every camera: zero rows (the output buffer needs no pre-fill)
+        for (uint32_t c = 0; c < C; ++c) {
+            float* o = colors + ((size_t)c * N + e) * 3;
+            o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;
+        }
+        return;
+    }
     const f3 mu{means[(size_t)e * 3], means[(size_t)e * 3 + 1], means[(size_t)e * 3 + 2]};
     const float* row = tile + lane * LS;
     for (uint32_t c = 0; c < C; ++c) {
         const int2 r = reinterpret_cast<const int2*>(radii)[(size_t)c * N + e];
-        if (!(r.x > 0 && r.y > 0)) continue;  // masked: output untouched, as the unfused op
+        if (!(r.x > 0 && r.y > 0)) {  // masked: zero row
+            float* o = colors + ((size_t)c * N + e) * 3;
+            o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;
+            continue;
+        }
         const f3 cp = cam_position(viewmats + c * 16);
         float x = mu.x - cp.x, y = mu.y - cp.y, z = mu.z - cp.z;
         if (DEG >= 1) {

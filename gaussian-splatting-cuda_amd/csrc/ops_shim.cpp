@@ -253,7 +253,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
     GSX_CHECK_INPUT(render_alphas);
     GSX_CHECK_INPUT(last_ids);
     GSX_CHECK_INPUT(v_render_colors);
-    GSX_CHECK_INPUT(v_render_alphas);
+    if (v_render_alphas.defined()) { GSX_CHECK_INPUT(v_render_alphas); }  // undefined = no gradient through the alpha output
     if (backgrounds.has_value()) { GSX_CHECK_INPUT(backgrounds.value()); }
     if (masks.has_value()) { GSX_CHECK_INPUT(masks.value()); }
     const uint32_t C = tile_offsets.size(0), N = means.size(0);
@@ -261,11 +261,11 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
     TORCH_CHECK(channels == 3, "Unsupported number of channels: ", channels);
     const gsx_cameras cams = make_cams(viewmats0, viewmats1, Ks, camera_model, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, C);
     const gsx_ut_params ut = make_ut(ut_params);
-    at::Tensor v_means = at::zeros_like(means);
-    at::Tensor v_quats = at::zeros_like(quats);
-    at::Tensor v_scales = at::zeros_like(scales);
-    at::Tensor v_colors = at::zeros_like(colors);
-    at::Tensor v_opacities = at::zeros_like(opacities);
+    at::Tensor v_means = at::empty_like(means);  // the C ABI overwrites all five (zero-fills itself where it scatters)
+    at::Tensor v_quats = at::empty_like(quats);
+    at::Tensor v_scales = at::empty_like(scales);
+    at::Tensor v_colors = at::empty_like(colors);
+    at::Tensor v_opacities = at::empty_like(opacities);
     const size_t wsb = gsx_rasterize_bwd_workspace_bytes(C, N, flatten_ids.size(0));
     at::Tensor ws = at::empty({(int64_t)wsb}, means.options().dtype(at::kByte));  // caching allocator, like CUB temp storage upstream
     check(gsx_rasterize_to_pixels_from_world_3dgs_bwd(
@@ -273,7 +273,8 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
               colors.data_ptr<float>(), channels, opacities.data_ptr<float>(), fptr(backgrounds), bptr(masks), image_width,
               image_height, tile_size, &cams, &ut, tile_offsets.data_ptr<int32_t>(),
               flatten_ids.numel() ? flatten_ids.data_ptr<int32_t>() : nullptr, render_alphas.data_ptr<float>(),
-              last_ids.data_ptr<int32_t>(), v_render_colors.data_ptr<float>(), v_render_alphas.data_ptr<float>(),
+              last_ids.data_ptr<int32_t>(), v_render_colors.data_ptr<float>(),
+              v_render_alphas.defined() ? v_render_alphas.data_ptr<float>() : nullptr,
               v_means.data_ptr<float>(), v_quats.data_ptr<float>(), v_scales.data_ptr<float>(), v_colors.data_ptr<float>(),
               v_opacities.data_ptr<float>(), ws.data_ptr(), wsb, cur_stream()),
           "rasterize_to_pixels_from_world_3dgs_bwd");
@@ -332,7 +333,7 @@ at::Tensor sh_colors_fwd(const uint32_t degrees_to_use, const at::Tensor means, 
     GSX_CHECK_INPUT(means); GSX_CHECK_INPUT(viewmats); GSX_CHECK_INPUT(coeffs); GSX_CHECK_INPUT(radii);
     TORCH_CHECK(means.scalar_type() == at::kFloat && coeffs.scalar_type() == at::kFloat && radii.scalar_type() == at::kInt, "dtype");
     const uint32_t C = viewmats.size(0), N = means.size(0), K = coeffs.size(-2);
-    at::Tensor colors = at::zeros({C, N, 3}, means.options());
+    at::Tensor colors = at::empty({C, N, 3}, means.options());  // the kernel writes every row (zeros where masked)
     check(gsx_sh_colors_fwd(degrees_to_use, C, N, K, means.data_ptr<float>(), viewmats.data_ptr<float>(), coeffs.data_ptr<float>(),
                             radii.data_ptr<int32_t>(), colors.data_ptr<float>(), cur_stream()), "sh_colors_fwd");
     return colors;
@@ -534,7 +535,20 @@ PYBIND11_MODULE(_gsx_ops, m) {
     m.def("intersect_offset", &gsplat::intersect_offset);
     m.def("projection_ut_3dgs_fused", &gsplat::projection_ut_3dgs_fused);
     m.def("rasterize_to_pixels_from_world_3dgs_fwd", &gsplat::rasterize_to_pixels_from_world_3dgs_fwd);
-    m.def("rasterize_to_pixels_from_world_3dgs_bwd", &gsplat::rasterize_to_pixels_from_world_3dgs_bwd);
+    m.def("rasterize_to_pixels_from_world_3dgs_bwd",
+          [](const at::Tensor means, const at::Tensor quats, const at::Tensor scales, const at::Tensor colors, const at::Tensor opacities,
+             const at::optional<at::Tensor> backgrounds, const at::optional<at::Tensor> masks, uint32_t image_width, uint32_t image_height,
+             uint32_t tile_size, const at::Tensor viewmats0, const at::optional<at::Tensor> viewmats1, const at::Tensor Ks,
+             const gsplat::CameraModelType camera_model, const UnscentedTransformParameters ut_params, ShutterType rs_type,
+             const at::optional<at::Tensor> radial_coeffs, const at::optional<at::Tensor> tangential_coeffs,
+             const at::optional<at::Tensor> thin_prism_coeffs, const at::Tensor tile_offsets, const at::Tensor flatten_ids,
+             const at::Tensor render_alphas, const at::Tensor last_ids, const at::Tensor v_render_colors,
+             const at::optional<at::Tensor> v_render_alphas) {  // None = no gradient through the alpha output
+              return gsplat::rasterize_to_pixels_from_world_3dgs_bwd(
+                  means, quats, scales, colors, opacities, backgrounds, masks, image_width, image_height, tile_size, viewmats0, viewmats1, Ks,
+                  camera_model, ut_params, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids,
+                  render_alphas, last_ids, v_render_colors, v_render_alphas.has_value() ? v_render_alphas.value() : at::Tensor());
+          });
     m.def("quats_to_rotmats", &gsplat::quats_to_rotmats);
     m.def("relocation", &gsplat::relocation);
     m.def("add_noise", &gsplat::add_noise);

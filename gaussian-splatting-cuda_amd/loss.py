@@ -71,10 +71,13 @@ class _PhotometricLoss(torch.autograd.Function):
         ctx.save_for_backward(render_hwc, gt_chw, ws)
         ctx.lambda_dssim = lambda_dssim
         ctx.mark_non_differentiable(loss3)
+        ctx.set_materialize_grads(False)
         return loss3[0], loss3
 
     @staticmethod
     def backward(ctx, grad_loss, _grad_parts):
+        if grad_loss is None:
+            return None, None, None
         render_hwc, gt_chw, ws = ctx.saved_tensors
         return ops.photometric_loss_bwd(render_hwc, gt_chw, ws, ctx.lambda_dssim, grad_loss, 1.0), None, None
 

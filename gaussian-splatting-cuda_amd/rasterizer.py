@@ -68,7 +68,7 @@ class SplatData:
 
 @dataclass
 class RenderOutput:
-    image: torch.Tensor = None
+    _image: torch.Tensor = None
     render_hwc: torch.Tensor = None
     alpha: torch.Tensor = None
     depth: torch.Tensor = None
@@ -80,6 +80,17 @@ class RenderOutput:
     height: int = 0
     n_isects: int = 0
     aux: dict = field(default_factory=dict)
+
+    @property
+    def image(self):
+        """[3,H,W] clamped to [0,1] (rasterizer.cpp:401); computed lazily from the blend's [1,H,W,3] output when only that was kept."""
+        if self._image is None and self.render_hwc is not None:
+            self._image = torch.clamp(self.render_hwc.squeeze(0).permute(2, 0, 1), 0.0, 1.0)
+        return self._image
+
+    @image.setter
+    def image(self, value):
+        self._image = value
 
 
 class SphericalHarmonicsFunction(torch.autograd.Function):
@@ -268,17 +279,22 @@ class GutRenderFunction(torch.autograd.Function):
                               flatten_ids, alphas, last_ids)
         ctx.extra = (bg, width, height, sh_degree, scaling_modifier, camera_model, radial, tangential, grad_sinks, ut)
         ctx.mark_non_differentiable(radii, means2d, depths, flatten_ids, isect_offsets)
+        ctx.set_materialize_grads(False)  # no zero tensors for the outputs nobody differentiates (six fill launches per step)
         return renders, alphas, radii, means2d, depths, flatten_ids, isect_offsets
 
     @staticmethod
     def backward(ctx, v_renders, v_alphas, *unused):
+        if v_renders is None and v_alphas is None:
+            return (None,) * 16
         (means, sh, sr, rr, orw, scales, quats, opac2, colors, radii, viewmat, K, isect_offsets, flatten_ids, alphas,
          last_ids) = ctx.saved_tensors
         bg, width, height, sh_degree, scaling_modifier, camera_model, radial, tangential, sinks, ut = ctx.extra
+        if v_renders is None:
+            v_renders = torch.zeros(alphas.shape[:-1] + (3,), dtype=alphas.dtype, device=alphas.device)
         v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_to_pixels_from_world_3dgs_bwd(
             means, quats, scales, colors, opac2, bg, None, width, height, TILE_SIZE, viewmat, None, K, camera_model, ut,
             ops.ShutterType.GLOBAL, radial, tangential, None, isect_offsets, flatten_ids, alphas, last_ids,
-            v_renders.contiguous(), v_alphas.contiguous())
+            v_renders.contiguous(), None if v_alphas is None else v_alphas.contiguous())
         if scaling_modifier != 1.0:
             v_scales = v_scales * scaling_modifier
         s = sinks or {}
@@ -308,8 +324,7 @@ def rasterize_fused(camera: Camera, model: SplatData, bg_color: Optional[torch.T
         model.means, model.sh, model.scaling_raw, model.rotation_raw, model.opacity_raw, viewmat, K, bg, W, H, sh_degree,
         scaling_modifier, cam_model, None, None, grad_sinks)
     out = RenderOutput()
-    out.image = torch.clamp(renders.squeeze(0).permute(2, 0, 1), 0.0, 1.0)
-    out.render_hwc = renders  # [1,H,W,3] unclamped: what loss.photometric_loss consumes
+    out.render_hwc = renders  # [1,H,W,3] unclamped: what loss.photometric_loss consumes; out.image is derived on first access
     out.alpha = alphas.squeeze(0).permute(2, 0, 1)
     out.means2d, out.depths = means2d, depths.squeeze(0)
     if with_visibility:  # only the densification strategies read these (three more N-sized kernels)
