@@ -13,6 +13,9 @@
 #include <torch/extension.h>
 #endif
 
+#include <cstdlib>
+#include <string>
+
 #include "../../include/gsx.h"
 #include "../../include/gsx_ops.h"
 
@@ -60,6 +63,13 @@ gsx_ut_params make_ut(const UnscentedTransformParameters& u) {
 
 }  // namespace
 
+namespace gsx_ext {
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned(const at::Tensor means2d, const at::Tensor radii,
+                                                                                 const at::Tensor depths, const uint32_t C,
+                                                                                 const uint32_t tile_size, const uint32_t tile_width,
+                                                                                 const uint32_t tile_height, const bool want_isect_ids);
+}
+
 namespace gsplat {
 
 at::Tensor spherical_harmonics_fwd(const uint32_t degrees_to_use, const at::Tensor dirs, const at::Tensor coeffs,
@@ -103,6 +113,12 @@ std::tuple<at::Tensor, at::Tensor> spherical_harmonics_bwd(const uint32_t K, con
     return std::make_tuple(v_coeffs, v_dirs);
 }
 
+static std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile_impl(const at::Tensor means2d, const at::Tensor radii, const at::Tensor depths,
+                                                                          const at::optional<at::Tensor> camera_ids,
+                                                                          const at::optional<at::Tensor> gaussian_ids, const uint32_t C,
+                                                                          const uint32_t tile_size, const uint32_t tile_width,
+                                                                          const uint32_t tile_height, const bool sort, const bool allow_binned);
+
 std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile(const at::Tensor means2d, const at::Tensor radii,
                                                               const at::Tensor depths,
                                                               const at::optional<at::Tensor> camera_ids,
@@ -110,6 +126,14 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile(const at::Tensor m
                                                               const uint32_t C, const uint32_t tile_size,
                                                               const uint32_t tile_width, const uint32_t tile_height,
                                                               const bool sort) {
+    return intersect_tile_impl(means2d, radii, depths, camera_ids, gaussian_ids, C, tile_size, tile_width, tile_height, sort, true);
+}
+
+static std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile_impl(const at::Tensor means2d, const at::Tensor radii, const at::Tensor depths,
+                                                                          const at::optional<at::Tensor> camera_ids,
+                                                                          const at::optional<at::Tensor> gaussian_ids, const uint32_t C,
+                                                                          const uint32_t tile_size, const uint32_t tile_width,
+                                                                          const uint32_t tile_height, const bool sort, const bool allow_binned) {
     const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(means2d));
     GSX_CHECK_INPUT(means2d);
     GSX_CHECK_INPUT(radii);
@@ -122,6 +146,12 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile(const at::Tensor m
     TORCH_CHECK(radii.scalar_type() == at::kInt, "radii must be int32");
     const uint32_t n_elements = means2d.numel() / 2;
     const uint32_t N = C ? n_elements / C : 0;
+    static const bool force_device_sort = [] { const char* e = getenv("GSX_INTERSECT"); return e && std::string(e) == "sort"; }();
+    if (allow_binned && sort && !force_device_sort && n_elements && gsx_intersect_bin_supported(tile_width, tile_height)) {
+        // same three outputs through the binned pipeline (LDS histograms + per-tile LDS sort), ~2x faster than the device-wide sort
+        auto r = gsx_ext::intersect_tile_binned(means2d, radii, depths, C, tile_size, tile_width, tile_height, true);
+        return std::make_tuple(std::get<0>(r), std::get<1>(r), std::get<2>(r));
+    }
     void* st = cur_stream();
     at::Tensor tiles_per_gauss = at::empty_like(depths, depths.options().dtype(at::kInt));
     int64_t n_isects = 0;
@@ -149,6 +179,14 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile(const at::Tensor m
               "intersect_tile(fill)");
     }
     return std::make_tuple(tiles_per_gauss, isect_ids, flatten_ids);
+}
+
+// the reference's algorithm (one device-wide stable radix sort of all keys), kept for tile grids beyond the LDS counters and as
+// the cross-check of the binned pipeline in the tests
+std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile_device_sort(const at::Tensor means2d, const at::Tensor radii, const at::Tensor depths,
+                                                                          const uint32_t C, const uint32_t tile_size, const uint32_t tile_width,
+                                                                          const uint32_t tile_height, const bool sort) {
+    return intersect_tile_impl(means2d, radii, depths, at::nullopt, at::nullopt, C, tile_size, tile_width, tile_height, sort, false);
 }
 
 at::Tensor intersect_offset(const at::Tensor isect_ids, const uint32_t C, const uint32_t tile_width,
@@ -406,6 +444,46 @@ void adam_step_split(at::Tensor param, at::Tensor exp_avg, at::Tensor exp_avg_sq
                               (float)bias_correction1_rcp, (float)bias_correction2_sqrt_rcp, cur_stream()), "adam_step_split");
 }
 
+// intersect_tile(sort = true) + intersect_offset through the binned pipeline: (tiles_per_gauss, isect_ids | empty, flatten_ids,
+// isect_offsets [C, tile_height, tile_width]); same values as the two reference ops.
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned(const at::Tensor means2d, const at::Tensor radii,
+                                                                                 const at::Tensor depths, const uint32_t C,
+                                                                                 const uint32_t tile_size, const uint32_t tile_width,
+                                                                                 const uint32_t tile_height, const bool want_isect_ids) {
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(means2d));
+    GSX_CHECK_INPUT(means2d); GSX_CHECK_INPUT(radii); GSX_CHECK_INPUT(depths);
+    TORCH_CHECK(means2d.dim() == 3, "intersect_tile_binned: means2d must be [C,N,2]");
+    TORCH_CHECK(means2d.scalar_type() == at::kFloat && depths.scalar_type() == at::kFloat && radii.scalar_type() == at::kInt, "dtype");
+    if (!gsx_intersect_bin_supported(tile_width, tile_height)) {  // tile grid too large for LDS counters: the device-wide sort
+        auto r = gsplat::intersect_tile(means2d, radii, depths, at::nullopt, at::nullopt, C, tile_size, tile_width, tile_height, true);
+        at::Tensor off = gsplat::intersect_offset(std::get<1>(r), C, tile_width, tile_height);
+        return std::make_tuple(std::get<0>(r), want_isect_ids ? std::get<1>(r) : at::empty({0}, std::get<1>(r).options()), std::get<2>(r), off);
+    }
+    const uint32_t n_elements = means2d.numel() / 2, N = C ? n_elements / C : 0;
+    void* st = cur_stream();
+    at::Tensor tiles_per_gauss = at::empty_like(depths, depths.options().dtype(at::kInt));
+    at::Tensor offsets = at::empty({(int64_t)C * tile_height * tile_width + 1}, depths.options().dtype(at::kInt));
+    const size_t cwb = gsx_intersect_bin_count_workspace_bytes(C, tile_width, tile_height);
+    at::Tensor cws = at::empty({(int64_t)cwb}, depths.options().dtype(at::kByte));
+    at::Tensor n_host = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+    check(gsx_intersect_bin_count(C, N, n_elements ? means2d.data_ptr<float>() : nullptr, n_elements ? radii.data_ptr<int32_t>() : nullptr, tile_size,
+                                  tile_width, tile_height, n_elements ? tiles_per_gauss.data_ptr<int32_t>() : nullptr, offsets.data_ptr<int32_t>(),
+                                  n_host.data_ptr<int64_t>(), cws.data_ptr(), cwb, st), "intersect_tile_binned(count)");
+    c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().synchronize();  // the one host sync, as upstream (Intersect.cpp:76)
+    const int64_t n_isects = n_host.data_ptr<int64_t>()[0];
+    at::Tensor flatten_ids = at::empty({n_isects}, depths.options().dtype(at::kInt));
+    at::Tensor isect_ids = at::empty({want_isect_ids ? n_isects : 0}, depths.options().dtype(at::kLong));
+    if (n_isects) {
+        const size_t fwb = gsx_intersect_bin_fill_workspace_bytes(C, tile_width, tile_height, n_isects);
+        at::Tensor fws = at::empty({(int64_t)fwb}, depths.options().dtype(at::kByte));
+        check(gsx_intersect_bin_fill(C, N, means2d.data_ptr<float>(), radii.data_ptr<int32_t>(), depths.data_ptr<float>(), tile_size, tile_width,
+                                     tile_height, offsets.data_ptr<int32_t>(), n_isects, cws.data_ptr(), flatten_ids.data_ptr<int32_t>(),
+                                     want_isect_ids ? isect_ids.data_ptr<int64_t>() : nullptr, fws.data_ptr(), fwb, st), "intersect_tile_binned(fill)");
+    }
+    at::Tensor isect_offsets = offsets.narrow(0, 0, (int64_t)C * tile_height * tile_width).view({(int64_t)C, (int64_t)tile_height, (int64_t)tile_width});
+    return std::make_tuple(tiles_per_gauss, isect_ids, flatten_ids, isect_offsets);
+}
+
 // fusedssim / fusedssim_backward (include/kernels/ssim.cuh:11-29): same tuple returns
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> fusedssim(double C1, double C2, const at::Tensor& img1_, const at::Tensor& img2_, bool train) {
     const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(img1_));
@@ -557,6 +635,11 @@ PYBIND11_MODULE(_gsx_ops, m) {
     m.def("sh_colors_bwd", &gsx_ext::sh_colors_bwd);
     m.def("splat_activations_fwd", &gsx_ext::splat_activations_fwd);
     m.def("splat_activations_bwd", &gsx_ext::splat_activations_bwd);
+    m.def("intersect_tile_binned", &gsx_ext::intersect_tile_binned);
+    m.def("intersect_tile_device_sort", [](const at::Tensor means2d, const at::Tensor radii, const at::Tensor depths, uint32_t C, uint32_t tile_size,
+                                           uint32_t tile_width, uint32_t tile_height, bool sort) {
+        return gsplat::intersect_tile_device_sort(means2d, radii, depths, C, tile_size, tile_width, tile_height, sort);
+    });
     m.def("adam_step", &gsx_ext::adam_step);
     m.def("adam_step_split", &gsx_ext::adam_step_split);
     m.def("fusedssim", &gsx_ext::fusedssim);

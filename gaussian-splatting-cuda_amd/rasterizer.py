@@ -269,8 +269,8 @@ class GutRenderFunction(torch.autograd.Function):
             camera_model, ut, ops.ShutterType.GLOBAL, radial, tangential, None)
         colors = ops.sh_colors_fwd(sh_degree, means_c, viewmat, sh_c, radii)
         tw, th = (width + TILE_SIZE - 1) // TILE_SIZE, (height + TILE_SIZE - 1) // TILE_SIZE
-        _, isect_ids, flatten_ids = ops.intersect_tile(means2d, radii, depths, None, None, 1, TILE_SIZE, tw, th, True)
-        isect_offsets = ops.intersect_offset(isect_ids, 1, tw, th)
+        # binned pipeline: flatten_ids + isect_offsets in one go (bit-identical to intersect_tile + intersect_offset, no isect_ids)
+        _, _, flatten_ids, isect_offsets = ops.intersect_tile_binned(means2d, radii, depths, 1, TILE_SIZE, tw, th, False)
         opac2 = opac.unsqueeze(0)
         renders, alphas, last_ids = ops.rasterize_to_pixels_from_world_3dgs_fwd(
             means_c, quats, scales, colors, opac2, bg, None, width, height, TILE_SIZE, viewmat, None, K, camera_model, ut,

@@ -160,6 +160,23 @@ int gsx_relocation(uint32_t N, const float* opacities, const float* scales, cons
 int gsx_add_noise(uint32_t N, const float* raw_opacities, const float* raw_scales, const float* raw_quats, const float* noise,
                   float* means, float current_lr, void* stream);
 
+/* Binned variant of intersect_tile(sort = true) + intersect_offset in one pipeline (same outputs, bit for bit): per-block
+ * LDS tile histograms -> per-tile prefix + exclusive scan = isect_offsets -> scatter into tile-major segments -> per-tile LDS
+ * sort by (depth bits, flatten index).  No device-wide sort, no global atomics.  tile_offsets has C*tiles + 1 entries (the
+ * last one is n_isects, also copied to the pinned host word).  Host protocol as above: bin_count -> sync -> allocate
+ * flatten_ids -> bin_fill(count_workspace = the workspace bin_count used).  isect_ids may be NULL (the blend kernels only
+ * need flatten_ids + offsets).  gsx_intersect_bin_supported: tile grids up to 36864 tiles per camera (LDS counters). */
+int gsx_intersect_bin_supported(uint32_t tile_width, uint32_t tile_height);
+size_t gsx_intersect_bin_count_workspace_bytes(uint32_t C, uint32_t tile_width, uint32_t tile_height);
+int gsx_intersect_bin_count(uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, uint32_t tile_size,
+                            uint32_t tile_width, uint32_t tile_height, int32_t* tiles_per_gauss, int32_t* tile_offsets,
+                            int64_t* n_isects_host_pinned, void* workspace, size_t workspace_bytes, void* stream);
+size_t gsx_intersect_bin_fill_workspace_bytes(uint32_t C, uint32_t tile_width, uint32_t tile_height, int64_t n_isects);
+int gsx_intersect_bin_fill(uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, const float* depths,
+                           uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, const int32_t* tile_offsets,
+                           int64_t n_isects, const void* count_workspace, int32_t* flatten_ids, int64_t* isect_ids, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 /* ---- next tier: fused Adam step -------------------------------------------------------
  * fast_gs::optimizer::adam_step_wrapper, fastgs/optimizer/include/adam_kernels.cuh:13-38:
  *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr * bc1_rcp * m / (sqrt(v) * bc2_sqrt_rcp + eps)

@@ -272,3 +272,30 @@ def test_blend_with_no_intersections(gsx_mod, raster_path):
     grads = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, alp, last, torch.randn(1, 48, 48, 3, device=DEV),
                                                         torch.randn(1, 48, 48, 1, device=DEV))
     assert all(float(g.abs().max()) == 0.0 for g in grads)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,N,W,H,rmax,nq", [(1, 5000, 256, 256, 20, 0), (2, 3000, 200, 120, 40, 16), (1, 30000, 64, 64, 30, 8),
+                                             (3, 1, 33, 17, 5, 0), (1, 100, 1920, 1080, 300, 4)])
+def test_intersect_tile_binned_equals_sorted_path(C, N, W, H, rmax, nq):
+    """The binned pipeline (LDS histograms + per-tile LDS sort, incl. the > 4096-key merge path: case 3) returns bit for bit
+    what intersect_tile(sort=True) + intersect_offset return; quantised depths (nq levels) exercise the flatten-index tie break."""
+    import gsx  # noqa: F401
+    from gsx import ops
+    g = torch.Generator().manual_seed(C * 1000 + N)
+    means2d = torch.rand(C, N, 2, generator=g) * torch.tensor([W * 1.2, H * 1.2]) - torch.tensor([W * 0.1, H * 0.1])
+    radii = torch.randint(0, rmax, (C, N, 2), generator=g, dtype=torch.int32)      # zeros = culled
+    depths = torch.rand(C, N, generator=g) * 10 + 0.1
+    if nq:
+        depths = torch.round(depths * nq / 10) * 10 / nq + 0.1
+    means2d, radii, depths = means2d.cuda(), radii.cuda(), depths.cuda()
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    tpg, ids, flat = ops.intersect_tile_device_sort(means2d, radii, depths, C, 16, tw, th, True)
+    off = ops.intersect_offset(ids, C, tw, th)
+    tpg2, ids2, flat2, off2 = ops.intersect_tile_binned(means2d, radii, depths, C, 16, tw, th, True)
+    assert torch.equal(tpg, tpg2) and torch.equal(off, off2)
+    assert torch.equal(ids, ids2) and torch.equal(flat, flat2)
+    _, ids3, flat3, off3 = ops.intersect_tile_binned(means2d, radii, depths, C, 16, tw, th, False)
+    assert ids3.numel() == 0 and torch.equal(flat, flat3) and torch.equal(off, off3)
+    if N >= 30000:
+        assert int((off.flatten()[1:] - off.flatten()[:-1]).max()) > 4096   # the merge path ran
