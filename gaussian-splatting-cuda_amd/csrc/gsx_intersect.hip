@@ -201,32 +201,76 @@ GSX_DEV void bitonic_sort_lds(uint64_t* s, int m) {
         }
 }
 
-// One wave per segment of up to TSORT_WAVE_CAP keys: the whole bitonic network runs inside a single wavefront, so the
-// steps are ordered by the wave's own LDS queue — no s_barrier, and 20 such waves fit a CU (8 KB each) to hide LDS latency.
-__global__ __launch_bounds__(64) void tile_sort_wave_kernel(uint32_t n_tiles, uint32_t tile_n_bits, uint32_t idx_bits,
-                                                            const int32_t* __restrict__ tile_offsets, const uint64_t* __restrict__ keys,
-                                                            int32_t* __restrict__ flatten_ids, int64_t* __restrict__ isect_ids) {
-    __shared__ uint64_t s_keys[TSORT_WAVE_CAP];
-    const uint32_t seg = blockIdx.x;
+// One wave per segment of up to TSORT_WAVE_CAP keys, no s_barrier (a single wavefront's LDS operations are ordered).
+// Merge sort instead of a bitonic network: the network moves all m keys through LDS log2(m)(log2(m)+1)/2 times (45 times at
+// m = 512: the kernel was LDS-bandwidth bound), the merge sort log2(64) + 1 times — every lane sorts its E keys in registers,
+// then six merge passes; in each pass a lane finds its merge-path split by binary search and produces E consecutive outputs.
+template <int E>
+GSX_DEV void merge_sort_wave(uint64_t* s, int lane) {
+    uint64_t r[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) r[e] = s[lane * E + e];
+#pragma unroll
+    for (int round = 0; round < E; ++round)  // odd-even transposition network on the lane's own keys
+#pragma unroll
+        for (int e = round & 1; e + 1 < E; e += 2) {
+            const uint64_t x = r[e], y = r[e + 1];
+            r[e] = x < y ? x : y;
+            r[e + 1] = x < y ? y : x;
+        }
+#pragma unroll
+    for (int e = 0; e < E; ++e) s[lane * E + e] = r[e];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int run = E; run < 64 * E; run <<= 1) {
+        const int o = lane * E;
+        const int pair0 = o & ~(2 * run - 1);
+        const int d = o - pair0;  // diagonal of this lane's first output inside the pair of runs
+        const uint64_t* A = s + pair0;
+        const uint64_t* B = A + run;
+        int lo = max(0, d - run), hi = min(d, run);
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (A[mid] <= B[d - 1 - mid]) lo = mid + 1; else hi = mid;
+        }
+        int ai = lo, bi = d - lo;
+        uint64_t a = ai < run ? A[ai] : ~0ull, b = bi < run ? B[bi] : ~0ull;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool ta = a <= b;
+            r[e] = ta ? a : b;
+            const int nxt = ta ? ++ai : ++bi;
+            const uint64_t v = nxt < run ? (ta ? A : B)[nxt] : ~0ull;
+            a = ta ? v : a;
+            b = ta ? b : v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // every lane has finished reading this pass
+#pragma unroll
+        for (int e = 0; e < E; ++e) s[lane * E + e] = r[e];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
+__global__ __launch_bounds__(256) void tile_sort_wave_kernel(uint32_t n_segments, uint32_t n_tiles, uint32_t tile_n_bits, uint32_t idx_bits,
+                                                             const int32_t* __restrict__ tile_offsets, const uint64_t* __restrict__ keys,
+                                                             int32_t* __restrict__ flatten_ids, int64_t* __restrict__ isect_ids) {
+    __shared__ uint64_t s_all[4][TSORT_WAVE_CAP];
+    const uint32_t seg = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (seg >= n_segments) return;
     const int64_t begin = tile_offsets[seg];
     const int n = (int)(tile_offsets[seg + 1] - tile_offsets[seg]);
     if (n <= 0 || n > TSORT_WAVE_CAP) return;
-    const int lane = threadIdx.x;
-    int m = 2;
+    uint64_t* s_keys = s_all[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    int m = 128;
     while (m < n) m <<= 1;
     for (int i = lane; i < m; i += 64) s_keys[i] = i < n ? keys[begin + i] : ~0ull;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    for (int k = 2; k <= m; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = lane; i < (m >> 1); i += 64) {
-                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-                const int hi = lo | j;
-                const uint64_t a = s_keys[lo], b = s_keys[hi];
-                const bool up = (lo & k) == 0;
-                if ((a > b) == up) { s_keys[lo] = b; s_keys[hi] = a; }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    switch (m) {
+    case 128: merge_sort_wave<2>(s_keys, lane); break;
+    case 256: merge_sort_wave<4>(s_keys, lane); break;
+    case 512: merge_sort_wave<8>(s_keys, lane); break;
+    default: merge_sort_wave<16>(s_keys, lane); break;
+    }
     const uint64_t idx_mask = (1ull << idx_bits) - 1ull;
     const int64_t cam_tile = (((int64_t)(seg / n_tiles) << tile_n_bits) | (int64_t)(seg % n_tiles)) << 32;
     for (int i = lane; i < n; i += 64) {
@@ -542,7 +586,7 @@ extern "C" int gsx_intersect_bin_fill(uint32_t C, uint32_t N, const float* means
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)bin_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(BIN_NB, C), dim3(BIN_BLOCK), lds, st, N, per_block, means2d, radii, depths, (float)tile_size,
                        tile_width, tile_height, idx_bits, tile_offsets, (const uint32_t*)count_workspace, keys);
-    hipLaunchKernelGGL(tile_sort_wave_kernel, dim3(nseg), dim3(64), 0, st, n_tiles, bit_width_u32(n_tiles), idx_bits, tile_offsets,
+    hipLaunchKernelGGL(tile_sort_wave_kernel, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, n_tiles, bit_width_u32(n_tiles), idx_bits, tile_offsets,
                        (const uint64_t*)keys, flatten_ids, isect_ids);
     hipLaunchKernelGGL(tile_sort_kernel, dim3(nseg), dim3(ISECT_BLOCK), 0, st, n_tiles, bit_width_u32(n_tiles), idx_bits, tile_offsets, keys, keys_alt,
                        flatten_ids, isect_ids);
