@@ -31,13 +31,15 @@ class GradBucket:
 
     def __init__(self, params):
         self.params = list(params)
-        n = sum(p.numel() for p in self.params)
-        p0 = self.params[0]
-        self.flat = torch.zeros(n, dtype=p0.dtype, device=p0.device)
-        off = 0
+        align = 64  # elements: every view starts on a 256 B boundary (the vectorised kernels need 16 B; pads are reduced along)
+        offs, off = [], 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+            offs.append(off)
+            off += (p.numel() + align - 1) // align * align
+        p0 = self.params[0]
+        self.flat = torch.zeros(off, dtype=p0.dtype, device=p0.device)
+        for p, o in zip(self.params, offs):
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
 
     def sinks(self, names=("means", "sh", "scaling_raw", "rotation_raw", "opacity_raw")):
         """name -> gradient view, for rasterize_fused(grad_sinks=...): backward overwrites the bucket in place."""

@@ -1,88 +1,134 @@
 """Optimizer of the training loop: the reference's FusedAdam and ExponentialLR
-(src/training/optimizers/fused_adam.cpp:20-96, scheduler.cpp:10-25, group set-up strategy_utils.cpp:20-55) on the
-fused HIP Adam kernel (csrc/gsx_adam.hip).
+(src/training/optimizers/fused_adam.cpp:20-96, scheduler.cpp:10-25, group set-up strategy_utils.cpp:20-55 /
+strategies/mcmc.cpp:476-499) on the fused HIP Adam kernels (csrc/gsx_adam.hip).
 
-Parameter groups, in the reference's order: means, sh0, shN, scaling, rotation, opacity.  Here sh0 / shN are the two
-column blocks of ONE [N,K,3] SH tensor (rasterizer.SplatData); each block keeps its own learning rate and Adam state and
-is updated by one vectorised launch over the dense tensor (gsx_adam_step_split; the two groups always share their step
-count, fused_adam.cpp:66).  Quirks kept from the reference (fused_adam.cpp:68-76): the shN group (i == 3) is not
-stepped during the first 1000 iterations although its step counter advances; with `skip_sh_steps` it is stepped only
-every second iteration until iteration 25000."""
+Parameter groups, in the reference's order: means, sh0, shN, scaling, rotation, opacity; betas (0.9, 0.999), eps 1e-15.
+Here sh0 / shN are the two column blocks of ONE [N,K,3] SH tensor (rasterizer.SplatData); each block keeps its own
+learning rate and is updated, together with the other block, by one vectorised launch over the dense tensor
+(gsx_adam_step_split; the two groups always share their step count, fused_adam.cpp:66).  Quirks kept from the reference
+(fused_adam.cpp:68-76): the shN group (i == 3) is not stepped during the first 1000 iterations although its step counter
+advances; with `skip_sh_steps` (a compile-time switch upstream, default off) it is stepped only every second iteration
+until iteration 25000.
+
+Groups address the model's tensors by name at step time, so a densification strategy may replace them by longer ones
+(`extend_state`) or reset the moments of relocated Gaussians (`reset_state`), as strategies/mcmc.cpp:85-112,252-330 do."""
 import math
 
 import torch
 
 from . import ops
 
+GROUPS = ("means", "sh0", "shN", "scaling", "rotation", "opacity")
+_ATTR = {"means": "means", "sh0": "sh", "shN": "sh", "scaling": "scaling_raw", "rotation": "rotation_raw", "opacity": "opacity_raw"}
+
 
 class FusedAdam:
-    def __init__(self, groups, betas=(0.9, 0.999), eps=1e-8, skip_sh_steps=False):
-        """groups: list of dicts {"name", "param" (leaf tensor or view of one), "grad" (callable -> tensor or None), "lr"}."""
-        self.groups = groups
+    def __init__(self, model, lrs, betas=(0.9, 0.999), eps=1e-15, skip_sh_steps=False):
+        """lrs: dict group name -> learning rate (all six of GROUPS)."""
+        self.model = model
+        self.groups = [{"name": n, "lr": float(lrs[n])} for n in GROUPS]
         self.betas, self.eps, self.skip_sh_steps = betas, eps, skip_sh_steps
-        self.state = {}
+        self.state = {}   # "means" | "sh" | "scaling" | "rotation" | "opacity" -> exp_avg / exp_avg_sq; step counts per group
 
     @staticmethod
     def for_splat_data(model, means_lr=0.00016, shs_lr=0.0025, scaling_lr=0.005, rotation_lr=0.001, opacity_lr=0.05,
                        scene_scale=1.0, **kw):
-        """strategy_utils.cpp:35-40 (default_optimization_params: parameters.hpp:19-23)."""
-        def g(name, param, grad, lr):
-            return {"name": name, "param": param, "grad": grad, "lr": lr}
-        sh_grad = lambda: model.sh.grad  # noqa: E731
-        sh0 = g("sh0", model.sh.data[:, :1], lambda: None if sh_grad() is None else sh_grad()[:, :1], shs_lr)
-        shN = g("shN", model.sh.data[:, 1:], lambda: None if sh_grad() is None else sh_grad()[:, 1:], shs_lr / 20.0)
-        if (model.sh.shape[1] * 3) % 4 == 0:  # K = 4 / 16: one vectorised launch over the dense tensor; else two strided ones
-            sh0.update(parent=model.sh, parent_grad=sh_grad)
-            shN.update(parent=model.sh, parent_grad=sh_grad)
-        return FusedAdam([
-            g("means", model.means, lambda: model.means.grad, means_lr * scene_scale),
-            sh0, shN,
-            g("scaling", model.scaling_raw, lambda: model.scaling_raw.grad, scaling_lr),
-            g("rotation", model.rotation_raw, lambda: model.rotation_raw.grad, rotation_lr),
-            g("opacity", model.opacity_raw, lambda: model.opacity_raw.grad, opacity_lr),
-        ], **kw)
+        """strategy_utils.cpp:35-40 (defaults: include/core/parameters.hpp:19-23)."""
+        return FusedAdam(model, {"means": means_lr * scene_scale, "sh0": shs_lr, "shN": shs_lr / 20.0, "scaling": scaling_lr,
+                                 "rotation": rotation_lr, "opacity": opacity_lr}, **kw)
 
+    # ---- state ---------------------------------------------------------------------------------------------------------
+    def _param(self, name):
+        return getattr(self.model, _ATTR[name])
+
+    def _moments(self, name):
+        """Moments of a group; sh0 / shN share one [N,K,3] pair when the split launch applies, else one dense pair per block."""
+        sh = self.model.sh
+        split = (sh.shape[1] * 3) % 4 == 0 and sh.shape[1] > 1
+        key = _ATTR[name] if (split or name not in ("sh0", "shN")) else name
+        st = self.state.get(key)
+        if st is None:
+            p = self._param(name)
+            if key == "sh0":
+                p = p[:, :1]
+            elif key == "shN":
+                p = p[:, 1:]
+            st = self.state[key] = {"exp_avg": torch.zeros(p.shape, dtype=p.dtype, device=p.device),
+                                    "exp_avg_sq": torch.zeros(p.shape, dtype=p.dtype, device=p.device)}
+        return st
+
+    def step_count(self, name):
+        return self.state.get("step:" + name, 0)
+
+    def reset_state(self, indices):
+        """Zero both moments of the given Gaussians in every group (MCMC::update_optimizer_for_relocate, mcmc.cpp:85-112)."""
+        for key, st in self.state.items():
+            if isinstance(st, dict):
+                st["exp_avg"][indices] = 0
+                st["exp_avg_sq"][indices] = 0
+
+    def extend_state(self, n_new):
+        """The model grew by n_new Gaussians at the end: append zero moments, keep the step counts (mcmc.cpp:264-318)."""
+        for key, st in self.state.items():
+            if isinstance(st, dict):
+                for k in ("exp_avg", "exp_avg_sq"):
+                    z = torch.zeros((n_new,) + tuple(st[k].shape[1:]), dtype=st[k].dtype, device=st[k].device)
+                    st[k] = torch.cat([st[k], z], 0)
+
+    def select_state(self, indices):
+        """Keep only the given Gaussians (MCMC::remove_gaussians, mcmc.cpp:404-444)."""
+        for key, st in self.state.items():
+            if isinstance(st, dict):
+                st["exp_avg"] = st["exp_avg"].index_select(0, indices)
+                st["exp_avg_sq"] = st["exp_avg_sq"].index_select(0, indices)
+
+    # ---- step ------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, iteration):
         b1, b2 = self.betas
-        pending = None  # the sh0 group waiting for shN: both blocks of one dense SH tensor go out in one launch
+        sh = self.model.sh
+        sh_grad = sh.grad
+        split_ok = (sh.shape[1] * 3) % 4 == 0 and sh.shape[1] > 1
+        do_sh = {}
         for i, grp in enumerate(self.groups, start=1):
-            grad = grp["grad"]()
-            if grad is None:
+            name = grp["name"]
+            p = self._param(name)
+            grad = sh_grad if name in ("sh0", "shN") else p.grad
+            if grad is None or (name == "shN" and sh.shape[1] == 1):
                 continue
-            st = self.state.get(grp["name"])
-            if st is None:
-                p = grp["param"]
-                st = self.state[grp["name"]] = {"step": 0}
-                if "parent" not in grp or grp["name"] == "sh0":
-                    shape = grp["parent"].shape if "parent" in grp else p.shape
-                    st["exp_avg"] = torch.zeros(shape, dtype=p.dtype, device=p.device)
-                    st["exp_avg_sq"] = torch.zeros(shape, dtype=p.dtype, device=p.device)
-            st["step"] += 1
+            self.state["step:" + name] = t = self.step_count(name) + 1
             skip = i == 3 and (iteration <= 1000 or (self.skip_sh_steps and iteration % 2 != 0 and iteration <= 25000))
-            if "parent" in grp:                       # sh0 / shN blocks of the single SH tensor
-                if grp["name"] == "sh0":
-                    pending = (grp, st)
-                    continue
-                g0, st0 = pending
-                pending = None
-                assert st0["step"] == st["step"], "sh0 / shN step counters diverged"
-                bc1_rcp = 1.0 / (1.0 - math.pow(b1, st["step"]))
-                bc2_sqrt_rcp = 1.0 / math.sqrt(1.0 - math.pow(b2, st["step"]))
-                parent = grp["parent"]
-                ops.adam_step_split(parent.data, st0["exp_avg"], st0["exp_avg_sq"], grp["parent_grad"](), 3, g0["lr"], grp["lr"], True, not skip,
-                                    b1, b2, self.eps, bc1_rcp, bc2_sqrt_rcp)
+            bc1_rcp = 1.0 / (1.0 - math.pow(b1, t))
+            bc2_sqrt_rcp = 1.0 / math.sqrt(1.0 - math.pow(b2, t))
+            if name in ("sh0", "shN"):
+                do_sh[name] = (not skip, grp["lr"], bc1_rcp, bc2_sqrt_rcp)
                 continue
             if skip:
                 continue
-            bc1_rcp = 1.0 / (1.0 - math.pow(b1, st["step"]))
-            bc2_sqrt_rcp = 1.0 / math.sqrt(1.0 - math.pow(b2, st["step"]))
-            p = grp["param"].data if isinstance(grp["param"], torch.Tensor) else grp["param"]
-            ops.adam_step(p, st["exp_avg"], st["exp_avg_sq"], grad, grp["lr"], b1, b2, self.eps, bc1_rcp, bc2_sqrt_rcp)
-        if pending is not None:                       # sh0 had a gradient but shN did not: step the block alone
-            g0, st0 = pending
-            ops.adam_step_split(g0["parent"].data, st0["exp_avg"], st0["exp_avg_sq"], g0["parent_grad"](), 3, g0["lr"], 0.0, True, False, b1, b2,
-                                self.eps, 1.0 / (1.0 - math.pow(b1, st0["step"])), 1.0 / math.sqrt(1.0 - math.pow(b2, st0["step"])))
+            st = self._moments(name)
+            ops.adam_step(p.data, st["exp_avg"], st["exp_avg_sq"], grad, grp["lr"], b1, b2, self.eps, bc1_rcp, bc2_sqrt_rcp)
+        if do_sh:
+            a = do_sh.get("sh0", (False, 0.0, 1.0, 1.0))
+            b = do_sh.get("shN", (False, 0.0, a[2], a[3]))
+            if split_ok and a[2:] == b[2:] and sh_grad.is_contiguous():
+                st = self._moments("sh0")
+                ops.adam_step_split(sh.data, st["exp_avg"], st["exp_avg_sq"], sh_grad, 3, a[1], b[1], a[0], b[0], b1, b2, self.eps, a[2], a[3])
+            else:  # K = 1 / 9 / 25 (K*3 not a multiple of 4): one row-strided launch per block, dense moments per block
+                assert not split_ok, "sh0 / shN step counters diverged"
+                if a[0]:
+                    st = self._moments("sh0")
+                    ops.adam_step(sh.data[:, :1], st["exp_avg"], st["exp_avg_sq"], sh_grad[:, :1], a[1], b1, b2, self.eps, a[2], a[3])
+                if b[0]:
+                    st = self._moments("shN")
+                    ops.adam_step(sh.data[:, 1:], st["exp_avg"], st["exp_avg_sq"], sh_grad[:, 1:], b[1], b1, b2, self.eps, b[2], b[3])
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.model.params():
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()
 
 
 class ExponentialLR:

@@ -1,0 +1,71 @@
+"""Training step of the `--gut` path (the caller side of the hot path): Trainer::train_step of the reference
+(src/training/trainer.cpp:579-800) restricted to what the gut / MCMC configuration executes:
+
+    render (rasterize_fused) -> photometric loss (trainer.cpp:103-127) -> backward
+    -> scale / opacity regularisers (trainer.cpp:132-160; their gradients are added analytically: reg * mean(exp(s)),
+       reg * mean(sigmoid(o)))
+    -> [N > 1 GPUs: one all-reduce of the flat gradient bucket, mean over the cameras of the step]
+    -> strategy.post_backward (SH degree schedule, relocation, growth, noise) -> strategy.step (fused Adam + lr decay)
+
+One process per GPU; rank r renders camera `cams[(it * world + r) % len(cams)]`.  Every rank holds a full replica and applies
+the identical update (the strategy's random draws come from a generator seeded identically on all ranks)."""
+import torch
+import torch.distributed as dist
+
+from . import distributed as gdist
+from . import loss as gloss
+from . import rasterizer
+from .strategy import MCMC, OptimizationParameters
+
+
+class Trainer:
+    def __init__(self, model, cameras, images, params: OptimizationParameters = None, background=None, scene_scale=1.0, seed=0):
+        """cameras: list of rasterizer.Camera; images: list of [3,H,W] ground-truth tensors on the device."""
+        self.model, self.cameras, self.images = model, cameras, images
+        self.params = params or OptimizationParameters()
+        self.bg = background
+        dev = model.means.device
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        for p in model.params():
+            p.requires_grad_(True)
+        self.strategy = MCMC(model, self.params, scene_scale, gen)
+        self.strategy.on_resize = self._rebuild_bucket
+        self._rebuild_bucket(model)
+        self.last_loss = None
+
+    def _rebuild_bucket(self, model):
+        self.bucket = gdist.GradBucket(model.params())
+        self.sinks = self.bucket.sinks()
+
+    @torch.no_grad()
+    def _add_regularisers(self):
+        p, m = self.params, self.model
+        if p.scale_reg > 0.0:   # d/ds_raw [reg * mean(exp(s_raw))]
+            m.scaling_raw.grad.add_(torch.exp(m.scaling_raw), alpha=p.scale_reg / m.scaling_raw.numel())
+        if p.opacity_reg > 0.0:  # d/do_raw [reg * mean(sigmoid(o_raw))]
+            s = torch.sigmoid(m.opacity_raw)
+            m.opacity_raw.grad.add_(s * (1.0 - s), alpha=p.opacity_reg / m.opacity_raw.numel())
+
+    def train_step(self, it):
+        i = (it * self.world + self.rank) % len(self.cameras)
+        out = rasterizer.rasterize_fused(self.cameras[i], self.model, self.bg, grad_sinks=self.sinks)
+        gt = self.images[i]
+        loss = gloss.photometric_loss(out.render_hwc, gt, self.params.lambda_dssim)
+        loss.backward()
+        self._add_regularisers()
+        self.bucket.all_reduce_mean()
+        self.strategy.post_backward(it, out)
+        self.strategy.step(it)
+        self.last_loss = loss.detach()
+        return self.last_loss
+
+    def train(self, iterations=None, start=1, log_every=0):
+        n = iterations or self.params.iterations
+        for it in range(start, start + n):
+            loss = self.train_step(it)
+            if log_every and it % log_every == 0 and self.rank == 0:
+                print(f"iter {it}: loss {float(loss):.5f}  gaussians {self.model.means.shape[0]}")
+        return self.last_loss

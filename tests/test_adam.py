@@ -70,7 +70,7 @@ def test_fused_adam_reference_quirks():
     assert torch.allclose(model.means, before[0] - 0.00016, atol=1e-7)
     assert torch.allclose(model.sh[:, :1], before[1][:, :1] - 0.0025, atol=1e-6)
     assert torch.equal(model.sh[:, 1:], before[1][:, 1:])
-    assert opt.state["shN"]["step"] == 1                    # ... although its step counter advanced (fused_adam.cpp:66-70)
+    assert opt.step_count("shN") == 1                       # ... although its step counter advanced (fused_adam.cpp:66-70)
     opt.step(iteration=1001)
     assert not torch.equal(model.sh[:, 1:], before[1][:, 1:])
     sched = optim.ExponentialLR(opt, 0.5, 0)
@@ -119,7 +119,7 @@ def test_fused_adam_matches_torch_adam_over_iterations(K):
     ref_sh0, ref_shN = ref[1][:, :1].detach().clone().requires_grad_(True), ref[1][:, 1:].detach().clone().requires_grad_(True)
     lrs = [0.00016, 0.0025, 0.0025 / 20, 0.005, 0.001, 0.05]
     topt = torch.optim.Adam([{"params": [t], "lr": lr} for t, lr in zip([ref[0], ref_sh0, ref_shN, ref[2], ref[3], ref[4]], lrs)],
-                            betas=(0.9, 0.999), eps=1e-8)
+                            betas=(0.9, 0.999), eps=1e-15)
     opt = optim.FusedAdam.for_splat_data(model)
     for it in range(1001, 1006):                      # past the shN freeze
         for p in params:

@@ -1,0 +1,94 @@
+"""End-to-end check of the training step (render -> fused L1/SSIM loss -> backward -> regularisers -> MCMC strategy -> fused
+Adam): a perturbed copy of a small scene is trained against renders of the original from four cameras and must converge."""
+import math
+
+import pytest
+import torch
+
+
+def _scene(dev, N=3000, K=4):
+    import gsx  # noqa: F401
+    from gsx import rasterizer, scenes
+    sc = scenes.scene_small(seed=5, N=N)
+    g = torch.Generator().manual_seed(3)
+    sc["sh"] = torch.cat([sc["sh"][:, :1], 0.05 * torch.randn(N, K - 1, 3, generator=g)], 1) if sc["sh"].shape[1] < K else sc["sh"]
+    sc["sh_degree"] = int(math.isqrt(K)) - 1
+    model = scenes.to_splat_data(sc, dev)
+    W, H = sc["width"], sc["height"]
+    cams = []
+    for k in range(4):
+        vm = sc["viewmat"].clone()
+        vm[0, 3] += 0.15 * math.cos(k * math.pi / 2)
+        vm[1, 3] += 0.15 * math.sin(k * math.pi / 2)
+        cams.append(rasterizer.Camera(viewmat=vm.to(dev), K=sc["K"].to(dev), width=W, height=H))
+    return sc, model, cams
+
+
+@pytest.mark.gpu
+def test_training_converges_and_mcmc_bookkeeping():
+    import gsx  # noqa: F401
+    from gsx import rasterizer, scenes, strategy, trainer
+    dev = "cuda:0"
+    sc, gt_model, cams = _scene(dev)
+    bg = sc["background"].to(dev)
+    with torch.no_grad():
+        images = [rasterizer.rasterize_fused(c, gt_model, bg).image.clone() for c in cams]
+    # the trainee: the same scene with perturbed colours, positions and opacities
+    g = torch.Generator().manual_seed(9)
+    sc2 = dict(sc)
+    model = scenes.to_splat_data(sc2, dev)
+    model.sh = (gt_model.sh + 0.3 * torch.randn(gt_model.sh.shape, generator=g).to(dev)).contiguous()
+    model.means = (gt_model.means + 0.01 * torch.randn(gt_model.means.shape, generator=g).to(dev)).contiguous()
+    model.opacity_raw = (gt_model.opacity_raw - 0.5).contiguous()
+    model.scaling_raw, model.rotation_raw = gt_model.scaling_raw.clone(), gt_model.rotation_raw.clone()
+    model.active_sh_degree = gt_model.active_sh_degree
+    params = strategy.OptimizationParameters(iterations=300, start_refine=50, refine_every=50, stop_refine=250, max_cap=3300,
+                                             sh_degree_interval=1000)
+    tr = trainer.Trainer(model, cams, images, params, bg, seed=1)
+    tr.strategy.NOISE_LR = 0.0            # noise off for the convergence check (it is exercised separately below)
+    first = float(sum(float(tr.train_step(it)) for it in range(1, 5)) / 4)
+    n0 = model.means.shape[0]
+    for it in range(5, 240):
+        tr.train_step(it)
+    last = float(sum(float(tr.train_step(it)) for it in range(240, 244)) / 4)
+    assert last < 0.55 * first, (first, last)
+    # growth by 5 % per refinement up to max_cap, moments extended with the model, step counts kept
+    n1 = model.means.shape[0]
+    assert n0 < n1 <= 3300
+    opt = tr.strategy.optimizer
+    assert opt.state["means"]["exp_avg"].shape[0] == n1 and opt.state["sh"]["exp_avg_sq"].shape[0] == n1
+    assert opt.step_count("means") == 243 and opt.step_count("shN") == 243
+    assert all(p.grad is not None and p.grad.shape == p.shape for p in model.params())
+    assert abs(opt.groups[0]["lr"] - 0.00016 * 0.01 ** (243 / 300)) < 1e-9
+
+
+@pytest.mark.gpu
+def test_mcmc_relocate_moves_dead_gaussians_onto_live_ones():
+    import gsx  # noqa: F401
+    from gsx import strategy
+    dev = "cuda:0"
+    sc, model, cams = _scene(dev, N=500)
+    for p in model.params():
+        p.requires_grad_(True)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0)
+    mc = strategy.MCMC(model, strategy.OptimizationParameters(), 1.0, gen)
+    for p in model.params():
+        p.grad = torch.ones_like(p)
+    mc.optimizer.step(1)
+    with torch.no_grad():
+        model.opacity_raw[:40] = -10.0           # dead: sigmoid(-10) < min_opacity
+    means_before = model.means.detach().clone()
+    n_dead = mc.relocate_gs()
+    assert n_dead == 40
+    moved = model.means.detach()[:40]
+    same = (moved[:, None, :] == means_before[None, 40:, :]).all(-1)      # [40, 460] exact matches
+    assert bool(same.any(1).all())                      # every dead Gaussian now sits exactly on a live one
+    assert float(torch.sigmoid(model.opacity_raw.detach()).min()) >= 0.005 - 1e-6
+    # the moments of the sampled (source) Gaussians were reset
+    src = same.float().argmax(dim=1) + 40
+    assert float(mc.optimizer.state["means"]["exp_avg"][src].abs().max()) == 0.0
+    # noise: displaces low-opacity Gaussians more than opaque ones, deterministic given the generator
+    m0 = model.means.detach().clone()
+    mc.inject_noise()
+    assert float((model.means.detach() - m0).abs().max()) > 0.0
