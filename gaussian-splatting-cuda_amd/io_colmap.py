@@ -1,0 +1,214 @@
+"""COLMAP sparse-model reader: cameras.bin / images.bin / points3D.bin -> rasterizer.Camera list +
+initial point cloud, following src/loader/formats/colmap.cpp (binary layouts :300-470, per-model intrinsics :684-840,
+world->camera [R|t] from (qvec, tvec) :25-51, camera centres = -R^T t :676) and the model initialisation of
+SplatData::init_model_from_pointcloud (src/core/splat_data.cpp:63-111, 506-600).
+
+Image files are NOT decoded here (no image codec in this environment): `ColmapScene.cameras[i].image_name` names the file a
+caller has to load; everything the rasterizer needs (pose, intrinsics, distortion, size) comes from the .bin files."""
+import os
+import struct
+from dataclasses import dataclass, field
+from typing import List
+
+import numpy as np
+import torch
+
+from . import ops
+from .rasterizer import Camera, SplatData
+
+# model id -> (name, number of parameters)   (colmap.cpp:117-129)
+CAMERA_MODELS = {0: ("SIMPLE_PINHOLE", 3), 1: ("PINHOLE", 4), 2: ("SIMPLE_RADIAL", 4), 3: ("RADIAL", 5), 4: ("OPENCV", 8),
+                 5: ("OPENCV_FISHEYE", 8), 6: ("FULL_OPENCV", 12), 7: ("FOV", 5), 8: ("SIMPLE_RADIAL_FISHEYE", 4), 9: ("RADIAL_FISHEYE", 5),
+                 10: ("THIN_PRISM_FISHEYE", 12)}
+
+
+def qvec2rotmat(q):
+    """colmap.cpp:25-51 (w, x, y, z)."""
+    w, x, y, z = (float(v) for v in q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], np.float32)
+
+
+def read_cameras_binary(path, scale_factor=1.0):
+    buf = open(path, "rb").read()
+    (n,), off, cams = struct.unpack_from("<Q", buf, 0), 8, {}
+    for _ in range(n):
+        cam_id, model_id, w, h = struct.unpack_from("<IiQQ", buf, off)
+        off += 24
+        if model_id not in CAMERA_MODELS:
+            raise RuntimeError(f"Unsupported camera-model id {model_id}")
+        name, cnt = CAMERA_MODELS[model_id]
+        params = list(struct.unpack_from("<%dd" % cnt, buf, off))
+        off += 8 * cnt
+        if scale_factor != 1.0:  # images_<k> folders: colmap.cpp:172-258, 365-383
+            w, h = int(w / scale_factor), int(h / scale_factor)
+            n_focal = 1 if name in ("SIMPLE_PINHOLE", "SIMPLE_RADIAL", "RADIAL", "SIMPLE_RADIAL_FISHEYE", "RADIAL_FISHEYE") else 2
+            for k in range(n_focal + 2):
+                params[k] /= scale_factor
+        cams[cam_id] = {"model": name, "width": int(w), "height": int(h), "params": np.array(params, np.float64).astype(np.float32)}
+    if off != len(buf):
+        raise RuntimeError("cameras.bin: trailing bytes")
+    return cams
+
+
+def read_images_binary(path):
+    buf = open(path, "rb").read()
+    (n,), off, images = struct.unpack_from("<Q", buf, 0), 8, []
+    for _ in range(n):
+        image_id, = struct.unpack_from("<I", buf, off)
+        q = np.array(struct.unpack_from("<4d", buf, off + 4), np.float64).astype(np.float32)
+        t = np.array(struct.unpack_from("<3d", buf, off + 36), np.float64).astype(np.float32)
+        cam_id, = struct.unpack_from("<I", buf, off + 60)
+        off += 64
+        end = buf.index(b"\0", off)
+        name = buf[off:end].decode("utf-8")
+        off = end + 1
+        npts, = struct.unpack_from("<Q", buf, off)
+        off += 8 + npts * 24
+        images.append({"id": image_id, "qvec": q, "tvec": t, "camera_id": cam_id, "name": name})
+    if off != len(buf):
+        raise RuntimeError("images.bin: trailing bytes")
+    return images
+
+
+def read_points3D_binary(path):
+    buf = open(path, "rb").read()
+    (n,), off = struct.unpack_from("<Q", buf, 0), 8
+    xyz, rgb = np.empty((n, 3), np.float32), np.empty((n, 3), np.uint8)
+    for i in range(n):
+        x, y, z = struct.unpack_from("<3d", buf, off + 8)
+        xyz[i] = (x, y, z)
+        rgb[i] = struct.unpack_from("<3B", buf, off + 32)
+        track_len, = struct.unpack_from("<Q", buf, off + 43)
+        off += 51 + 8 * track_len
+    if off != len(buf):
+        raise RuntimeError("points3D.bin: trailing bytes")
+    return xyz, rgb
+
+
+@dataclass
+class ColmapCamera:
+    camera: Camera
+    image_name: str
+    image_path: str
+    uid: int
+    model: str
+
+
+@dataclass
+class ColmapScene:
+    cameras: List[ColmapCamera] = field(default_factory=list)
+    camera_locations: np.ndarray = None   # [n,3] world-space centres
+    scene_center: np.ndarray = None       # their mean (colmap.cpp:  scene centre used for the scene scale)
+    points: np.ndarray = None             # [P,3] float32
+    colors: np.ndarray = None             # [P,3] uint8
+
+
+def _intrinsics(model, p):
+    """colmap.cpp:684-840 -> (fx, fy, cx, cy, radial, tangential, gsplat camera model)."""
+    PIN, FISH = ops.CameraModelType.PINHOLE, ops.CameraModelType.FISHEYE
+    if model == "SIMPLE_PINHOLE":
+        return p[0], p[0], p[1], p[2], None, None, PIN
+    if model == "PINHOLE":
+        return p[0], p[1], p[2], p[3], None, None, PIN
+    if model == "SIMPLE_RADIAL":
+        return p[0], p[0], p[1], p[2], (np.array([p[3]], np.float32) if p[3] != 0 else None), None, PIN
+    if model == "RADIAL":
+        return p[0], p[0], p[1], p[2], p[3:5].copy(), None, PIN
+    if model == "OPENCV":
+        return p[0], p[1], p[2], p[3], p[4:6].copy(), p[6:8].copy(), PIN
+    if model == "FULL_OPENCV":
+        return p[0], p[1], p[2], p[3], np.array([p[4], p[5], p[8], p[9], p[10], p[11]], np.float32), p[6:8].copy(), PIN
+    if model == "OPENCV_FISHEYE":
+        return p[0], p[1], p[2], p[3], p[4:8].copy(), None, FISH
+    if model == "RADIAL_FISHEYE":
+        return p[0], p[0], p[1], p[2], p[3:5].copy(), None, FISH
+    if model == "SIMPLE_RADIAL_FISHEYE":
+        return p[0], p[0], p[1], p[2], p[3:4].copy(), None, FISH
+    if model == "THIN_PRISM_FISHEYE":
+        raise RuntimeError("THIN_PRISM_FISHEYE camera model is not supported but could be implemented in 3DGUT pretty easily")
+    if model == "FOV":
+        raise RuntimeError("FOV camera model is not supported.")
+    raise RuntimeError("Unsupported camera model")
+
+
+def _pad4(a):
+    """rasterizer.cpp:183-195 pads distortion vectors to >= 4 entries."""
+    if a is None:
+        return None
+    out = np.zeros(max(4, len(a)), np.float32)
+    out[:len(a)] = a
+    return out
+
+
+def load_colmap(base_path, images_folder="images", device="cpu"):
+    sparse = os.path.join(base_path, "sparse", "0")
+    if not os.path.isdir(sparse):
+        sparse = os.path.join(base_path, "sparse")
+    suffix = images_folder.rsplit("_", 1)[-1] if "_" in images_folder else ""
+    try:
+        factor = float(suffix)
+        factor = factor if 0 < factor <= 16 else 1.0
+    except ValueError:
+        factor = 1.0
+    cams = read_cameras_binary(os.path.join(sparse, "cameras.bin"), factor)
+    images = read_images_binary(os.path.join(sparse, "images.bin"))
+    scene = ColmapScene()
+    locs = []
+    for uid, img in enumerate(images):
+        if img["camera_id"] not in cams:
+            raise RuntimeError(f"Camera ID {img['camera_id']} not found")
+        c = cams[img["camera_id"]]
+        R, t = qvec2rotmat(img["qvec"]), img["tvec"]
+        locs.append(-R.T @ t)
+        fx, fy, cx, cy, radial, tangential, kind = _intrinsics(c["model"], c["params"])
+        vm = np.eye(4, dtype=np.float32)
+        vm[:3, :3], vm[:3, 3] = R, t
+        K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float32)
+        radial, tangential = _pad4(radial), _pad4(tangential)
+        cam = Camera(viewmat=torch.from_numpy(vm).to(device), K=torch.from_numpy(K).to(device), width=c["width"], height=c["height"],
+                     camera_model=kind, radial=None if radial is None else torch.from_numpy(radial).to(device),
+                     tangential=None if tangential is None else torch.from_numpy(tangential).to(device))
+        scene.cameras.append(ColmapCamera(cam, img["name"], os.path.join(base_path, images_folder, img["name"]), uid, c["model"]))
+    scene.camera_locations = np.stack(locs) if locs else np.zeros((0, 3), np.float32)
+    scene.scene_center = scene.camera_locations.mean(0) if locs else np.zeros(3, np.float32)
+    p3d = os.path.join(sparse, "points3D.bin")
+    if os.path.exists(p3d):
+        scene.points, scene.colors = read_points3D_binary(p3d)
+    return scene
+
+
+def mean_neighbor_distances(points):
+    """compute_mean_neighbor_distances (splat_data.cpp:63-111): mean distance to the (up to) 3 nearest neighbours farther
+    than 1e-4 (squared 1e-8) among the 4 nearest results, 0.01 when there is none."""
+    from scipy.spatial import cKDTree
+    n = points.shape[0]
+    if n <= 1:
+        return np.full(n, 0.01, np.float32)
+    k = min(4, n)
+    d, _ = cKDTree(points).query(points, k=k)
+    d = d.reshape(n, k).astype(np.float32)
+    out = np.empty(n, np.float32)
+    for i in range(n):
+        valid = d[i][(d[i] * d[i]) > 1e-8][:3]
+        out[i] = valid.mean() if valid.size else 0.01
+    return out
+
+
+def init_model_from_pointcloud(points, colors_u8, scene_center, sh_degree=3, init_scaling=0.1, init_opacity=0.5, device="cpu"):
+    """SplatData::init_model_from_pointcloud (splat_data.cpp:506-600), non-random branch.  Returns (SplatData, scene_scale)."""
+    pts = np.ascontiguousarray(points, np.float32)
+    cols = colors_u8.astype(np.float32) / 255.0
+    scene_scale = float(np.median(np.linalg.norm(pts - np.asarray(scene_center, np.float32)[None], axis=1)))
+    nn = np.maximum(mean_neighbor_distances(pts), 1e-7)
+    scaling = np.repeat(np.log(np.sqrt(nn) * init_scaling)[:, None], 3, 1).astype(np.float32)
+    rotation = np.zeros((pts.shape[0], 4), np.float32)
+    rotation[:, 0] = 1
+    opacity = np.full((pts.shape[0], 1), np.log(init_opacity / (1 - init_opacity)), np.float32)
+    K = (sh_degree + 1) ** 2
+    sh = np.zeros((pts.shape[0], K, 3), np.float32)
+    sh[:, 0] = (cols - 0.5) / 0.28209479177387814
+    t = lambda a: torch.from_numpy(a).to(device)  # noqa: E731
+    return SplatData(means=t(pts), sh=t(sh), scaling_raw=t(scaling), rotation_raw=t(rotation), opacity_raw=t(opacity),
+                     active_sh_degree=0), scene_scale

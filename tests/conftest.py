@@ -12,6 +12,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    # the extension is built in-tree by __graft_entry__.build(); build it here if a fresh checkout has not done so yet
+    lib = os.path.join(ROOT, "gaussian-splatting-cuda_amd", "libgsx.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "gaussian-splatting-cuda_amd", "build.py")])
+
+
 def pytest_collection_modifyitems(config, items):
     # GPU tests are only collected for execution when a GPU is present; on CPU they are skipped so
     # `-m "not gpu"` and a plain run both stay green.

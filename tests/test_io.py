@@ -1,0 +1,159 @@
+"""Model / dataset IO: 3DGS PLY layout and round trip, COLMAP binary sparse model, point-cloud initialisation."""
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+
+def _model(N=37, K=16, seed=0):
+    import gsx  # noqa: F401
+    from gsx.rasterizer import SplatData
+    g = torch.Generator().manual_seed(seed)
+    return SplatData(means=torch.randn(N, 3, generator=g), sh=torch.randn(N, K, 3, generator=g), scaling_raw=torch.randn(N, 3, generator=g),
+                     rotation_raw=torch.randn(N, 4, generator=g), opacity_raw=torch.randn(N, 1, generator=g), active_sh_degree=3)
+
+
+@pytest.mark.parametrize("K", [16, 4, 1])
+def test_ply_layout_and_round_trip(tmp_path, K):
+    from gsx import io_ply
+    m = _model(K=K)
+    path = io_ply.save_ply(m, str(tmp_path), iteration=7000)
+    assert path.endswith("splat_7000.ply")
+    raw = open(path, "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    lines = head.decode().splitlines()
+    assert lines[:3] == ["ply", "format binary_little_endian 1.0", "element vertex 37"]
+    names = [ln.split()[2] for ln in lines[3:]]
+    assert names == io_ply.attribute_names(K) and all(ln.startswith("property float ") for ln in lines[3:])
+    assert names[:9] == ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"] and names[-8:] == ["opacity", "scale_0", "scale_1",
+                                                                                                        "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+    rows = np.frombuffer(body, "<f4").reshape(37, len(names))
+    assert np.array_equal(rows[:, 3:6], np.zeros((37, 3), np.float32))                 # normals
+    assert np.array_equal(rows[:, 6:9], m.sh[:, 0].numpy())                            # f_dc = (r, g, b) of basis 0
+    if K > 1:  # f_rest is channel-major: all red coefficients first (transpose(1,2).flatten(1), splat_data.cpp:492-493)
+        assert np.array_equal(rows[:, 9:9 + (K - 1)], m.sh[:, 1:, 0].numpy())
+        assert np.array_equal(rows[:, 9 + 2 * (K - 1):9 + 3 * (K - 1)], m.sh[:, 1:, 2].numpy())
+    q = rows[:, -4:]
+    np.testing.assert_allclose(np.linalg.norm(q, axis=1), 1.0, rtol=1e-6)              # quaternion stored normalised
+    back = io_ply.load_ply(path)
+    assert torch.equal(back.means, m.means) and torch.equal(back.opacity_raw, m.opacity_raw) and torch.equal(back.scaling_raw, m.scaling_raw)
+    if K > 1:
+        assert torch.equal(back.sh, m.sh) and back.active_sh_degree == int(np.sqrt(K)) - 1
+    else:  # no f_rest block: the loader substitutes 15 zero bands (ply.cpp:552-554)
+        assert torch.equal(back.sh[:, :1], m.sh) and back.sh.shape[1] == 16 and float(back.sh[:, 1:].abs().max()) == 0.0
+    assert torch.allclose(back.rotation_raw, torch.nn.functional.normalize(m.rotation_raw, dim=-1), atol=1e-7)
+
+
+def test_ply_loader_locates_properties_by_name(tmp_path):
+    from gsx import io_ply
+    # shuffled order, a double and an uchar property in between, no rotation / f_rest
+    dt = np.dtype([("opacity", "<f4"), ("junk", "u1"), ("z", "<f4"), ("x", "<f8"), ("y", "<f4"), ("f_dc_2", "<f4"), ("f_dc_0", "<f4"),
+                   ("f_dc_1", "<f4"), ("scale_0", "<f4"), ("scale_1", "<f4"), ("scale_2", "<f4")])
+    v = np.zeros(5, dt)
+    for n in dt.names:
+        v[n] = np.arange(5) + (hash(n) % 7)
+    types = {"<f4": "float", "<f8": "double", "u1": "uchar", "|u1": "uchar"}
+    header = "ply\nformat binary_little_endian 1.0\ncomment made by hand\nelement vertex 5\n" + "".join(
+        f"property {types[dt[n].str]} {n}\n" for n in dt.names) + "end_header\n"
+    p = tmp_path / "x.ply"
+    p.write_bytes(header.encode() + v.tobytes())
+    m = io_ply.load_ply(str(p))
+    assert np.array_equal(m.means.numpy(), np.stack([v["x"], v["y"], v["z"]], 1).astype(np.float32))
+    assert np.array_equal(m.sh[:, 0].numpy(), np.stack([v["f_dc_0"], v["f_dc_1"], v["f_dc_2"]], 1))
+    assert np.array_equal(m.rotation_raw.numpy(), np.tile([[1, 0, 0, 0]], (5, 1)).astype(np.float32))    # identity default
+    assert m.sh.shape == (5, 16, 3)
+    with pytest.raises(RuntimeError):
+        io_ply.load_ply(str(tmp_path / "missing.ply"))
+    (tmp_path / "ascii.ply").write_bytes(b"ply\nformat ascii 1.0\nelement vertex 0\nend_header\n")
+    with pytest.raises(RuntimeError):
+        io_ply.load_ply(str(tmp_path / "ascii.ply"))
+
+
+def _write_colmap(root, trailing=False):
+    sp = root / "sparse" / "0"
+    sp.mkdir(parents=True)
+    cams = [(1, 1, 640, 480, [500.0, 510.0, 320.0, 240.0]),                               # PINHOLE
+            (2, 0, 800, 600, [700.0, 400.0, 300.0]),                                      # SIMPLE_PINHOLE
+            (3, 4, 1000, 800, [900.0, 905.0, 500.0, 400.0, 0.1, -0.05, 0.001, 0.002]),    # OPENCV
+            (4, 5, 1000, 800, [400.0, 405.0, 500.0, 400.0, 0.01, 0.02, 0.03, 0.04])]      # OPENCV_FISHEYE
+    b = struct.pack("<Q", len(cams))
+    for cid, mid, w, h, ps in cams:
+        b += struct.pack("<IiQQ", cid, mid, w, h) + struct.pack("<%dd" % len(ps), *ps)
+    (sp / "cameras.bin").write_bytes(b + (b"x" if trailing else b""))
+    rng = np.random.default_rng(0)
+    imgs = []
+    b = struct.pack("<Q", 4)
+    for i in range(4):
+        q = rng.standard_normal(4)
+        q /= np.linalg.norm(q)
+        t = rng.standard_normal(3)
+        name = f"img_{i}.png"
+        npts = i  # a few fake 2-D observations to skip over
+        b += struct.pack("<I4d3dI", 10 + i, *q, *t, i + 1) + name.encode() + b"\0" + struct.pack("<Q", npts) + b"\0" * (24 * npts)
+        imgs.append((q, t, name))
+    (sp / "images.bin").write_bytes(b)
+    pts = rng.standard_normal((6, 3))
+    cols = rng.integers(0, 255, (6, 3))
+    b = struct.pack("<Q", 6)
+    for i in range(6):
+        b += struct.pack("<Q3d3BdQ", i, *pts[i], *[int(c) for c in cols[i]], 0.5, i % 3) + b"\0" * (8 * (i % 3))
+    (sp / "points3D.bin").write_bytes(b)
+    (root / "images").mkdir()
+    return cams, imgs, pts, cols
+
+
+def test_colmap_binary_reader(tmp_path):
+    import gsx  # noqa: F401
+    from gsx import io_colmap, ops
+    cams, imgs, pts, cols = _write_colmap(tmp_path)
+    sc = io_colmap.load_colmap(str(tmp_path))
+    assert len(sc.cameras) == 4 and [c.image_name for c in sc.cameras] == [f"img_{i}.png" for i in range(4)]
+    for i, c in enumerate(sc.cameras):
+        q, t, _ = imgs[i]
+        R = io_colmap.qvec2rotmat(q.astype(np.float32))
+        vm = c.camera.viewmat.numpy()
+        np.testing.assert_allclose(vm[:3, :3], R, atol=1e-6)
+        np.testing.assert_allclose(vm[:3, 3], t.astype(np.float32), atol=1e-6)             # world -> camera [R|t]
+        np.testing.assert_allclose(R @ sc.camera_locations[i] + t, 0, atol=1e-5)           # centre = -R^T t
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-5)
+    K0, K1 = sc.cameras[0].camera.K.numpy(), sc.cameras[1].camera.K.numpy()
+    assert (K0[0, 0], K0[1, 1], K0[0, 2], K0[1, 2]) == (500.0, 510.0, 320.0, 240.0)
+    assert (K1[0, 0], K1[1, 1], K1[0, 2], K1[1, 2]) == (700.0, 700.0, 400.0, 300.0)        # SIMPLE_PINHOLE: one focal
+    c2, c3 = sc.cameras[2].camera, sc.cameras[3].camera
+    assert c2.camera_model == ops.CameraModelType.PINHOLE and c3.camera_model == ops.CameraModelType.FISHEYE
+    np.testing.assert_allclose(c2.radial.numpy(), [0.1, -0.05, 0, 0], atol=1e-7)           # padded to 4 (rasterizer.cpp:183-195)
+    np.testing.assert_allclose(c2.tangential.numpy(), [0.001, 0.002, 0, 0], atol=1e-7)
+    np.testing.assert_allclose(c3.radial.numpy(), [0.01, 0.02, 0.03, 0.04], atol=1e-7)
+    assert (c2.width, c2.height) == (1000, 800)
+    np.testing.assert_allclose(sc.points, pts.astype(np.float32))
+    assert np.array_equal(sc.colors, cols.astype(np.uint8))
+    # images_2: intrinsics and size divided by the folder's factor (colmap.cpp:172-258)
+    (tmp_path / "images_2").mkdir()
+    half = io_colmap.load_colmap(str(tmp_path), images_folder="images_2")
+    Kh = half.cameras[0].camera.K.numpy()
+    assert (Kh[0, 0], Kh[1, 1], Kh[0, 2], Kh[1, 2]) == (250.0, 255.0, 160.0, 120.0) and half.cameras[0].camera.width == 320
+
+
+def test_colmap_trailing_bytes_rejected(tmp_path):
+    import gsx  # noqa: F401
+    from gsx import io_colmap
+    _write_colmap(tmp_path, trailing=True)
+    with pytest.raises(RuntimeError, match="trailing"):
+        io_colmap.load_colmap(str(tmp_path))
+
+
+def test_init_model_from_pointcloud():
+    import gsx  # noqa: F401
+    from gsx import io_colmap
+    pts = np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0], [0, 0, 3], [0, 0, 0]], np.float32)     # a duplicate point (distance 0 is skipped)
+    cols = np.array([[255, 0, 128]] * 5, np.uint8)
+    m, scale = io_colmap.init_model_from_pointcloud(pts, cols, np.zeros(3), sh_degree=3)
+    assert m.sh.shape == (5, 16, 3) and m.active_sh_degree == 0
+    np.testing.assert_allclose(m.sh[0, 0].numpy(), (np.array([1, 0, 128 / 255]) - 0.5) / 0.28209479177387814, rtol=1e-5, atol=2e-7)
+    assert float(m.sh[:, 1:].abs().max()) == 0 and torch.equal(m.rotation_raw[:, 0], torch.ones(5))
+    np.testing.assert_allclose(torch.sigmoid(m.opacity_raw).numpy(), 0.5, rtol=1e-6)
+    # point 0: the 4 nearest are itself (0), its duplicate (0), then 1, 2 -> valid neighbours {1, 2} (3 is not among the 4 results)
+    np.testing.assert_allclose(float(m.scaling_raw[0, 0]), np.log(np.sqrt(1.5) * 0.1), rtol=1e-5)
+    assert scale == float(np.median(np.linalg.norm(pts, axis=1)))
