@@ -49,13 +49,64 @@ class GradBucket:
     def zero_(self):
         self.flat.zero_()
 
+    @staticmethod
+    def _reduce_mean(t):
+        """In-place mean over the ranks.  RCCL averages inside the collective (no extra pass over the bucket); gloo sums."""
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            t.mul_(1.0 / dist.get_world_size())
+
     def all_reduce_mean(self, async_op=False):
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return None
-        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+        self.last_reduced_bytes = self.nbytes()
         if async_op:
-            return work
-        self.flat.mul_(1.0 / dist.get_world_size())
+            return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True)
+        self._reduce_mean(self.flat)
+        return None
+
+    def all_reduce_mean_rows(self, visible, dense_above=0.75):
+        """Same result as all_reduce_mean() when the gradient rows of Gaussians outside `visible` ([N] bool / uint8, this rank's
+        camera) are zero — true for the render backward: a Gaussian no camera of the step sees has a zero gradient row on every
+        rank.  Only the union of the visible rows travels: one small MAX all-reduce of the mask, then ONE all-reduce of the
+        compacted rows (at S-1M a camera sees ~40 % of the Gaussians: 94 MB instead of 236 MB over xGMI, where the ring is
+        per-link bound).  Falls back to the dense collective when the union exceeds `dense_above` of the rows."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return None
+        n = self.params[0].shape[0]
+        assert all(p.shape[0] == n for p in self.params), "row compaction needs per-Gaussian parameters"
+        # When the last probe found (almost) everything visible, the mask exchange and its host sync are pure overhead: go dense
+        # for the next 32 steps, then probe again.  Every rank sees the same union, so every rank takes the same branch.
+        if getattr(self, "_dense_steps_left", 0) > 0:
+            self._dense_steps_left -= 1
+            return self.all_reduce_mean()
+        mask = visible.reshape(-1).to(torch.uint8).contiguous()
+        dist.all_reduce(mask, op=dist.ReduceOp.MAX)
+        idx = mask.nonzero().squeeze(1)              # one host sync: every rank learns the same row count
+        m = idx.numel()
+        if m > dense_above * n:
+            self._dense_steps_left = 32
+            self.last_reduced_bytes = self.nbytes()
+            self._reduce_mean(self.flat)
+            return None
+        self.last_reduced_bytes = mask.numel() + m * (self.flat.element_size() * sum(p.numel() // n for p in self.params))
+        if m == 0:
+            return None
+        widths = [p.numel() // n for p in self.params]
+        need = m * sum(widths)
+        if getattr(self, "_compact", None) is None or self._compact.numel() < need:
+            self._compact = torch.empty(int(need * 1.25) + 64, dtype=self.flat.dtype, device=self.flat.device)
+        views, off = [], 0
+        for p, w in zip(self.params, widths):
+            v = self._compact[off:off + m * w].view((m,) + tuple(p.shape[1:]))
+            torch.index_select(p.grad, 0, idx, out=v)
+            views.append(v)
+            off += m * w
+        self._reduce_mean(self._compact[:off])
+        for p, v in zip(self.params, views):
+            p.grad.index_copy_(0, idx, v)
         return None
 
     def nbytes(self):

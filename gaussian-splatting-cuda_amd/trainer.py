@@ -2,9 +2,9 @@
 (src/training/trainer.cpp:579-800) restricted to what the gut / MCMC configuration executes:
 
     render (rasterize_fused) -> photometric loss (trainer.cpp:103-127) -> backward
+    -> [N > 1 GPUs: all-reduce of the gradient rows some camera of the step saw, mean over the cameras]
     -> scale / opacity regularisers (trainer.cpp:132-160; their gradients are added analytically: reg * mean(exp(s)),
-       reg * mean(sigmoid(o)))
-    -> [N > 1 GPUs: one all-reduce of the flat gradient bucket, mean over the cameras of the step]
+       reg * mean(sigmoid(o)); identical on every rank, so added after the reduction)
     -> strategy.post_backward (SH degree schedule, relocation, growth, noise) -> strategy.step (fused Adam + lr decay)
 
 One process per GPU; rank r renders camera `cams[(it * world + r) % len(cams)]`.  Every rank holds a full replica and applies
@@ -55,8 +55,9 @@ class Trainer:
         gt = self.images[i]
         loss = gloss.photometric_loss(out.render_hwc, gt, self.params.lambda_dssim)
         loss.backward()
-        self._add_regularisers()
-        self.bucket.all_reduce_mean()
+        if self.world > 1:  # only rows some camera of the step saw are non-zero: compacted all-reduce
+            self.bucket.all_reduce_mean_rows((out.aux["radii_full"] > 0).all(-1))
+        self._add_regularisers()  # identical on every rank (functions of the replicated parameters): added after the reduction
         self.strategy.post_backward(it, out)
         self.strategy.step(it)
         self.last_loss = loss.detach()

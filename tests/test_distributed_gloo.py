@@ -78,3 +78,40 @@ def test_single_process_is_a_noop():
     assert b.all_reduce_mean() is None and torch.all(p.grad == 2.0)
     b.zero_()
     assert torch.all(p.grad == 0)
+
+
+def _rows_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import gsx  # noqa: F401
+    from gsx import distributed as gdist
+    gdist.init_from_env(backend="gloo")
+    N = 1000
+    g = torch.Generator().manual_seed(100 + rank)
+    shapes = [(N, 3), (N, 16, 3), (N, 3), (N, 4), (N, 1)]
+    visible = torch.rand(N, generator=g) < 0.3                      # this rank's camera sees ~30 % of the Gaussians
+    grads = [torch.randn(s, generator=g) * visible.view(-1, *([1] * (len(s) - 1))) for s in shapes]
+    for mode in ("rows", "dense", "rows_fallback"):
+        params = [torch.zeros(s, requires_grad=True) for s in shapes]
+        bucket = gdist.GradBucket(params)
+        for p, gr in zip(params, grads):
+            p.grad.copy_(gr)
+        if mode == "dense":
+            bucket.all_reduce_mean()
+        else:
+            bucket.all_reduce_mean_rows(visible, dense_above=0.75 if mode == "rows" else 0.1)
+        if mode == "rows":
+            assert bucket.last_reduced_bytes < 0.7 * bucket.nbytes()
+        np.save(os.path.join(out_dir, "%s_%d.npy" % (mode, rank)), np.concatenate([p.grad.numpy().reshape(-1) for p in params]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_visible_row_all_reduce_equals_dense(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_rows_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    dense = np.load(tmp_path / "dense_0.npy")
+    for mode in ("rows", "rows_fallback"):
+        for r in range(world):
+            got = np.load(tmp_path / ("%s_%d.npy" % (mode, r)))
+            assert np.array_equal(got, dense), (mode, r)             # bit-identical to the dense collective on 2 ranks
+    assert np.array_equal(np.load(tmp_path / "dense_1.npy"), dense)
