@@ -467,6 +467,7 @@ GSX_DEV void butterfly_reduce16(float (&x)[16], float (&z)[4]) {
                  "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\t"
                  "s_nop 1"
                  : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]));
+#if defined(GSX_BFLY_ROWSHR)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float v = y[2 * j] + y[2 * j + 1];
@@ -476,6 +477,25 @@ GSX_DEV void butterfly_reduce16(float (&x)[16], float (&z)[4]) {
         v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));  // row_shr:8
         z[j] = v;
     }
+#else
+    // Inside a row the halving continues (4 values x 16 lanes -> 1 value per lane): exchange distance 8 (row_ror:8) keeps the
+    // pair selected by lane bit 3, distance 4 (ds_swizzle xor 4, LDS crossbar: no VALU slot) the value selected by lane bit 2,
+    // then the quad is summed with two quad_perm adds.  12 VALU instead of 20 for the four 16-lane row sums.
+    // On return every lane of quad q (= (lane >> 2) & 3) of row r holds the total of value 4*q + {0,2,1,3}[r] in z[0].
+    const uint32_t ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const bool hi8 = (ln & 8u) != 0u, hi4 = (ln & 4u) != 0u;
+    const float v0 = y[0] + y[1], v1 = y[2] + y[3], v2 = y[4] + y[5], v3 = y[6] + y[7];
+    float k0 = hi8 ? v2 : v0, k1 = hi8 ? v3 : v1;
+    const float s0 = hi8 ? v0 : v2, s1 = hi8 ? v1 : v3;
+    k0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0x128, 0xf, 0xf, true));  // row_ror:8
+    k1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0x128, 0xf, 0xf, true));
+    float k = hi4 ? k1 : k0;
+    const float sd = hi4 ? k0 : k1;
+    k += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, sd), 0x101F));                   // lane ^ 4
+    k += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, k), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    k += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, k), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    z[0] = k;
+#endif
 }
 
 template <int KIND>
@@ -526,6 +546,10 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
     if (bg) tail -= bg[0] * vr + bg[1] * vg + bg[2] * vb;
     tail *= T_final;
 
+    // moment whose total this lane's quad holds after butterfly_reduce16: 4 * quad + {0,2,1,3}[row]
+    const uint32_t bf_row = lane >> 4;
+    const uint32_t mom_of_lane = 4u * ((lane >> 2) & 3u) + ((bf_row == 1u) ? 2u : (bf_row == 2u ? 1u : bf_row));
+    (void)mom_of_lane;
     int32_t wave_last = bin_final;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, o));
@@ -597,6 +621,7 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
                 x[15] = 0.f;
                 float z[4];
                 butterfly_reduce16(x, z);
+#if defined(GSX_BFLY_ROWSHR)
                 if ((lane & 15u) == 15u) {
                     const uint32_t row = lane >> 4;
                     const uint32_t k0 = (row == 1u) ? 2u : (row == 2u ? 1u : row);  // {0,2,1,3}
@@ -605,6 +630,9 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
                     atomicAdd(&s_acc[8 + k0][t], z[2]);
                     atomicAdd(&s_acc[12 + k0][t], z[3]);
                 }
+#else
+                if ((lane & 3u) == 0u) atomicAdd(&s_acc[mom_of_lane][t], z[0]);  // 16 lanes, one moment each
+#endif
             }
             if (lane == 0 && touched) atomicOr(&s_touched[sub >> 6], touched);
         }
