@@ -143,32 +143,48 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_count_kernel(uint32_t N, uint32
     for (uint32_t t = threadIdx.x; t < n_tiles; t += BIN_BLOCK) out[t] = s_hist[t];
 }
 
-// block_hist[c][b][t] -> exclusive prefix over b; tile_counts[c*n_tiles + t] = total
+// block_hist[c][b][t] -> exclusive prefix over b; tile_counts[c*n_tiles + t] = total.
+// 32 tiles x 8 groups of 32 blocks per workgroup: every thread keeps its 32 counts in registers, the 8 group sums of a tile meet
+// in LDS (8 160 tiles alone would be 32 workgroups of strictly serial 256-step columns).
 __global__ __launch_bounds__(ISECT_BLOCK) void bin_prefix_kernel(uint32_t C, uint32_t n_tiles, uint32_t* __restrict__ block_hist,
                                                                  uint32_t* __restrict__ tile_counts) {
-    const uint32_t g = blockIdx.x * ISECT_BLOCK + threadIdx.x;
-    if (g >= C * n_tiles) return;
-    const uint32_t c = g / n_tiles, t = g - c * n_tiles;
-    uint32_t* col = block_hist + (size_t)c * BIN_NB * n_tiles + t;
-    uint32_t run = 0;
-    for (uint32_t b = 0; b < BIN_NB; b += 8) {
-        uint32_t v[8];
+    static_assert(BIN_NB == 256 && ISECT_BLOCK == 256, "layout below assumes 8 groups of 32 blocks");
+    __shared__ uint32_t s_sum[8][32];
+    const uint32_t tl = threadIdx.x & 31u, grp = threadIdx.x >> 5;
+    const uint32_t g = blockIdx.x * 32u + tl;
+    const bool ok = g < C * n_tiles;
+    const uint32_t c = ok ? g / n_tiles : 0u, t = ok ? g - c * n_tiles : 0u;
+    uint32_t* col = block_hist + ((size_t)c * BIN_NB + grp * 32u) * n_tiles + t;
+    uint32_t v[32], sum = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = col[(size_t)(b + k) * n_tiles];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            col[(size_t)(b + k) * n_tiles] = run;
-            run += v[k];
-        }
+    for (int k = 0; k < 32; ++k) {
+        v[k] = ok ? col[(size_t)k * n_tiles] : 0u;
+        sum += v[k];
     }
-    tile_counts[g] = run;
+    s_sum[grp][tl] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) {
+        const uint32_t sv = s_sum[k][tl];
+        run += k < grp ? sv : 0u;
+        total += sv;
+    }
+    if (!ok) return;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        col[(size_t)k * n_tiles] = run;
+        run += v[k];
+    }
+    if (grp == 0) tile_counts[g] = total;
 }
 
 __global__ __launch_bounds__(BIN_BLOCK) void bin_scatter_kernel(uint32_t N, uint32_t per_block, const float* __restrict__ means2d,
                                                                   const int32_t* __restrict__ radii, const float* __restrict__ depths,
                                                                   float tile_size, uint32_t tw, uint32_t th, uint32_t idx_bits,
                                                                   const int32_t* __restrict__ tile_offsets,
-                                                                  const uint32_t* __restrict__ block_hist, uint64_t* __restrict__ keys) {
+                                                                  const uint32_t* __restrict__ block_hist, uint64_t* __restrict__ keys,
+                                                                  uint32_t capacity) {
     extern __shared__ uint32_t s_cur[];
     const uint32_t n_tiles = tw * th, c = blockIdx.y, b = blockIdx.x;
     const uint32_t* pre = block_hist + ((size_t)c * BIN_NB + b) * n_tiles;
@@ -182,7 +198,10 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_scatter_kernel(uint32_t N, uint
         if (!tile_rect(means2d, radii, idx, tile_size, tw, th, x0, y0, x1, y1)) continue;
         const uint64_t key = ((uint64_t)__float_as_uint(depths[idx]) << idx_bits) | (uint64_t)idx;
         for (uint32_t i = y0; i < y1; ++i)
-            for (uint32_t j = x0; j < x1; ++j) keys[atomicAdd(&s_cur[i * tw + j], 1u)] = key;
+            for (uint32_t j = x0; j < x1; ++j) {
+                const uint32_t pos = atomicAdd(&s_cur[i * tw + j], 1u);
+                if (pos < capacity) keys[pos] = key;  // capacity < n_isects only when an optimistic caller under-estimated: it re-runs
+            }
     }
 }
 
@@ -252,13 +271,14 @@ GSX_DEV void merge_sort_wave(uint64_t* s, int lane) {
 
 __global__ __launch_bounds__(256) void tile_sort_wave_kernel(uint32_t n_segments, uint32_t n_tiles, uint32_t tile_n_bits, uint32_t idx_bits,
                                                              const int32_t* __restrict__ tile_offsets, const uint64_t* __restrict__ keys,
-                                                             int32_t* __restrict__ flatten_ids, int64_t* __restrict__ isect_ids) {
+                                                             int32_t* __restrict__ flatten_ids, int64_t* __restrict__ isect_ids,
+                                                             int64_t capacity) {
     __shared__ uint64_t s_all[4][TSORT_WAVE_CAP];
     const uint32_t seg = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (seg >= n_segments) return;
     const int64_t begin = tile_offsets[seg];
     const int n = (int)(tile_offsets[seg + 1] - tile_offsets[seg]);
-    if (n <= 0 || n > TSORT_WAVE_CAP) return;
+    if (n <= 0 || n > TSORT_WAVE_CAP || begin + n > capacity) return;
     uint64_t* s_keys = s_all[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
     int m = 128;
@@ -283,12 +303,12 @@ __global__ __launch_bounds__(256) void tile_sort_wave_kernel(uint32_t n_segments
 __global__ __launch_bounds__(ISECT_BLOCK) void tile_sort_kernel(uint32_t n_tiles, uint32_t tile_n_bits, uint32_t idx_bits,
                                                                 const int32_t* __restrict__ tile_offsets, uint64_t* __restrict__ keys,
                                                                 uint64_t* __restrict__ keys_alt, int32_t* __restrict__ flatten_ids,
-                                                                int64_t* __restrict__ isect_ids) {
+                                                                int64_t* __restrict__ isect_ids, int64_t capacity) {
     __shared__ uint64_t s_keys[TSORT_CAP];
     const uint32_t seg = blockIdx.x;
     const int64_t begin = tile_offsets[seg];
     const int n = (int)(tile_offsets[seg + 1] - tile_offsets[seg]);
-    if (n <= TSORT_WAVE_CAP) return;  // sorted by tile_sort_wave_kernel
+    if (n <= TSORT_WAVE_CAP || begin + n > capacity) return;  // small segments: tile_sort_wave_kernel
     const uint64_t idx_mask = (1ull << idx_bits) - 1ull;
     const int64_t cam_tile = (((int64_t)(seg / n_tiles) << tile_n_bits) | (int64_t)(seg % n_tiles)) << 32;
     if (n <= TSORT_CAP) {
@@ -543,7 +563,7 @@ extern "C" int gsx_intersect_bin_count(uint32_t C, uint32_t N, const float* mean
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(bin_count_kernel, dim3(BIN_NB, C), dim3(BIN_BLOCK), lds, st, N, per_block, means2d, radii, (float)tile_size, tile_width,
                        tile_height, tiles_per_gauss, hist);
-    hipLaunchKernelGGL(bin_prefix_kernel, dim3((nseg + ISECT_BLOCK - 1) / ISECT_BLOCK), dim3(ISECT_BLOCK), 0, st, C, n_tiles, hist, counts);
+    hipLaunchKernelGGL(bin_prefix_kernel, dim3((nseg + 31) / 32), dim3(ISECT_BLOCK), 0, st, C, n_tiles, hist, counts);
     // offsets[t] = intersections before (camera, tile) t; offsets[nseg] = n_isects
     (void)tmp; (void)temp;
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, nseg + 1, (const uint32_t*)counts, tile_offsets);
@@ -585,10 +605,10 @@ extern "C" int gsx_intersect_bin_fill(uint32_t C, uint32_t N, const float* means
     const size_t lds = (size_t)n_tiles * 4;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)bin_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(BIN_NB, C), dim3(BIN_BLOCK), lds, st, N, per_block, means2d, radii, depths, (float)tile_size,
-                       tile_width, tile_height, idx_bits, tile_offsets, (const uint32_t*)count_workspace, keys);
+                       tile_width, tile_height, idx_bits, tile_offsets, (const uint32_t*)count_workspace, keys, (uint32_t)n_isects);
     hipLaunchKernelGGL(tile_sort_wave_kernel, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, n_tiles, bit_width_u32(n_tiles), idx_bits, tile_offsets,
-                       (const uint64_t*)keys, flatten_ids, isect_ids);
+                       (const uint64_t*)keys, flatten_ids, isect_ids, n_isects);
     hipLaunchKernelGGL(tile_sort_kernel, dim3(nseg), dim3(ISECT_BLOCK), 0, st, n_tiles, bit_width_u32(n_tiles), idx_bits, tile_offsets, keys, keys_alt,
-                       flatten_ids, isect_ids);
+                       flatten_ids, isect_ids, n_isects);
     return check_launch("intersect_bin_fill");
 }

@@ -13,8 +13,13 @@
 #include <torch/extension.h>
 #endif
 
+#include <ATen/hip/HIPEvent.h>
+
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <string>
+#include <tuple>
 
 #include "../../include/gsx.h"
 #include "../../include/gsx_ops.h"
@@ -469,16 +474,50 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
     check(gsx_intersect_bin_count(C, N, n_elements ? means2d.data_ptr<float>() : nullptr, n_elements ? radii.data_ptr<int32_t>() : nullptr, tile_size,
                                   tile_width, tile_height, n_elements ? tiles_per_gauss.data_ptr<int32_t>() : nullptr, offsets.data_ptr<int32_t>(),
                                   n_host.data_ptr<int64_t>(), cws.data_ptr(), cwb, st), "intersect_tile_binned(count)");
-    c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().synchronize();  // the one host sync, as upstream (Intersect.cpp:76)
-    const int64_t n_isects = n_host.data_ptr<int64_t>()[0];
-    at::Tensor flatten_ids = at::empty({n_isects}, depths.options().dtype(at::kInt));
-    at::Tensor isect_ids = at::empty({want_isect_ids ? n_isects : 0}, depths.options().dtype(at::kLong));
-    if (n_isects) {
-        const size_t fwb = gsx_intersect_bin_fill_workspace_bytes(C, tile_width, tile_height, n_isects);
+    // The op's outputs have exactly n_isects rows, so the host has to read that number (the one sync of the op, as upstream:
+    // Intersect.cpp:76).  To keep the GPU busy meanwhile, the fill is launched optimistically into buffers sized from the last
+    // total seen for this problem shape (+25 %); the host then waits only for the 4-byte copy, not for the fill.  If the guess
+    // was too small the fill is repeated with the exact size.
+    at::cuda::CUDAEvent total_ready;
+    total_ready.record(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
+    static std::mutex hint_mutex;
+    static std::map<std::tuple<int, uint32_t, uint32_t, uint32_t, uint32_t>, int64_t> hints;
+    const auto key = std::make_tuple((int)means2d.get_device(), C, N, tile_width, tile_height);
+    int64_t hint = 0;
+    {
+        std::lock_guard<std::mutex> lock(hint_mutex);
+        auto it = hints.find(key);
+        if (it != hints.end()) hint = it->second;
+    }
+    at::Tensor flatten_ids, isect_ids;
+    auto fill = [&](int64_t capacity) {
+        flatten_ids = at::empty({capacity}, depths.options().dtype(at::kInt));
+        isect_ids = at::empty({want_isect_ids ? capacity : 0}, depths.options().dtype(at::kLong));
+        const size_t fwb = gsx_intersect_bin_fill_workspace_bytes(C, tile_width, tile_height, capacity);
         at::Tensor fws = at::empty({(int64_t)fwb}, depths.options().dtype(at::kByte));
         check(gsx_intersect_bin_fill(C, N, means2d.data_ptr<float>(), radii.data_ptr<int32_t>(), depths.data_ptr<float>(), tile_size, tile_width,
-                                     tile_height, offsets.data_ptr<int32_t>(), n_isects, cws.data_ptr(), flatten_ids.data_ptr<int32_t>(),
+                                     tile_height, offsets.data_ptr<int32_t>(), capacity, cws.data_ptr(), flatten_ids.data_ptr<int32_t>(),
                                      want_isect_ids ? isect_ids.data_ptr<int64_t>() : nullptr, fws.data_ptr(), fwb, st), "intersect_tile_binned(fill)");
+    };
+    int64_t capacity = 0;
+    if (hint > 0 && n_elements) {
+        capacity = std::min<int64_t>(hint + hint / 4 + 4096, 0x7FFFFFFFll);
+        fill(capacity);
+    }
+    total_ready.synchronize();
+    const int64_t n_isects = n_host.data_ptr<int64_t>()[0];
+    {
+        std::lock_guard<std::mutex> lock(hint_mutex);
+        hints[key] = n_isects;
+    }
+    if (capacity > 0 && n_isects <= capacity) {
+        flatten_ids = flatten_ids.narrow(0, 0, n_isects);
+        if (want_isect_ids) isect_ids = isect_ids.narrow(0, 0, n_isects);
+    } else if (n_isects > 0) {
+        fill(n_isects);
+    } else {
+        flatten_ids = at::empty({0}, depths.options().dtype(at::kInt));
+        isect_ids = at::empty({0}, depths.options().dtype(at::kLong));
     }
     at::Tensor isect_offsets = offsets.narrow(0, 0, (int64_t)C * tile_height * tile_width).view({(int64_t)C, (int64_t)tile_height, (int64_t)tile_width});
     return std::make_tuple(tiles_per_gauss, isect_ids, flatten_ids, isect_offsets);

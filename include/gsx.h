@@ -165,7 +165,9 @@ int gsx_add_noise(uint32_t N, const float* raw_opacities, const float* raw_scale
  * sort by (depth bits, flatten index).  No device-wide sort, no global atomics.  tile_offsets has C*tiles + 1 entries (the
  * last one is n_isects, also copied to the pinned host word).  Host protocol as above: bin_count -> sync -> allocate
  * flatten_ids -> bin_fill(count_workspace = the workspace bin_count used).  isect_ids may be NULL (the blend kernels only
- * need flatten_ids + offsets).  gsx_intersect_bin_supported: tile grids up to 36864 tiles per camera (LDS counters). */
+ * need flatten_ids + offsets).  bin_fill's `n_isects` is the CAPACITY of flatten_ids / isect_ids / the workspace: a caller
+ * that can guess an upper bound may launch bin_fill before the host has read the exact total (nothing beyond the capacity is
+ * written; if the total turns out larger, the outputs are incomplete and bin_fill must be re-run with enough room).  gsx_intersect_bin_supported: tile grids up to 36864 tiles per camera (LDS counters). */
 int gsx_intersect_bin_supported(uint32_t tile_width, uint32_t tile_height);
 size_t gsx_intersect_bin_count_workspace_bytes(uint32_t C, uint32_t tile_width, uint32_t tile_height);
 int gsx_intersect_bin_count(uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, uint32_t tile_size,

@@ -299,3 +299,26 @@ def test_intersect_tile_binned_equals_sorted_path(C, N, W, H, rmax, nq):
     assert ids3.numel() == 0 and torch.equal(flat, flat3) and torch.equal(off, off3)
     if N >= 30000:
         assert int((off.flatten()[1:] - off.flatten()[:-1]).max()) > 4096   # the merge path ran
+
+
+@pytest.mark.gpu
+def test_intersect_tile_binned_optimistic_capacity_overflow():
+    """The fill is launched into buffers sized from the previous total for the same problem shape; when the guess is too small
+    (second call: 3x the radii) it is repeated with the exact size; when it is too large (third call) the outputs are narrowed."""
+    import gsx  # noqa: F401
+    from gsx import ops
+    C, N, W, H = 1, 4000, 320, 240
+    g = torch.Generator().manual_seed(7)
+    means2d = (torch.rand(C, N, 2, generator=g) * torch.tensor([W, H])).cuda()
+    depths = (torch.rand(C, N, generator=g) * 5 + 0.2).cuda()
+    base = torch.randint(1, 8, (C, N, 2), generator=g, dtype=torch.int32)
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    sizes = []
+    for scale in (1, 3, 1):
+        radii = (base * scale).cuda()
+        tpg, ids, flat = ops.intersect_tile_device_sort(means2d, radii, depths, C, 16, tw, th, True)
+        off = ops.intersect_offset(ids, C, tw, th)
+        tpg2, ids2, flat2, off2 = ops.intersect_tile_binned(means2d, radii, depths, C, 16, tw, th, True)
+        assert torch.equal(ids, ids2) and torch.equal(flat, flat2) and torch.equal(off, off2) and torch.equal(tpg, tpg2)
+        sizes.append(flat.numel())
+    assert sizes[1] > 1.3 * sizes[0]
