@@ -116,12 +116,26 @@ GSX_DEV void sh_stage_rows(const float* __restrict__ coeffs, uint32_t n, uint32_
         const uint32_t q_per_row = K3 >> 2;
         const uint32_t total = rows * q_per_row;
         const float4* src = reinterpret_cast<const float4*>(coeffs + (size_t)e0 * K3);
-        for (uint32_t j = lane; j < total; j += 64) {
-            const uint32_t e = j / q_per_row, r = (j - e * q_per_row) << 2;
-            if (!((live >> e) & 1ull)) continue;
-            const float4 v = src[j];
-            float* d = tile + e * ls + r;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        // batches of 6 loads per lane issued back to back (6 KiB in flight per wave) before the first LDS write
+        constexpr int B = 6;
+        for (uint32_t j0 = lane; j0 < total; j0 += 64 * B) {
+            float4 v[B];
+            uint32_t off[B];
+            bool ok[B];
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const uint32_t j = j0 + 64u * b;
+                const uint32_t e = j / q_per_row;
+                off[b] = e * ls + ((j - e * q_per_row) << 2);
+                ok[b] = j < total && ((live >> (e & 63u)) & 1ull);
+                if (ok[b]) v[b] = src[j];
+            }
+#pragma unroll
+            for (int b = 0; b < B; ++b)
+                if (ok[b]) {
+                    float* d = tile + off[b];
+                    d[0] = v[b].x; d[1] = v[b].y; d[2] = v[b].z; d[3] = v[b].w;
+                }
         }
     } else {
         const uint32_t total = rows * nb3;
@@ -292,7 +306,7 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_colors_fwd_kernel(uint32_t C, uin
     const unsigned long long live_mask = __ballot(any_live);
     float* tile = sh_lds + wave * 64u * LS;
     if (e0 < N) sh_stage_rows(coeffs, N, e0, K * 3u, NB3, live_mask, tile, LS, lane);
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the tile is private to this wave: no block barrier
     if (e >= N) return;
     if (!any_live) {  // masked for every camera: zero rows (the output buffer needs no pre-fill)
         for (uint32_t c = 0; c < C; ++c) {
@@ -362,7 +376,7 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_colors_bwd_kernel(uint32_t C, uin
         const unsigned long long live_mask = __ballot(any_live);
         sh_stage_rows(coeffs, N, e0, K3, NB3, live_mask, tile, LS, lane);
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the tile is private to this wave: no block barrier
     float vc[NB3];
 #pragma unroll
     for (int k = 0; k < (int)NB3; ++k) vc[k] = 0.f;
@@ -400,22 +414,31 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_colors_bwd_kernel(uint32_t C, uin
             }
         }
     }
-    __syncthreads();  // staged coefficients fully consumed: reuse the tile for the output rows
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the tile is private to this wave: no block barrier  // staged coefficients fully consumed: reuse the tile for the output rows
     if (e < N) {
 #pragma unroll
         for (int k = 0; k < (int)NB3; ++k) row[k] = vc[k];
         for (uint32_t j = NB3; j < K3; ++j) row[j] = 0.f;
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the tile is private to this wave: no block barrier
     if (e0 < N) {
         const uint32_t rows = min(64u, N - e0);
         float* dst = v_coeffs + (size_t)e0 * K3;
         if ((K3 & 3u) == 0u) {
             const uint32_t q_per_row = K3 >> 2, total = rows * q_per_row;
-            for (uint32_t j = lane; j < total; j += 64) {
-                const uint32_t er = j / q_per_row, rr = (j - er * q_per_row) << 2;
-                const float* sp = tile + er * LS + rr;
-                reinterpret_cast<float4*>(dst)[j] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+            constexpr int B = 6;  // LDS reads of a batch overlap; the stores are fire-and-forget
+            for (uint32_t j0 = lane; j0 < total; j0 += 64 * B) {
+                float4 v[B];
+#pragma unroll
+                for (int b = 0; b < B; ++b) {
+                    const uint32_t j = min(j0 + 64u * b, total - 1u);
+                    const uint32_t er = j / q_per_row, rr = (j - er * q_per_row) << 2;
+                    const float* sp = tile + er * LS + rr;
+                    v[b] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                }
+#pragma unroll
+                for (int b = 0; b < B; ++b)
+                    if (j0 + 64u * b < total) reinterpret_cast<float4*>(dst)[j0 + 64u * b] = v[b];
             }
         } else {
             const uint32_t total = rows * K3;
