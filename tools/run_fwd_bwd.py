@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import gsx  # noqa: E402,F401
+from gsx import loss as gloss  # noqa: E402
 from gsx import rasterizer, scenes  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
@@ -16,11 +17,15 @@ scene = {"1m": scenes.scene_1m, "5m": scenes.scene_5m}[os.environ.get("GSX_SCENE
 model = scenes.to_splat_data(scene, dev)
 cam = rasterizer.Camera(viewmat=scene["viewmat"].to(dev), K=scene["K"].to(dev), width=scene["width"], height=scene["height"])
 bg = scene["background"].to(dev)
-if mode == "all":
+if mode in ("all", "unfused"):
     for p in model.params():
         p.requires_grad_(True)
+target = torch.rand(3, scene["height"], scene["width"], generator=torch.Generator().manual_seed(1234)).to(dev)
 for _ in range(n):
-    if mode == "all":
+    if mode == "all":      # the bench step: fused render + fused L1/SSIM loss + backward
+        out = rasterizer.rasterize_fused(cam, model, bg)
+        gloss.photometric_loss(out.render_hwc, target, 0.2).backward()
+    elif mode == "unfused":
         out = rasterizer.rasterize(cam, model, bg)
         out.image.sum().backward()
     else:
