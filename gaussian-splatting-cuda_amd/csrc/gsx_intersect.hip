@@ -395,12 +395,6 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t n, const uint32
     }
 }
 
-static size_t bin_scan_temp_bytes(uint32_t n) {
-    size_t bytes = 0;
-    (void)rocprim::exclusive_scan(nullptr, bytes, (const uint32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)n, rocprim::plus<int32_t>(), 0, false);
-    return bytes;
-}
-
 struct I32ToI64 {
     __host__ __device__ int64_t operator()(int32_t v) const { return (int64_t)v; }
 };
@@ -532,7 +526,7 @@ extern "C" int gsx_intersect_bin_supported(uint32_t tile_width, uint32_t tile_he
 
 extern "C" size_t gsx_intersect_bin_count_workspace_bytes(uint32_t C, uint32_t tile_width, uint32_t tile_height) {
     const uint32_t nseg = C * tile_width * tile_height;
-    return bin_hist_bytes(C, tile_width * tile_height) + align_up((size_t)(nseg + 1) * 4, 256) + align_up(bin_scan_temp_bytes(nseg + 1), 256) + 256;
+    return bin_hist_bytes(C, tile_width * tile_height) + align_up((size_t)(nseg + 1) * 4, 256) + 256;
 }
 
 extern "C" int gsx_intersect_bin_count(uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, uint32_t tile_size,
@@ -556,8 +550,6 @@ extern "C" int gsx_intersect_bin_count(uint32_t C, uint32_t N, const float* mean
     }
     uint32_t* hist = (uint32_t*)workspace;
     uint32_t* counts = (uint32_t*)((char*)workspace + bin_hist_bytes(C, n_tiles));
-    void* tmp = (char*)counts + align_up((size_t)(nseg + 1) * 4, 256);
-    size_t temp = bin_scan_temp_bytes(nseg + 1);
     const uint32_t per_block = (N + BIN_NB - 1) / BIN_NB;
     const size_t lds = (size_t)n_tiles * 4;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -565,7 +557,6 @@ extern "C" int gsx_intersect_bin_count(uint32_t C, uint32_t N, const float* mean
                        tile_height, tiles_per_gauss, hist);
     hipLaunchKernelGGL(bin_prefix_kernel, dim3((nseg + 31) / 32), dim3(ISECT_BLOCK), 0, st, C, n_tiles, hist, counts);
     // offsets[t] = intersections before (camera, tile) t; offsets[nseg] = n_isects
-    (void)tmp; (void)temp;
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, nseg + 1, (const uint32_t*)counts, tile_offsets);
     if (n_isects_host_pinned) {
         *n_isects_host_pinned = 0;  // 4 of the 8 bytes are copied

@@ -446,11 +446,12 @@ constexpr int BCH = 128;  // Gaussians per backward chunk
 #define GSX_GATOMIC(p, v) atomicAdd((p), (v))
 #endif
 
-// reduce x[0..15] over the 64 lanes; on return lane 16*r+15 holds in z[j] the total of value 4*j + {0,2,1,3}[r].
+// reduce x[0..15] over the 64 lanes; every lane of quad q = (lane >> 2) & 3 of row r = lane >> 4 returns the total of value
+// 4*q + {0,2,1,3}[r].
 // The swaps are issued through inline asm: with hipcc/ROCm 7.2 `r[0] + r[1]` on the result of
 // __builtin_amdgcn_permlane{32,16}_swap compiles to `v_add v, vdst, vdst` (the second result is lost; see
 // tools/butterfly_probe.hip).  `s_nop 1` = the two wait states a VALU write needs before v_permlane*_swap reads it.
-GSX_DEV void butterfly_reduce16(float (&x)[16], float (&z)[4]) {
+GSX_DEV float butterfly_reduce16(float (&x)[16]) {
     asm volatile("s_nop 1\n\t"
                  "v_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\t"
                  "v_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7\n\t"
@@ -467,21 +468,9 @@ GSX_DEV void butterfly_reduce16(float (&x)[16], float (&z)[4]) {
                  "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\t"
                  "s_nop 1"
                  : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]));
-#if defined(GSX_BFLY_ROWSHR)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float v = y[2 * j] + y[2 * j + 1];
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));  // row_shr:1
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));  // row_shr:2
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));  // row_shr:4
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));  // row_shr:8
-        z[j] = v;
-    }
-#else
     // Inside a row the halving continues (4 values x 16 lanes -> 1 value per lane): exchange distance 8 (row_ror:8) keeps the
     // pair selected by lane bit 3, distance 4 (ds_swizzle xor 4, LDS crossbar: no VALU slot) the value selected by lane bit 2,
     // then the quad is summed with two quad_perm adds.  12 VALU instead of 20 for the four 16-lane row sums.
-    // On return every lane of quad q (= (lane >> 2) & 3) of row r holds the total of value 4*q + {0,2,1,3}[r] in z[0].
     const uint32_t ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const bool hi8 = (ln & 8u) != 0u, hi4 = (ln & 4u) != 0u;
     const float v0 = y[0] + y[1], v1 = y[2] + y[3], v2 = y[4] + y[5], v3 = y[6] + y[7];
@@ -494,8 +483,7 @@ GSX_DEV void butterfly_reduce16(float (&x)[16], float (&z)[4]) {
     k += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, sd), 0x101F));                   // lane ^ 4
     k += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, k), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
     k += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, k), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
-    z[0] = k;
-#endif
+    return k;
 }
 
 template <int KIND>
@@ -549,7 +537,6 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
     // moment whose total this lane's quad holds after butterfly_reduce16: 4 * quad + {0,2,1,3}[row]
     const uint32_t bf_row = lane >> 4;
     const uint32_t mom_of_lane = 4u * ((lane >> 2) & 3u) + ((bf_row == 1u) ? 2u : (bf_row == 2u ? 1u : bf_row));
-    (void)mom_of_lane;
     int32_t wave_last = bin_final;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, o));
@@ -619,20 +606,8 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
                 x[4] = aw * uu; x[5] = aw * uv; x[6] = aw * vv; x[7] = aw * du; x[8] = aw * dv;
                 x[9] = bw; x[10] = bw * du; x[11] = bw * dv; x[12] = bw * uu; x[13] = bw * uv; x[14] = bw * vv;
                 x[15] = 0.f;
-                float z[4];
-                butterfly_reduce16(x, z);
-#if defined(GSX_BFLY_ROWSHR)
-                if ((lane & 15u) == 15u) {
-                    const uint32_t row = lane >> 4;
-                    const uint32_t k0 = (row == 1u) ? 2u : (row == 2u ? 1u : row);  // {0,2,1,3}
-                    atomicAdd(&s_acc[k0][t], z[0]);
-                    atomicAdd(&s_acc[4 + k0][t], z[1]);
-                    atomicAdd(&s_acc[8 + k0][t], z[2]);
-                    atomicAdd(&s_acc[12 + k0][t], z[3]);
-                }
-#else
-                if ((lane & 3u) == 0u) atomicAdd(&s_acc[mom_of_lane][t], z[0]);  // 16 lanes, one moment each
-#endif
+                const float total = butterfly_reduce16(x);
+                if ((lane & 3u) == 0u) atomicAdd(&s_acc[mom_of_lane][t], total);  // 16 lanes, one moment each
             }
             if (lane == 0 && touched) atomicOr(&s_touched[sub >> 6], touched);
         }
