@@ -243,7 +243,7 @@ __global__ __launch_bounds__(RB) void raster_bwd_kernel(RasterArgs a, const floa
                 alpha = pair_alpha<HOIST>(s, ray_o, ray_d, gro, grd, grd_n, gc, vis, il);
                 if (alpha < ALPHA_MIN) valid = false;
             }
-            if (__ballot(valid) == 0ull) continue;
+            if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
             float acc[NACC];
 #pragma unroll
             for (int k = 0; k < NACC; ++k) acc[k] = 0.f;

@@ -17,7 +17,7 @@
 // 2. Sub-tile culling.  Each wave owns an 8x8 quadrant.  alpha >= 1/255 needs
 //    |L d|^2 <= log2(255 o) * den(d); den is convex, so its maximum over the tile is at a corner and the
 //    bounding box of that ellipse in (u,v) is a conservative footprint.  Every wave tests 64 staged
-//    Gaussians at a time (one per lane) against its quadrant, __ballot()s the survivors and walks only
+//    Gaussians at a time (one per lane) against its quadrant, __builtin_amdgcn_ballot_w64()s the survivors and walks only
 //    the set bits, front to back.  A skipped Gaussian has alpha < 1/255 on all 64 pixels, so results are
 //    unchanged (the reference `continue`s on exactly those pairs, Fwd.cu:240).
 // 3. Staging.  Chunks of 256 Gaussians, records in LDS as four float4 SoA planes (conflict-free per-lane
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
     float T = 1.f;
     uint32_t cur_idx = 0;
     float out_r = 0.f, out_g = 0.f, out_b = 0.f;
-    bool wave_done = __ballot(!done) == 0ull;
+    bool wave_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
     RawG raw;
     int32_t g_pre = 0;  // packed path: only the flatten id is prefetched, the 64 B record is gathered at staging time
     bool have = (int32_t)tid < FCH && range_start + (int32_t)tid < range_end;
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
                 const float4 c = s_cull[buf][sub + lane];
                 hit = (c.x + c.z >= wb[0]) && (c.x - c.z <= wb[1]) && (c.y + c.w >= wb[2]) && (c.y - c.w <= wb[3]);
             }
-            unsigned long long todo = __ballot(hit);
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(hit);
             GSX_STAT_ADD(1, min(64, chunk_size - sub));
             GSX_STAT_ADD(0, __popcll(todo));
 #ifdef GSX_STATS
@@ -375,14 +375,16 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
                 cur_idx = take ? (uint32_t)(chunk_start + t) : cur_idx;
                 done = done || stop;
 #ifdef GSX_STATS
-                { const unsigned long long c = __ballot(take); GSX_STAT_ADD(2, c != 0ull); GSX_STAT_ADD(3, __popcll(c));
+                { const unsigned long long c = __builtin_amdgcn_ballot_w64(take); GSX_STAT_ADD(2, c != 0ull); GSX_STAT_ADD(3, __popcll(c));
                   const unsigned long long bm[4] = {0x0F0F0F0Full, 0xF0F0F0F0ull, 0x0F0F0F0Full << 32, 0xF0F0F0F0ull << 32};
                   int nb = 0;
                   for (int q = 0; q < 4; ++q) { const int hb = (c & bm[q]) != 0ull; st_b[q] += hb; nb += hb; st_s[q] += ((c >> (16 * q)) & 0xffffull) != 0ull; }
                   GSX_STAT_ADD(5, nb); }
 #endif
-                if (__ballot(!done) == 0ull) { wave_done = true; GSX_STAT_ADD(4, __popcll(todo)); break; }
             }
+            // all 64 pixels saturated: tested once per 64 candidates, not per Gaussian (a ballot of the loop-carried predicate
+            // costs two VALU slots; the saturated lanes run with weight 0 until then, which leaves the result unchanged)
+            if (__builtin_amdgcn_ballot_w64(!done) == 0ull) wave_done = true;
 #ifdef GSX_STATS
             GSX_STAT_ADD(6, max(max(st_b[0], st_b[1]), max(st_b[2], st_b[3])));
             GSX_STAT_ADD(7, max(max(st_s[0], st_s[1]), max(st_s[2], st_s[3])));
@@ -574,7 +576,7 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
                 const float4 c = s_cull[sub + lane];
                 hit = (c.x + c.z >= wb[0]) && (c.x - c.z <= wb[1]) && (c.y + c.w >= wb[2]) && (c.y - c.w <= wb[3]);
             }
-            unsigned long long todo = __ballot(hit);
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(hit);
             unsigned long long touched = 0ull;
             while (todo) {
                 const int t = sub + __builtin_ctzll(todo);
@@ -583,12 +585,14 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
                 const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
                 float du, dv, num2, rden;
                 const float alpha = fast_alpha(u, v, r0, r1, r2, du, dv, num2, rden);
-                const bool valid = (chunk_end - t <= bin_final) && alpha >= ALPHA_MIN;
-                if (__ballot(valid) == 0ull) continue;
+                // one comparison feeds the ballot directly (a ballot of `a && b` goes through a VGPR round trip)
+                const float alpha_in = (chunk_end - t <= bin_final) ? alpha : 0.f;
+                const bool valid = alpha_in >= ALPHA_MIN;
+                if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
                 touched |= 1ull << (t - sub);
                 // branch-free: lanes that do not take this Gaussian run with alpha = 0, which makes every
                 // update below the identity (ra = 1, fac = 0) and every moment weight zero.
-                const float al = valid ? alpha : 0.f;
+                const float al = valid ? alpha_in : 0.f;
                 const float ra = __builtin_amdgcn_rcpf(1.f - al);
                 T *= ra;
                 const float fac = al * T;

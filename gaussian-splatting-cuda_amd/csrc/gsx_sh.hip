@@ -160,7 +160,7 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_fwd_kernel(uint32_t n, uint32_t K
     const uint32_t e0 = blockIdx.x * SH_BLOCK + wave * 64u;
     const uint32_t e = e0 + lane;
     const bool live = e < n && (masks == nullptr || masks[e] != 0);
-    const unsigned long long live_mask = __ballot(live);
+    const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(live);
     float* tile = sh_lds + wave * 64u * LS;
     if (e0 < n) sh_stage_rows(coeffs, n, e0, K * 3u, NB3, live_mask, tile, LS, lane);
     __syncthreads();
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(uint32_t n, uint32_t K
     float* tile = sh_lds + wave * 64u * LS;
     float* row = tile + lane * LS;
     if (VDIRS && DEG >= 1 && e0 < n) {
-        const unsigned long long live_mask = __ballot(live);
+        const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(live);
         sh_stage_rows(coeffs, n, e0, K3, NB3, live_mask, tile, LS, lane);
     }
     __syncthreads();
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_colors_fwd_kernel(uint32_t C, uin
             const int2 r = reinterpret_cast<const int2*>(radii)[(size_t)c * N + e];
             any_live |= (r.x > 0 && r.y > 0);
         }
-    const unsigned long long live_mask = __ballot(any_live);
+    const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(any_live);
     float* tile = sh_lds + wave * 64u * LS;
     if (e0 < N) sh_stage_rows(coeffs, N, e0, K * 3u, NB3, live_mask, tile, LS, lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the tile is private to this wave: no block barrier
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_colors_bwd_kernel(uint32_t C, uin
     float* tile = sh_lds + wave * 64u * LS;
     float* row = tile + lane * LS;
     if (DEG >= 1 && e0 < N) {
-        const unsigned long long live_mask = __ballot(any_live);
+        const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(any_live);
         sh_stage_rows(coeffs, N, e0, K3, NB3, live_mask, tile, LS, lane);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the tile is private to this wave: no block barrier
