@@ -427,6 +427,11 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_fwd(
     return check_launch("rasterize_to_pixels_from_world_3dgs_fwd");
 }
 
+extern "C" const void* gsx_rasterize_fwd_packed_records(const void* fwd_workspace, size_t workspace_bytes, uint32_t C, uint32_t N) {
+    if (!fwd_workspace || workspace_bytes < raster_fwd_fast_workspace_bytes(C, N)) return nullptr;
+    return (const void*)(((uintptr_t)fwd_workspace + 255) & ~(uintptr_t)255);
+}
+
 extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd(
     uint32_t N, int64_t n_isects, const float* means, const float* quats, const float* scales, const float* colors,
     uint32_t channels, const float* opacities, const float* backgrounds, const uint8_t* masks, uint32_t image_width,
@@ -434,6 +439,19 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd(
     const int32_t* tile_offsets, const int32_t* flatten_ids, const float* render_alphas, const int32_t* last_ids,
     const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats, float* v_scales,
     float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes, void* stream) {
+    return gsx_rasterize_to_pixels_from_world_3dgs_bwd_packed(N, n_isects, means, quats, scales, colors, channels, opacities, backgrounds, masks,
+                                                              image_width, image_height, tile_size, cams, ut, tile_offsets, flatten_ids,
+                                                              render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales,
+                                                              v_colors, v_opacities, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd_packed(
+    uint32_t N, int64_t n_isects, const float* means, const float* quats, const float* scales, const float* colors,
+    uint32_t channels, const float* opacities, const float* backgrounds, const uint8_t* masks, uint32_t image_width,
+    uint32_t image_height, uint32_t tile_size, const gsx_cameras* cams, const gsx_ut_params* ut,
+    const int32_t* tile_offsets, const int32_t* flatten_ids, const float* render_alphas, const int32_t* last_ids,
+    const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats, float* v_scales,
+    float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes, const void* packed_records, void* stream) {
     (void)ut;
     RasterArgs a;
     int rc = fill_args(a, N, n_isects, means, quats, scales, colors, channels, opacities, backgrounds, masks, image_width,
@@ -461,7 +479,7 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd(
     const bool hoist = cams->shutter == GSX_SHUTTER_GLOBAL;
     if (hoist && cam_kind(*cams) != CAM_OPENCV_FISHEYE && !force_generic()) {
         if (launch_raster_bwd_fast(cam_kind(*cams), a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats,
-                                   v_scales, v_colors, v_opacities, workspace, workspace_bytes, st))
+                                   v_scales, v_colors, v_opacities, workspace, workspace_bytes, (const float4*)packed_records, st))
             return check_launch("rasterize_to_pixels_from_world_3dgs_bwd(fast)");
     }
     zero_outputs();

@@ -39,7 +39,7 @@ size_t raster_fwd_fast_workspace_bytes(uint32_t C, uint32_t N);
 bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, const int32_t* last_ids,
                             const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats,
                             float* v_scales, float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes,
-                            hipStream_t st);
+                            const float4* packed_from_fwd, hipStream_t st);
 size_t raster_bwd_fast_workspace_bytes(uint32_t C, uint32_t N, int64_t n_isects);
 
 }  // namespace gsx

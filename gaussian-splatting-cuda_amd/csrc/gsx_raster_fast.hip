@@ -755,13 +755,18 @@ size_t raster_bwd_fast_workspace_bytes(uint32_t C, uint32_t N, int64_t n_isects)
 bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, const int32_t* last_ids,
                             const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats,
                             float* v_scales, float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes,
-                            hipStream_t st) {
+                            const float4* packed_from_fwd, hipStream_t st) {
     if (workspace == nullptr || workspace_bytes < raster_bwd_fast_workspace_bytes(a.C, a.N, a.n_isects)) return false;
     const uint32_t n_tiles = a.tw * a.th;
     const dim3 grid(((n_tiles + 7u) / 8u) * 8u, a.C), block(RB);
     float4* ws_rec = (float4*)workspace;
     int32_t* ws_head = (int32_t*)((char*)workspace + (((size_t)a.n_isects * 64 + 255) / 256) * 256);
-    pack_into(a, (char*)ws_head + (((size_t)a.C * a.N * 4 + 255) / 256) * 256, st, ws_head);  // also sets every list head to -1
+    if (packed_from_fwd) {  // the forward of the same inputs left its packed records with the caller: only the list heads are reset
+        a.packed = packed_from_fwd;
+        (void)hipMemsetAsync(ws_head, 0xFF, (size_t)a.C * a.N * 4, st);
+    } else {
+        pack_into(a, (char*)ws_head + (((size_t)a.C * a.N * 4 + 255) / 256) * 256, st, ws_head);  // also sets every list head to -1
+    }
     const dim3 ggrid((a.N + 255u) / 256u), gblock(256);
     if (kind == CAM_PERFECT_PINHOLE) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_fast_kernel<CAM_PERFECT_PINHOLE>), grid, block, 0, st, a, render_alphas,

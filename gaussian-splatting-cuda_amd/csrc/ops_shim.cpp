@@ -68,6 +68,11 @@ gsx_ut_params make_ut(const UnscentedTransformParameters& u) {
 
 }  // namespace
 
+// Side channel of the fused render path (gsx_ext::rasterize_fwd_keep_ws / bwd with fwd_ws): the blend forward hands its
+// workspace (packed per-Gaussian records) to the caller, the backward of the same inputs takes it back and skips re-packing.
+static thread_local at::Tensor* g_fwd_ws_out = nullptr;
+static thread_local const at::Tensor* g_fwd_ws_in = nullptr;
+
 namespace gsx_ext {
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned(const at::Tensor means2d, const at::Tensor radii,
                                                                                  const at::Tensor depths, const uint32_t C,
@@ -273,6 +278,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> rasterize_to_pixels_from_world_3d
               flatten_ids.numel() ? flatten_ids.data_ptr<int32_t>() : nullptr, renders.data_ptr<float>(),
               alphas.data_ptr<float>(), last_ids.data_ptr<int32_t>(), fws.data_ptr(), fwsb, cur_stream()),
           "rasterize_to_pixels_from_world_3dgs_fwd");
+    if (g_fwd_ws_out) *g_fwd_ws_out = fws;
     return std::make_tuple(renders, alphas, last_ids);
 }
 
@@ -311,7 +317,9 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
     at::Tensor v_opacities = at::empty_like(opacities);
     const size_t wsb = gsx_rasterize_bwd_workspace_bytes(C, N, flatten_ids.size(0));
     at::Tensor ws = at::empty({(int64_t)wsb}, means.options().dtype(at::kByte));  // caching allocator, like CUB temp storage upstream
-    check(gsx_rasterize_to_pixels_from_world_3dgs_bwd(
+    const void* packed = (g_fwd_ws_in && g_fwd_ws_in->defined())
+                             ? gsx_rasterize_fwd_packed_records(g_fwd_ws_in->data_ptr(), (size_t)g_fwd_ws_in->numel(), C, N) : nullptr;
+    check(gsx_rasterize_to_pixels_from_world_3dgs_bwd_packed(
               N, flatten_ids.size(0), means.data_ptr<float>(), quats.data_ptr<float>(), scales.data_ptr<float>(),
               colors.data_ptr<float>(), channels, opacities.data_ptr<float>(), fptr(backgrounds), bptr(masks), image_width,
               image_height, tile_size, &cams, &ut, tile_offsets.data_ptr<int32_t>(),
@@ -319,7 +327,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
               last_ids.data_ptr<int32_t>(), v_render_colors.data_ptr<float>(),
               v_render_alphas.defined() ? v_render_alphas.data_ptr<float>() : nullptr,
               v_means.data_ptr<float>(), v_quats.data_ptr<float>(), v_scales.data_ptr<float>(), v_colors.data_ptr<float>(),
-              v_opacities.data_ptr<float>(), ws.data_ptr(), wsb, cur_stream()),
+              v_opacities.data_ptr<float>(), ws.data_ptr(), wsb, packed, cur_stream()),
           "rasterize_to_pixels_from_world_3dgs_bwd");
     return std::make_tuple(v_means, v_quats, v_scales, v_colors, v_opacities);
 }
@@ -629,6 +637,18 @@ void adam_step(at::Tensor param, at::Tensor exp_avg, at::Tensor exp_avg_sq, cons
 #ifndef GSX_NO_PYBIND
 namespace py = pybind11;
 
+// (renders, alphas, last_ids) -> (renders, alphas, last_ids, workspace)
+template <class... A>
+static auto keep_fwd_ws(std::tuple<at::Tensor, at::Tensor, at::Tensor> (*fn)(A...)) {
+    return [fn](A... a) {
+        at::Tensor ws;
+        struct Reset { ~Reset() { g_fwd_ws_out = nullptr; } } reset;
+        g_fwd_ws_out = &ws;
+        auto r = fn(a...);
+        return std::make_tuple(std::get<0>(r), std::get<1>(r), std::get<2>(r), ws);
+    };
+}
+
 PYBIND11_MODULE(_gsx_ops, m) {
     m.doc() = "gsplat operator surface on the MI355X HIP backend (libgsx.so)";
     py::class_<UnscentedTransformParameters>(m, "UnscentedTransformParameters")
@@ -652,6 +672,7 @@ PYBIND11_MODULE(_gsx_ops, m) {
     m.def("intersect_offset", &gsplat::intersect_offset);
     m.def("projection_ut_3dgs_fused", &gsplat::projection_ut_3dgs_fused);
     m.def("rasterize_to_pixels_from_world_3dgs_fwd", &gsplat::rasterize_to_pixels_from_world_3dgs_fwd);
+    m.def("rasterize_fwd_keep_ws", keep_fwd_ws(&gsplat::rasterize_to_pixels_from_world_3dgs_fwd));
     m.def("rasterize_to_pixels_from_world_3dgs_bwd",
           [](const at::Tensor means, const at::Tensor quats, const at::Tensor scales, const at::Tensor colors, const at::Tensor opacities,
              const at::optional<at::Tensor> backgrounds, const at::optional<at::Tensor> masks, uint32_t image_width, uint32_t image_height,
@@ -660,7 +681,10 @@ PYBIND11_MODULE(_gsx_ops, m) {
              const at::optional<at::Tensor> radial_coeffs, const at::optional<at::Tensor> tangential_coeffs,
              const at::optional<at::Tensor> thin_prism_coeffs, const at::Tensor tile_offsets, const at::Tensor flatten_ids,
              const at::Tensor render_alphas, const at::Tensor last_ids, const at::Tensor v_render_colors,
-             const at::optional<at::Tensor> v_render_alphas) {  // None = no gradient through the alpha output
+             const at::optional<at::Tensor> v_render_alphas,  // None = no gradient through the alpha output
+             const at::optional<at::Tensor> fwd_ws) {           // workspace kept from rasterize_fwd_keep_ws of the same inputs
+              struct Reset { ~Reset() { g_fwd_ws_in = nullptr; } } reset;
+              g_fwd_ws_in = fwd_ws.has_value() ? &fwd_ws.value() : nullptr;
               return gsplat::rasterize_to_pixels_from_world_3dgs_bwd(
                   means, quats, scales, colors, opacities, backgrounds, masks, image_width, image_height, tile_size, viewmats0, viewmats1, Ks,
                   camera_model, ut_params, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids,

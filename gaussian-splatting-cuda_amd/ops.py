@@ -27,8 +27,18 @@ spherical_harmonics_bwd = _C.spherical_harmonics_bwd
 intersect_tile = _C.intersect_tile
 intersect_offset = _C.intersect_offset
 projection_ut_3dgs_fused = _C.projection_ut_3dgs_fused
-rasterize_to_pixels_from_world_3dgs_fwd = _C.rasterize_to_pixels_from_world_3dgs_fwd
-rasterize_to_pixels_from_world_3dgs_bwd = _C.rasterize_to_pixels_from_world_3dgs_bwd
+
+
+def rasterize_to_pixels_from_world_3dgs_fwd(*args, keep_ws=False):
+    """gsplat::rasterize_to_pixels_from_world_3dgs_fwd; keep_ws=True also returns the workspace (packed per-Gaussian records)
+    that the backward of the same inputs can take back (fwd_ws=) instead of re-packing."""
+    return _C.rasterize_fwd_keep_ws(*args) if keep_ws else _C.rasterize_to_pixels_from_world_3dgs_fwd(*args)
+
+
+def rasterize_to_pixels_from_world_3dgs_bwd(*args, fwd_ws=None):
+    return _C.rasterize_to_pixels_from_world_3dgs_bwd(*args, fwd_ws)
+
+
 quats_to_rotmats = _C.quats_to_rotmats
 relocation = _C.relocation
 add_noise = _C.add_noise

@@ -272,9 +272,10 @@ class GutRenderFunction(torch.autograd.Function):
         # binned pipeline: flatten_ids + isect_offsets in one go (bit-identical to intersect_tile + intersect_offset, no isect_ids)
         _, _, flatten_ids, isect_offsets = ops.intersect_tile_binned(means2d, radii, depths, 1, TILE_SIZE, tw, th, False)
         opac2 = opac.unsqueeze(0)
-        renders, alphas, last_ids = ops.rasterize_to_pixels_from_world_3dgs_fwd(
+        renders, alphas, last_ids, fwd_ws = ops.rasterize_to_pixels_from_world_3dgs_fwd(
             means_c, quats, scales, colors, opac2, bg, None, width, height, TILE_SIZE, viewmat, None, K, camera_model, ut,
-            ops.ShutterType.GLOBAL, radial, tangential, None, isect_offsets, flatten_ids)
+            ops.ShutterType.GLOBAL, radial, tangential, None, isect_offsets, flatten_ids, keep_ws=True)
+        ctx.fwd_ws = fwd_ws  # packed per-Gaussian records of exactly these inputs: the backward does not pack again
         ctx.save_for_backward(means_c, sh_c, sr, rr, orw, scales, quats, opac2, colors, radii, viewmat, K, isect_offsets,
                               flatten_ids, alphas, last_ids)
         ctx.extra = (bg, width, height, sh_degree, scaling_modifier, camera_model, radial, tangential, grad_sinks, ut)
@@ -294,7 +295,7 @@ class GutRenderFunction(torch.autograd.Function):
         v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_to_pixels_from_world_3dgs_bwd(
             means, quats, scales, colors, opac2, bg, None, width, height, TILE_SIZE, viewmat, None, K, camera_model, ut,
             ops.ShutterType.GLOBAL, radial, tangential, None, isect_offsets, flatten_ids, alphas, last_ids,
-            v_renders.contiguous(), None if v_alphas is None else v_alphas.contiguous())
+            v_renders.contiguous(), None if v_alphas is None else v_alphas.contiguous(), fwd_ws=ctx.fwd_ws)
         if scaling_modifier != 1.0:
             v_scales = v_scales * scaling_modifier
         s = sinks or {}

@@ -129,9 +129,9 @@ int gsx_rasterize_to_pixels_from_world_3dgs_fwd(uint32_t N, int64_t n_isects, co
  * (camera, Gaussian), so that staging a tile gathers ONE cache line per Gaussian instead of five (means, quats,
  * scales, opacities, colours live in five arrays).  NULL / too small = records are built from the raw arrays. */
 size_t gsx_rasterize_fwd_workspace_bytes(uint32_t C, uint32_t N);
-/* Gradient outputs v_means [N,3], v_quats [N,4], v_scales [N,3], v_colors [C,N,3], v_opacities [C,N]
- * must be zero-initialised by the caller (upstream: at::zeros_like, Rasterization.cpp:190-194); the
- * gradients are accumulated into them.
+/* Gradient outputs v_means [N,3], v_quats [N,4], v_scales [N,3], v_colors [C,N,3], v_opacities [C,N] are OVERWRITTEN
+ * (upstream accumulates into tensors its wrapper zero-fills, Rasterization.cpp:190-194: same values).  v_render_alphas
+ * may be NULL (no gradient through the alpha output).
  * `workspace` (optional; size from gsx_rasterize_bwd_workspace_bytes): with it the fast path writes one 64 B
  * moment record per (tile, Gaussian), and a second kernel sums them and applies the chain rule once per
  * (camera, Gaussian), instead of issuing 14 device-scope float atomics per (tile, Gaussian) — on MI355X those
@@ -149,6 +149,21 @@ int gsx_rasterize_to_pixels_from_world_3dgs_bwd(uint32_t N, int64_t n_isects, co
                                                 float* v_means, float* v_quats, float* v_scales, float* v_colors,
                                                 float* v_opacities, void* workspace, size_t workspace_bytes,
                                                 void* stream);
+/* Same, for a caller that kept the forward's workspace alive: `packed_records` = gsx_rasterize_fwd_packed_records(the
+ * workspace the forward of the SAME inputs ran with) lets the backward skip re-packing the per-(camera, Gaussian) records
+ * (NULL = pack again).  The caller guarantees that neither the inputs nor that workspace changed in between. */
+const void* gsx_rasterize_fwd_packed_records(const void* fwd_workspace, size_t workspace_bytes, uint32_t C, uint32_t N);
+int gsx_rasterize_to_pixels_from_world_3dgs_bwd_packed(uint32_t N, int64_t n_isects, const float* means,
+                                                       const float* quats, const float* scales, const float* colors,
+                                                       uint32_t channels, const float* opacities, const float* backgrounds,
+                                                       const uint8_t* masks, uint32_t image_width, uint32_t image_height,
+                                                       uint32_t tile_size, const gsx_cameras* cams, const gsx_ut_params* ut,
+                                                       const int32_t* tile_offsets, const int32_t* flatten_ids,
+                                                       const float* render_alphas, const int32_t* last_ids,
+                                                       const float* v_render_colors, const float* v_render_alphas,
+                                                       float* v_means, float* v_quats, float* v_scales, float* v_colors,
+                                                       float* v_opacities, void* workspace, size_t workspace_bytes,
+                                                       const void* packed_records, void* stream);
 
 /* ---- the remaining gsplat/Ops.h functions (Ops.h:45-65), so libgsx can stand in for the whole gsplat_backend --- */
 /* gsplat::quats_to_rotmats, QuatToRotmatCUDA.cu:13-39: quats [N,4] wxyz -> rotmats [N,3,3] row-major */
