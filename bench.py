@@ -201,6 +201,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    n_isects_timed = state["n_isects"]  # (the train-iteration leg below moves the Gaussians: later steps have another count)
     blend_ms = timer.mean_ms()
     timer.reset()
     timer.only, timer.enabled = None, True   # per-op pass (outside the timed region)
@@ -246,7 +247,7 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        I = state["n_isects"]  # noqa: E741
+        I = n_isects_timed  # noqa: E741
         P = W * H
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
         K = (deg + 1) ** 2
