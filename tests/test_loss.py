@@ -134,3 +134,17 @@ def test_gpu_photometric_loss_vs_oracle(C, H, W):
     ref.backward()
     assert abs(ref.item() - val.item()) < 2e-6
     assert (R2.grad - R.grad / 3.0).abs().max().item() <= 1e-4 * np.abs(og).max()
+
+
+@pytest.mark.gpu
+def test_gpu_metrics_psnr_ssim():
+    import gsx  # noqa: F401
+    from gsx import metrics
+    torch.manual_seed(3)
+    a = torch.rand(3, 60, 90, device="cuda")
+    b = (a + 0.05 * torch.randn_like(a)).clamp(0, 1)
+    ref_ssim = _torch_ssim_map(a.double().cpu().unsqueeze(0), b.double().cpu().unsqueeze(0)).mean().item()
+    assert abs(metrics.ssim(a, b) - ref_ssim) < 1e-5
+    mse = ((a - b) ** 2).reshape(3, -1).mean(1)
+    assert abs(metrics.psnr(a, b) - float((20 * torch.log10(1.0 / mse.sqrt())).mean())) < 1e-4
+    assert metrics.psnr(a, a) == pytest.approx(100.0, abs=1e-3)      # MSE clamped at 1e-10
