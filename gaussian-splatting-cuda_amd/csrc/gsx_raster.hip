@@ -409,7 +409,8 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_fwd(
     const dim3 grid(a.tw, a.th, a.C), block(RB);
     hipStream_t st = (hipStream_t)stream;
     const bool hoist = cams->shutter == GSX_SHUTTER_GLOBAL;
-    if (hoist && cam_kind(*cams) != CAM_OPENCV_FISHEYE && !force_generic()) {
+    if (hoist && cam_kind(*cams) != CAM_OPENCV_FISHEYE && !force_generic() && workspace != nullptr &&
+        workspace_bytes >= raster_fwd_fast_workspace_bytes(a.C, a.N)) {
         launch_raster_fwd_fast(cam_kind(*cams), a, renders, alphas, last_ids, workspace, workspace_bytes, st);
         return check_launch("rasterize_to_pixels_from_world_3dgs_fwd(fast)");
     }

@@ -218,19 +218,9 @@ GSX_DEV void footprint(float4 r0, float4 r1, float4 r2, const float tb[4], float
 // one staged Gaussian: the 64 B record (AoS, read at a wave-uniform index with one base address) + the cull plane entry
 struct StagedRec { float4 r0, r1, r2, r3, cull; };
 
-GSX_DEV void stage_one(const RasterArgs& a, const CamFrame& cf, const float tb[4], int32_t g, const RawG& raw, StagedRec& o) {
-    if (a.packed) {
-        const float4* p = a.packed + (size_t)g * 4;
-        o.r0 = p[0]; o.r1 = p[1]; o.r2 = p[2]; o.r3 = p[3];
-    } else {
-        FastRec r;
-        make_record<false>(raw, cf, tb, r);
-        const bool never = !(r.lo + LOG2_255 > 0.f) || !(fabsf(r.l00) < INFINITY);
-        o.r0 = make_float4(r.u0, r.v0, r.l00, r.l01);
-        o.r1 = make_float4(r.l11, never ? -INFINITY : r.lo, r.d1, r.d2);
-        o.r2 = make_float4(r.d3, r.d4, r.d5, raw.rgb.x);
-        o.r3 = make_float4(raw.rgb.y, raw.rgb.z, 0.f, 0.f);
-    }
+GSX_DEV void stage_one(const RasterArgs& a, const float tb[4], int32_t g, StagedRec& o) {
+    const float4* p = a.packed + (size_t)g * 4;
+    o.r0 = p[0]; o.r1 = p[1]; o.r2 = p[2]; o.r3 = p[3];
     float hx, hy;
     footprint(o.r0, o.r1, o.r2, tb, hx, hy);
     o.cull = make_float4(o.r0.x, o.r0.y, hx, hy);
@@ -304,8 +294,6 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
         return;
     }
     const Camera<KIND> cam(a.cams, cid, a.W, a.H);
-    const ShutterPoses sp(a.cams.viewmats0 + cid * 16, nullptr);
-    const CamFrame cf = make_cam_frame(sp);
     float u, v;
     const bool ray_ok = pixel_uv(cam, i, j, u, v);
     bool done = !inside || !ray_ok;
@@ -321,16 +309,15 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
     uint32_t cur_idx = 0;
     float out_r = 0.f, out_g = 0.f, out_b = 0.f;
     bool wave_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
-    RawG raw;
-    int32_t g_pre = 0;  // packed path: only the flatten id is prefetched, the 64 B record is gathered at staging time
+    int32_t g_pre = 0;  // the flatten id of the next chunk is prefetched, its 64 B packed record is gathered at staging time
     bool have = (int32_t)tid < FCH && range_start + (int32_t)tid < range_end;
-    if (have) { if (a.packed) g_pre = a.flatten_ids[range_start + (int32_t)tid]; else load_raw(a, range_start + (int32_t)tid, raw); }
+    if (have) g_pre = a.flatten_ids[range_start + (int32_t)tid];
     for (int32_t b = 0; b < n_chunks; ++b) {
         const int buf = b & 1;
         const int32_t chunk_start = range_start + FCH * b;
         if (have) {
             StagedRec sr;
-            stage_one(a, cf, tb, g_pre, raw, sr);
+            stage_one(a, tb, g_pre, sr);
             s_rec[buf][tid][0] = sr.r0; s_rec[buf][tid][1] = sr.r1; s_rec[buf][tid][2] = sr.r2; s_rec[buf][tid][3] = sr.r3;
             s_cull[buf][tid] = sr.cull;
         }
@@ -338,10 +325,7 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
         __syncthreads();
         if (s_wdone[buf][0] & s_wdone[buf][1] & s_wdone[buf][2] & s_wdone[buf][3]) break;  // Fwd.cu:188-190
         have = (b + 1 < n_chunks) && (int32_t)tid < FCH && (chunk_start + FCH + (int32_t)tid < range_end);
-        if (have) {  // in flight during the pixel loop
-            if (a.packed) g_pre = a.flatten_ids[chunk_start + FCH + (int32_t)tid];
-            else load_raw(a, chunk_start + FCH + (int32_t)tid, raw);
-        }
+        if (have) g_pre = a.flatten_ids[chunk_start + FCH + (int32_t)tid];  // in flight during the pixel loop
         if (wave_done) continue;
         const int32_t chunk_size = min(FCH, range_end - chunk_start);
         for (int32_t sub = 0; sub < chunk_size && !wave_done; sub += 64) {
@@ -413,8 +397,7 @@ void launch_raster_fwd_fast(int kind, RasterArgs a, float* renders, float* alpha
                             size_t workspace_bytes, hipStream_t st) {
     const uint32_t n_tiles = a.tw * a.th;
     const dim3 grid(((n_tiles + 7u) / 8u) * 8u, a.C), block(RB);
-    a.packed = nullptr;
-    if (workspace != nullptr && workspace_bytes >= raster_fwd_fast_workspace_bytes(a.C, a.N)) pack_into(a, workspace, st);
+    pack_into(a, workspace, st);
     if (kind == CAM_PERFECT_PINHOLE)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_fwd_fast_kernel<CAM_PERFECT_PINHOLE>), grid, block, 0, st, a, renders, alphas, last_ids);
     else
@@ -513,8 +496,6 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
     const size_t pix = (size_t)cid * a.H * a.W + (size_t)min(i, a.H - 1) * a.W + min(j, a.W - 1);
     const float* bg = a.backgrounds ? a.backgrounds + cid * 3 : nullptr;
     const Camera<KIND> cam(a.cams, cid, a.W, a.H);
-    const ShutterPoses sp(a.cams.viewmats0 + cid * 16, nullptr);
-    const CamFrame cf = make_cam_frame(sp);
     float u, v;
     const bool ray_ok = pixel_uv(cam, i, j, u, v);
     const bool active = inside && ray_ok;
@@ -553,12 +534,9 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
         const int32_t chunk_end = block_last - BCH * b;  // inclusive; slot t holds sorted index chunk_end - t
         const int32_t chunk_size = min(BCH, chunk_end + 1 - range_start);
         if ((int32_t)tid < chunk_size) {
-            RawG raw;
-            int32_t g;
-            if (a.packed) g = a.flatten_ids[chunk_end - (int32_t)tid];
-            else { load_raw(a, chunk_end - (int32_t)tid, raw); g = raw.g; }
+            const int32_t g = a.flatten_ids[chunk_end - (int32_t)tid];
             StagedRec sr;
-            stage_one(a, cf, tb, g, raw, sr);
+            stage_one(a, tb, g, sr);
             s_rec[tid][0] = sr.r0; s_rec[tid][1] = sr.r1; s_rec[tid][2] = sr.r2; s_rec[tid][3] = sr.r3;
             s_cull[tid] = sr.cull;
             s_gid[tid] = g;

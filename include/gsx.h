@@ -127,7 +127,7 @@ int gsx_rasterize_to_pixels_from_world_3dgs_fwd(uint32_t N, int64_t n_isects, co
                                                 size_t workspace_bytes, void* stream);
 /* `workspace` (optional; gsx_rasterize_fwd_workspace_bytes): room for one packed 64 B camera-space record per
  * (camera, Gaussian), so that staging a tile gathers ONE cache line per Gaussian instead of five (means, quats,
- * scales, opacities, colours live in five arrays).  NULL / too small = records are built from the raw arrays. */
+ * scales, opacities, colours live in five arrays).  NULL / too small = the reference-order (generic) kernels. */
 size_t gsx_rasterize_fwd_workspace_bytes(uint32_t C, uint32_t N);
 /* Gradient outputs v_means [N,3], v_quats [N,4], v_scales [N,3], v_colors [C,N,3], v_opacities [C,N] are OVERWRITTEN
  * (upstream accumulates into tensors its wrapper zero-fills, Rasterization.cpp:190-194: same values).  v_render_alphas
