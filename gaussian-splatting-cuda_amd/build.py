@@ -50,7 +50,8 @@ def build_libgsx(force=False, verbose=False):
         objs.append(o)
         # -fno-slp-vectorize: v_pk_fma_f32 / v_pk_mul_f32 issue at ~7.5 cycles per wave64 instruction on gfx950 vs ~2.9 for the
         # scalar forms (tools/valu_probe.hip), so SLP-packed fp32 math is a net loss in the VALU-bound blend loops
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-c", s, "-o", o]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"] + \
+            os.environ.get("GSX_EXTRA_HIPCC_FLAGS", "").split() + ["-c", s, "-o", o]  # (tuning experiments: -DGSX_FCH=..., ...)
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for cmd, p in procs:
         out, _ = p.communicate()

@@ -45,7 +45,10 @@ __device__ unsigned long long g_stats[8];
 #define GSX_BWD_WAVES 4
 #endif
 
-constexpr int FCH = 128;  // Gaussians per forward chunk (double buffered: 2 x 64 B x FCH of LDS)
+#ifndef GSX_FCH
+#define GSX_FCH 128
+#endif
+constexpr int FCH = GSX_FCH;  // Gaussians per forward chunk (double buffered)
 constexpr float LOG2_255 = 7.994353436858858f;
 constexpr float HALF_LOG2E = 0.7213475204444817f;  // 0.5 * log2(e)
 
@@ -425,7 +428,10 @@ void launch_raster_fwd_fast(int kind, RasterArgs a, float* renders, float* alpha
 // are not coherent, device-scope float atomics are served memory-side and 14 of them per (tile, Gaussian) cost
 // more than all the arithmetic of the kernel).
 constexpr int NMOM = 16;
-constexpr int BCH = 128;  // Gaussians per backward chunk
+#ifndef GSX_BCH
+#define GSX_BCH 128
+#endif
+constexpr int BCH = GSX_BCH;  // Gaussians per backward chunk
 
 #if defined(GSX_ABLATE)
 #define GSX_GATOMIC(p, v) atomicAdd((p), (v))
