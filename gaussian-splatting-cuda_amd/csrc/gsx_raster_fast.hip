@@ -17,12 +17,15 @@
 // 2. Sub-tile culling.  Each wave owns an 8x8 quadrant.  alpha >= 1/255 needs
 //    |L d|^2 <= log2(255 o) * den(d); den is convex, so its maximum over the tile is at a corner and the
 //    bounding box of that ellipse in (u,v) is a conservative footprint.  Every wave tests 64 staged
-//    Gaussians at a time (one per lane) against its quadrant, __builtin_amdgcn_ballot_w64()s the survivors and walks only
+//    Gaussians at a time (one per lane) against its quadrant, ballots the survivors and walks only
 //    the set bits, front to back.  A skipped Gaussian has alpha < 1/255 on all 64 pixels, so results are
 //    unchanged (the reference `continue`s on exactly those pairs, Fwd.cu:240).
-// 3. Staging.  Chunks of 256 Gaussians, records in LDS as four float4 SoA planes (conflict-free per-lane
-//    cull reads, broadcast reads in the pixel loop), double buffered: the gathers of chunk b+1 are in
-//    flight while chunk b is composited; one barrier per chunk.
+// 3. Staging.  pack_records_kernel turns every (camera, Gaussian) into ONE 64 B record (centre, factor L, log2 opacity, the
+//    normalised denominator quadratic, colour) once per launch; a tile gathers one cache line per intersection.  Chunks of
+//    128 Gaussians, records in LDS as AoS float4 x 4 (four wave-uniform ds_read_b128 in the pixel loop) plus a separate
+//    float4 cull plane (u0, v0, hx, hy: conflict-free per-lane reads), double buffered in the forward: the flatten ids of
+//    chunk b+1 are in flight while chunk b is composited; one barrier per chunk.  The backward of the same inputs can take
+//    the forward's packed records back (gsx_rasterize_..._bwd_packed).
 // 4. Dispatch.  1-D grid, XCD-aware: block b runs on XCD b % 8, so each XCD is given a contiguous band of
 //    tiles and neighbouring tiles (which share Gaussians) hit the same 4 MiB L2.
 #include "gsx_raster_common.hpp"
@@ -67,21 +70,10 @@ GSX_DEV CamFrame make_cam_frame(const ShutterPoses& sp) {
     return f;
 }
 
-// raw per-Gaussian parameters in flight between the gather and the record computation
+// raw per-Gaussian parameters (inputs of make_record: pack kernel and the backward's gather kernel)
 struct RawG {
     f3 mu; float4 q; f3 sc; float opac; f3 rgb; int32_t g;
 };
-
-GSX_DEV void load_raw(const RasterArgs& a, int32_t idx, RawG& r) {
-    const int32_t g = a.flatten_ids[idx];
-    const int32_t gi = (a.C == 1) ? g : (int32_t)((uint32_t)g % a.N);
-    r.g = g;
-    r.mu = {a.means[(size_t)gi * 3], a.means[(size_t)gi * 3 + 1], a.means[(size_t)gi * 3 + 2]};
-    r.q = reinterpret_cast<const float4*>(a.quats)[gi];
-    r.sc = {a.scales[(size_t)gi * 3], a.scales[(size_t)gi * 3 + 1], a.scales[(size_t)gi * 3 + 2]};
-    r.opac = a.opacities[g];
-    r.rgb = {a.colors[(size_t)g * 3], a.colors[(size_t)g * 3 + 1], a.colors[(size_t)g * 3 + 2]};
-}
 
 // Everything the pixel loop needs for one Gaussian (see header comment).  tb = tile bounds in (u,v).
 struct FastRec {
