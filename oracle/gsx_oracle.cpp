@@ -128,6 +128,15 @@ template <typename T> inline Q4<T> quat_slerp(Q4<T> x, Q4<T> y, T a) {
     return {(s0 * x.w + s1 * z.w) / sd, (s0 * x.x + s1 * z.x) / sd, (s0 * x.y + s1 * z.y) / sd, (s0 * x.z + s1 * z.z) / sd};
 }
 
+template <typename T> inline M3<T> quat_to_rotmat(const T* quat);
+// quat_scale_to_preci_half, gsplat/Utils.cuh (the blend kernels' M = diag(1/s) R^T: M^T M is the precision matrix)
+template <typename T> inline M3<T> preci_half(const T* quat, const T* scale) {
+    M3<T> R = quat_to_rotmat(quat), M;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) M.a[r][c] = (T(1) / scale[r]) * R.a[c][r];
+    return M;
+}
+
 // gsplat/Utils.cuh:80-102 quat_to_rotmat (wxyz, normalises with rsqrt)
 template <typename T> inline M3<T> quat_to_rotmat(const T* quat) {
     T w = quat[0], x = quat[1], y = quat[2], z = quat[3];
@@ -832,9 +841,7 @@ void raster_fwd(uint32_t C, uint32_t N, int64_t n_isects, const T* means, const 
                     int32_t gi = g % (int32_t)N;  // means/quats/scales are [N]; colours/opacities are [C,N]
                     xyz[k] = {means[gi * 3], means[gi * 3 + 1], means[gi * 3 + 2]};
                     opac[k] = opacities[g];
-                    M3<T> R = quat_to_rotmat(quats + gi * 4);
-                    for (int r = 0; r < 3; ++r)
-                        for (int c = 0; c < 3; ++c) iscl[k].a[r][c] = (T(1) / scales[gi * 3 + r]) * R.a[c][r];
+                    iscl[k] = preci_half(quats + gi * 4, scales + gi * 3);
                 }
             for (uint32_t py_ = 0; py_ < tile_size; ++py_)
                 for (uint32_t px_ = 0; px_ < tile_size; ++px_) {
@@ -1098,6 +1105,13 @@ void add_noise(int64_t N, const T* raw_opacities, const T* raw_scales, const T* 
 // extern "C" surface (loaded with ctypes by oracle/oracle.py)
 // ------------------------------------------------------------------------------------------
 #define GSX_ORACLE_INSTANTIATE(SUF, T)                                                                                   \
+    extern "C" void gsx_oracle_preci_half_##SUF(int64_t n, const T* quats, const T* scales, T* out) {                   \
+        for (int64_t i = 0; i < n; ++i) {                                                                                \
+            M3<T> M = preci_half(quats + i * 4, scales + i * 3);                                                         \
+            for (int r = 0; r < 3; ++r)                                                                                  \
+                for (int c = 0; c < 3; ++c) out[i * 9 + r * 3 + c] = M.a[r][c];                                          \
+        }                                                                                                                \
+    }                                                                                                                    \
     extern "C" void gsx_oracle_quat_to_rotmat_##SUF(int64_t n, const T* quats, T* out) {                                 \
         for (int64_t i = 0; i < n; ++i) {                                                                                \
             M3<T> R = quat_to_rotmat(quats + i * 4);                                                                     \

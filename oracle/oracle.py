@@ -61,6 +61,15 @@ def quat_to_rotmat(quats):
     return out
 
 
+def preci_half(quats, scales):
+    """M = diag(1/s) R^T of the blend kernels (quat_scale_to_preci_half): M^T M is the reference's precision matrix."""
+    dt = quats.dtype
+    q, sc = _c(quats, dt).reshape(-1, 4), _c(scales, dt).reshape(-1, 3)
+    out = np.empty((q.shape[0], 3, 3), dt)
+    getattr(lib(), "gsx_oracle_preci_half_" + _suf(dt))(ctypes.c_int64(q.shape[0]), _p(q), _p(sc), _p(out))
+    return out
+
+
 def projection_ut(means, quats, scales, opacities, viewmats0, Ks, width, height, eps2d=0.3, near_plane=0.01,
                   far_plane=1e4, radius_clip=0.0, calc_compensations=False, camera_model=PINHOLE,
                   ut=(0.1, 2.0, 0.0, 0.1, True), shutter=SHUTTER_GLOBAL, viewmats1=None, radial=None,

@@ -35,6 +35,14 @@ def quat_to_rotmat(quats):
     return out
 
 
+def quat_scale_to_covar_preci(quats, scales):
+    q = np.ascontiguousarray(quats, np.float32).reshape(-1, 4)
+    s = np.ascontiguousarray(scales, np.float32).reshape(-1, 3)
+    cov, pre = np.empty((q.shape[0], 3, 3), np.float32), np.empty((q.shape[0], 3, 3), np.float32)
+    lib().ref_quat_scale_to_covar_preci(ctypes.c_int64(q.shape[0]), _p(q), _p(s), _p(cov), _p(pre))
+    return cov, pre
+
+
 def spherical_harmonics(degree, dirs, coeffs, v_colors=None):
     d = np.ascontiguousarray(dirs, np.float32)
     c = np.ascontiguousarray(coeffs, np.float32)

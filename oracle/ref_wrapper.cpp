@@ -19,6 +19,14 @@ extern "C" void ref_quat_to_rotmat(int64_t n, const float* quats, float* out) {
     std::memcpy(out, R.data_ptr<float>(), sizeof(float) * n * 9);
 }
 
+// (covars, precis) = reference::quat_scale_to_covar_preci(quats, scales, true, true, false): full 3x3 matrices
+extern "C" void ref_quat_scale_to_covar_preci(int64_t n, const float* quats, const float* scales, float* covars, float* precis) {
+    auto [c, p] = reference::quat_scale_to_covar_preci(f32(quats, {n, 4}), f32(scales, {n, 3}), true, true, false);
+    auto cc = c.contiguous(), pc = p.contiguous();
+    std::memcpy(covars, cc.data_ptr<float>(), sizeof(float) * n * 9);
+    std::memcpy(precis, pc.data_ptr<float>(), sizeof(float) * n * 9);
+}
+
 // colors = reference::spherical_harmonics(degree, dirs, coeffs); optional grads through torch autograd
 extern "C" void ref_spherical_harmonics(int degree, int64_t n, int64_t K, const float* dirs, const float* coeffs,
                                         float* colors, const float* v_colors, float* v_coeffs, float* v_dirs) {

@@ -58,6 +58,10 @@ def main():
     # --- quaternion -> rotation matrix ---
     quats = rng.standard_normal((256, 4)).astype(np.float32)
     np.savez_compressed(os.path.join(OUT, "quat_torch_impl.npz"), quats=quats, rotmats=ref.quat_to_rotmat(quats))
+    # covariance / precision of (quat, scale): pins the M = diag(1/s) R^T factor the world-space blend evaluates Gaussians with
+    scales = np.exp(rng.uniform(-3.0, 0.5, (quats.shape[0], 3))).astype(np.float32)
+    cov, pre = ref.quat_scale_to_covar_preci(quats, scales)
+    np.savez_compressed(os.path.join(OUT, "covar_preci_torch_impl.npz"), quats=quats, scales=scales, covars=cov, precis=pre)
     print("golden vectors written to", OUT)
 
 

@@ -85,3 +85,18 @@ def test_quat_to_rotmat_vs_torch_impl():
     g = np.load(os.path.join(GOLDEN, "quat_torch_impl.npz"))
     R = oracle.quat_to_rotmat(g["quats"])
     np.testing.assert_allclose(R, g["rotmats"], rtol=1e-5, atol=1e-5)
+
+
+def test_preci_half_vs_torch_impl_covar_preci():
+    """The factor M = diag(1/s) R^T the world-space blend evaluates every Gaussian with (gro = M (o - mu), grd = M d) against the
+    reference's quat_scale_to_covar_preci (tests/torch_impl.cpp:38-78): M^T M = precision, M^-1 M^-T = covariance."""
+    g = np.load(os.path.join(GOLDEN, "covar_preci_torch_impl.npz"))
+    for dt, tol in ((np.float32, 2e-4), (np.float64, 2e-5)):
+        M = oracle.preci_half(g["quats"].astype(dt), g["scales"].astype(dt))
+        preci = np.einsum("nki,nkj->nij", M, M)
+        scale = np.abs(g["precis"]).max(axis=(1, 2), keepdims=True)
+        assert (np.abs(preci - g["precis"]) / scale).max() < tol
+        Minv = np.linalg.inv(M.astype(np.float64))
+        covar = np.einsum("nik,njk->nij", Minv, Minv)
+        cscale = np.abs(g["covars"]).max(axis=(1, 2), keepdims=True)
+        assert (np.abs(covar - g["covars"]) / cscale).max() < tol
