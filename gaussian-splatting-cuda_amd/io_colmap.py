@@ -3,8 +3,8 @@ initial point cloud, following src/loader/formats/colmap.cpp (binary layouts :30
 world->camera [R|t] from (qvec, tvec) :25-51, camera centres = -R^T t :676) and the model initialisation of
 SplatData::init_model_from_pointcloud (src/core/splat_data.cpp:63-111, 506-600).
 
-Image files are NOT decoded here (no image codec in this environment): `ColmapScene.cameras[i].image_name` names the file a
-caller has to load; everything the rasterizer needs (pose, intrinsics, distortion, size) comes from the .bin files."""
+Everything the rasterizer needs (pose, intrinsics, distortion, size) comes from the sparse model (.bin, or .txt when the
+binary files are absent); `ColmapScene.load_images()` decodes the image files through io_image."""
 import os
 import struct
 from dataclasses import dataclass, field
@@ -87,6 +87,67 @@ def read_points3D_binary(path):
     return xyz, rgb
 
 
+MODEL_IDS = {name: (mid, cnt) for mid, (name, cnt) in CAMERA_MODELS.items()}
+
+
+def _data_lines(path):
+    with open(path, "r") as f:
+        return [ln.strip() for ln in f if ln.strip() and not ln.lstrip().startswith("#")]
+
+
+def _scale_params(name, params, w, h, scale_factor):
+    if scale_factor == 1.0:
+        return params, w, h
+    n_focal = 1 if name in ("SIMPLE_PINHOLE", "SIMPLE_RADIAL", "RADIAL", "SIMPLE_RADIAL_FISHEYE", "RADIAL_FISHEYE") else 2
+    params = list(params)
+    for k in range(n_focal + 2):
+        params[k] /= scale_factor
+    return params, int(w / scale_factor), int(h / scale_factor)
+
+
+def read_cameras_text(path, scale_factor=1.0):
+    """cameras.txt: CAMERA_ID MODEL WIDTH HEIGHT PARAMS[] (colmap.cpp: text readers)."""
+    cams = {}
+    for ln in _data_lines(path):
+        tok = ln.split()
+        cam_id, name, w, h = int(tok[0]), tok[1], int(tok[2]), int(tok[3])
+        if name not in MODEL_IDS:
+            raise RuntimeError(f"Unsupported camera model {name}")
+        params = [float(v) for v in tok[4:4 + MODEL_IDS[name][1]]]
+        params, w, h = _scale_params(name, params, w, h, scale_factor)
+        cams[cam_id] = {"model": name, "width": w, "height": h, "params": np.array(params, np.float64).astype(np.float32)}
+    return cams
+
+
+def read_images_text(path):
+    """images.txt: two lines per image (IMAGE_ID QW QX QY QZ TX TY TZ CAMERA_ID NAME / POINTS2D[])."""
+    images = []
+    with open(path, "r") as f:
+        lines = [ln.rstrip("\n") for ln in f if not ln.lstrip().startswith("#")]
+    i = 0
+    while i < len(lines):
+        if not lines[i].strip():
+            i += 1
+            continue
+        tok = lines[i].split()
+        images.append({"id": int(tok[0]), "qvec": np.array([float(v) for v in tok[1:5]], np.float64).astype(np.float32),
+                       "tvec": np.array([float(v) for v in tok[5:8]], np.float64).astype(np.float32), "camera_id": int(tok[8]),
+                       "name": " ".join(tok[9:])})
+        i += 2  # skip the 2-D observations line (possibly empty)
+    return images
+
+
+def read_points3D_text(path):
+    """points3D.txt: POINT3D_ID X Y Z R G B ERROR TRACK[] (colmap.cpp:612-645)."""
+    rows = [ln.split() for ln in _data_lines(path)]
+    for r in rows:
+        if len(r) < 8:
+            raise RuntimeError("Invalid format in point3D.txt: " + " ".join(r))
+    xyz = np.array([[float(r[1]), float(r[2]), float(r[3])] for r in rows], np.float32).reshape(-1, 3)
+    rgb = np.array([[int(r[4]), int(r[5]), int(r[6])] for r in rows], np.uint8).reshape(-1, 3)
+    return xyz, rgb
+
+
 @dataclass
 class ColmapCamera:
     camera: Camera
@@ -98,11 +159,16 @@ class ColmapCamera:
 
 @dataclass
 class ColmapScene:
+    """`load_images(device)` decodes every camera's image file (io_image) into float [3,H,W] tensors, in camera order."""
     cameras: List[ColmapCamera] = field(default_factory=list)
     camera_locations: np.ndarray = None   # [n,3] world-space centres
     scene_center: np.ndarray = None       # their mean (colmap.cpp:  scene centre used for the scene scale)
     points: np.ndarray = None             # [P,3] float32
     colors: np.ndarray = None             # [P,3] uint8
+
+    def load_images(self, device="cpu", res_div=1, max_width=0):
+        from . import io_image
+        return [io_image.load_and_get_image(c.image_path, res_div, max_width, device) for c in self.cameras]
 
 
 def _intrinsics(model, p):
@@ -152,8 +218,15 @@ def load_colmap(base_path, images_folder="images", device="cpu"):
         factor = factor if 0 < factor <= 16 else 1.0
     except ValueError:
         factor = 1.0
-    cams = read_cameras_binary(os.path.join(sparse, "cameras.bin"), factor)
-    images = read_images_binary(os.path.join(sparse, "images.bin"))
+    def pick(stem):
+        b, t = os.path.join(sparse, stem + ".bin"), os.path.join(sparse, stem + ".txt")
+        return (b, True) if os.path.exists(b) else (t, False)
+    cpath, cbin = pick("cameras")
+    ipath, ibin = pick("images")
+    if not os.path.exists(cpath) or not os.path.exists(ipath):
+        raise RuntimeError(f"COLMAP sparse model not found under {sparse} (cameras / images .bin or .txt)")
+    cams = read_cameras_binary(cpath, factor) if cbin else read_cameras_text(cpath, factor)
+    images = read_images_binary(ipath) if ibin else read_images_text(ipath)
     scene = ColmapScene()
     locs = []
     for uid, img in enumerate(images):
@@ -173,9 +246,11 @@ def load_colmap(base_path, images_folder="images", device="cpu"):
         scene.cameras.append(ColmapCamera(cam, img["name"], os.path.join(base_path, images_folder, img["name"]), uid, c["model"]))
     scene.camera_locations = np.stack(locs) if locs else np.zeros((0, 3), np.float32)
     scene.scene_center = scene.camera_locations.mean(0) if locs else np.zeros(3, np.float32)
-    p3d = os.path.join(sparse, "points3D.bin")
+    p3d, p3d_txt = os.path.join(sparse, "points3D.bin"), os.path.join(sparse, "points3D.txt")
     if os.path.exists(p3d):
         scene.points, scene.colors = read_points3D_binary(p3d)
+    elif os.path.exists(p3d_txt):
+        scene.points, scene.colors = read_points3D_text(p3d_txt)
     return scene
 
 

@@ -157,3 +157,58 @@ def test_init_model_from_pointcloud():
     # point 0: the 4 nearest are itself (0), its duplicate (0), then 1, 2 -> valid neighbours {1, 2} (3 is not among the 4 results)
     np.testing.assert_allclose(float(m.scaling_raw[0, 0]), np.log(np.sqrt(1.5) * 0.1), rtol=1e-5)
     assert scale == float(np.median(np.linalg.norm(pts, axis=1)))
+
+
+def test_image_io_sizes_and_round_trip(tmp_path):
+    import gsx  # noqa: F401
+    from gsx import io_image
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    rgba = rng.integers(0, 255, (48, 80, 4), dtype=np.uint8)
+    Image.fromarray(rgba, "RGBA").save(tmp_path / "a.png")
+    a = io_image.load_image(str(tmp_path / "a.png"))
+    assert a.shape == (48, 80, 3) and np.array_equal(a, rgba[:, :, :3])                     # alpha dropped, bit-identical
+    assert io_image.load_image(str(tmp_path / "a.png"), res_div=2).shape == (24, 40, 3)
+    assert io_image.load_image(str(tmp_path / "a.png"), res_div=4, max_width=16).shape == (9, 16, 3)   # 16 * 12 // 20 = 9
+    assert io_image.target_size(100, 300, 1, 150) == (50, 150) and io_image.target_size(7, 7, 8, 0) == (1, 1)
+    half = io_image.load_image(str(tmp_path / "a.png"), res_div=2).astype(np.float32)
+    box = rgba[:, :, :3].astype(np.float32).reshape(24, 2, 40, 2, 3).mean((1, 3))
+    assert np.abs(half - box).max() <= 1.0                                                   # box reduction for exact divisors
+    Image.fromarray(rgba[:, :, 0], "L").save(tmp_path / "g.png")
+    g = io_image.load_image(str(tmp_path / "g.png"))
+    assert g.shape == (48, 80, 3) and np.array_equal(g[:, :, 0], g[:, :, 2])                 # grey -> RGB
+    t = io_image.load_and_get_image(str(tmp_path / "a.png"))
+    assert t.shape == (3, 48, 80) and t.dtype == torch.float32 and float(t.max()) <= 1.0
+    io_image.save_image(str(tmp_path / "b.png"), t)
+    assert np.array_equal(io_image.load_image(str(tmp_path / "b.png")), rgba[:, :, :3])      # float -> 8 bit -> same bytes
+    with pytest.raises(ValueError):
+        io_image.load_image(str(tmp_path / "a.png"), res_div=3)
+    with pytest.raises(RuntimeError):
+        io_image.load_image(str(tmp_path / "missing.png"))
+
+
+def test_colmap_text_reader_matches_binary(tmp_path):
+    import gsx  # noqa: F401
+    from gsx import io_colmap
+    root_b, root_t = tmp_path / "bin", tmp_path / "txt"
+    root_b.mkdir()
+    cams, imgs, pts, cols = _write_colmap(root_b)
+    sp = root_t / "sparse" / "0"
+    sp.mkdir(parents=True)
+    (root_t / "images").mkdir()
+    names = {0: "SIMPLE_PINHOLE", 1: "PINHOLE", 4: "OPENCV", 5: "OPENCV_FISHEYE"}
+    (sp / "cameras.txt").write_text("# Camera list\n" + "".join(
+        f"{cid} {names[mid]} {w} {h} " + " ".join(repr(p) for p in ps) + "\n" for cid, mid, w, h, ps in cams))
+    (sp / "images.txt").write_text("# Image list\n" + "".join(
+        f"{10 + i} " + " ".join(repr(float(v)) for v in list(q) + list(t)) + f" {i + 1} {name}\n" + ("1.0 2.0 -1 " * i).strip() + "\n"
+        for i, (q, t, name) in enumerate(imgs)))
+    (sp / "points3D.txt").write_text("# 3D point list\n" + "".join(
+        f"{i} " + " ".join(repr(float(v)) for v in pts[i]) + " " + " ".join(str(int(c)) for c in cols[i]) + " 0.5 1 2\n" for i in range(6)))
+    a, b = io_colmap.load_colmap(str(root_b)), io_colmap.load_colmap(str(root_t))
+    assert len(a.cameras) == len(b.cameras) == 4
+    for ca, cb in zip(a.cameras, b.cameras):
+        assert ca.image_name == cb.image_name and ca.model == cb.model
+        assert torch.equal(ca.camera.viewmat, cb.camera.viewmat) and torch.equal(ca.camera.K, cb.camera.K)
+    assert np.array_equal(a.points, b.points) and np.array_equal(a.colors, b.colors)
+    with pytest.raises(RuntimeError):
+        io_colmap.load_colmap(str(tmp_path / "nowhere"))
