@@ -46,3 +46,41 @@ def test_ops_module_imports_and_mirrors_ops_h():
     assert int(ops.CameraModelType.FISHEYE) == 2 and int(ops.ShutterType.GLOBAL) == 4
     ut = ops.UnscentedTransformParameters()
     assert abs(ut.alpha - 0.1) < 1e-7 and ut.beta == 2.0 and ut.require_all_sigma_points_valid
+
+
+def test_argument_validation_of_the_next_tier_entry_points():
+    """Null pointers, undersized workspaces and unsupported shapes are rejected before any launch (runs without a GPU)."""
+    import torch  # noqa: F401
+    c = ctypes
+    lib = c.CDLL(os.path.join(ROOT, "gaussian-splatting-cuda_amd", "libgsx.so"))
+    lib.gsx_last_error.restype = c.c_char_p
+    for f in ("gsx_photometric_loss_workspace_bytes", "gsx_intersect_bin_count_workspace_bytes", "gsx_intersect_bin_fill_workspace_bytes",
+              "gsx_rasterize_fwd_workspace_bytes", "gsx_rasterize_bwd_workspace_bytes"):
+        getattr(lib, f).restype = c.c_size_t
+    lib.gsx_rasterize_fwd_packed_records.restype = c.c_void_p
+    u32, f32 = c.c_uint32, c.c_float
+    # Adam: n == 0 is a no-op, null pointers / split beyond cols / unaligned cols are errors
+    assert lib.gsx_adam_step(c.c_uint64(0), u32(3), c.c_uint64(3), c.c_uint64(3), None, None, None, None, f32(0), f32(0), f32(0), f32(0), f32(1), f32(1), None) == 0
+    assert lib.gsx_adam_step(c.c_uint64(4), u32(3), c.c_uint64(3), c.c_uint64(3), None, None, None, None, f32(0), f32(0), f32(0), f32(0), f32(1), f32(1), None) == -1
+    buf = (c.c_float * 64)()
+    assert lib.gsx_adam_step_split(c.c_uint64(2), u32(12), u32(13), buf, buf, buf, buf, f32(0), f32(0), 1, 1, f32(0), f32(0), f32(0), f32(1), f32(1), None) == -1
+    assert lib.gsx_adam_step_split(c.c_uint64(2), u32(9), u32(3), buf, buf, buf, buf, f32(0), f32(0), 1, 1, f32(0), f32(0), f32(0), f32(1), f32(1), None) == -2
+    # SSIM / loss
+    assert lib.gsx_fused_ssim_fwd(u32(0), u32(3), u32(8), u32(8), f32(1e-4), f32(9e-4), None, None, None, None, None, None, None) == 0
+    assert lib.gsx_fused_ssim_fwd(u32(1), u32(3), u32(8), u32(8), f32(1e-4), f32(9e-4), None, None, None, None, None, None, None) == -1
+    assert lib.gsx_fused_ssim_fwd(u32(1), u32(3), u32(8), u32(8), f32(1e-4), f32(9e-4), buf, buf, buf, buf, None, None, None) == -1   # 1 of 3 maps
+    need = lib.gsx_photometric_loss_workspace_bytes(u32(1), u32(32), u32(48))
+    assert need >= 9 * 32 * 48 * 4
+    assert lib.gsx_photometric_loss_fwd(u32(1), u32(32), u32(48), f32(0.2), buf, buf, buf, buf, c.c_size_t(16), None) == -3
+    assert b"workspace" in lib.gsx_last_error()
+    assert lib.gsx_photometric_loss_bwd(u32(1), u32(32), u32(48), f32(0.2), None, f32(1), buf, buf, None, c.c_size_t(need), buf, None) == -1
+    # binned intersection: tile grid limit, workspace, empty input
+    assert lib.gsx_intersect_bin_supported(u32(120), u32(68)) == 1 and lib.gsx_intersect_bin_supported(u32(480), u32(270)) == 0
+    off = (c.c_int32 * 16)()
+    assert lib.gsx_intersect_bin_count(u32(1), u32(8), buf, off, u32(16), u32(480), u32(270), None, off, None, buf, c.c_size_t(1 << 30), None) == -2
+    assert lib.gsx_intersect_bin_count(u32(1), u32(8), buf, off, u32(16), u32(2), u32(2), None, off, None, buf, c.c_size_t(8), None) == -3
+    assert lib.gsx_intersect_bin_fill(u32(1), u32(8), buf, off, buf, u32(16), u32(2), u32(2), off, c.c_int64(0), buf, off, None, None, c.c_size_t(0), None) == 0
+    assert lib.gsx_intersect_bin_fill_workspace_bytes(u32(1), u32(2), u32(2), c.c_int64(100)) >= 2 * 100 * 8
+    # blend workspaces
+    assert lib.gsx_rasterize_fwd_packed_records(None, c.c_size_t(0), u32(1), u32(8)) is None
+    assert lib.gsx_rasterize_bwd_workspace_bytes(u32(1), u32(1000), c.c_int64(5000)) >= 5000 * 64 + 1000 * 4 + 1000 * 64
