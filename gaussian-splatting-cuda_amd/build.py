@@ -69,7 +69,7 @@ def build_ops_module(force=False):
     import torch
     out = ops_module_path()
     src = os.path.join(CSRC, "ops_shim.cpp")
-    deps = [src, os.path.join(INCLUDE, "gsx.h"), os.path.join(INCLUDE, "gsx_ops.h")]
+    deps = [src, os.path.join(INCLUDE, "gsx.h"), os.path.join(INCLUDE, "gsx_ops.h"), os.path.join(INCLUDE, "gsx_training_ops.h")]
     if not (force or _newer(out, deps)):
         return out
     tp = os.path.dirname(torch.__file__)

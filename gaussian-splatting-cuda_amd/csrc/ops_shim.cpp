@@ -23,6 +23,7 @@
 
 #include "../../include/gsx.h"
 #include "../../include/gsx_ops.h"
+#include "../../include/gsx_training_ops.h"
 
 namespace {
 
@@ -632,6 +633,36 @@ void adam_step(at::Tensor param, at::Tensor exp_avg, at::Tensor exp_avg_sq, cons
 }  // namespace gsx_ext
 
 // ---------------------------------------------------------------------------------------------
+// Link-level drop-ins for the reference's Adam and SSIM operators (include/gsx_training_ops.h)
+// ---------------------------------------------------------------------------------------------
+namespace fast_gs::optimizer {
+
+void adam_step_wrapper(at::Tensor& param, at::Tensor& exp_avg, at::Tensor& exp_avg_sq, const at::Tensor& param_grad, const float lr,
+                       const float beta1, const float beta2, const float eps, const float bias_correction1_rcp,
+                       const float bias_correction2_sqrt_rcp) {
+    gsx_ext::adam_step(param, exp_avg, exp_avg_sq, param_grad, lr, beta1, beta2, eps, bias_correction1_rcp, bias_correction2_sqrt_rcp);
+}
+
+void adam_step(float* param, float* exp_avg, float* exp_avg_sq, const float* param_grad, const int n_elements, const float lr,
+               const float beta1, const float beta2, const float eps, const float bias_correction1_rcp,
+               const float bias_correction2_sqrt_rcp) {
+    if (n_elements <= 0) return;
+    check(gsx_adam_step(1, (uint32_t)n_elements, (uint64_t)n_elements, (uint64_t)n_elements, param, exp_avg, exp_avg_sq, param_grad, lr, beta1,
+                        beta2, eps, bias_correction1_rcp, bias_correction2_sqrt_rcp, cur_stream()), "adam_step");
+}
+
+}  // namespace fast_gs::optimizer
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> fusedssim(float C1, float C2, at::Tensor& img1, at::Tensor& img2, bool train) {
+    return gsx_ext::fusedssim(C1, C2, img1, img2, train);
+}
+
+at::Tensor fusedssim_backward(float C1, float C2, at::Tensor& img1, at::Tensor& img2, at::Tensor& dL_dmap, at::Tensor& dm_dmu1,
+                              at::Tensor& dm_dsigma1_sq, at::Tensor& dm_dsigma12) {
+    return gsx_ext::fusedssim_backward(C1, C2, img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Python bindings (names as in gsplat/Ops.h)
 // ---------------------------------------------------------------------------------------------
 #ifndef GSX_NO_PYBIND
@@ -704,6 +735,10 @@ PYBIND11_MODULE(_gsx_ops, m) {
         return gsplat::intersect_tile_device_sort(means2d, radii, depths, C, tile_size, tile_width, tile_height, sort);
     });
     m.def("adam_step", &gsx_ext::adam_step);
+    m.def("adam_step_wrapper", [](at::Tensor param, at::Tensor exp_avg, at::Tensor exp_avg_sq, const at::Tensor grad, float lr, float beta1, float beta2,
+                                  float eps, float bc1_rcp, float bc2_sqrt_rcp) {  // the reference's signature (adam_api.h:11-21)
+        fast_gs::optimizer::adam_step_wrapper(param, exp_avg, exp_avg_sq, grad, lr, beta1, beta2, eps, bc1_rcp, bc2_sqrt_rcp);
+    });
     m.def("adam_step_split", &gsx_ext::adam_step_split);
     m.def("fusedssim", &gsx_ext::fusedssim);
     m.def("fusedssim_backward", &gsx_ext::fusedssim_backward);

@@ -33,7 +33,10 @@ def test_gpu_adam_dense_and_strided_vs_oracle():
         m, v = (rng.random(shape) * 0.1).astype(np.float32), (rng.random(shape) * 0.01).astype(np.float32)
         P, M, V, G = (torch.from_numpy(a.copy()).to(dev) for a in (p, m, v, g))
         bc1, bc2 = 1.0 / (1 - 0.9 ** 3), 1.0 / np.sqrt(1 - 0.999 ** 3)
-        ops.adam_step(P, M, V, G, 1e-2, 0.9, 0.999, 1e-8, bc1, bc2)
+        if len(shape) == 1:   # the reference's own entry point (fast_gs::optimizer::adam_step_wrapper, adam_api.h:11-21)
+            ops.adam_step_wrapper(P, M, V, G, 1e-2, 0.9, 0.999, 1e-8, bc1, bc2)
+        else:
+            ops.adam_step(P, M, V, G, 1e-2, 0.9, 0.999, 1e-8, bc1, bc2)
         rp, rm, rv = oracle.adam_step(p, m, v, g, 1e-2, 0.9, 0.999, 1e-8, 3)
         np.testing.assert_allclose(P.cpu().numpy(), rp, rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(M.cpu().numpy(), rm, rtol=1e-6, atol=1e-8)

@@ -84,3 +84,20 @@ def test_argument_validation_of_the_next_tier_entry_points():
     # blend workspaces
     assert lib.gsx_rasterize_fwd_packed_records(None, c.c_size_t(0), u32(1), u32(8)) is None
     assert lib.gsx_rasterize_bwd_workspace_bytes(u32(1), u32(1000), c.c_int64(5000)) >= 5000 * 64 + 1000 * 4 + 1000 * 64
+
+
+def test_shim_exports_the_reference_operator_symbols():
+    """The C++ shim defines, with the reference's exact (mangled) signatures, every operator the `--gut` training step links
+    against: the ten gsplat:: functions of Ops.h, fast_gs::optimizer::adam_step(_wrapper) and fusedssim(_backward)."""
+    import glob
+    import subprocess
+    so = glob.glob(os.path.join(ROOT, "gaussian-splatting-cuda_amd", "_gsx_ops*.so"))[0]
+    syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    for needle in ["_ZN6gsplat23spherical_harmonics_fwd", "_ZN6gsplat23spherical_harmonics_bwd", "_ZN6gsplat14intersect_tile",
+                   "_ZN6gsplat16intersect_offset", "_ZN6gsplat24projection_ut_3dgs_fused",
+                   "_ZN6gsplat39rasterize_to_pixels_from_world_3dgs_fwd", "_ZN6gsplat39rasterize_to_pixels_from_world_3dgs_bwd",
+                   "_ZN6gsplat16quats_to_rotmats", "_ZN6gsplat10relocation", "_ZN6gsplat9add_noise",
+                   "_ZN7fast_gs9optimizer17adam_step_wrapperERN2at6TensorES3_S3_RKS2_ffffff",
+                   "_ZN7fast_gs9optimizer9adam_stepEPfS1_S1_PKfiffffff", "_Z9fusedssimffRN2at6TensorES1_b",
+                   "_Z18fusedssim_backwardffRN2at6TensorES1_S1_S1_S1_S1_"]:
+        assert needle in syms, needle
