@@ -107,15 +107,15 @@ __global__ __launch_bounds__(ISECT_BLOCK) void isect_offset_kernel(int64_t n_ise
 //   3. scan     exclusive scan of the C*tiles totals = the reference's isect_offsets (+ the grand total = n_isects);
 //   4. scatter  the same blocks reload (tile offset + block prefix) as LDS cursors, claim slots with returning LDS atomics and
 //               write 64-bit keys (depth bits << idx_bits | flatten index) into their tile's segment — unordered inside it;
-//   5. sort     one block per tile: bitonic sort of the segment in LDS (segments above 4096 keys: LDS-sorted chunks, then
-//               rank merges through the two key buffers), then flatten_ids = low bits, isect_ids (on request) =
+//   5. sort     one wave per tile (up to 1024 keys; a 256-thread block up to 4096): merge sort of the segment in LDS (segments
+//               above 4096 keys: LDS-sorted chunks, then rank merges through the two key buffers), then flatten_ids = low bits, isect_ids (on request) =
 //               (camera|tile) << 32 | depth bits.  Keys are unique, so the result is exactly the stable sort upstream.
 // No global atomics anywhere (device-scope atomics resolve at the memory side on MI355X: ~14 G/s measured, 0.24 ms for the
 // 3.4 M increments of a naive tile counter).  Tile grids above 36 K tiles per camera (LDS) use the device-wide sort instead.
 constexpr uint32_t BIN_NB = 256;          // Gaussian slices (blocks) per camera
 constexpr uint32_t BIN_MAX_TILES = 36864; // 144 KB of LDS counters
 constexpr int TSORT_CAP = 4096;           // keys sorted in LDS per block (32 KB)
-constexpr int TSORT_WAVE_CAP = 1024;      // keys sorted by one wave without block barriers (8 KB)
+constexpr int TSORT_WAVE_CAP = 1024;      // keys sorted by one wave without block barriers (8 KB); measured faster than a block up to here
 constexpr int BIN_BLOCK = 1024;           // count / scatter: 16 waves share one LDS counter array
 
 __global__ __launch_bounds__(BIN_BLOCK) void bin_count_kernel(uint32_t N, uint32_t per_block, const float* __restrict__ means2d,
@@ -205,32 +205,31 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_scatter_kernel(uint32_t N, uint
     }
 }
 
-// in-LDS bitonic sort of m (power of two, <= TSORT_CAP) keys, ascending
-GSX_DEV void bitonic_sort_lds(uint64_t* s, int m) {
-    for (int k = 2; k <= m; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < (m >> 1); i += ISECT_BLOCK) {
-                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));  // index with bit j clear
-                const int hi = lo | j;
-                const uint64_t a = s[lo], b = s[hi];
-                const bool up = (lo & k) == 0;
-                if ((a > b) == up) { s[lo] = b; s[hi] = a; }
-            }
-            __syncthreads();
-        }
-}
-
 // One wave per segment of up to TSORT_WAVE_CAP keys, no s_barrier (a single wavefront's LDS operations are ordered).
 // Merge sort instead of a bitonic network: the network moves all m keys through LDS log2(m)(log2(m)+1)/2 times (45 times at
 // m = 512: the kernel was LDS-bandwidth bound), the merge sort log2(64) + 1 times — every lane sorts its E keys in registers,
 // then six merge passes; in each pass a lane finds its merge-path split by binary search and produces E consecutive outputs.
-template <int E>
-GSX_DEV void merge_sort_wave(uint64_t* s, int lane) {
+// LDS layout: one pad key after every 32 (index i lives at i + (i >> 5)).  A lane's keys sit E apart from its neighbour's and
+// the merge cursors of neighbouring lanes about E/2 apart: without the pad, lanes 32/E (or 64/E) apart hit the same banks
+// (8 B keys, 64 banks x 4 B) — 72 % of the LDS cycles of this kernel were bank-conflict cycles at E = 8..16.
+GSX_DEV int spad(int i) { return i + (i >> 5); }
+
+template <int NT>
+GSX_DEV void group_sync() {
+    if (NT == 64) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // one wavefront: its LDS operations are ordered
+    else __syncthreads();
+}
+
+// Sort NT * E keys in LDS with NT threads (NT = 64: one wave, no barrier; NT = 256: a block).  Thread t first sorts keys
+// [t E, (t+1) E) in registers, then log2(NT) merge passes: it finds the merge-path split of its E outputs by binary search and
+// merges them sequentially.
+template <int E, int NT>
+GSX_DEV void merge_sort_lds(uint64_t* s, int t) {
     uint64_t r[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) r[e] = s[lane * E + e];
+    for (int e = 0; e < E; ++e) r[e] = s[spad(t * E + e)];
 #pragma unroll
-    for (int round = 0; round < E; ++round)  // odd-even transposition network on the lane's own keys
+    for (int round = 0; round < E; ++round)  // odd-even transposition network on the thread's own keys
 #pragma unroll
         for (int e = round & 1; e + 1 < E; e += 2) {
             const uint64_t x = r[e], y = r[e + 1];
@@ -238,34 +237,33 @@ GSX_DEV void merge_sort_wave(uint64_t* s, int lane) {
             r[e + 1] = x < y ? y : x;
         }
 #pragma unroll
-    for (int e = 0; e < E; ++e) s[lane * E + e] = r[e];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (int run = E; run < 64 * E; run <<= 1) {
-        const int o = lane * E;
+    for (int e = 0; e < E; ++e) s[spad(t * E + e)] = r[e];
+    group_sync<NT>();
+    for (int run = E; run < NT * E; run <<= 1) {
+        const int o = t * E;
         const int pair0 = o & ~(2 * run - 1);
-        const int d = o - pair0;  // diagonal of this lane's first output inside the pair of runs
-        const uint64_t* A = s + pair0;
-        const uint64_t* B = A + run;
+        const int d = o - pair0;  // diagonal of this thread's first output inside the pair of runs
+        const int A = pair0, B = pair0 + run;  // run starts
         int lo = max(0, d - run), hi = min(d, run);
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if (A[mid] <= B[d - 1 - mid]) lo = mid + 1; else hi = mid;
+            if (s[spad(A + mid)] <= s[spad(B + d - 1 - mid)]) lo = mid + 1; else hi = mid;
         }
         int ai = lo, bi = d - lo;
-        uint64_t a = ai < run ? A[ai] : ~0ull, b = bi < run ? B[bi] : ~0ull;
+        uint64_t a = ai < run ? s[spad(A + ai)] : ~0ull, b = bi < run ? s[spad(B + bi)] : ~0ull;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const bool ta = a <= b;
             r[e] = ta ? a : b;
             const int nxt = ta ? ++ai : ++bi;
-            const uint64_t v = nxt < run ? (ta ? A : B)[nxt] : ~0ull;
+            const uint64_t v = nxt < run ? s[spad((ta ? A : B) + nxt)] : ~0ull;
             a = ta ? v : a;
             b = ta ? b : v;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // every lane has finished reading this pass
+        group_sync<NT>();  // every thread has finished reading this pass
 #pragma unroll
-        for (int e = 0; e < E; ++e) s[lane * E + e] = r[e];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int e = 0; e < E; ++e) s[spad(t * E + e)] = r[e];
+        group_sync<NT>();
     }
 }
 
@@ -273,7 +271,7 @@ __global__ __launch_bounds__(256) void tile_sort_wave_kernel(uint32_t n_segments
                                                              const int32_t* __restrict__ tile_offsets, const uint64_t* __restrict__ keys,
                                                              int32_t* __restrict__ flatten_ids, int64_t* __restrict__ isect_ids,
                                                              int64_t capacity) {
-    __shared__ uint64_t s_all[4][TSORT_WAVE_CAP];
+    __shared__ uint64_t s_all[4][TSORT_WAVE_CAP + TSORT_WAVE_CAP / 32];
     const uint32_t seg = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (seg >= n_segments) return;
     const int64_t begin = tile_offsets[seg];
@@ -283,18 +281,18 @@ __global__ __launch_bounds__(256) void tile_sort_wave_kernel(uint32_t n_segments
     const int lane = threadIdx.x & 63;
     int m = 128;
     while (m < n) m <<= 1;
-    for (int i = lane; i < m; i += 64) s_keys[i] = i < n ? keys[begin + i] : ~0ull;
+    for (int i = lane; i < m; i += 64) s_keys[spad(i)] = i < n ? keys[begin + i] : ~0ull;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     switch (m) {
-    case 128: merge_sort_wave<2>(s_keys, lane); break;
-    case 256: merge_sort_wave<4>(s_keys, lane); break;
-    case 512: merge_sort_wave<8>(s_keys, lane); break;
-    default: merge_sort_wave<16>(s_keys, lane); break;
+    case 128: merge_sort_lds<2, 64>(s_keys, lane); break;
+    case 256: merge_sort_lds<4, 64>(s_keys, lane); break;
+    case 512: merge_sort_lds<8, 64>(s_keys, lane); break;
+    default: merge_sort_lds<16, 64>(s_keys, lane); break;
     }
     const uint64_t idx_mask = (1ull << idx_bits) - 1ull;
     const int64_t cam_tile = (((int64_t)(seg / n_tiles) << tile_n_bits) | (int64_t)(seg % n_tiles)) << 32;
     for (int i = lane; i < n; i += 64) {
-        const uint64_t k = s_keys[i];
+        const uint64_t k = s_keys[spad(i)];
         flatten_ids[begin + i] = (int32_t)(k & idx_mask);
         if (isect_ids) isect_ids[begin + i] = cam_tile | (int64_t)(k >> idx_bits);
     }
@@ -304,21 +302,22 @@ __global__ __launch_bounds__(ISECT_BLOCK) void tile_sort_kernel(uint32_t n_tiles
                                                                 const int32_t* __restrict__ tile_offsets, uint64_t* __restrict__ keys,
                                                                 uint64_t* __restrict__ keys_alt, int32_t* __restrict__ flatten_ids,
                                                                 int64_t* __restrict__ isect_ids, int64_t capacity) {
-    __shared__ uint64_t s_keys[TSORT_CAP];
+    __shared__ uint64_t s_keys[TSORT_CAP + TSORT_CAP / 32];
     const uint32_t seg = blockIdx.x;
     const int64_t begin = tile_offsets[seg];
     const int n = (int)(tile_offsets[seg + 1] - tile_offsets[seg]);
     if (n <= TSORT_WAVE_CAP || begin + n > capacity) return;  // small segments: tile_sort_wave_kernel
     const uint64_t idx_mask = (1ull << idx_bits) - 1ull;
     const int64_t cam_tile = (((int64_t)(seg / n_tiles) << tile_n_bits) | (int64_t)(seg % n_tiles)) << 32;
+    const int t = threadIdx.x;
     if (n <= TSORT_CAP) {
-        int m = 2;
-        while (m < n) m <<= 1;
-        for (int i = threadIdx.x; i < m; i += ISECT_BLOCK) s_keys[i] = i < n ? keys[begin + i] : ~0ull;
+        const int m = n <= 2048 ? 2048 : 4096;
+        for (int i = t; i < m; i += ISECT_BLOCK) s_keys[spad(i)] = i < n ? keys[begin + i] : ~0ull;
         __syncthreads();
-        bitonic_sort_lds(s_keys, m);
-        for (int i = threadIdx.x; i < n; i += ISECT_BLOCK) {
-            const uint64_t k = s_keys[i];
+        if (m == 2048) merge_sort_lds<8, ISECT_BLOCK>(s_keys, t);
+        else merge_sort_lds<16, ISECT_BLOCK>(s_keys, t);
+        for (int i = t; i < n; i += ISECT_BLOCK) {
+            const uint64_t k = s_keys[spad(i)];
             flatten_ids[begin + i] = (int32_t)(k & idx_mask);
             if (isect_ids) isect_ids[begin + i] = cam_tile | (int64_t)(k >> idx_bits);
         }
@@ -329,10 +328,10 @@ __global__ __launch_bounds__(ISECT_BLOCK) void tile_sort_kernel(uint32_t n_tiles
     uint64_t* dst = keys_alt + begin;
     for (int c0 = 0; c0 < n; c0 += TSORT_CAP) {
         const int cn = min(TSORT_CAP, n - c0);
-        for (int i = threadIdx.x; i < TSORT_CAP; i += ISECT_BLOCK) s_keys[i] = i < cn ? src[c0 + i] : ~0ull;
+        for (int i = t; i < TSORT_CAP; i += ISECT_BLOCK) s_keys[spad(i)] = i < cn ? src[c0 + i] : ~0ull;
         __syncthreads();
-        bitonic_sort_lds(s_keys, TSORT_CAP);
-        for (int i = threadIdx.x; i < cn; i += ISECT_BLOCK) src[c0 + i] = s_keys[i];
+        merge_sort_lds<16, ISECT_BLOCK>(s_keys, t);
+        for (int i = t; i < cn; i += ISECT_BLOCK) src[c0 + i] = s_keys[spad(i)];
         __syncthreads();
     }
     for (int run = TSORT_CAP; run < n; run <<= 1) {
