@@ -228,14 +228,21 @@ GSX_DEV void merge_sort_lds(uint64_t* s, int t) {
     uint64_t r[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) r[e] = s[spad(t * E + e)];
+    // Batcher's odd-even merge sort network on the thread's own keys (E a power of two: 1 / 5 / 19 / 63 compare-exchanges for
+    // E = 2 / 4 / 8 / 16; all indices are compile-time constants after unrolling)
 #pragma unroll
-    for (int round = 0; round < E; ++round)  // odd-even transposition network on the thread's own keys
+    for (int p = 1; p < E; p <<= 1)
 #pragma unroll
-        for (int e = round & 1; e + 1 < E; e += 2) {
-            const uint64_t x = r[e], y = r[e + 1];
-            r[e] = x < y ? x : y;
-            r[e + 1] = x < y ? y : x;
-        }
+        for (int k = p; k >= 1; k >>= 1)
+#pragma unroll
+            for (int j = k % p; j + k < E; j += 2 * k)
+#pragma unroll
+                for (int i = 0; i < k; ++i)
+                    if (i + j + k < E && (i + j) / (2 * p) == (i + j + k) / (2 * p)) {
+                        const uint64_t x = r[i + j], y = r[i + j + k];
+                        r[i + j] = x < y ? x : y;
+                        r[i + j + k] = x < y ? y : x;
+                    }
 #pragma unroll
     for (int e = 0; e < E; ++e) s[spad(t * E + e)] = r[e];
     group_sync<NT>();
