@@ -345,7 +345,7 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
                 const float alpha = fast_alpha(u, v, r0, r1, r2, du, dv, num2, rden);
                 // branch-free compositing step (Fwd.cu:240-259): lanes that skip this Gaussian run with weight 0
                 const bool contrib = !done && alpha >= ALPHA_MIN;
-                const float next_T = T * (1.f - alpha);
+                const float next_T = fmaf(-alpha, T, T);  // T (1 - alpha) with one rounding, one VALU slot
                 const bool stop = contrib && next_T <= 1e-4f;
                 const bool take = contrib && !stop;
                 const float w = take ? alpha * T : 0.f;
