@@ -212,3 +212,44 @@ def test_colmap_text_reader_matches_binary(tmp_path):
     assert np.array_equal(a.points, b.points) and np.array_equal(a.colors, b.colors)
     with pytest.raises(RuntimeError):
         io_colmap.load_colmap(str(tmp_path / "nowhere"))
+
+
+def test_transforms_json_reader(tmp_path):
+    import json
+    import gsx  # noqa: F401
+    from gsx import io_transforms
+    rng = np.random.default_rng(4)
+    frames = []
+    for i in range(3):
+        q = rng.standard_normal(4)
+        q /= np.linalg.norm(q)
+        from gsx.io_colmap import qvec2rotmat
+        c2w = np.eye(4)
+        c2w[:3, :3] = qvec2rotmat(q.astype(np.float32))
+        c2w[:3, 3] = rng.standard_normal(3)
+        frames.append({"file_path": f"./train/r_{i}", "transform_matrix": c2w.tolist()})
+    (tmp_path / "transforms_train.json").write_text(json.dumps({"camera_angle_x": 0.6911, "w": 800, "h": 800, "frames": frames}))
+    sc = io_transforms.load_transforms(str(tmp_path))
+    assert len(sc.cameras) == 3 and sc.cameras[0].image_name == "r_0"
+    K = sc.cameras[0].camera.K.numpy()
+    f = 0.5 * 800 / np.tan(0.5 * 0.6911)
+    assert abs(K[0, 0] - f) < 1e-3 and K[1, 1] == K[0, 0] and (K[0, 2], K[1, 2]) == (400.0, 400.0)
+    for fr, c in zip(frames, sc.cameras):
+        c2w = np.array(fr["transform_matrix"])
+        vm = c.camera.viewmat.numpy().astype(np.float64)
+        # the reference also turns the WORLD by pi about y (w2c * RotY(pi), transforms.cpp:209-210): centre and viewing direction
+        # (the camera looks along -z of the Blender camera frame = +z of ours) come out with x and z negated
+        flip = np.array([-1.0, 1.0, -1.0])
+        np.testing.assert_allclose(-vm[:3, :3].T @ vm[:3, 3], flip * c2w[:3, 3], atol=1e-5)
+        np.testing.assert_allclose(vm[2, :3], flip * -c2w[:3, 2], atol=1e-5)
+        assert abs(np.linalg.det(vm[:3, :3]) - 1.0) < 1e-5
+    (tmp_path / "bad.json").write_text(json.dumps({"camera_angle_x": 0.7, "w": 800, "h": 600, "frames": frames}))
+    with pytest.raises(RuntimeError, match="camera_angle_y"):
+        io_transforms.load_transforms(str(tmp_path / "bad.json"))
+    (tmp_path / "dist.json").write_text(json.dumps({"fl_x": 500, "fl_y": 500, "w": 8, "h": 8, "k1": 0.1, "frames": frames}))
+    with pytest.raises(RuntimeError, match="distortion"):
+        io_transforms.load_transforms(str(tmp_path / "dist.json"))
+    pts, cols = io_transforms.generate_random_point_cloud()
+    assert pts.shape == (10000, 3) and cols.dtype == np.uint8 and np.abs(pts).max() <= 1.0
+    torch.manual_seed(8128)
+    assert np.array_equal(pts, (torch.rand(10000, 3) * 2.0 - 1.0).numpy())              # the reference's draw (torch seed 8128)
