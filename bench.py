@@ -116,6 +116,33 @@ def cpu_baseline(scene, threads):
     return dt, int(o["flatten_ids"].shape[0])
 
 
+def cpu_reference_stages(scene_small):
+    """The stages the reference's own CPU code (tests/torch_impl.cpp compiled unmodified into oracle/_ref) implements —
+    EWA projection (not the UT projection of the hot path), SH evaluation, tile intersection (a serial loop upstream) — timed on
+    the reference's CPU-runnable case (cfg1 / S-small, 10 k Gaussians @256x256).  There is no CPU rasterizer upstream to time."""
+    import numpy as np
+    from oracle import ref
+    if not ref.available():
+        return None
+    f = lambda k: np.ascontiguousarray(scene_small[k].numpy(), np.float32)  # noqa: E731
+    means, quats, scales = f("means"), f("quats"), f("scales")
+    vm, K = f("viewmat")[None], f("K")[None]
+    W, H = scene_small["width"], scene_small["height"]
+    out = {}
+    t0 = time.perf_counter()
+    radii, m2d, dep, _ = ref.ewa_projection(means, quats, scales, vm, K, W, H)
+    out["ewa_projection_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+    dirs = means - np.linalg.inv(vm[0].astype(np.float64))[:3, 3].astype(np.float32)
+    t0 = time.perf_counter()
+    ref.spherical_harmonics(scene_small["sh_degree"], dirs, f("sh"))
+    out["spherical_harmonics_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+    t0 = time.perf_counter()
+    ref.isect_tiles(m2d, radii, dep, 16, (W + 15) // 16, (H + 15) // 16, True)
+    out["isect_tiles_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+    out["workload"] = "S-small (BASELINE configs[0]): %d Gaussians, %dx%d" % (means.shape[0], W, H)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -296,6 +323,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             threads = os.cpu_count() or 1
             dt, i_cpu = cpu_baseline(scene, threads)
+            try:
+                stages = cpu_reference_stages(scenes.scene_small())
+            except Exception as e:  # the reference build is optional on the GPU box
+                stages = {"error": str(e)[:200]}
+            if stages:
+                result["cpu_reference_stages"] = stages
             result["cpu_baseline"] = {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": threads, "kind": "port",
                                       "sample": "oracle (CPU restatement, OpenMP) forward+backward of ONE full frame of the "
                                                 "same workload (%d isects): %.2f s" % (i_cpu, dt)}
