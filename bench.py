@@ -152,7 +152,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL)")
     ap.add_argument("--unfused", action="store_true", help="reference-style glue (one torch op per activation / SH pre-post step)")
-    ap.add_argument("--dense-allreduce", action="store_true", help="all-reduce the whole gradient bucket instead of the visible rows")
+    ap.add_argument("--sparse-allreduce", action="store_true", help="exchange only the gradient rows of Gaussians some camera saw")
     ap.add_argument("--l1-loss", action="store_true", help="plain torch L1 loss instead of the reference's fused L1 + SSIM loss")
     ap.add_argument("--no-train-iter", action="store_true", help="skip the extra full-iteration timing (loss + backward + Adam)")
     args = ap.parse_args()
@@ -202,10 +202,12 @@ def main():
         loss = gloss.photometric_loss(out.render_hwc, target, 0.2) if fused_loss else (out.image - target).abs().mean()
         loss.backward()
         if world > 1:
-            if args.dense_allreduce or args.unfused:
-                bucket.all_reduce_mean()
-            else:  # rows no camera of the step sees are zero on every rank: only the union of the visible rows travels
+            if args.sparse_allreduce and not args.unfused:
+                # rows no camera of the step sees are zero on every rank: only the union of the visible rows travels (in S-1M every
+                # camera sees ~all Gaussians, so this falls back to the dense collective after one probe)
                 bucket.all_reduce_mean_rows((out.aux["radii_full"] > 0).all(-1))
+            else:
+                bucket.all_reduce_mean()
         state["n_isects"] = out.n_isects
 
     for _ in range(args.warmup):

@@ -49,10 +49,21 @@ class GradBucket:
     def zero_(self):
         self.flat.zero_()
 
-    @staticmethod
-    def _reduce_mean(t):
+    _avg_ok = None  # does the backend average inside the collective?  Probed once, identically on every rank.
+
+    @classmethod
+    def _reduce_mean(cls, t):
         """In-place mean over the ranks.  RCCL averages inside the collective (no extra pass over the bucket); gloo sums."""
-        if dist.get_backend() == "nccl":
+        if cls._avg_ok is None:
+            cls._avg_ok = False
+            if dist.get_backend() == "nccl":
+                try:
+                    probe = torch.ones(1, dtype=t.dtype, device=t.device)
+                    dist.all_reduce(probe, op=dist.ReduceOp.AVG)
+                    cls._avg_ok = True
+                except Exception:  # noqa: BLE001  (an RCCL build without ncclAvg: every rank lands here)
+                    cls._avg_ok = False
+        if cls._avg_ok:
             dist.all_reduce(t, op=dist.ReduceOp.AVG)
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
