@@ -507,13 +507,13 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
 
     const float T_final = 1.f - render_alphas[pix];
     float T = T_final;
-    float buf_r = 0.f, buf_g = 0.f, buf_b = 0.f;
     const int32_t bin_final = active ? last_ids[pix] : -1;
     const float vr = v_render_colors[pix * 3], vg = v_render_colors[pix * 3 + 1], vb = v_render_colors[pix * 3 + 2];
     const float va = v_render_alphas ? v_render_alphas[pix] : 0.f;
     float tail = va;  // T_final * ra * (v_alpha_out - bg . v_out)   (Bwd.cu:307-316)
     if (bg) tail -= bg[0] * vr + bg[1] * vg + bg[2] * vb;
     tail *= T_final;
+    float tbuf = tail;  // tail - v . (colour buffer behind the current Gaussian)
 
     // moment whose total this lane's quad holds after butterfly_reduce16: 4 * quad + {0,2,1,3}[row]
     const uint32_t bf_row = lane >> 4;
@@ -574,13 +574,15 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
                 const float fac = al * T;
                 float x[16];
                 x[0] = fac * vr; x[1] = fac * vg; x[2] = fac * vb;
-                float v_alpha = (r2.w * T - buf_r * ra) * vr + (r3.x * T - buf_g * ra) * vg + (r3.y * T - buf_b * ra) * vb;
-                v_alpha = fmaf(tail, ra, v_alpha);
-                buf_r = fmaf(r2.w, fac, buf_r); buf_g = fmaf(r3.x, fac, buf_g); buf_b = fmaf(r3.y, fac, buf_b);
+                // dL/dalpha = sum_c v_c (colour_c T - buffer_c ra) + tail ra  (Bwd.cu:286-316) only needs the scalars
+                // cv = v . colour and tbuf = tail - v . buffer: one accumulator instead of the three colour buffers
+                const float cv = fmaf(r3.y, vb, fmaf(r3.x, vg, r2.w * vr));
+                const float v_alpha = fmaf(T, cv, ra * tbuf);
+                tbuf = fmaf(-cv, fac, tbuf);
                 // clamped alpha (>= 0.999) carries no gradient to opacity / geometry (Bwd.cu:318)
-                const float av = (al < 0.999f) ? al * v_alpha : 0.f;   // o * v_opacity;  dalpha/dD = -alpha/2
-                const float aw = -0.5f * av * rden;                    // a = (dL/dD) / den'
-                const float bw = aw * (num2 * rden);                   // b = a * D * (0.5 log2 e)
+                const float av = (al < 0.999f) ? al * v_alpha : 0.f;   // o * v_opacity
+                const float aw = av * rden;                            // -2 (dL/dD) / den'  (dalpha/dD = -alpha/2: the gather kernel applies the -1/2)
+                const float bw = aw * (num2 * rden);                   // the same times D (0.5 log2 e)
                 const float uu = du * du, uv = du * dv, vv = dv * dv;
                 x[3] = av;
                 x[4] = aw * uu; x[5] = aw * uv; x[6] = aw * vv; x[7] = aw * du; x[8] = aw * dv;
@@ -656,7 +658,7 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
         const float tb0[4] = {0.f, 0.f, 0.f, 0.f};
         FastRec r;
         make_record<true>(raw, cf, tb0, r);
-        const float kap = 2.f * r.inv_d0;
+        const float kap = -r.inv_d0;  // 2 / d0 times the -1/2 of dalpha/dD that the blend kernel leaves out of its moment weights
         const float Mauu = Mo[4] * kap, Mauv = Mo[5] * kap, Mavv = Mo[6] * kap, Mau = Mo[7] * kap, Mav = Mo[8] * kap;
         const float kb = kap / HALF_LOG2E;  // b was accumulated with D scaled by 0.5 log2 e
         const float Mb1 = Mo[9] * kb, Mbu = Mo[10] * kb, Mbv = Mo[11] * kb, Mbuu = Mo[12] * kb, Mbuv = Mo[13] * kb, Mbvv = Mo[14] * kb;
