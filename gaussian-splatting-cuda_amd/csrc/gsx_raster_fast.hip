@@ -583,10 +583,11 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
                 const float av = (al < 0.999f) ? al * v_alpha : 0.f;   // o * v_opacity
                 const float aw = av * rden;                            // -2 (dL/dD) / den'  (dalpha/dD = -alpha/2: the gather kernel applies the -1/2)
                 const float bw = aw * (num2 * rden);                   // the same times D (0.5 log2 e)
-                const float uu = du * du, uv = du * dv, vv = dv * dv;
                 x[3] = av;
-                x[4] = aw * uu; x[5] = aw * uv; x[6] = aw * vv; x[7] = aw * du; x[8] = aw * dv;
-                x[9] = bw; x[10] = bw * du; x[11] = bw * dv; x[12] = bw * uu; x[13] = bw * uv; x[14] = bw * vv;
+                x[7] = aw * du; x[8] = aw * dv;                         // first-order moments, then the second-order ones from them
+                x[4] = x[7] * du; x[5] = x[7] * dv; x[6] = x[8] * dv;   // (10 products instead of 13 with du^2, du dv, dv^2 formed first)
+                x[9] = bw; x[10] = bw * du; x[11] = bw * dv;
+                x[12] = x[10] * du; x[13] = x[10] * dv; x[14] = x[11] * dv;
                 x[15] = 0.f;
                 const float total = butterfly_reduce16(x);
                 if ((lane & 3u) == 0u) atomicAdd(&s_acc[mom_of_lane][t], total);  // 16 lanes, one moment each
