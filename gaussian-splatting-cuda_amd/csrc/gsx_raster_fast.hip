@@ -347,7 +347,7 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
                 const bool contrib = !done && alpha >= ALPHA_MIN;
                 const float next_T = fmaf(-alpha, T, T);  // T (1 - alpha) with one rounding, one VALU slot
                 const bool stop = contrib && next_T <= 1e-4f;
-                const bool take = contrib && !stop;
+                const bool take = contrib != stop;  // stop implies contrib: xor of the two lane masks on the scalar unit (no second compare)
                 const float w = take ? alpha * T : 0.f;
                 out_r = fmaf(r2.w, w, out_r); out_g = fmaf(r3.x, w, out_g); out_b = fmaf(r3.y, w, out_b);
                 T = take ? next_T : T;
