@@ -39,9 +39,8 @@ def main():
     tr = trainer.Trainer(model, cams, images, params, bg, seed=0)
 
     def evaluate():
-        with torch.no_grad():
-            out = [rasterizer.rasterize_fused(c, model, bg).image for c in cams]
-        return (sum(metrics.psnr(o, t) for o, t in zip(out, images)) / len(cams), sum(metrics.ssim(o, t) for o, t in zip(out, images)) / len(cams))
+        r = metrics.evaluate(model, cams, images, bg)
+        return r["psnr"], r["ssim"]
 
     print("before: PSNR %.2f dB  SSIM %.4f" % evaluate())
     tr.train(iters, log_every=max(1, iters // 4))

@@ -121,3 +121,25 @@ def load_ply(path, device="cpu"):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)  # noqa: E731
     return SplatData(means=t(means), sh=t(sh), scaling_raw=t(scaling), rotation_raw=t(rotation), opacity_raw=t(opacity),
                      active_sh_degree=degree)
+
+
+def load_point_cloud_ply(path):
+    """load_simple_ply_point_cloud (src/loader/formats/transforms.cpp:264-380): positions float32 [N,3] and colours uint8 [N,3]
+    (red / green / blue properties, white when absent) of a plain point-cloud PLY, e.g. the `points3d.ply` of a Blender scene."""
+    if not os.path.exists(path):
+        raise RuntimeError(f"PLY file not found: {path}")
+    buf = np.memmap(path, dtype=np.uint8, mode="r")
+    off, count, props = _parse_header(bytes(buf[:min(len(buf), 1 << 20)]))
+    dt = np.dtype({"names": [p[0] for p in props], "formats": [p[1] for p in props]})
+    if off + count * dt.itemsize > len(buf):
+        raise RuntimeError("PLY: file truncated")
+    v = np.frombuffer(buf, dtype=dt, count=count, offset=off)
+    if not all(n in dt.names for n in ("x", "y", "z")):
+        raise RuntimeError("PLY file missing vertex positions")
+    xyz = np.stack([v["x"], v["y"], v["z"]], 1).astype(np.float32)
+    if all(n in dt.names for n in ("red", "green", "blue")):
+        rgb = np.stack([v["red"], v["green"], v["blue"]], 1)
+        rgb = rgb.astype(np.uint8) if rgb.dtype.kind in "ui" else np.clip(rgb * 255.0, 0, 255).astype(np.uint8)
+    else:
+        rgb = np.full((count, 3), 255, np.uint8)
+    return np.ascontiguousarray(xyz), np.ascontiguousarray(rgb)

@@ -19,3 +19,22 @@ def psnr(pred, target, data_range=1.0):
 def ssim(pred, target):
     with torch.no_grad():
         return float(loss.fused_ssim(pred, target, "same", train=False))
+
+
+def evaluate(model, cameras, images, background=None):
+    """MetricsEvaluator::evaluate (metrics.cpp:400-470) without LPIPS: mean PSNR / SSIM of the rendered test views and the time
+    per rendered image."""
+    import time
+
+    from . import rasterizer
+    ps, ss = [], []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for cam, gt in zip(cameras, images):
+            img = rasterizer.rasterize_fused(cam, model, background).image
+            ps.append(psnr(img, gt))
+            ss.append(ssim(img, gt))
+    torch.cuda.synchronize()
+    n = max(1, len(ps))
+    return {"psnr": sum(ps) / n, "ssim": sum(ss) / n, "elapsed_time_per_image_s": (time.perf_counter() - t0) / n, "num_images": len(ps)}

@@ -253,3 +253,25 @@ def test_transforms_json_reader(tmp_path):
     assert pts.shape == (10000, 3) and cols.dtype == np.uint8 and np.abs(pts).max() <= 1.0
     torch.manual_seed(8128)
     assert np.array_equal(pts, (torch.rand(10000, 3) * 2.0 - 1.0).numpy())              # the reference's draw (torch seed 8128)
+
+
+def test_point_cloud_ply_reader(tmp_path):
+    import gsx  # noqa: F401
+    from gsx import io_ply
+    dt = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("red", "u1"), ("green", "u1"), ("blue", "u1")])
+    v = np.zeros(7, dt)
+    rng = np.random.default_rng(1)
+    for n in ("x", "y", "z"):
+        v[n] = rng.standard_normal(7)
+    for n in ("red", "green", "blue"):
+        v[n] = rng.integers(0, 255, 7)
+    header = "ply\nformat binary_little_endian 1.0\nelement vertex 7\n" + "".join(
+        f"property {'float' if dt[n].kind == 'f' else 'uchar'} {n}\n" for n in dt.names) + "end_header\n"
+    (tmp_path / "pc.ply").write_bytes(header.encode() + v.tobytes())
+    xyz, rgb = io_ply.load_point_cloud_ply(str(tmp_path / "pc.ply"))
+    assert np.array_equal(xyz, np.stack([v["x"], v["y"], v["z"]], 1)) and np.array_equal(rgb, np.stack([v["red"], v["green"], v["blue"]], 1))
+    dt2 = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4")])
+    header2 = "ply\nformat binary_little_endian 1.0\nelement vertex 2\nproperty float x\nproperty float y\nproperty float z\nend_header\n"
+    (tmp_path / "nocol.ply").write_bytes(header2.encode() + np.zeros(2, dt2).tobytes())
+    xyz2, rgb2 = io_ply.load_point_cloud_ply(str(tmp_path / "nocol.ply"))
+    assert xyz2.shape == (2, 3) and np.all(rgb2 == 255)
