@@ -2,9 +2,13 @@
 """bench.py — the hot path's headline benchmark (BASELINE.json): forward + backward of the `--gut`
 rasterizer at 1 M Gaussians / SH degree 3 / 1920x1080 (configs[1], "S-1M"), on N GPUs of one node.
 
-A step = one pass of the hot path over one camera per rank:
+A step = one TRAINING ITERATION of the hot path over one camera per rank (the "train iters/s" of BASELINE's metric):
     activations -> projection_ut -> SH colours (+0.5, clamp) -> intersect_tile (+sort) -> intersect_offset -> blend fwd
-    -> L1 loss -> blend bwd -> SH bwd -> activation Jacobians [-> gradient all-reduce when N > 1]
+    -> photometric loss (0.8 L1 + 0.2 (1 - SSIM)) -> blend bwd -> SH bwd -> activation Jacobians
+    [-> gradient all-reduce when N > 1] -> fused Adam on all six parameter groups
+The camera changes EVERY step (8 poses on a 0.4 m orbit around the cfg2 pose, pose 0 = cfg2 itself), so n_isects differs from
+step to step and intersect_tile's capacity hint is not trivially right; hint misses and host synchronisations per step are
+reported.  The second half of BASELINE's metric, fwd+bwd ms/frame (no optimizer), is measured in a separate loop (`fwd_bwd`).
 Default: the fused glue kernels of rasterize_fused (gradients written straight into the flat all-reduce bucket);
 --unfused runs the reference-style chain of torch ops around the seven gsplat operators.
 Inputs are resident in HBM before the timed region.  N > 1: launched by torch.distributed.run, one rank per
@@ -65,7 +69,7 @@ class OpTimer:
         self.names = ["projection_ut_3dgs_fused", "spherical_harmonics_fwd", "spherical_harmonics_bwd", "intersect_tile",
                       "intersect_offset", "rasterize_to_pixels_from_world_3dgs_fwd", "rasterize_to_pixels_from_world_3dgs_bwd",
                       "sh_colors_fwd", "sh_colors_bwd", "splat_activations_fwd", "splat_activations_bwd",
-                      "photometric_loss_fwd", "photometric_loss_bwd", "intersect_tile_binned"]
+                      "photometric_loss_fwd", "photometric_loss_bwd", "intersect_tile_binned", "adam_step", "adam_step_split"]
         self.orig = {n: getattr(ops_mod, n) for n in self.names}
         self.events = {n: [] for n in self.names}
         self.enabled = False
@@ -143,6 +147,34 @@ def cpu_reference_stages(scene_small):
     return out
 
 
+def camera_poses(scene, n=8, radius=0.4):
+    """n world->camera poses: pose 0 is the scene's own camera (cfg2), the others sit on an orbit of `radius` metres around it
+    (with a +-0.5 m dolly) and look at the centre of the Gaussian slab, so consecutive steps see different tile intersections."""
+    from gsx import scenes
+    zc = float(scene["means"][:, 2].mean())
+    poses = [scene["viewmat"].clone()]
+    for k in range(1, n):
+        a = 2 * math.pi * k / n
+        eye = (radius * math.cos(a), radius * math.sin(a), 0.5 * math.sin(2 * a))
+        poses.append(scenes.look_at_viewmat(eye, (0.0, 0.0, zc)))
+    return poses
+
+
+def load_pmc(workload_key):
+    """Counter-derived per-launch figures of the blend kernels (HBM bytes, VALU instructions), measured with rocprofv3 --pmc in
+    separate passes and committed under profiles/: valid only for the workload they were measured on."""
+    path = os.path.join(ROOT, "profiles", "pmc.json")
+    if not os.path.exists(path):
+        return {}
+    try:
+        return json.load(open(path)).get(workload_key, {})
+    except Exception:  # noqa: BLE001
+        return {}
+
+
+VALU_PEAK_LANE_OPS = 78.6e12  # fp32 vector lane-operations / s: 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz (157.3 TFLOP/s / 2)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,8 +185,10 @@ def main():
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL)")
     ap.add_argument("--unfused", action="store_true", help="reference-style glue (one torch op per activation / SH pre-post step)")
     ap.add_argument("--sparse-allreduce", action="store_true", help="exchange only the gradient rows of Gaussians some camera saw")
+    ap.add_argument("--sharded-adam", action="store_true", help="N > 1: reduce-scatter -> Adam on 1/N of the rows -> all-gather of the parameters")
     ap.add_argument("--l1-loss", action="store_true", help="plain torch L1 loss instead of the reference's fused L1 + SSIM loss")
-    ap.add_argument("--no-train-iter", action="store_true", help="skip the extra full-iteration timing (loss + backward + Adam)")
+    ap.add_argument("--no-fwd-bwd", action="store_true", help="skip the extra fwd+bwd (no optimizer) timing loop")
+    ap.add_argument("--fixed-camera", action="store_true", help="the cfg2 camera on every step (default: 8 poses around it, one per step)")
     args = ap.parse_args()
 
     import gsx  # noqa: F401
@@ -176,152 +210,169 @@ def main():
     for p in model.params():
         p.requires_grad_(True)
     bucket = gdist.GradBucket(model.params())
-    # camera of this rank: cfg2 pose on a 5 cm orbit (rank 0 of a 1-GPU run = exactly the cfg2 camera)
-    vm = scene["viewmat"].clone()
-    if world > 1:
-        a = 2 * math.pi * rank / world
-        vm[0, 3], vm[1, 3] = 0.05 * math.cos(a), 0.05 * math.sin(a)
-    cam = rasterizer.Camera(viewmat=vm.to(dev), K=scene["K"].to(dev), width=W, height=H)
+    poses = [scene["viewmat"].clone()] if args.fixed_camera else camera_poses(scene)
+    cams = [rasterizer.Camera(viewmat=vm.to(dev), K=scene["K"].to(dev), width=W, height=H) for vm in poses]
     bg = scene["background"].to(dev)
-    g = torch.Generator().manual_seed(1234 + rank)
-    target = torch.rand(3, H, W, generator=g).to(dev)
+    g = torch.Generator().manual_seed(1234)
+    targets = [torch.rand(3, H, W, generator=g).to(dev) for _ in range(min(len(cams), 2))]  # (which noise image is irrelevant to the timing)
     fused_loss = not (args.l1_loss or args.unfused)
+    opt = optim.FusedAdam.for_splat_data(model)  # reference learning rates (include/core/parameters.hpp:19-23)
+    sharded = gdist.ShardedAdam(opt, bucket) if (args.sharded_adam and world > 1) else None
 
     timer = OpTimer(ops)
-    state = {}
-
     sinks = bucket.sinks()
+    counter = {"i": 0, "isects": []}
 
-    def step():
+    def step(with_adam=True):
+        i = counter["i"]
+        counter["i"] += 1
+        cam = cams[(i * world + rank) % len(cams)]  # every step, every rank: another camera
         # fused glue: gradients are written straight into the flat bucket (no zero fill, no AccumulateGrad adds)
-        out = rasterizer.rasterize_fused(cam, model, bg, grad_sinks=sinks) if not args.unfused else None
         if args.unfused:
             bucket.zero_()
             out = rasterizer.rasterize(cam, model, bg)
+        else:
+            out = rasterizer.rasterize_fused(cam, model, bg, grad_sinks=sinks)
         # the reference's photometric loss (trainer.cpp:103-127): 0.8 L1 + 0.2 (1 - SSIM), fused on the blend's own layout
+        target = targets[i % len(targets)]
         loss = gloss.photometric_loss(out.render_hwc, target, 0.2) if fused_loss else (out.image - target).abs().mean()
         loss.backward()
-        if world > 1:
-            if args.sparse_allreduce and not args.unfused:
-                # rows no camera of the step sees are zero on every rank: only the union of the visible rows travels (in S-1M every
-                # camera sees ~all Gaussians, so this falls back to the dense collective after one probe)
-                bucket.all_reduce_mean_rows((out.aux["radii_full"] > 0).all(-1))
-            else:
-                bucket.all_reduce_mean()
-        state["n_isects"] = out.n_isects
+        if sharded is not None and with_adam:
+            sharded.step(1001 + i)  # reduce-scatter -> Adam on this rank's rows -> all-gather of the updated parameters
+        else:
+            if world > 1:
+                if args.sparse_allreduce and not args.unfused:
+                    # rows no camera of the step sees are zero on every rank: only the union of the visible rows travels
+                    bucket.all_reduce_mean_rows((out.aux["radii_full"] > 0).all(-1))
+                else:
+                    bucket.all_reduce_mean()
+            if with_adam:
+                opt.step(1001 + i)  # past the shN warm-up (fused_adam.cpp:66-70): all six groups are updated
+        counter["isects"].append(out.n_isects)
 
+    def timed(n, with_adam):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(with_adam)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    # ---- leg 0 (outside the contract's timed region): fwd+bwd ms/frame, no optimizer: the parameters stay the cfg2 scene ----
+    fwd_bwd_ms = None
+    if not args.no_fwd_bwd:
+        for _ in range(max(2, min(args.warmup, 3))):
+            step(False)
+        counter["i"] = 0
+        fwd_bwd_ms = timed(args.steps, False) / args.steps * 1e3
+    # ---- the contract: W warm-up steps, then EXACTLY K timed training iterations ------------------------------------------
+    counter["i"] = 0
     for _ in range(args.warmup):
-        step()
+        step(True)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # Timed region: only the two blend ops (the roofline kernels) are bracketed with HIP events — each event record opens a
-    # ~5 us bubble on the stream, 22 ops x 2 events would cost ~0.1 ms per step.  The per-op table of the other ops is
-    # measured in a separate pass after the timed region.
+    ops.shim_stats(True)
+    counter["isects"] = []
+    # Only the two blend ops (the roofline kernels) are bracketed with HIP events inside the timed region — each event record opens
+    # a ~5 us bubble on the stream, 24 ops x 2 events would cost ~0.1 ms per step.  The per-op table of the other ops is measured
+    # in a separate pass after the timed region.
     timer.enabled = True
     timer.only = {"rasterize_to_pixels_from_world_3dgs_fwd", "rasterize_to_pixels_from_world_3dgs_bwd"}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(args.steps, True)
     timer.enabled = False
-    n_isects_timed = state["n_isects"]  # (the train-iteration leg below moves the Gaussians: later steps have another count)
+    host_syncs, binned_calls, hint_misses, hint_cold = ops.shim_stats(True)
+    isects_timed = list(counter["isects"])
     blend_ms = timer.mean_ms()
     timer.reset()
-    timer.only, timer.enabled = None, True   # per-op pass (outside the timed region)
-    for _ in range(min(args.steps, 10)):
-        step()
+    timer.only, timer.enabled = None, True   # per-op pass (outside the timed region), same camera sequence
+    counter["i"] = 0
+    for _ in range(min(args.steps, 8)):
+        step(True)
     torch.cuda.synchronize()
     timer.enabled = False
     all_ms = timer.mean_ms()
     all_ms.update(blend_ms)                  # the blend ops keep their timed-region figures
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # second part of the BASELINE metric ("train iters/s"): the same step followed by the fused Adam update of all six
-    # parameter groups (optim.FusedAdam, reference lrs) — timed separately, after and outside the K contract steps.
-    train_iter_ms = None
-    if not args.no_train_iter and not args.unfused:
-        # (.grad of every parameter already is its view of the flat bucket the backward writes into)
-        opt = optim.FusedAdam.for_splat_data(model)
-        it = [1000]
-
-        def train_iter():
-            it[0] += 1
-            step()
-            opt.step(it[0])
-
-        for _ in range(2):
-            train_iter()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            train_iter()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        tt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        train_iter_ms = float(tt.item()) / args.steps * 1e3
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        I = n_isects_timed  # noqa: E741
+        I = sum(isects_timed) / max(1, len(isects_timed))  # noqa: E741  (mean over the timed steps: the camera changes every step)
         P = W * H
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
         K = (deg + 1) ** 2
         ab = algorithmic_bytes(N, 1, I, P, tiles, deg, K)
-        op_ms = all_ms
+        n_params = sum(p.numel() for p in model.params())
+        ab["adam_step"] = ab["adam_step_split"] = None  # priced together below
         kernels = {}
-        for n, ms in op_ms.items():
+        adam_ms = sum(all_ms.pop(n, 0.0) * len(timer.events.get(n, [])) for n in ("adam_step", "adam_step_split"))
+        for n, ms in all_ms.items():
             gbs = ab[n] / (ms * 1e-3) / 1e9
             kernels[n] = {"ms": round(ms, 4), "algorithmic_bytes": int(ab[n]), "GBps": round(gbs, 1),
                           "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
-        blend = [n for n in op_ms if n.startswith("rasterize_to_pixels")]
-        dom = max(blend or list(op_ms), key=lambda n: op_ms[n])
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(dom)
-            except Exception:
-                traffic = None
+        n_adam_steps = max(1, min(args.steps, 8))
+        if adam_ms > 0:
+            ms = adam_ms / n_adam_steps
+            gbs = 28 * n_params / (ms * 1e-3) / 1e9  # p, m, v read + written, g read
+            kernels["fused_adam (6 groups)"] = {"ms": round(ms, 4), "algorithmic_bytes": 28 * n_params, "GBps": round(gbs, 1),
+                                                "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
+        blend = [n for n in all_ms if n.startswith("rasterize_to_pixels")]
+        dom = max(blend or list(all_ms), key=lambda n: all_ms[n])
+        wl_key = {"1m": "s1m_1080p", "5m": "s5m_4k", "small": "small"}[args.scene]
+        pmc = load_pmc(wl_key)
+        pm = pmc.get(dom, {})
         roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": kernels[dom]["frac_hbm"], "traffic": traffic,
-                    "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"], "avg_launch_ms": kernels[dom]["ms"]}
+                    "frac": kernels[dom]["frac_hbm"], "traffic": pm.get("hbm_bytes"),
+                    "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"], "avg_launch_ms": kernels[dom]["ms"],
+                    "traffic_source": pmc.get("source") if pm.get("hbm_bytes") else None}
+        workload = {"1m": "S-1M (BASELINE configs[1]): 1M random Gaussians, SH deg 3, 1920x1080, one camera per GPU per iteration",
+                    "5m": "S-5M (BASELINE configs[4]): 5M random Gaussians, SH deg 3, 3840x2160, one camera per GPU per iteration",
+                    "small": "S-small (BASELINE configs[0]): 10k Gaussians, SH deg 0, 256x256"}[args.scene]
         result = {
-            "metric": "train iters/s: fwd+bwd frames/s through the gut rasterizer, 1M Gaussians @1080p SH3",
+            "metric": "train iters/s (render + loss + backward + Adam), 1M Gaussians @1080p SH3; fwd+bwd ms/frame in `fwd_bwd`",
             "value": round(world * args.steps / elapsed, 4),
-            "unit": "frames/s",
+            "unit": "iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "S-1M (BASELINE configs[1]): 1M random Gaussians, SH deg 3, 1920x1080, fwd+bwd, "
-                                   "one camera per GPU" if args.scene == "1m" else args.scene,
-                       "n_gaussians": N, "width": W, "height": H, "sh_degree": deg, "n_isects": I,
-                       "cameras_per_step": world, "grad_allreduce_bytes": int(getattr(bucket, "last_reduced_bytes", 0)) if world > 1 else 0,
-                       "grad_bucket_bytes": bucket.nbytes()},
+            "config": {"workload": workload, "n_gaussians": N, "width": W, "height": H, "sh_degree": deg,
+                       "cameras": "cfg2 pose only" if args.fixed_camera else "%d poses (cfg2 + a 0.4 m orbit around it), a different one every step" % len(cams),
+                       "n_isects_mean": round(I, 1), "n_isects_min": min(isects_timed), "n_isects_max": max(isects_timed),
+                       "cameras_per_step": world,
+                       "grad_exchange": ("none" if world == 1 else ("reduce-scatter + sharded Adam + all-gather" if sharded is not None else
+                                         ("all-reduce of visible rows" if args.sparse_allreduce else "dense all-reduce"))),
+                       "grad_allreduce_bytes": int(getattr(bucket, "last_reduced_bytes", 0)) if world > 1 else 0,
+                       "grad_bucket_bytes": bucket.nbytes(),
+                       "host_syncs_per_step": round(host_syncs / args.steps, 2),
+                       "intersect_hint_misses": int(hint_misses), "intersect_cold_calls": int(hint_cold)},
             "gaussians_x_pixels_per_s": round(world * N * P / (elapsed / args.steps), 1),
-            "pairs_per_s_fwd": round(256.0 * I / (op_ms.get("rasterize_to_pixels_from_world_3dgs_fwd", float("nan")) * 1e-3), 1),
+            "pairs_per_s_fwd": round(256.0 * I / (all_ms.get("rasterize_to_pixels_from_world_3dgs_fwd", float("nan")) * 1e-3), 1),
             "roofline": roofline,
             "kernels": kernels,
             "loss": "fused L1 + SSIM (lambda 0.2)" if fused_loss else "torch L1",
         }
-        if train_iter_ms is not None:
-            result["train_iter"] = {"ms": round(train_iter_ms, 4), "iters_per_s": round(1e3 / train_iter_ms, 3),
-                                    "frames_per_s": round(world * 1e3 / train_iter_ms, 3),
-                                    "what": "render + fused L1/SSIM loss + backward + grad all-reduce + fused Adam (6 groups)"}
+        # the blend kernels are VALU-issue bound: second roofline against the fp32 vector peak, from the committed counters
+        valu = {}
+        for n in blend:
+            c = pmc.get(n, {}).get("valu_insts")
+            if c:
+                lane_ops = c * 64.0 / (all_ms[n] * 1e-3)
+                valu[n] = {"bound": "valu", "achieved": round(lane_ops / 1e12, 2), "peak": round(VALU_PEAK_LANE_OPS / 1e12, 1),
+                           "unit": "T lane-op/s", "frac": round(lane_ops / VALU_PEAK_LANE_OPS, 4), "valu_insts_per_launch": c}
+        if valu:
+            result["roofline_valu"] = dict(valu, source=pmc.get("source"))
+        if fwd_bwd_ms is not None:
+            result["fwd_bwd"] = {"ms_per_frame": round(fwd_bwd_ms, 4), "frames_per_s": round(world * 1e3 / fwd_bwd_ms, 3),
+                                 "what": "render + fused loss + backward (+ gradient all-reduce), no optimizer; same camera sequence"}
         if world == 1 and not args.no_cpu_baseline:
             threads = os.cpu_count() or 1
             dt, i_cpu = cpu_baseline(scene, threads)
@@ -332,8 +383,8 @@ def main():
             if stages:
                 result["cpu_reference_stages"] = stages
             result["cpu_baseline"] = {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": threads, "kind": "port",
-                                      "sample": "oracle (CPU restatement, OpenMP) forward+backward of ONE full frame of the "
-                                                "same workload (%d isects): %.2f s" % (i_cpu, dt)}
+                                      "sample": "oracle (CPU restatement, OpenMP) forward+backward (no loss, no Adam) of ONE full frame of "
+                                                "the same workload, cfg2 camera (%d isects): %.2f s" % (i_cpu, dt)}
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

@@ -2,6 +2,8 @@
 
   libgsx.so                      hipcc --offload-arch=gfx950  csrc/*.hip      (kernels + C ABI, no torch)
   _gsx_ops.<abi>.so              g++                           csrc/ops_shim.cpp (namespace gsplat on at::Tensor + pybind11)
+  libgsx_gsplat_backend.so       g++ -DGSX_NO_PYBIND           csrc/ops_shim.cpp (the same shim without Python: what a reference build links
+                                                                instead of its `gsplat_backend` static library)
 
 hipcc is invoked directly (not torch.utils.cpp_extension, which would run hipify over the sources).
 """
@@ -64,12 +66,42 @@ def build_libgsx(force=False, verbose=False):
     return LIBGSX
 
 
+COMPAT = os.path.join(os.path.dirname(HERE), "compat", "gsplat")
+BACKEND = os.path.join(HERE, "libgsx_gsplat_backend.so")
+
+
+def _shim_deps():
+    src = os.path.join(CSRC, "ops_shim.cpp")
+    return src, [src, os.path.join(INCLUDE, "gsx.h"), os.path.join(INCLUDE, "gsx_ops.h"), os.path.join(INCLUDE, "gsx_training_ops.h")] + \
+        [os.path.join(COMPAT, h) for h in ("Ops.h", "Cameras.h", "Common.h", "Projection.h")]
+
+
+def torch_cxx_flags():
+    """Include / link flags of a TU that uses at::Tensor against this box's torch wheel (shared by the shim builds and the
+    reference-call-site compile test)."""
+    import torch
+    tp = os.path.dirname(torch.__file__)
+    inc = ["-std=c++17", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-D_GLIBCXX_USE_CXX11_ABI=1",
+           "-I" + os.path.join(tp, "include"), "-I" + os.path.join(tp, "include", "torch", "csrc", "api", "include"), "-I/opt/rocm/include"]
+    link = ["-L" + os.path.join(tp, "lib"), "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip", "-Wl,-rpath," + os.path.join(tp, "lib")]
+    return inc, link
+
+
+def build_backend_lib(force=False):
+    """ops_shim.cpp without the pybind11 module: `namespace gsplat` (+ the Adam / SSIM drop-ins) as a plain shared library."""
+    src, deps = _shim_deps()
+    if not (force or _newer(BACKEND, deps)):
+        return BACKEND
+    inc, link = torch_cxx_flags()
+    _run(["g++", "-O2", "-fPIC", "-shared", "-DGSX_NO_PYBIND=1"] + inc + [src, "-o", BACKEND, "-L" + HERE, "-lgsx"] + link + ["-Wl,-rpath,$ORIGIN"])
+    return BACKEND
+
+
 def build_ops_module(force=False):
     import pybind11
     import torch
     out = ops_module_path()
-    src = os.path.join(CSRC, "ops_shim.cpp")
-    deps = [src, os.path.join(INCLUDE, "gsx.h"), os.path.join(INCLUDE, "gsx_ops.h"), os.path.join(INCLUDE, "gsx_training_ops.h")]
+    src, deps = _shim_deps()
     if not (force or _newer(out, deps)):
         return out
     tp = os.path.dirname(torch.__file__)
@@ -85,8 +117,11 @@ def build_ops_module(force=False):
 
 
 def build_all(force=False, verbose=False):
+    import concurrent.futures as cf
     build_libgsx(force, verbose)
-    build_ops_module(force)
+    with cf.ThreadPoolExecutor(2) as ex:  # the two shim builds are independent (each ~40 s of g++ over the ATen headers)
+        for f in [ex.submit(build_ops_module, force), ex.submit(build_backend_lib, force)]:
+            f.result()
 
 
 if __name__ == "__main__":

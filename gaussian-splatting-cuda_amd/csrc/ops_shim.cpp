@@ -15,6 +15,7 @@
 
 #include <ATen/hip/HIPEvent.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -30,6 +31,12 @@ namespace {
 #define GSX_CHECK_INPUT(x)                                         \
     TORCH_CHECK((x).is_cuda(), #x " must be a CUDA tensor");       \
     TORCH_CHECK((x).is_contiguous(), #x " must be contiguous")
+
+// the reference's DEVICE_GUARD (Common.h:18-19); the is_cuda check comes first so that a CPU tensor gets CHECK_INPUT's message
+// instead of the guard's internal assert
+#define GSX_DEVICE_GUARD(x)                                    \
+    TORCH_CHECK((x).is_cuda(), #x " must be a CUDA tensor");   \
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(x))
 
 inline void* cur_stream() { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream(); }
 inline void check(int rc, const char* op) { TORCH_CHECK(rc == GSX_OK, op, " failed (", rc, "): ", gsx_last_error()); }
@@ -74,6 +81,10 @@ gsx_ut_params make_ut(const UnscentedTransformParameters& u) {
 static thread_local at::Tensor* g_fwd_ws_out = nullptr;
 static thread_local const at::Tensor* g_fwd_ws_in = nullptr;
 
+// counters for bench.py (host synchronisations and capacity-hint outcomes of intersect_tile); never read by the ops themselves
+struct ShimStats { std::atomic<int64_t> host_syncs{0}, binned_calls{0}, hint_misses{0}, hint_cold{0}; };
+static ShimStats g_stats;
+
 namespace gsx_ext {
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned(const at::Tensor means2d, const at::Tensor radii,
                                                                                  const at::Tensor depths, const uint32_t C,
@@ -85,7 +96,7 @@ namespace gsplat {
 
 at::Tensor spherical_harmonics_fwd(const uint32_t degrees_to_use, const at::Tensor dirs, const at::Tensor coeffs,
                                    const at::optional<at::Tensor> masks) {
-    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(dirs));
+    GSX_DEVICE_GUARD(dirs);
     GSX_CHECK_INPUT(dirs);
     GSX_CHECK_INPUT(coeffs);
     if (masks.has_value()) { GSX_CHECK_INPUT(masks.value()); }
@@ -104,7 +115,7 @@ std::tuple<at::Tensor, at::Tensor> spherical_harmonics_bwd(const uint32_t K, con
                                                            const at::Tensor dirs, const at::Tensor coeffs,
                                                            const at::optional<at::Tensor> masks,
                                                            const at::Tensor v_colors, bool compute_v_dirs) {
-    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(dirs));
+    GSX_DEVICE_GUARD(dirs);
     GSX_CHECK_INPUT(dirs);
     GSX_CHECK_INPUT(coeffs);
     GSX_CHECK_INPUT(v_colors);
@@ -145,7 +156,7 @@ static std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile_impl(const 
                                                                           const at::optional<at::Tensor> gaussian_ids, const uint32_t C,
                                                                           const uint32_t tile_size, const uint32_t tile_width,
                                                                           const uint32_t tile_height, const bool sort, const bool allow_binned) {
-    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(means2d));
+    GSX_DEVICE_GUARD(means2d);
     GSX_CHECK_INPUT(means2d);
     GSX_CHECK_INPUT(radii);
     GSX_CHECK_INPUT(depths);
@@ -177,6 +188,7 @@ static std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile_impl(const 
                                        n_host.data_ptr<int64_t>(), ws.data_ptr(), wsb, st),
               "intersect_tile(count)");
         c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().synchronize();  // the one host sync, as upstream (Intersect.cpp:76)
+        g_stats.host_syncs++;
         n_isects = n_host.data_ptr<int64_t>()[0];
     }
     at::Tensor isect_ids = at::empty({n_isects}, depths.options().dtype(at::kLong));
@@ -202,7 +214,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile_device_sort(const 
 
 at::Tensor intersect_offset(const at::Tensor isect_ids, const uint32_t C, const uint32_t tile_width,
                             const uint32_t tile_height) {
-    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(isect_ids));
+    GSX_DEVICE_GUARD(isect_ids);
     GSX_CHECK_INPUT(isect_ids);
     TORCH_CHECK(isect_ids.scalar_type() == at::kLong, "isect_ids must be int64");
     at::Tensor offsets = at::empty({(int64_t)C, (int64_t)tile_height, (int64_t)tile_width}, isect_ids.options().dtype(at::kInt));
@@ -219,7 +231,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> projectio
     const float far_plane, const float radius_clip, const bool calc_compensations, const CameraModelType camera_model,
     const UnscentedTransformParameters ut_params, ShutterType rs_type, const at::optional<at::Tensor> radial_coeffs,
     const at::optional<at::Tensor> tangential_coeffs, const at::optional<at::Tensor> thin_prism_coeffs) {
-    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(means));
+    GSX_DEVICE_GUARD(means);
     GSX_CHECK_INPUT(means);
     GSX_CHECK_INPUT(quats);
     GSX_CHECK_INPUT(scales);
@@ -251,7 +263,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> rasterize_to_pixels_from_world_3d
     const UnscentedTransformParameters ut_params, ShutterType rs_type, const at::optional<at::Tensor> radial_coeffs,
     const at::optional<at::Tensor> tangential_coeffs, const at::optional<at::Tensor> thin_prism_coeffs,
     const at::Tensor tile_offsets, const at::Tensor flatten_ids) {
-    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(means));
+    GSX_DEVICE_GUARD(means);
     GSX_CHECK_INPUT(means);
     GSX_CHECK_INPUT(quats);
     GSX_CHECK_INPUT(scales);
@@ -292,7 +304,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
     const at::optional<at::Tensor> tangential_coeffs, const at::optional<at::Tensor> thin_prism_coeffs,
     const at::Tensor tile_offsets, const at::Tensor flatten_ids, const at::Tensor render_alphas,
     const at::Tensor last_ids, const at::Tensor v_render_colors, const at::Tensor v_render_alphas) {
-    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(means));
+    GSX_DEVICE_GUARD(means);
     GSX_CHECK_INPUT(means);
     GSX_CHECK_INPUT(quats);
     GSX_CHECK_INPUT(scales);
@@ -334,7 +346,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
 }
 
 at::Tensor quats_to_rotmats(const at::Tensor quats) {
-    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(quats));
+    GSX_DEVICE_GUARD(quats);
     GSX_CHECK_INPUT(quats);
     const uint32_t N = quats.size(0);
     at::Tensor rotmats = at::empty({N, 3, 3}, quats.options());
@@ -344,7 +356,7 @@ at::Tensor quats_to_rotmats(const at::Tensor quats) {
 
 std::tuple<at::Tensor, at::Tensor> relocation(at::Tensor opacities, at::Tensor scales, at::Tensor ratios, at::Tensor binoms,
                                               const int n_max) {
-    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(opacities));
+    GSX_DEVICE_GUARD(opacities);
     GSX_CHECK_INPUT(opacities);
     GSX_CHECK_INPUT(scales);
     GSX_CHECK_INPUT(ratios);
@@ -360,7 +372,7 @@ std::tuple<at::Tensor, at::Tensor> relocation(at::Tensor opacities, at::Tensor s
 
 void add_noise(at::Tensor raw_opacities, at::Tensor raw_scales, at::Tensor raw_quats, at::Tensor noise, at::Tensor means,
                const float current_lr) {
-    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(raw_opacities));
+    GSX_DEVICE_GUARD(raw_opacities);
     GSX_CHECK_INPUT(raw_opacities);
     GSX_CHECK_INPUT(raw_scales);
     GSX_CHECK_INPUT(raw_quats);
@@ -381,7 +393,7 @@ namespace gsx_ext {
 // colors [C,N,3] = clamp_min(SH(means - campos, coeffs | radii > 0) + 0.5, 0); masked rows are zero
 at::Tensor sh_colors_fwd(const uint32_t degrees_to_use, const at::Tensor means, const at::Tensor viewmats,
                          const at::Tensor coeffs, const at::Tensor radii) {
-    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(means));
+    GSX_DEVICE_GUARD(means);
     GSX_CHECK_INPUT(means); GSX_CHECK_INPUT(viewmats); GSX_CHECK_INPUT(coeffs); GSX_CHECK_INPUT(radii);
     TORCH_CHECK(means.scalar_type() == at::kFloat && coeffs.scalar_type() == at::kFloat && radii.scalar_type() == at::kInt, "dtype");
     const uint32_t C = viewmats.size(0), N = means.size(0), K = coeffs.size(-2);
@@ -396,7 +408,7 @@ std::tuple<at::Tensor, at::Tensor> sh_colors_bwd(const uint32_t degrees_to_use, 
                                                  const at::Tensor coeffs, const at::Tensor radii, const at::Tensor colors,
                                                  const at::Tensor v_colors, const at::optional<at::Tensor> v_means_in,
                                                  const at::optional<at::Tensor> v_coeffs_out, const at::optional<at::Tensor> v_means_out) {
-    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(means));
+    GSX_DEVICE_GUARD(means);
     GSX_CHECK_INPUT(means); GSX_CHECK_INPUT(viewmats); GSX_CHECK_INPUT(coeffs); GSX_CHECK_INPUT(radii); GSX_CHECK_INPUT(colors); GSX_CHECK_INPUT(v_colors);
     const uint32_t C = viewmats.size(0), N = means.size(0), K = coeffs.size(-2);
     at::Tensor vc = (v_coeffs_out.has_value() && v_coeffs_out->defined()) ? v_coeffs_out.value() : at::empty_like(coeffs);
@@ -413,7 +425,7 @@ std::tuple<at::Tensor, at::Tensor> sh_colors_bwd(const uint32_t degrees_to_use, 
 
 std::tuple<at::Tensor, at::Tensor, at::Tensor> splat_activations_fwd(const at::Tensor scaling_raw, const at::Tensor rotation_raw,
                                                                      const at::Tensor opacity_raw) {
-    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(scaling_raw));
+    GSX_DEVICE_GUARD(scaling_raw);
     GSX_CHECK_INPUT(scaling_raw); GSX_CHECK_INPUT(rotation_raw); GSX_CHECK_INPUT(opacity_raw);
     const uint32_t N = scaling_raw.size(0);
     at::Tensor scales = at::empty_like(scaling_raw), quats = at::empty_like(rotation_raw);
@@ -429,7 +441,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> splat_activations_bwd(const at::T
                                                                      const at::optional<at::Tensor> out_scaling,
                                                                      const at::optional<at::Tensor> out_rotation,
                                                                      const at::optional<at::Tensor> out_opacity) {
-    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(scaling_raw));
+    GSX_DEVICE_GUARD(scaling_raw);
     GSX_CHECK_INPUT(scaling_raw); GSX_CHECK_INPUT(rotation_raw); GSX_CHECK_INPUT(opacity_raw);
     GSX_CHECK_INPUT(v_scales); GSX_CHECK_INPUT(v_quats); GSX_CHECK_INPUT(v_opacities);
     const uint32_t N = scaling_raw.size(0);
@@ -445,7 +457,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> splat_activations_bwd(const at::T
 
 void adam_step_split(at::Tensor param, at::Tensor exp_avg, at::Tensor exp_avg_sq, const at::Tensor grad, int64_t split, double lr_a, double lr_b,
                      bool step_a, bool step_b, double beta1, double beta2, double eps, double bias_correction1_rcp, double bias_correction2_sqrt_rcp) {
-    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(param));
+    GSX_DEVICE_GUARD(param);
     TORCH_CHECK(param.is_cuda() && grad.is_cuda() && exp_avg.is_cuda() && exp_avg_sq.is_cuda(), "adam_step_split: CUDA tensors required");
     TORCH_CHECK(param.is_contiguous() && grad.is_contiguous() && exp_avg.is_contiguous() && exp_avg_sq.is_contiguous(), "adam_step_split: dense tensors required");
     TORCH_CHECK(param.sizes() == grad.sizes() && param.sizes() == exp_avg.sizes() && param.sizes() == exp_avg_sq.sizes() && param.dim() >= 2,
@@ -464,7 +476,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
                                                                                  const at::Tensor depths, const uint32_t C,
                                                                                  const uint32_t tile_size, const uint32_t tile_width,
                                                                                  const uint32_t tile_height, const bool want_isect_ids) {
-    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(means2d));
+    GSX_DEVICE_GUARD(means2d);
     GSX_CHECK_INPUT(means2d); GSX_CHECK_INPUT(radii); GSX_CHECK_INPUT(depths);
     TORCH_CHECK(means2d.dim() == 3, "intersect_tile_binned: means2d must be [C,N,2]");
     TORCH_CHECK(means2d.scalar_type() == at::kFloat && depths.scalar_type() == at::kFloat && radii.scalar_type() == at::kInt, "dtype");
@@ -484,9 +496,11 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
                                   tile_width, tile_height, n_elements ? tiles_per_gauss.data_ptr<int32_t>() : nullptr, offsets.data_ptr<int32_t>(),
                                   n_host.data_ptr<int64_t>(), cws.data_ptr(), cwb, st), "intersect_tile_binned(count)");
     // The op's outputs have exactly n_isects rows, so the host has to read that number (the one sync of the op, as upstream:
-    // Intersect.cpp:76).  To keep the GPU busy meanwhile, the fill is launched optimistically into buffers sized from the last
-    // total seen for this problem shape (+25 %); the host then waits only for the 4-byte copy, not for the fill.  If the guess
-    // was too small the fill is repeated with the exact size.
+    // Intersect.cpp:76).  To keep the GPU busy meanwhile, the fill is launched optimistically into buffers sized from a capacity
+    // hint; the host then waits only for the 4-byte copy, not for the fill.  If the guess was too small the fill is repeated with
+    // the exact size.  The hint is the ONLY state the shim keeps between calls: a process-wide map {(device, C, N, tile grid) ->
+    // recent maximum of n_isects}, mutex protected, decaying 2 % per call so that one outlier view does not pin memory for ever.
+    // It never changes a result (the outputs are narrowed to the exact length); it only decides whether the fill runs once or twice.
     at::cuda::CUDAEvent total_ready;
     total_ready.record(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
     static std::mutex hint_mutex;
@@ -510,15 +524,20 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
     };
     int64_t capacity = 0;
     if (hint > 0 && n_elements) {
-        capacity = std::min<int64_t>(hint + hint / 4 + 4096, 0x7FFFFFFFll);
+        capacity = std::min<int64_t>(hint + hint / 8 + 4096, 0x7FFFFFFFll);
         fill(capacity);
     }
     total_ready.synchronize();
+    g_stats.host_syncs++;
     const int64_t n_isects = n_host.data_ptr<int64_t>()[0];
     {
         std::lock_guard<std::mutex> lock(hint_mutex);
-        hints[key] = n_isects;
+        int64_t& h = hints[key];
+        h = std::max<int64_t>(n_isects, h - h / 50);  // running maximum with a slow decay
     }
+    g_stats.binned_calls++;
+    if (capacity > 0 && n_isects > capacity) g_stats.hint_misses++;
+    if (capacity == 0 && n_isects > 0) g_stats.hint_cold++;
     if (capacity > 0 && n_isects <= capacity) {
         flatten_ids = flatten_ids.narrow(0, 0, n_isects);
         if (want_isect_ids) isect_ids = isect_ids.narrow(0, 0, n_isects);
@@ -534,7 +553,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
 
 // fusedssim / fusedssim_backward (include/kernels/ssim.cuh:11-29): same tuple returns
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> fusedssim(double C1, double C2, const at::Tensor& img1_, const at::Tensor& img2_, bool train) {
-    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(img1_));
+    GSX_DEVICE_GUARD(img1_);
     TORCH_CHECK(img1_.is_cuda() && img2_.is_cuda() && img1_.dim() == 4 && img1_.sizes() == img2_.sizes(), "fusedssim: two [B,CH,H,W] CUDA tensors required");
     TORCH_CHECK(img1_.scalar_type() == at::kFloat && img2_.scalar_type() == at::kFloat, "fusedssim: float32 required");
     const at::Tensor img1 = img1_.contiguous(), img2 = img2_.contiguous();
@@ -550,7 +569,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> fusedssim(double C1, 
 
 at::Tensor fusedssim_backward(double C1, double C2, const at::Tensor& img1_, const at::Tensor& img2_, const at::Tensor& dL_dmap_,
                               const at::Tensor& dm_dmu1, const at::Tensor& dm_dsigma1_sq, const at::Tensor& dm_dsigma12) {
-    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(img1_));
+    GSX_DEVICE_GUARD(img1_);
     TORCH_CHECK(img1_.is_cuda() && img1_.dim() == 4 && img1_.sizes() == img2_.sizes() && img1_.sizes() == dL_dmap_.sizes(), "fusedssim_backward: shape mismatch");
     TORCH_CHECK(dm_dmu1.sizes() == img1_.sizes() && dm_dsigma1_sq.sizes() == img1_.sizes() && dm_dsigma12.sizes() == img1_.sizes(),
                 "fusedssim_backward: derivative maps of the forward (train = true) required");
@@ -565,7 +584,7 @@ at::Tensor fusedssim_backward(double C1, double C2, const at::Tensor& img1_, con
 
 // fused photometric loss on the blend's [C,H,W,3] output; returns (loss3 = {loss, l1, ssim}, workspace for the backward)
 std::tuple<at::Tensor, at::Tensor> photometric_loss_fwd(const at::Tensor& render, const at::Tensor& gt, double lambda_dssim) {
-    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(render));
+    GSX_DEVICE_GUARD(render);
     TORCH_CHECK(render.is_cuda() && gt.is_cuda() && render.dim() == 4 && render.size(3) == 3 && render.is_contiguous(), "photometric_loss: render must be contiguous [C,H,W,3]");
     TORCH_CHECK(gt.dim() == 4 && gt.size(0) == render.size(0) && gt.size(1) == 3 && gt.size(2) == render.size(1) && gt.size(3) == render.size(2) &&
                     gt.is_contiguous(), "photometric_loss: gt must be contiguous [C,3,H,W]");
@@ -581,7 +600,7 @@ std::tuple<at::Tensor, at::Tensor> photometric_loss_fwd(const at::Tensor& render
 
 at::Tensor photometric_loss_bwd(const at::Tensor& render, const at::Tensor& gt, const at::Tensor& ws, double lambda_dssim,
                                 const c10::optional<at::Tensor>& grad_loss, double grad_scale) {
-    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(render));
+    GSX_DEVICE_GUARD(render);
     const uint32_t C = (uint32_t)render.size(0), H = (uint32_t)render.size(1), W = (uint32_t)render.size(2);
     at::Tensor v = at::empty_like(render);
     const float* gl = nullptr;
@@ -599,7 +618,7 @@ at::Tensor photometric_loss_bwd(const at::Tensor& render, const at::Tensor& gt, 
 // fused Adam step on a parameter (or a row-strided view of one: dims after the first must be dense)
 void adam_step(at::Tensor param, at::Tensor exp_avg, at::Tensor exp_avg_sq, const at::Tensor grad, double lr, double beta1,
                double beta2, double eps, double bias_correction1_rcp, double bias_correction2_sqrt_rcp) {
-    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(param));
+    GSX_DEVICE_GUARD(param);
     TORCH_CHECK(param.is_cuda() && grad.is_cuda() && exp_avg.is_cuda() && exp_avg_sq.is_cuda(), "adam_step: CUDA tensors required");
     TORCH_CHECK(exp_avg.is_contiguous() && exp_avg_sq.is_contiguous(), "adam_step: optimizer states must be contiguous");
     TORCH_CHECK(param.sizes() == grad.sizes() && param.numel() == exp_avg.numel() && param.numel() == exp_avg_sq.numel(), "adam_step: shape mismatch");
@@ -725,6 +744,11 @@ PYBIND11_MODULE(_gsx_ops, m) {
     m.def("relocation", &gsplat::relocation);
     m.def("add_noise", &gsplat::add_noise);
     m.def("abi_version", []() { return gsx_abi_version(); });
+    m.def("shim_stats", [](bool reset) {  // (host_syncs, binned intersect calls, capacity-hint misses, cold calls without a hint)
+        auto r = std::make_tuple((int64_t)g_stats.host_syncs, (int64_t)g_stats.binned_calls, (int64_t)g_stats.hint_misses, (int64_t)g_stats.hint_cold);
+        if (reset) { g_stats.host_syncs = 0; g_stats.binned_calls = 0; g_stats.hint_misses = 0; g_stats.hint_cold = 0; }
+        return r;
+    });
     m.def("sh_colors_fwd", &gsx_ext::sh_colors_fwd);
     m.def("sh_colors_bwd", &gsx_ext::sh_colors_bwd);
     m.def("splat_activations_fwd", &gsx_ext::splat_activations_fwd);

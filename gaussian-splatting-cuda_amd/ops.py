@@ -58,3 +58,4 @@ fusedssim = _C.fusedssim
 fusedssim_backward = _C.fusedssim_backward
 photometric_loss_fwd = _C.photometric_loss_fwd
 photometric_loss_bwd = _C.photometric_loss_bwd
+shim_stats = _C.shim_stats

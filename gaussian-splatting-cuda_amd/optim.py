@@ -84,10 +84,13 @@ class FusedAdam:
 
     # ---- step ------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def step(self, iteration):
+    def step(self, iteration, rows=None):
+        """One Adam step of every group.  rows=(lo, hi) restricts the update to that block of Gaussians (distributed.ShardedAdam:
+        the other blocks are updated by the other ranks); step counters and bias corrections advance as for a full step."""
         b1, b2 = self.betas
         sh = self.model.sh
         sh_grad = sh.grad
+        r = (lambda t: t) if rows is None else (lambda t: t[rows[0]:rows[1]])
         split_ok = (sh.shape[1] * 3) % 4 == 0 and sh.shape[1] > 1
         do_sh = {}
         for i, grp in enumerate(self.groups, start=1):
@@ -106,21 +109,21 @@ class FusedAdam:
             if skip:
                 continue
             st = self._moments(name)
-            ops.adam_step(p.data, st["exp_avg"], st["exp_avg_sq"], grad, grp["lr"], b1, b2, self.eps, bc1_rcp, bc2_sqrt_rcp)
+            ops.adam_step(r(p.data), r(st["exp_avg"]), r(st["exp_avg_sq"]), r(grad), grp["lr"], b1, b2, self.eps, bc1_rcp, bc2_sqrt_rcp)
         if do_sh:
             a = do_sh.get("sh0", (False, 0.0, 1.0, 1.0))
             b = do_sh.get("shN", (False, 0.0, a[2], a[3]))
             if split_ok and a[2:] == b[2:] and sh_grad.is_contiguous():
                 st = self._moments("sh0")
-                ops.adam_step_split(sh.data, st["exp_avg"], st["exp_avg_sq"], sh_grad, 3, a[1], b[1], a[0], b[0], b1, b2, self.eps, a[2], a[3])
+                ops.adam_step_split(r(sh.data), r(st["exp_avg"]), r(st["exp_avg_sq"]), r(sh_grad), 3, a[1], b[1], a[0], b[0], b1, b2, self.eps, a[2], a[3])
             else:  # K = 1 / 9 / 25 (K*3 not a multiple of 4): one row-strided launch per block, dense moments per block
                 assert not split_ok, "sh0 / shN step counters diverged"
                 if a[0]:
                     st = self._moments("sh0")
-                    ops.adam_step(sh.data[:, :1], st["exp_avg"], st["exp_avg_sq"], sh_grad[:, :1], a[1], b1, b2, self.eps, a[2], a[3])
+                    ops.adam_step(r(sh.data)[:, :1], r(st["exp_avg"]), r(st["exp_avg_sq"]), r(sh_grad)[:, :1], a[1], b1, b2, self.eps, a[2], a[3])
                 if b[0]:
                     st = self._moments("shN")
-                    ops.adam_step(sh.data[:, 1:], st["exp_avg"], st["exp_avg_sq"], sh_grad[:, 1:], b[1], b1, b2, self.eps, b[2], b[3])
+                    ops.adam_step(r(sh.data)[:, 1:], r(st["exp_avg"]), r(st["exp_avg_sq"]), r(sh_grad)[:, 1:], b[1], b1, b2, self.eps, b[2], b[3])
 
     def zero_grad(self, set_to_none=True):
         for p in self.model.params():

@@ -186,6 +186,22 @@ class GUTRasterizationFunction(torch.autograd.Function):
         return (v_means, v_quats, v_scales, v_colors, v_opac, v_bg) + (None,) * 14
 
 
+def _distortion_args(camera: Camera, cam_model, device):
+    """Distortion coefficients as the kernels read them (rasterizer.cpp:183-195): radial padded to >= 4 (6 for the OpenCV
+    pinhole model, Cameras.cuh:483), tangential to 2; None when the camera has none."""
+    def _pad(t, n):
+        if t is None or t.numel() == 0:
+            return None
+        t = t.reshape(-1).to(device, torch.float32)
+        if t.numel() < n:
+            t = torch.nn.functional.pad(t, (0, n - t.numel()))
+        return t.contiguous()
+    radial, tangential = _pad(camera.radial, 4), _pad(camera.tangential, 2)
+    if radial is not None and cam_model == ops.CameraModelType.PINHOLE and radial.numel() < 6:
+        radial = torch.nn.functional.pad(radial, (0, 6 - radial.numel()))
+    return radial, tangential
+
+
 def rasterize(camera: Camera, model: SplatData, bg_color: Optional[torch.Tensor], scaling_modifier: float = 1.0,
               packed: bool = False, antialiased: bool = False, sh_degree: Optional[int] = None) -> RenderOutput:
     """gs::training::rasterize, RGB render mode (the only one that works on this path upstream, SURVEY §8 a11)."""
@@ -203,16 +219,7 @@ def rasterize(camera: Camera, model: SplatData, bg_color: Optional[torch.Tensor]
     cam_model = camera.camera_model if camera.camera_model is not None else ops.CameraModelType.PINHOLE
     ut = ops.UnscentedTransformParameters()
 
-    def _pad(t, n):
-        if t is None or t.numel() == 0:
-            return None
-        t = t.reshape(-1).to(means.device, torch.float32)
-        if t.numel() < n:
-            t = torch.nn.functional.pad(t, (0, n - t.numel()))
-        return t.contiguous()
-    radial, tangential = _pad(camera.radial, 4), _pad(camera.tangential, 2)
-    if radial is not None and cam_model == ops.CameraModelType.PINHOLE and radial.numel() < 6:
-        radial = torch.nn.functional.pad(radial, (0, 6 - radial.numel()))  # the pinhole kernel reads 6 (Cameras.cuh:483)
+    radial, tangential = _distortion_args(camera, cam_model, means.device)
 
     # 1. projection (no grad)
     radii, means2d, depths, conics, _ = fully_fused_projection_with_ut(
@@ -321,9 +328,10 @@ def rasterize_fused(camera: Camera, model: SplatData, bg_color: Optional[torch.T
     sh_degree = model.active_sh_degree if sh_degree is None else sh_degree
     cam_model = camera.camera_model if camera.camera_model is not None else ops.CameraModelType.PINHOLE
     bg = bg_color.reshape(1, -1).to(model.means.device).contiguous() if (bg_color is not None and bg_color.numel() > 0) else None
+    radial, tangential = _distortion_args(camera, cam_model, model.means.device)
     renders, alphas, radii, means2d, depths, flatten_ids, isect_offsets = GutRenderFunction.apply(
         model.means, model.sh, model.scaling_raw, model.rotation_raw, model.opacity_raw, viewmat, K, bg, W, H, sh_degree,
-        scaling_modifier, cam_model, None, None, grad_sinks)
+        scaling_modifier, cam_model, radial, tangential, grad_sinks)
     out = RenderOutput()
     out.render_hwc = renders  # [1,H,W,3] unclamped: what loss.photometric_loss consumes; out.image is derived on first access
     out.alpha = alphas.squeeze(0).permute(2, 0, 1)

@@ -56,3 +56,23 @@ def rel_l2(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def parity_record(name, **values):
+    """Parity numbers of the -m gpu tests are kept, not just asserted: one JSON line per record in gpurun_out/parity.jsonl (merged back
+    from the GPU box by gpurun; summarised into the tracked profiles/parity_rNN.md by tools/parity_report.py) and on stdout (-s)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rec = {"test": name}
+    for k, v in values.items():
+        rec[k] = (float(v) if isinstance(v, (float, np.floating)) else int(v) if isinstance(v, (int, np.integer)) else v)
+    line = json.dumps(rec)
+    print("PARITY " + line)
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "parity.jsonl"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+    return rec

@@ -115,3 +115,56 @@ def test_visible_row_all_reduce_equals_dense(tmp_path):
             got = np.load(tmp_path / ("%s_%d.npy" % (mode, r)))
             assert np.array_equal(got, dense), (mode, r)             # bit-identical to the dense collective on 2 ranks
     assert np.array_equal(np.load(tmp_path / "dense_1.npy"), dense)
+
+
+class _RowSGD:
+    """Stand-in for optim.FusedAdam in the CPU test of ShardedAdam (the fused Adam kernel needs a GPU): same step(iteration, rows=)
+    contract, elementwise update, so a row-sharded step followed by the all-gather must equal the replicated step bit for bit."""
+
+    def __init__(self, params, lr=0.1):
+        self.params, self.lr, self.calls = params, lr, []
+
+    def step(self, iteration, rows=None):
+        self.calls.append(rows)
+        for p in self.params:
+            sl = slice(None) if rows is None else slice(rows[0], rows[1])
+            p.data[sl] -= self.lr * p.grad[sl] * (1.0 + 0.01 * iteration)
+
+
+def _sharded_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import gsx  # noqa: F401
+    from gsx import distributed as gdist
+    gdist.init_from_env(backend="gloo")
+    for N in (1000, 1001):                                          # divisible by the world size / not (fallback: all-reduce + full step)
+        shapes = [(N, 3), (N, 16, 3), (N, 3), (N, 4), (N, 1)]
+        g0 = torch.Generator().manual_seed(7)
+        init = [torch.randn(s, generator=g0) for s in shapes]        # identical replicas
+        g = torch.Generator().manual_seed(100 + rank)
+        grads = [torch.randn(s, generator=g) for s in shapes]        # this rank's camera
+        out = {}
+        for mode in ("replicated", "sharded"):
+            params = [t.clone().requires_grad_(True) for t in init]
+            bucket = gdist.GradBucket(params)
+            for p, gr in zip(params, grads):
+                p.grad.copy_(gr)
+            opt = _RowSGD(params)
+            if mode == "replicated":
+                h = bucket.all_reduce_mean(async_op=True)            # the asynchronous handle completes the MEAN
+                h.wait()
+                opt.step(3)
+            else:
+                gdist.ShardedAdam(opt, bucket).step(3)
+                assert opt.calls == ([(rank * (N // world), (rank + 1) * (N // world))] if N % world == 0 else [None])
+            out[mode] = np.concatenate([p.detach().numpy().reshape(-1) for p in params])
+        assert np.array_equal(out["replicated"], out["sharded"])
+        np.save(os.path.join(out_dir, "sharded_%d_%d.npy" % (N, rank)), out["sharded"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_optimizer_step_equals_replicated(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_sharded_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for N in (1000, 1001):
+        assert np.array_equal(np.load(tmp_path / ("sharded_%d_0.npy" % N)), np.load(tmp_path / ("sharded_%d_1.npy" % N)))

@@ -66,6 +66,33 @@ def test_fused_equals_unfused(mods, deg):
         assert rel_l2(b.grad.cpu().numpy(), a.grad.cpu().numpy()) < 1e-4, n
 
 
+def test_fused_keeps_distortion(mods):
+    """A distorted COLMAP-style camera: the fused render must apply radial / tangential coefficients like rasterize()
+    (rasterizer.cpp:183-195) — and differ from the undistorted render, so the test cannot pass on dropped coefficients."""
+    distributed, ops, rasterizer, scenes = mods
+    sc, cam = _setup(scenes, rasterizer, 2)
+    bg = sc["background"].to(DEV) + 0.2
+    cam_d = rasterizer.Camera(viewmat=cam.viewmat, K=cam.K, width=cam.width, height=cam.height,
+                              radial=torch.tensor([-0.12, 0.03]), tangential=torch.tensor([0.004, -0.003]))
+
+    def run(fn, c):
+        model = scenes.to_splat_data(sc, DEV)
+        for p in model.params():
+            p.requires_grad_(True)
+        out = fn(c, model, bg)
+        (out.image.sum() + 0.3 * out.alpha.sum()).backward()
+        return model, out
+
+    m_ref, o_ref = run(rasterizer.rasterize, cam_d)
+    m_fus, o_fus = run(rasterizer.rasterize_fused, cam_d)
+    _, o_plain = run(rasterizer.rasterize_fused, cam)
+    assert float((o_fus.image - o_plain.image).abs().max()) > 1e-2      # the coefficients matter
+    assert o_ref.n_isects == o_fus.n_isects
+    assert float((o_ref.image - o_fus.image).abs().max()) < 2e-5
+    for a, b, n in zip(m_ref.params(), m_fus.params(), ["means", "sh", "scaling_raw", "rotation_raw", "opacity_raw"]):
+        assert rel_l2(b.grad.cpu().numpy(), a.grad.cpu().numpy()) < 1e-3, n
+
+
 def test_fused_ops_vs_torch(mods):
     """The two fused glue ops against the torch expressions they replace."""
     _, ops, _, _ = mods
