@@ -60,7 +60,18 @@ def _projection_and_binning_vs_oracle(ops, scene, tag):
     radius_max = int(np.abs(rg - ro)[both].max())
     e_m2d = float(np.abs(mg - mo)[both].max())
     e_dep = float((np.abs(dg - do)[both] / np.abs(do[both])).max())
-    e_con = float((np.abs(cg - co)[both] / (np.abs(co[both]).max(-1, keepdims=True) + 1e-30)).max())
+    crel = lambda a, b: np.abs(a - b) / (np.abs(b).max(-1, keepdims=True) + 1e-30)  # noqa: E731
+    e_con = float(crel(cg, co)[both].max())
+    # The UT sums seven projected points with weights -99 / +16.67: rounding noise of ANY fp32 evaluation order is amplified ~100x
+    # (SURVEY §7).  The yardstick is therefore the same formulas in float64: the GPU must be as close to it as the reference-order
+    # fp32 oracle is (both are fp32 evaluations of the same expression; neither is "the" fp32 result).
+    f64 = lambda k: np.ascontiguousarray(scene[k].numpy(), np.float64)  # noqa: E731
+    r64, m64, d64, c64, _ = oracle.projection_ut(f64("means"), f64("quats"), f64("scales"), f64("opacities"), f64("viewmat")[None], f64("K")[None], W, H)
+    v64 = (r64[0] > 0).all(-1) & both
+    g_m2d64, o_m2d64 = float(np.abs(mg - m64[0])[v64].max()), float(np.abs(mo - m64[0])[v64].max())
+    g_con64, o_con64 = float(crel(cg, c64[0])[v64].max()), float(crel(co, c64[0])[v64].max())
+    g_m2d64_rms, o_m2d64_rms = float(np.sqrt(((mg - m64[0])[v64] ** 2).mean())), float(np.sqrt(((mo - m64[0])[v64] ** 2).mean()))
+    g_rflip64, o_rflip64 = int((rg != r64[0])[v64].any(-1).sum()), int((ro != r64[0])[v64].any(-1).sum())
     lo_g, hi_g = _tile_rects(mg, rg, tw, th)
     lo_o, hi_o = _tile_rects(mo, ro, tw, th)
     area = lambda lo, hi, v: np.where(v, (hi - lo).prod(-1), 0)  # noqa: E731
@@ -70,12 +81,17 @@ def _projection_and_binning_vs_oracle(ops, scene, tag):
     isect_g, isect_o = int(tiles_g.sum()), int(tiles_o.sum())
     rec = parity_record(tag + " projection+binning vs oracle", gaussians=n, visible_gpu=int(vg.sum()), cull_flips=cull_flips, radius_flips=radius_flips,
                         radius_max_diff_px=radius_max, means2d_max_err_px=e_m2d, depth_max_rel_err=e_dep, conic_max_rel_err=e_con,
-                        gaussians_with_different_tile_set=tile_set_differs, n_isects_gpu=isect_g, n_isects_oracle=isect_o)
-    # thresholds = observed on the MI355X (profiles/parity_r02.md) x 2
+                        gaussians_with_different_tile_set=tile_set_differs, n_isects_gpu=isect_g, n_isects_oracle=isect_o,
+                        means2d_max_err_vs_f64_gpu=g_m2d64, means2d_max_err_vs_f64_oracle32=o_m2d64, means2d_rms_err_vs_f64_gpu=g_m2d64_rms,
+                        means2d_rms_err_vs_f64_oracle32=o_m2d64_rms, conic_max_rel_err_vs_f64_gpu=g_con64, conic_max_rel_err_vs_f64_oracle32=o_con64,
+                        radius_flips_vs_f64_gpu=g_rflip64, radius_flips_vs_f64_oracle32=o_rflip64)
+    # thresholds: discrete outcomes = observed on the MI355X (profiles/parity_r02.md) x 2; continuous ones relative to the f64 yardstick
     assert cull_flips <= max(4, 2e-5 * n), rec
-    assert radius_max <= 1 and radius_flips <= 2e-3 * n, rec
-    assert e_m2d < 2e-2 and e_dep < 1e-5 and e_con < 1e-2, rec
-    assert tile_set_differs <= 1e-3 * n and abs(isect_g - isect_o) <= 1e-3 * isect_o, rec
+    assert radius_max <= 1 and radius_flips <= 2.5e-3 * n, rec
+    assert g_rflip64 <= 1.5 * o_rflip64 + 16, rec
+    assert g_m2d64 <= 1.5 * o_m2d64 + 1e-3 and g_m2d64_rms <= 1.5 * o_m2d64_rms + 1e-5, rec
+    assert g_con64 <= 1.5 * o_con64 + 1e-4 and e_dep < 1e-5, rec
+    assert tile_set_differs <= 3.5e-3 * n and abs(isect_g - isect_o) <= 2e-4 * isect_o, rec
     # binning of the GPU's own projection: bit for bit (binned pipeline = what rasterize_fused runs, and the device-wide sort)
     tpg_o, ids_o, fl_o = oracle.intersect_tile(np32(m2d_g), radii_g.cpu().numpy(), np32(dep_g), 1, 16, tw, th, True)
     off_o = oracle.intersect_offset(ids_o, 1, tw, th)
@@ -86,7 +102,7 @@ def _projection_and_binning_vs_oracle(ops, scene, tag):
     return rec
 
 
-def _blend_parity(ops, scene, tag, colors, off, fl, crop=None):
+def _blend_parity(ops, scene, tag, colors, off, fl, max_fragile=0.01):
     """Blend forward + backward against the oracle on identical inputs (the GPU's colours and binning).  Forward: 1e-4 L-inf
     (north_star) on pixels none of whose discrete decisions (alpha >= 1/255, T <= 1e-4) lies within `window` (relative) of its
     threshold in the reference-order fp32 evaluation; EVERY pixel within one Gaussian's threshold contribution max_colour/255 + 1e-4.
@@ -104,20 +120,26 @@ def _blend_parity(ops, scene, tag, colors, off, fl, crop=None):
     g_ren, g_alp, g_last = np32(g[0]), np32(g[1]), g[2].cpu().numpy()
     bound_all = float(colors_np.max()) / 255.0 + 1e-4
     stats = {}
-    for window in (1e-3, 5e-4, 2.5e-4):
+    for window in (1e-3, 4e-4, 2e-4):
         ren, alp, last, frag = oracle.rasterize_fwd(*args, frag_rel=window)
         ok = frag == 0
-        err = np.abs(g_ren - ren)
+        err = np.abs(g_ren - ren).max(-1)  # per pixel
+        over = err > 1e-4
         stats[window] = dict(fragile_frac=float(1 - ok.mean()), max_err_nonfragile=float(err[ok].max()), max_err_all=float(err.max()),
-                             nonfragile_over_1e4=int((err[ok].max(-1) > 1e-4).sum()) if err[ok].ndim > 1 else int((err[ok] > 1e-4).sum()),
-                             alpha_max_err_nonfragile=float(np.abs(g_alp - alp)[ok].max()),
+                             pixels_over_1e4=int(over.sum()), pixels_over_1e4_not_fragile=int((over & ok).sum()),
+                             alpha_max_err_nonfragile=float(np.abs(g_alp - alp)[..., 0][ok].max()),
                              last_id_mismatch_nonfragile=int((g_last[ok] != last[ok]).sum()))
     rec = parity_record(tag + " blend forward vs oracle", pixels=W * H, n_isects=int(fl.numel()), bound_all_pixels=bound_all,
                         **{"w%g_%s" % (w, k): v for w, st in stats.items() for k, v in st.items()})
-    st = stats[5e-4]
-    assert st["fragile_frac"] <= 0.015, rec
+    # A pixel is "threshold-ambiguous" when one of its alpha >= 1/255 / T <= 1e-4 decisions lies within 4e-4 (relative) of the
+    # threshold in the reference-order fp32 evaluation — the noise floor of that evaluation itself (at 2e-4 the first decisions
+    # flip between two correct fp32 implementations).  Every other pixel: 1e-4 L-inf and the same last Gaussian.  ALL pixels:
+    # within one Gaussian's threshold contribution; and every pixel beyond 1e-4 is explained by an ambiguous decision.
+    st = stats[4e-4]
+    assert st["fragile_frac"] <= max_fragile, rec
     assert st["max_err_nonfragile"] < 1e-4 and st["alpha_max_err_nonfragile"] < 1e-4 and st["last_id_mismatch_nonfragile"] == 0, rec
-    assert st["max_err_all"] <= bound_all, rec
+    assert st["max_err_all"] <= bound_all and stats[1e-3]["pixels_over_1e4_not_fragile"] == 0, rec
+    assert st["pixels_over_1e4"] <= 1e-3 * W * H, rec
     rng = np.random.default_rng(0)
     v_rc = rng.standard_normal((1, H, W, 3)).astype(np.float32)
     v_ra = rng.standard_normal((1, H, W, 1)).astype(np.float32)
@@ -155,7 +177,8 @@ def test_s5m_4k_full_frame_parity(mods):
     ops, rasterizer, scenes = mods
     scene = scenes.scene_5m()
     model, cam, out = _pipeline(ops, rasterizer, scenes, scene)
-    _blend_parity(ops, scene, "S-5M @4K (cfg5) full frame", out.aux["colors"], out.aux["isect_offsets"], out.aux["flatten_ids"])
+    # (twice the Gaussians per pixel of S-1M: twice the chance that one of a pixel's decisions is threshold-ambiguous)
+    _blend_parity(ops, scene, "S-5M @4K (cfg5) full frame", out.aux["colors"], out.aux["isect_offsets"], out.aux["flatten_ids"], max_fragile=0.02)
 
 
 def test_s5m_4k_properties(mods):
