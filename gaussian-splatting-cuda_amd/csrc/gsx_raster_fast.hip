@@ -30,11 +30,14 @@
 //    tiles and neighbouring tiles (which share Gaussians) hit the same 4 MiB L2.
 #include "gsx_raster_common.hpp"
 
+#include <cstdlib>
+#include <string>
+
 namespace gsx {
 
 #ifdef GSX_STATS
 // debug build only (tools/fwd_stats.py): counters for tuning the culling / early-exit behaviour
-__device__ unsigned long long g_stats[8];
+__device__ unsigned long long g_stats[16];
 #define GSX_STAT_ADD(i, v) do { if (lane == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
 #else
 #define GSX_STAT_ADD(i, v) do { } while (0)
@@ -609,6 +612,358 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward, Gaussian-major ("GM") variant: lanes = Gaussians, loop over pixels
+// ------------------------------------------------------------------------------------------------
+// raster_bwd_fast_kernel above evaluates one Gaussian per step on the 64 pixels of a quadrant and pays, per step, a 16-value
+// reduction over the wave (the butterfly, ~35 VALU) plus an LDS atomic — and 71 % of the lanes carry no weight, because a thin
+// ellipse covers a fraction of an 8x8 block.  This kernel transposes the loop: the tile's Gaussians are binned per 4x4 pixel block
+// (the footprint of a thin ellipse fits a 4x4 block much better: 42 % useful lanes), 64 Gaussians of a block's list sit on the 64
+// lanes, and the wave walks the 16 pixels of the block.  Per pixel every lane evaluates ITS Gaussian; the back-to-front recurrences
+//     T_j = T_in * prod_{i<=j} 1/(1-alpha_i)            tbuf_j = tbuf_in - sum_{i<j} (c_i . v) alpha_i T_i
+// become one multiplicative and one additive DPP scan over the lanes (6 instructions each), and the 15 moments of a Gaussian are
+// summed over the pixels in the lane's own registers: no cross-lane reduction at all.  After the 16 pixels the lane adds its
+// partial moments to the tile's LDS accumulator (15 ds_add_f32 per 64 Gaussians x 16 pixels, instead of one per Gaussian x 64
+// pixels).  The per-pixel state (u, v, upstream gradient, T, tbuf, last id) lives in LDS and is read with a wave-uniform address
+// (broadcast, no VALU); the last lane writes the carries back for the block's next batch.
+// Moment records / list heads / the gather kernel are those of the pixel-major kernel (same 15 moments, same layout).
+// Measured and simulated numbers: DESIGN.md §4.
+constexpr int GS = 256;   // Gaussians per super-chunk (one per thread at staging time)
+
+// Inclusive scans of FOUR independent values (the four pixels of a row of the 4x4 block) over the 64 lanes: Hillis-Steele inside each
+// row of 16 lanes (row_shr 1, 2, 4, 8), then the row totals travel with row_bcast:15 (lane 15 of rows 0 / 2 -> rows 1 / 3) and
+// row_bcast:31 (lane 31 -> rows 2, 3).  Written as DPP instructions with dst == src1 and bound_ctrl:0: a lane whose source lies
+// outside its row (or whose row is masked off) is not written and keeps its value — the identity of the scan — which is what a
+// multiplicative scan needs (through __builtin_amdgcn_update_dpp the compiler materialises the identity 1.0 and emits v_mov +
+// v_mov_dpp + v_mul per step).  Four values per step: the three other DPPs are the wait states a VALU write needs before a DPP
+// read of the same register (no s_nop inside the chain).
+#define GSX_SCAN4_STEP(OP, CTRL) OP " %0, %0, %0 " CTRL "\n\t" OP " %1, %1, %1 " CTRL "\n\t" OP " %2, %2, %2 " CTRL "\n\t" OP " %3, %3, %3 " CTRL "\n\t"
+#define GSX_SCAN4(OP)                                                     \
+    asm volatile("s_nop 1\n\t"                                            \
+                 GSX_SCAN4_STEP(OP, "row_shr:1 row_mask:0xf bank_mask:0xf")   \
+                 GSX_SCAN4_STEP(OP, "row_shr:2 row_mask:0xf bank_mask:0xf")   \
+                 GSX_SCAN4_STEP(OP, "row_shr:4 row_mask:0xf bank_mask:0xf")   \
+                 GSX_SCAN4_STEP(OP, "row_shr:8 row_mask:0xf bank_mask:0xf")   \
+                 GSX_SCAN4_STEP(OP, "row_bcast:15 row_mask:0xa bank_mask:0xf") \
+                 GSX_SCAN4_STEP(OP, "row_bcast:31 row_mask:0xc bank_mask:0xf") \
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]))
+GSX_DEV void wave_scan4_mul(float (&x)[4]) { GSX_SCAN4("v_mul_f32_dpp"); }
+GSX_DEV void wave_scan4_add(float (&x)[4]) { GSX_SCAN4("v_add_f32_dpp"); }
+#undef GSX_SCAN4
+#undef GSX_SCAN4_STEP
+
+// One row (4 pixels) of a 4x4 block for the 64 Gaussians of a batch (raster_bwd_gm_kernel).  CLAMP = false when no Gaussian of the
+// batch can reach alpha 0.999 (opacity < 0.999: alpha = o exp(-s) stays below it), which drops the clamp and its gradient mask.
+struct GmLaneRec { float u0, v0, l00, l01, l11, lo, d1, d2, d3, d4, d5, cr, cg, cb; int32_t idx; };
+struct GmRowPix { float T[4], tb[4], vr[4], vg[4], vb[4]; int32_t binf[4]; };
+
+template <bool CLAMP>
+GSX_DEV void gm_row(const GmLaneRec& g, const GmRowPix& px, const float (&du)[4], const float (&dv)[4], const float (&num2)[4],
+                    const float (&rden)[4], float (&acc)[15], float (&T_out)[4], float (&tb_out)[4]) {
+    float al[4], ra[4], P[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        float alpha = __builtin_amdgcn_exp2f(fmaf(-num2[h], rden[h], g.lo));
+        if (CLAMP) alpha = fminf(0.999f, alpha);
+        const bool valid = (g.idx <= px.binf[h]) && (alpha >= ALPHA_MIN);
+        al[h] = valid ? alpha : 0.f;
+        P[h] = ra[h] = __builtin_amdgcn_rcpf(1.f - al[h]);
+    }
+    wave_scan4_mul(P);
+    float T[4], fac[4], cv[4], e[4], S[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        T[h] = px.T[h] * P[h];                                   // transmittance in front of this Gaussian
+        fac[h] = al[h] * T[h];
+        cv[h] = fmaf(g.cb, px.vb[h], fmaf(g.cg, px.vg[h], g.cr * px.vr[h]));
+        S[h] = e[h] = cv[h] * fac[h];
+    }
+    wave_scan4_add(S);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const float tbuf = (px.tb[h] + e[h]) - S[h];             // tail - v . (colour accumulated behind this Gaussian)
+        const float v_alpha = fmaf(T[h], cv[h], ra[h] * tbuf);
+        float av = al[h] * v_alpha;
+        if (CLAMP) av = (al[h] < 0.999f) ? av : 0.f;             // clamped alpha carries no gradient (Bwd.cu:318)
+        const float aw = av * rden[h];
+        const float bw = aw * (num2[h] * rden[h]);
+        acc[0] = fmaf(fac[h], px.vr[h], acc[0]); acc[1] = fmaf(fac[h], px.vg[h], acc[1]); acc[2] = fmaf(fac[h], px.vb[h], acc[2]);
+        acc[3] += av;
+        const float x7 = aw * du[h], x8 = aw * dv[h], x10 = bw * du[h], x11 = bw * dv[h];
+        acc[4] = fmaf(x7, du[h], acc[4]); acc[5] = fmaf(x7, dv[h], acc[5]); acc[6] = fmaf(x8, dv[h], acc[6]);
+        acc[7] += x7; acc[8] += x8; acc[9] += bw; acc[10] += x10; acc[11] += x11;
+        acc[12] = fmaf(x10, du[h], acc[12]); acc[13] = fmaf(x10, dv[h], acc[13]); acc[14] = fmaf(x11, dv[h], acc[14]);
+        T_out[h] = T[h]; tb_out[h] = tbuf - e[h];
+    }
+}
+
+// pixel owned by thread `tid` in the GM kernel: wave = 8x8 quadrant, DPP row (16 lanes) = 4x4 block of the quadrant
+GSX_DEV void thread_pixel_gm(uint32_t tid, uint32_t tile_x, uint32_t tile_y, uint32_t& i, uint32_t& j) {
+    const uint32_t wave = tid >> 6, sb = (tid >> 4) & 3u, p = tid & 15u;
+    j = tile_x * TILE + (wave & 1u) * 8u + (sb & 1u) * 4u + (p & 3u);
+    i = tile_y * TILE + (wave >> 1) * 8u + (sb >> 1) * 4u + (p >> 2);
+}
+
+#ifndef GSX_GM_WAVES
+#define GSX_GM_WAVES 4
+#endif
+
+template <int KIND>
+__global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gm_kernel(RasterArgs a, const float* __restrict__ render_alphas,
+                                                                          const int32_t* __restrict__ last_ids,
+                                                                          const float* __restrict__ v_render_colors,
+                                                                          const float* __restrict__ v_render_alphas,
+                                                                          float4* __restrict__ ws_rec, int32_t* __restrict__ ws_head) {
+    // record planes: 0 u0, 1 v0, 2 l00, 3 l01, 4 l11, 5 lo, 6 d1, 7 d2, 8 d3, 9 d4, 10 d5, 11 red, 12 green, 13 blue, 14 hx, 15 hy
+    __shared__ float s_rec[16][GS];
+    __shared__ float s_acc[15][GS];
+    __shared__ int32_t s_gid[GS];
+    __shared__ uint32_t s_touched[GS / 32];
+    __shared__ uint8_t s_list[20][GS];   // [wave * 5 + k]: slots of the super-chunk whose footprint touches 4x4 block k (k < 4) / the 8x8 quadrant (k = 4)
+    __shared__ float s_T[RB], s_tbuf[RB];   // per pixel: the two loop-carried quantities of the back-to-front recurrence (two b32 planes: a
+                                            // wave-uniform ds_read_b32 costs 4.9 LDS cycles, a ds_read_b64 16.5: tools/lds_probe.hip)
+    __shared__ uint32_t s_lock;
+    __shared__ float4 s_uvb[KIND == CAM_PERFECT_PINHOLE ? 1 : RB];   // distorted cameras: per pixel (u, v, last id, -)
+    __shared__ float s_bounds[4][4];
+    __shared__ int32_t s_blockmax;
+    const uint32_t cid = blockIdx.y;
+    uint32_t tile_id;
+    if (!swizzled_tile(blockIdx.x, a.tw * a.th, tile_id)) return;
+    if (a.masks != nullptr && !a.masks[(size_t)cid * a.th * a.tw + tile_id]) return;  // Bwd.cu:84-86
+    const uint32_t tile_y = tile_id / a.tw, tile_x = tile_id - tile_y * a.tw;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t uwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);   // the same number, known to be wave-uniform
+    uint32_t i, j;
+    thread_pixel_gm(tid, tile_x, tile_y, i, j);
+    const bool inside = i < a.H && j < a.W;
+    const size_t pix = (size_t)cid * a.H * a.W + (size_t)min(i, a.H - 1) * a.W + min(j, a.W - 1);
+    const float* bg = a.backgrounds ? a.backgrounds + cid * 3 : nullptr;
+    const Camera<KIND> cam(a.cams, cid, a.W, a.H);
+    float u, v;
+    const bool ray_ok = pixel_uv(cam, i, j, u, v);
+    const bool active = inside && ray_ok;
+    if (tid == 0) { s_blockmax = -1; s_lock = 0u; }
+    float wb[4], tb[4];
+    uv_bounds(active, u, v, wave, lane, s_bounds, wb, tb);   // contains a barrier
+
+    const int32_t* toff = a.tile_offsets + (size_t)cid * a.th * a.tw;
+    const int32_t range_start = toff[tile_id];
+    const int32_t range_end = (cid == a.C - 1 && tile_id == a.tw * a.th - 1) ? (int32_t)a.n_isects : toff[tile_id + 1];
+
+    {   // per-pixel carries -> LDS
+        const float T_final = 1.f - render_alphas[pix];
+        float tail = v_render_alphas ? v_render_alphas[pix] : 0.f;   // T_final * (v_alpha_out - bg . v_out)   (Bwd.cu:307-316)
+        if (bg) tail -= bg[0] * v_render_colors[pix * 3] + bg[1] * v_render_colors[pix * 3 + 1] + bg[2] * v_render_colors[pix * 3 + 2];
+        s_T[tid] = T_final; s_tbuf[tid] = tail * T_final;
+        if (KIND != CAM_PERFECT_PINHOLE) s_uvb[tid] = make_float4(u, v, __int_as_float(active ? last_ids[pix] : -1), 0.f);
+    }
+    // bounds and last id of this lane's 4x4 block (row of 16 lanes), then as wave-uniform scalars per block
+    float bu0 = active ? u : INFINITY, bu1 = active ? u : -INFINITY, bv0 = active ? v : INFINITY, bv1 = active ? v : -INFINITY;
+    int32_t blast = active ? last_ids[pix] : -1;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        bu0 = fminf(bu0, __shfl_xor(bu0, o)); bu1 = fmaxf(bu1, __shfl_xor(bu1, o));
+        bv0 = fminf(bv0, __shfl_xor(bv0, o)); bv1 = fmaxf(bv1, __shfl_xor(bv1, o));
+        blast = max(blast, __shfl_xor(blast, o));
+    }
+    float sbb[4][4];
+    int32_t sb_last[4];
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb) {
+        sbb[sb][0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bu0), sb * 16));
+        sbb[sb][1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bu1), sb * 16));
+        sbb[sb][2] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv0), sb * 16));
+        sbb[sb][3] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv1), sb * 16));
+        sb_last[sb] = __builtin_amdgcn_readlane(blast, sb * 16);
+    }
+    const int32_t wave_last = max(max(sb_last[0], sb_last[1]), max(sb_last[2], sb_last[3]));
+    if (lane == 0) atomicMax(&s_blockmax, wave_last);
+    __syncthreads();
+    const int32_t block_last = min(s_blockmax, range_end - 1);
+    if (block_last < range_start) return;
+    const int32_t n_super = (block_last - range_start + GS) / GS;
+
+    for (int32_t sc = 0; sc < n_super; ++sc) {
+        __syncthreads();  // previous super-chunk's records are written, LDS planes are free
+        const int32_t chunk_end = block_last - GS * sc;  // inclusive; slot t holds sorted index chunk_end - t (back to front)
+        const int32_t chunk_size = min(GS, chunk_end + 1 - range_start);
+        if ((int32_t)tid < chunk_size) {
+            const int32_t g = a.flatten_ids[chunk_end - (int32_t)tid];
+            StagedRec sr;
+            stage_one(a, tb, g, sr);
+            s_rec[0][tid] = sr.r0.x; s_rec[1][tid] = sr.r0.y; s_rec[2][tid] = sr.r0.z; s_rec[3][tid] = sr.r0.w;
+            s_rec[4][tid] = sr.r1.x; s_rec[5][tid] = sr.r1.y; s_rec[6][tid] = sr.r1.z; s_rec[7][tid] = sr.r1.w;
+            s_rec[8][tid] = sr.r2.x; s_rec[9][tid] = sr.r2.y; s_rec[10][tid] = sr.r2.z; s_rec[11][tid] = sr.r2.w;
+            s_rec[12][tid] = sr.r3.x; s_rec[13][tid] = sr.r3.y; s_rec[14][tid] = sr.cull.z; s_rec[15][tid] = sr.cull.w;
+            s_gid[tid] = g;
+        }
+#pragma unroll
+        for (int k = 0; k < 15; ++k) s_acc[k][tid] = 0.f;
+        if (tid < GS / 32) s_touched[tid] = 0u;
+        __syncthreads();
+
+        if (wave == 0) { GSX_STAT_ADD(10, 1); GSX_STAT_ADD(11, chunk_size); }
+        // ---- bin the super-chunk's Gaussians into the lists of this wave's four 4x4 blocks (back-to-front order is kept) ----
+        uint32_t cnt[5] = {0u, 0u, 0u, 0u, 0u};
+        for (int32_t c0 = 0; c0 < chunk_size; c0 += 64) {
+            const int32_t c = c0 + (int32_t)lane;
+            const bool in = c < chunk_size;
+            const float cu = s_rec[0][c & (GS - 1)], cv_ = s_rec[1][c & (GS - 1)], chx = s_rec[14][c & (GS - 1)], chy = s_rec[15][c & (GS - 1)];
+            const int32_t idx = chunk_end - c;
+            bool any = false;
+#pragma unroll
+            for (int sb = 0; sb < 5; ++sb) {
+                bool hit = any;   // k = 4: the union of the four blocks
+                if (sb < 4) {
+                    hit = in && idx <= sb_last[sb] && (cu + chx >= sbb[sb][0]) && (cu - chx <= sbb[sb][1]) && (cv_ + chy >= sbb[sb][2]) &&
+                          (cv_ - chy <= sbb[sb][3]);
+                    any = any || hit;
+                }
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+                if (hit) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    s_list[wave * 5 + sb][cnt[sb] + rank] = (uint8_t)c;
+                }
+                cnt[sb] += (uint32_t)__popcll(m);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- batches of 64 Gaussians: per 4x4 block (16 pixels per batch) or, when the footprints are large, per quadrant ----
+        // Thin small ellipses touch few 4x4 blocks: one list per block keeps the lanes busy.  A Gaussian that covers most of the
+        // quadrant would sit in all four lists (four record loads, four flushes, four partly filled batches): then ONE batch per
+        // 64 Gaussians of the quadrant's list walks all 64 pixels and flushes once.  Both costs are known exactly from the list
+        // lengths (pixel rows to process), so every wave picks the cheaper one for every super-chunk.
+        const uint32_t rows4 = 4u * (((cnt[0] + 63u) >> 6) + ((cnt[1] + 63u) >> 6) + ((cnt[2] + 63u) >> 6) + ((cnt[3] + 63u) >> 6));
+        const uint32_t rows8 = 16u * ((cnt[4] + 63u) >> 6);
+        const bool per_quadrant = rows8 <= rows4;
+        GSX_STAT_ADD(12, per_quadrant ? 1 : 0); GSX_STAT_ADD(13, per_quadrant ? rows8 : rows4);
+        const float su = 1.f / cam.fx, sv = 1.f / cam.fy;
+        const int n_units = per_quadrant ? 1 : 4;
+#pragma unroll 1
+        for (int unit = 0; unit < n_units; ++unit) {
+            const int list_id = per_quadrant ? 4 : unit;
+            const uint32_t n_list = cnt[list_id];
+            GSX_STAT_ADD(8, n_list); GSX_STAT_ADD(9, (n_list + 63u) / 64u);
+            const uint8_t* list = s_list[wave * 5 + list_id];
+#pragma unroll 1
+            for (uint32_t b0 = 0; b0 < n_list; b0 += 64) {
+                const bool have = b0 + lane < n_list;
+                const uint32_t slot = have ? (uint32_t)list[b0 + lane] : 0u;
+                GmLaneRec g;
+                g.idx = chunk_end - (int32_t)slot;
+                g.u0 = s_rec[0][slot]; g.v0 = s_rec[1][slot]; g.l00 = s_rec[2][slot]; g.l01 = s_rec[3][slot]; g.l11 = s_rec[4][slot];
+                g.lo = have ? s_rec[5][slot] : -INFINITY;   // idle lanes: alpha = 0
+                g.d1 = s_rec[6][slot]; g.d2 = s_rec[7][slot]; g.d3 = s_rec[8][slot]; g.d4 = s_rec[9][slot]; g.d5 = s_rec[10][slot];
+                g.cr = s_rec[11][slot]; g.cg = s_rec[12][slot]; g.cb = s_rec[13][slot];
+                float acc[15];
+#pragma unroll
+                for (int k = 0; k < 15; ++k) acc[k] = 0.f;
+                // no lane of the batch can reach the alpha clamp (log2 opacity below log2 0.999): the cheaper row body
+                const bool clamp = __builtin_amdgcn_ballot_w64(g.lo > -0.0015f) != 0ull;
+                const int sb_first = per_quadrant ? 0 : unit, sb_end = per_quadrant ? 4 : unit + 1;
+#pragma unroll 1
+                for (int sb = sb_first; sb < sb_end; ++sb) {
+                    float* carry_T = &s_T[wave * 64 + sb * 16];
+                    float* carry_b = &s_tbuf[wave * 64 + sb * 16];
+                    const float4* uvb = &s_uvb[KIND == CAM_PERFECT_PINHOLE ? 0 : wave * 64 + sb * 16];
+                    // origin of the 4x4 block (wave-uniform): pixel (bx + px, by + py)
+                    const uint32_t bx = tile_x * TILE + (uwave & 1u) * 8u + ((uint32_t)sb & 1u) * 4u, by = tile_y * TILE + (uwave >> 1) * 8u + ((uint32_t)sb >> 1) * 4u;
+                    const float bu = ((float)bx + 0.5f - cam.cx) * su, bv = ((float)by + 0.5f - cam.cy) * sv;   // perfect pinhole: (u, v) of its pixel (0, 0)
+                    float duc[4];   // perfect pinhole: du of the block's four columns (dv is constant along a row)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) duc[c] = fmaf((float)c, su, bu - g.u0);
+                    const float dv00 = bv - g.v0;
+#pragma unroll 1
+                    for (int row = 0; row < 4; ++row) {
+                        GmRowPix px;
+                        float du[4], dv[4], num2[4], rden[4];
+                        const uint32_t y = by + (uint32_t)row;
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) {
+                            const int pp = row * 4 + h;
+                            px.T[h] = carry_T[pp]; px.tb[h] = carry_b[pp];            // wave-uniform addresses: LDS broadcast
+                            // read-only per-pixel inputs: wave-uniform addresses into the global tensors
+                            const uint32_t x = bx + (uint32_t)h;
+                            const size_t gp = (size_t)cid * a.H * a.W + (size_t)min(y, a.H - 1) * a.W + min(x, a.W - 1);
+                            px.vr[h] = v_render_colors[gp * 3]; px.vg[h] = v_render_colors[gp * 3 + 1]; px.vb[h] = v_render_colors[gp * 3 + 2];
+                            if (KIND == CAM_PERFECT_PINHOLE) {
+                                px.binf[h] = (y < a.H && x < a.W) ? last_ids[gp] : -1;
+                            } else {
+                                const float4 q = uvb[pp];
+                                px.binf[h] = __float_as_int(q.z);
+                                du[h] = q.x - g.u0; dv[h] = q.y - g.v0;
+                            }
+                        }
+                        if (KIND == CAM_PERFECT_PINHOLE) {
+                            // separable pixel grid: everything that depends on the row only is hoisted out of the four pixels
+                            const float dvr = fmaf((float)row, sv, dv00);
+                            const float t1 = g.l11 * dvr, t1sq = t1 * t1, t0r = g.l01 * dvr;
+                            const float Ar = fmaf(dvr, fmaf(g.d5, dvr, g.d2), 1.f), Br = fmaf(g.d4, dvr, g.d1);
+#pragma unroll
+                            for (int h = 0; h < 4; ++h) {
+                                du[h] = duc[h]; dv[h] = dvr;
+                                const float t0 = fmaf(g.l00, du[h], t0r);
+                                num2[h] = fmaf(t0, t0, t1sq);
+                                rden[h] = __builtin_amdgcn_rcpf(fmaf(du[h], fmaf(g.d3, du[h], Br), Ar));
+                            }
+                        } else {
+#pragma unroll
+                            for (int h = 0; h < 4; ++h) {
+                                const float t0 = fmaf(g.l01, dv[h], g.l00 * du[h]);
+                                const float t1 = g.l11 * dv[h];
+                                num2[h] = fmaf(t0, t0, t1 * t1);
+                                rden[h] = __builtin_amdgcn_rcpf(fmaf(du[h], fmaf(g.d3, du[h], fmaf(g.d4, dv[h], g.d1)), fmaf(dv[h], fmaf(g.d5, dv[h], g.d2), 1.f)));
+                            }
+                        }
+                        float T_out[4], tb_out[4];
+                        if (clamp) gm_row<true>(g, px, du, dv, num2, rden, acc, T_out, tb_out);
+                        else gm_row<false>(g, px, du, dv, num2, rden, acc, T_out, tb_out);
+                        if (lane == 63u) {   // carries for this block's next batch
+#pragma unroll
+                            for (int h = 0; h < 4; ++h) { carry_T[row * 4 + h] = T_out[h]; carry_b[row * 4 + h] = tb_out[h]; }
+                        }
+                    }
+                }
+                // Partial moments -> the tile's accumulator.  The slots of one batch are distinct, so inside a wave a plain
+                // read-add-write is race free; the four waves of the tile exclude each other with a wave-level lock.  (ds_add_f32
+                // is serialised by the LDS at ~3 cycles per active lane — 192 cycles per wave64 instruction, tools/lds_probe.hip —
+                // which made a 15-atomic flush cost more than the batch's arithmetic; integer LDS atomics run at 4 cycles.)
+                if (lane == 0u) {
+                    uint32_t expected = 0u;
+                    while (!__hip_atomic_compare_exchange_strong(&s_lock, &expected, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                        expected = 0u;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (have) {
+                    float cur[15];
+#pragma unroll
+                    for (int k = 0; k < 15; ++k) cur[k] = s_acc[k][slot];
+#pragma unroll
+                    for (int k = 0; k < 15; ++k) s_acc[k][slot] = cur[k] + acc[k];
+                    atomicOr(&s_touched[slot >> 5], 1u << (slot & 31u));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0u) __hip_atomic_store(&s_lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __syncthreads();
+
+        // one thread per touched Gaussian of the super-chunk: 64 B moment record at its sorted index, chained per Gaussian
+        if ((int32_t)tid < chunk_size && ((s_touched[tid >> 5] >> (tid & 31u)) & 1u)) {
+            const int32_t isect = chunk_end - (int32_t)tid;
+            const int32_t prev = atomicExch(&ws_head[s_gid[tid]], isect);
+            float4* rec = ws_rec + (size_t)isect * 4;
+            rec[0] = make_float4(s_acc[0][tid], s_acc[1][tid], s_acc[2][tid], s_acc[3][tid]);
+            rec[1] = make_float4(s_acc[4][tid], s_acc[5][tid], s_acc[6][tid], s_acc[7][tid]);
+            rec[2] = make_float4(s_acc[8][tid], s_acc[9][tid], s_acc[10][tid], s_acc[11][tid]);
+            rec[3] = make_float4(s_acc[12][tid], s_acc[13][tid], s_acc[14][tid], __int_as_float(prev));
+        }
+    }
+}
+
 // Sum the moment records of every (camera, Gaussian) (lists built by raster_bwd_fast_kernel) and apply the chain
 // rule once: moments -> (B0, B1, h, a_i, u0, v0, m_z) -> (A, m) -> (M, mu) -> (quat, scale) (Utils.cuh:104-158).
 // One thread per Gaussian; colours / opacities are per camera, means / quats / scales are shared by the cameras.
@@ -747,6 +1102,26 @@ bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, 
         pack_into(a, (char*)ws_head + (((size_t)a.C * a.N * 4 + 255) / 256) * 256, st, ws_head);  // also sets every list head to -1
     }
     const dim3 ggrid((a.N + 255u) / 256u), gblock(256);
+    // Two backward kernels, same records and gather.  Gaussian-major wins when the projected Gaussians are small next to a 4x4 pixel
+    // block's neighbourhood (S-1M: 767 vs 862 us), pixel-major when they cover many blocks (S-5M @4K: 2.47 vs 2.76 ms): DESIGN.md §4.
+    // The proxy available without a host read is the mean number of 16x16 tiles per Gaussian; GSX_BWD=pm|gm forces one (tests, tools).
+    static const int forced = [] { const char* e = getenv("GSX_BWD"); return !e ? 0 : (std::string(e) == "pm" ? 1 : (std::string(e) == "gm" ? 2 : 0)); }();
+    const bool gaussian_major = forced ? forced == 2 : (double)a.n_isects < 4.5 * (double)a.C * (double)a.N;
+    if (gaussian_major) {
+        if (kind == CAM_PERFECT_PINHOLE)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_gm_kernel<CAM_PERFECT_PINHOLE>), grid, block, 0, st, a, render_alphas, last_ids,
+                               v_render_colors, v_render_alphas, ws_rec, ws_head);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_gm_kernel<CAM_OPENCV_PINHOLE>), grid, block, 0, st, a, render_alphas, last_ids,
+                               v_render_colors, v_render_alphas, ws_rec, ws_head);
+        if (kind == CAM_PERFECT_PINHOLE)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_bwd_gather_kernel<CAM_PERFECT_PINHOLE>), ggrid, gblock, 0, st, a, ws_rec, ws_head, v_means,
+                               v_quats, v_scales, v_colors, v_opacities);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_bwd_gather_kernel<CAM_OPENCV_PINHOLE>), ggrid, gblock, 0, st, a, ws_rec, ws_head, v_means,
+                               v_quats, v_scales, v_colors, v_opacities);
+        return true;
+    }
     if (kind == CAM_PERFECT_PINHOLE) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_fast_kernel<CAM_PERFECT_PINHOLE>), grid, block, 0, st, a, render_alphas,
                            last_ids, v_render_colors, v_render_alphas, ws_rec, ws_head);
@@ -766,7 +1141,7 @@ bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, 
 #ifdef GSX_STATS
 extern "C" void gsx_debug_read_stats(unsigned long long* out, int reset) {
     (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(gsx::g_stats), sizeof(unsigned long long) * 8);
-    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(gsx::g_stats), z, sizeof(z)); }
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(gsx::g_stats), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(gsx::g_stats), z, sizeof(z)); }
 }
 #endif

@@ -1,0 +1,50 @@
+"""Times the two blend ops in isolation (HIP events, median of n launches) on S-1M or S-5M: the A/B harness for kernel variants
+selected by environment switches (GSX_BWD=pm|gm, ...), one process per variant.   python tools/blend_ab.py [1m|5m] [n]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import gsx  # noqa: E402,F401
+from gsx import ops, rasterizer, scenes  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "1m"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+dev = "cuda:0"
+scene = {"1m": scenes.scene_1m, "5m": scenes.scene_5m}[which]()
+W, H = scene["width"], scene["height"]
+model = scenes.to_splat_data(scene, dev)
+cam = rasterizer.Camera(viewmat=scene["viewmat"].to(dev), K=scene["K"].to(dev), width=W, height=H)
+with torch.no_grad():
+    out = rasterizer.rasterize(cam, model, scene["background"].to(dev))
+d = lambda k: scene[k].to(dev)  # noqa: E731
+ut = ops.UnscentedTransformParameters()
+colors, off, fl = out.aux["colors"].contiguous(), out.aux["isect_offsets"], out.aux["flatten_ids"]
+common = (d("means"), d("quats"), d("scales"), colors, d("opacities")[None].contiguous(), d("background")[None].contiguous(), None, W, H, 16,
+          d("viewmat")[None].contiguous(), None, d("K")[None].contiguous(), ops.CameraModelType.PINHOLE, ut, ops.ShutterType.GLOBAL, None, None, None, off, fl)
+g = torch.Generator(device=dev).manual_seed(0)
+v_rc, v_ra = torch.randn(1, H, W, 3, device=dev, generator=g), torch.randn(1, H, W, 1, device=dev, generator=g)
+
+
+def timeit(fn):
+    for _ in range(3):
+        fn()
+    ts = []
+    for _ in range(n):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = fn()
+        e.record()
+        e.synchronize()
+        ts.append(s.elapsed_time(e))
+    ts.sort()
+    return ts[len(ts) // 2], r
+
+
+t_f, fwd = timeit(lambda: ops.rasterize_to_pixels_from_world_3dgs_fwd(*common, keep_ws=True))
+t_b, bwd = timeit(lambda: ops.rasterize_to_pixels_from_world_3dgs_bwd(*common, fwd[1], fwd[2], v_rc, v_ra, fwd_ws=fwd[3]))
+chk = [float(x.double().abs().sum()) for x in bwd]
+print("%s GSX_BWD=%s n_isects=%d  fwd %.4f ms  bwd %.4f ms  |grads|_1 = %s" % (which, os.environ.get("GSX_BWD", "-"), fl.numel(), t_f, t_b,
+                                                                              " ".join("%.6g" % c for c in chk)))
