@@ -148,52 +148,76 @@ class ShardedAdam:
     all-gather of the updated parameters.  Same bytes over xGMI as the all-reduce (a ring all-reduce IS a reduce-scatter followed by
     an all-gather), but the optimizer touches 1/world of the rows on every rank (59 M parameters: 0.27 ms -> 0.03 ms at 8 GPUs) and
     the second half of the exchange carries parameters instead of gradients.  Every rank ends the step with bit-identical
-    parameters (the all-gather distributes ONE computed copy of each row).  Rows are split in `world` contiguous blocks; when the
-    Gaussian count is not divisible by the world size the step falls back to all-reduce + replicated Adam.
-    The moments stay full-size on every rank (the densification strategy indexes them by global row); only this rank's block is
-    ever read or written while the partition is stable."""
+    parameters (the all-gather distributes ONE computed copy of each row).
 
-    def __init__(self, optimizer, bucket):
+    Rows are split in `world` contiguous blocks of ceil(n / world).  When n is divisible by the world size the exchange is RCCL's
+    in-place reduce-scatter / all-gather; otherwise (while the model grows) the gradient is all-reduced and the updated blocks are
+    merged with one SUM all-reduce of the parameters with the foreign rows zeroed (each row has exactly one owner: same bits).
+    The Adam moments stay full-size on every rank (the densification strategy indexes them by global row) but only the owner's copy
+    of a row is current; when the partition moves (the Gaussian count changed) the moments are merged the same way first."""
+
+    def __init__(self, optimizer, bucket=None):
         self.opt, self.bucket = optimizer, bucket
+        self._bounds = None   # (n, lo, hi) of the partition the moments were last updated under
 
-    def _reduce_scatter_mean(self, g, lo, hi):
+    @staticmethod
+    def _merge_owned_rows(t, lo, hi):
+        """Every rank ends with the owners' rows: zero the rows this rank does not own, SUM over the ranks."""
+        t[:lo].zero_()
+        t[hi:].zero_()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    def _reduce_mean(self, g, lo, hi, even):
         world = dist.get_world_size()
-        if dist.get_backend() == "nccl":  # RCCL: in-place reduce-scatter (output = this rank's block of the input)
-            GradBucket._reduce_mean(torch.zeros(1, dtype=g.dtype, device=g.device)) if GradBucket._avg_ok is None else None
+        if even and dist.get_backend() == "nccl":  # RCCL: in-place reduce-scatter (output = this rank's block of the input)
+            if GradBucket._avg_ok is None:
+                GradBucket._reduce_mean(torch.zeros(1, dtype=g.dtype, device=g.device))
             flat = g.reshape(-1)
             per = flat.numel() // world
             out = flat[dist.get_rank() * per:(dist.get_rank() + 1) * per]
             dist.reduce_scatter_tensor(out, flat, op=dist.ReduceOp.AVG if GradBucket._avg_ok else dist.ReduceOp.SUM)
             if not GradBucket._avg_ok:
                 out.mul_(1.0 / world)
-        else:  # gloo has no reduce-scatter: all-reduce, every rank then reads its block only
+        else:  # gloo has no reduce-scatter; uneven blocks: all-reduce, every rank then reads its block only
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
             g[lo:hi].mul_(1.0 / world)
 
-    def _all_gather_rows(self, p, lo, hi):
-        flat = p.reshape(-1)
-        per = flat.numel() // dist.get_world_size()
-        mine = flat[dist.get_rank() * per:(dist.get_rank() + 1) * per]
-        if dist.get_backend() != "nccl":
-            mine = mine.clone()
-        dist.all_gather_into_tensor(flat, mine)
+    def _gather_rows(self, p, lo, hi, even):
+        if even and dist.get_backend() == "nccl":  # RCCL: in-place all-gather (input = this rank's block of the output)
+            flat = p.reshape(-1)
+            per = flat.numel() // dist.get_world_size()
+            dist.all_gather_into_tensor(flat, flat[dist.get_rank() * per:(dist.get_rank() + 1) * per])
+        else:
+            self._merge_owned_rows(p, lo, hi)
 
     @torch.no_grad()
-    def step(self, iteration):
+    def step(self, iteration, bucket=None):
         world, rank = dist.get_world_size(), dist.get_rank()
+        self.bucket = bucket if bucket is not None else self.bucket
         params = self.bucket.params
         n = params[0].shape[0]
-        if n % world != 0 or any(p.shape[0] != n for p in params):
-            self.bucket.all_reduce_mean()
-            self.opt.step(iteration)
-            return
-        lo, hi = rank * (n // world), (rank + 1) * (n // world)
+        assert all(p.shape[0] == n for p in params), "row sharding needs per-Gaussian parameters"
+        per = (n + world - 1) // world
+        lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
+        even = n % world == 0
+        if self._bounds is not None and self._bounds[0] != n:
+            # the partition moves: bring every rank's moments up to date under the OLD partition before rows change owner.
+            # (rows appended or reset by the densification strategy since are zero on every rank; merging zeros keeps them zero)
+            n_old, lo_old, hi_old = self._bounds
+            for st in self.opt.state.values():
+                if isinstance(st, dict):
+                    for k in ("exp_avg", "exp_avg_sq"):
+                        grown = st[k].shape[0] - n_old   # rows appended after the last step: owned by nobody yet, identical everywhere
+                        head = st[k][:n_old]
+                        self._merge_owned_rows(head, lo_old, hi_old)
+                        assert grown >= 0
+        self._bounds = (n, lo, hi)
         for p in params:
-            self._reduce_scatter_mean(p.grad, lo, hi)
+            self._reduce_mean(p.grad, lo, hi, even)
         self.bucket.last_reduced_bytes = self.bucket.nbytes()
         self.opt.step(iteration, rows=(lo, hi))
         for p in params:
-            self._all_gather_rows(p.data, lo, hi)
+            self._gather_rows(p.data, lo, hi, even)
 
 
 def shard_cameras(cameras, rank, world):

@@ -11,32 +11,12 @@ copies are one indexed copy.
 Multi-GPU (one camera per rank): every rank must take identical decisions — pass a `generator` seeded identically on all
 ranks (the sampling and the noise are the only random draws); torch's multinomial / randn are deterministic given the
 generator state and identical inputs."""
-from dataclasses import dataclass
-
 import torch
 
 from . import ops, optim
 
 
-@dataclass
-class OptimizationParameters:
-    """include/core/parameters.hpp:17-37 (the fields the gut / MCMC training loop reads)."""
-    iterations: int = 30000
-    sh_degree_interval: int = 1000
-    means_lr: float = 0.00016
-    shs_lr: float = 0.0025
-    opacity_lr: float = 0.05
-    scaling_lr: float = 0.005
-    rotation_lr: float = 0.001
-    lambda_dssim: float = 0.2
-    min_opacity: float = 0.005
-    refine_every: int = 100
-    start_refine: int = 500
-    stop_refine: int = 25000
-    sh_degree: int = 3
-    opacity_reg: float = 0.01
-    scale_reg: float = 0.01
-    max_cap: int = 1000000
+from .parameters import OptimizationParameters  # noqa: E402,F401  (include/core/parameters.hpp:15-93 + the JSON parameter files)
 
 
 class MCMC:
@@ -59,6 +39,7 @@ class MCMC:
                                                         params.opacity_lr, scene_scale)
         self.scheduler = optim.ExponentialLR(self.optimizer, 0.01 ** (1.0 / params.iterations), 0)
         self.on_resize = None   # callback(model) after add_new_gs replaced the parameter tensors (e.g. rebuild the gradient bucket)
+        self._grew = False      # add_new_gs replaced the parameters this iteration: they carry no gradient (see step)
 
     # ---- helpers ---------------------------------------------------------------------------------------------------------
     def is_refining(self, it):
@@ -123,6 +104,7 @@ class MCMC:
             old = getattr(m, name)
             setattr(m, name, torch.cat([old.data, old.data.index_select(0, sampled)], 0).requires_grad_(True))
         self.optimizer.extend_state(n_new)
+        self._grew = True
         if self.on_resize is not None:
             self.on_resize(m)
         return n_new
@@ -146,9 +128,15 @@ class MCMC:
             self.add_new_gs()
         self.inject_noise()
 
-    def step(self, it):
+    def step(self, it, optimizer_step=None):
+        """mcmc.cpp:395-402 (optimizer_step: replacement for self.optimizer.step, e.g. distributed.ShardedAdam.step).  On an iteration in which add_new_gs grew the model, upstream's freshly concatenated parameter tensors
+        have an undefined gradient, so FusedAdam::step skips every group (no update, no step_count++, fused_adam.cpp:33-36): the
+        iteration's gradient is dropped, the scheduler still advances.  Same here."""
         if it < self.params.iterations:
-            self.optimizer.step(it)
+            if self._grew:
+                self._grew = False
+            else:
+                (optimizer_step or self.optimizer.step)(it)
             self.scheduler.step()
 
     @torch.no_grad()

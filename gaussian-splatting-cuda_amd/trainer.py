@@ -19,8 +19,11 @@ from .strategy import MCMC, OptimizationParameters
 
 
 class Trainer:
-    def __init__(self, model, cameras, images, params: OptimizationParameters = None, background=None, scene_scale=1.0, seed=0):
-        """cameras: list of rasterizer.Camera; images: list of [3,H,W] ground-truth tensors on the device."""
+    def __init__(self, model, cameras, images, params: OptimizationParameters = None, background=None, scene_scale=1.0, seed=0,
+                 sharded_adam=False):
+        """cameras: list of rasterizer.Camera; images: list of [3,H,W] ground-truth tensors on the device.
+        sharded_adam (world > 1): reduce-scatter -> Adam on this rank's 1/world of the Gaussians -> all-gather of the parameters
+        (distributed.ShardedAdam) instead of all-reduce + replicated Adam."""
         self.model, self.cameras, self.images = model, cameras, images
         self.params = params or OptimizationParameters()
         self.bg = background
@@ -34,6 +37,7 @@ class Trainer:
         self.strategy = MCMC(model, self.params, scene_scale, gen)
         self.strategy.on_resize = self._rebuild_bucket
         self._rebuild_bucket(model)
+        self.sharded = gdist.ShardedAdam(self.strategy.optimizer) if (sharded_adam and self.world > 1) else None
         self.last_loss = None
 
     def _rebuild_bucket(self, model):
@@ -55,11 +59,18 @@ class Trainer:
         gt = self.images[i]
         loss = gloss.photometric_loss(out.render_hwc, gt, self.params.lambda_dssim)
         loss.backward()
-        if self.world > 1:  # only rows some camera of the step saw are non-zero: compacted all-reduce
-            self.bucket.all_reduce_mean_rows((out.aux["radii_full"] > 0).all(-1))
-        self._add_regularisers()  # identical on every rank (functions of the replicated parameters): added after the reduction
-        self.strategy.post_backward(it, out)
-        self.strategy.step(it)
+        if self.sharded is not None:
+            # the regularisers are the same on every rank, so adding them before the mean over the ranks gives the same sum; the
+            # exchange itself (reduce-scatter ... all-gather) brackets the optimizer step and is skipped with it when the model grew
+            self._add_regularisers()
+            self.strategy.post_backward(it, out)
+            self.strategy.step(it, optimizer_step=lambda i: self.sharded.step(i, self.bucket))
+        else:
+            if self.world > 1:  # only rows some camera of the step saw are non-zero: compacted all-reduce
+                self.bucket.all_reduce_mean_rows((out.aux["radii_full"] > 0).all(-1))
+            self._add_regularisers()  # identical on every rank (functions of the replicated parameters): added after the reduction
+            self.strategy.post_backward(it, out)
+            self.strategy.step(it)
         self.last_loss = loss.detach()
         return self.last_loss
 

@@ -136,7 +136,7 @@ def _sharded_worker(rank, world, port, out_dir):
     import gsx  # noqa: F401
     from gsx import distributed as gdist
     gdist.init_from_env(backend="gloo")
-    for N in (1000, 1001):                                          # divisible by the world size / not (fallback: all-reduce + full step)
+    for N in (1000, 1001):                                          # divisible by the world size / not (uneven blocks)
         shapes = [(N, 3), (N, 16, 3), (N, 3), (N, 4), (N, 1)]
         g0 = torch.Generator().manual_seed(7)
         init = [torch.randn(s, generator=g0) for s in shapes]        # identical replicas
@@ -155,7 +155,8 @@ def _sharded_worker(rank, world, port, out_dir):
                 opt.step(3)
             else:
                 gdist.ShardedAdam(opt, bucket).step(3)
-                assert opt.calls == ([(rank * (N // world), (rank + 1) * (N // world))] if N % world == 0 else [None])
+                per = (N + world - 1) // world
+                assert opt.calls == [(min(N, rank * per), min(N, (rank + 1) * per))]
             out[mode] = np.concatenate([p.detach().numpy().reshape(-1) for p in params])
         assert np.array_equal(out["replicated"], out["sharded"])
         np.save(os.path.join(out_dir, "sharded_%d_%d.npy" % (N, rank)), out["sharded"])

@@ -1,0 +1,63 @@
+"""The world > 1 branch of the training step on real kernels: two ranks (both on GPU 0, gloo — RCCL refuses two ranks on one device)
+run Trainer.train_step through relocation and growth with (a) the compacted all-reduce + replicated Adam and (b) reduce-scatter ->
+sharded Adam -> all-gather, and must end with bit-identical replicas; (a) and (b) must agree with each other to rounding."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir, sharded):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import gsx  # noqa: F401
+    from gsx import distributed as gdist
+    from gsx import parameters, rasterizer, scenes, trainer
+    from tests.test_gpu_training import _scene
+    torch.cuda.set_device(0)
+    gdist.init_from_env(backend="gloo")
+    dev = "cuda:0"
+    sc, gt_model, cams = _scene(dev, N=2000)          # N divisible by the world size: the sharded path is taken until the model grows
+    bg = sc["background"].to(dev)
+    with torch.no_grad():
+        images = [rasterizer.rasterize_fused(c, gt_model, bg).image.clone() for c in cams]
+    g = torch.Generator().manual_seed(9)
+    model = scenes.to_splat_data(dict(sc), dev)
+    model.sh = (gt_model.sh + 0.3 * torch.randn(gt_model.sh.shape, generator=g).to(dev)).contiguous()
+    model.opacity_raw = (gt_model.opacity_raw - 0.5).contiguous()
+    with torch.no_grad():
+        model.opacity_raw[:50] = -10.0                # dead Gaussians: relocation has work to do
+    prm = parameters.OptimizationParameters(iterations=200, start_refine=10, refine_every=10, stop_refine=100, max_cap=2400, sh_degree_interval=1000)
+    tr = trainer.Trainer(model, cams, images, prm, bg, seed=3, sharded_adam=sharded)
+    for it in range(1, 46):
+        tr.train_step(it)
+    torch.cuda.synchronize()
+    flat = torch.cat([p.detach().reshape(-1) for p in model.params()]).cpu().numpy()
+    np.save(os.path.join(out_dir, "params_%d_%d.npy" % (int(sharded), rank)), flat)
+    np.save(os.path.join(out_dir, "count_%d_%d.npy" % (int(sharded), rank)), np.array([model.means.shape[0], tr.strategy.optimizer.step_count("means")]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sharded", [False, True])
+def test_two_rank_training_keeps_replicas_bit_identical(tmp_path, sharded):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), sharded), nprocs=world, join=True)
+    a, b = np.load(tmp_path / ("params_%d_0.npy" % int(sharded))), np.load(tmp_path / ("params_%d_1.npy" % int(sharded)))
+    assert a.shape == b.shape and np.array_equal(a, b)               # replicas identical after relocation + growth + 45 steps
+    n, steps = np.load(tmp_path / ("count_%d_0.npy" % int(sharded)))
+    assert n > 2000 and steps < 45                                    # the model grew; growth iterations skip the optimizer
+    assert np.isfinite(a).all()
