@@ -303,9 +303,15 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
     const int32_t range_end = (cid == a.C - 1 && tile_id == a.tw * a.th - 1) ? (int32_t)a.n_isects : toff[tile_id + 1];
     const int32_t n_chunks = (range_end - range_start + FCH - 1) / FCH;
 
+    // Compositing state.  The alpha clamp min(0.999, .) is folded into the exponential: the loop works with alpha' = alpha / 0.999
+    // = clamp01(exp2(lo' - ...)) (lo' = lo - log2 0.999 and colours scaled by 0.999 at staging time; the [0,1] clamp is an output
+    // modifier of v_exp_f32, not an instruction).  A pixel that is finished carries the threshold +inf, so "skip below 1/255" and
+    // "done" are ONE comparison; the T <= 1e-4 stop (rare: a pixel stops once) is handled in a wave-uniform side branch.
+    constexpr float K999 = 0.999f, LOG2_K999 = -0.0014434168696687174f, THR = (1.f / 255.f) / 0.999f;
     float T = 1.f;
     uint32_t cur_idx = 0;
     float out_r = 0.f, out_g = 0.f, out_b = 0.f;
+    float thr = done ? INFINITY : THR;
     bool wave_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
     int32_t g_pre = 0;  // the flatten id of the next chunk is prefetched, its 64 B packed record is gathered at staging time
     bool have = (int32_t)tid < FCH && range_start + (int32_t)tid < range_end;
@@ -316,6 +322,7 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
         if (have) {
             StagedRec sr;
             stage_one(a, tb, g_pre, sr);
+            sr.r1.y -= LOG2_K999; sr.r2.w *= K999; sr.r3.x *= K999; sr.r3.y *= K999;
             s_rec[buf][tid][0] = sr.r0; s_rec[buf][tid][1] = sr.r1; s_rec[buf][tid][2] = sr.r2; s_rec[buf][tid][3] = sr.r3;
             s_cull[buf][tid] = sr.cull;
         }
@@ -336,41 +343,37 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
             unsigned long long todo = __builtin_amdgcn_ballot_w64(hit);
             GSX_STAT_ADD(1, min(64, chunk_size - sub));
             GSX_STAT_ADD(0, __popcll(todo));
-#ifdef GSX_STATS
-            int st_b[4] = {0, 0, 0, 0}, st_s[4] = {0, 0, 0, 0};
-#endif
             while (todo) {
                 const int t = sub + __builtin_ctzll(todo);
                 todo &= todo - 1ull;
                 const float4* rp = s_rec[buf][t];
                 const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
-                float du, dv, num2, rden;
-                const float alpha = fast_alpha(u, v, r0, r1, r2, du, dv, num2, rden);
-                // branch-free compositing step (Fwd.cu:240-259): lanes that skip this Gaussian run with weight 0
-                const bool contrib = !done && alpha >= ALPHA_MIN;
-                const float next_T = fmaf(-alpha, T, T);  // T (1 - alpha) with one rounding, one VALU slot
-                const bool stop = contrib && next_T <= 1e-4f;
-                const bool take = contrib != stop;  // stop implies contrib: xor of the two lane masks on the scalar unit (no second compare)
-                const float w = take ? alpha * T : 0.f;
+                const float du = u - r0.x, dv = v - r0.y;
+                const float t0 = fmaf(r0.w, dv, r0.z * du);
+                const float t1 = r1.x * dv;
+                const float num2 = fmaf(t0, t0, t1 * t1);
+                const float den = fmaf(du, fmaf(r2.x, du, fmaf(r2.y, dv, r1.z)), fmaf(dv, fmaf(r2.z, dv, r1.w), 1.f));
+                const float ap = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(fmaf(-num2, __builtin_amdgcn_rcpf(den), r1.y)), 0.f, 1.f);
+                bool take = ap >= thr;                       // alpha >= 1/255 and the pixel is not finished (Fwd.cu:240)
+                float w = take ? ap * T : 0.f;               // alpha T / 0.999
+                T = fmaf(-K999, w, T);                       // T (1 - alpha), in place
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(T <= 1e-4f) != 0ull, 0)) {
+                    // some pixel stops here: it does NOT take this Gaussian (Fwd.cu:245-248).  Its transmittance is put back
+                    // (T + alpha T: equal to the old value to one rounding; only 1 - T of a finished pixel is ever read again).
+                    const bool stop = T <= 1e-4f;
+                    take = take && !stop;
+                    T = stop ? fmaf(K999, w, T) : T;
+                    w = stop ? 0.f : w;
+                    thr = stop ? INFINITY : thr;
+                }
                 out_r = fmaf(r2.w, w, out_r); out_g = fmaf(r3.x, w, out_g); out_b = fmaf(r3.y, w, out_b);
-                T = take ? next_T : T;
                 cur_idx = take ? (uint32_t)(chunk_start + t) : cur_idx;
-                done = done || stop;
 #ifdef GSX_STATS
-                { const unsigned long long c = __builtin_amdgcn_ballot_w64(take); GSX_STAT_ADD(2, c != 0ull); GSX_STAT_ADD(3, __popcll(c));
-                  const unsigned long long bm[4] = {0x0F0F0F0Full, 0xF0F0F0F0ull, 0x0F0F0F0Full << 32, 0xF0F0F0F0ull << 32};
-                  int nb = 0;
-                  for (int q = 0; q < 4; ++q) { const int hb = (c & bm[q]) != 0ull; st_b[q] += hb; nb += hb; st_s[q] += ((c >> (16 * q)) & 0xffffull) != 0ull; }
-                  GSX_STAT_ADD(5, nb); }
+                { const unsigned long long c = __builtin_amdgcn_ballot_w64(take); GSX_STAT_ADD(2, c != 0ull); GSX_STAT_ADD(3, __popcll(c)); }
 #endif
             }
-            // all 64 pixels saturated: tested once per 64 candidates, not per Gaussian (a ballot of the loop-carried predicate
-            // costs two VALU slots; the saturated lanes run with weight 0 until then, which leaves the result unchanged)
-            if (__builtin_amdgcn_ballot_w64(!done) == 0ull) wave_done = true;
-#ifdef GSX_STATS
-            GSX_STAT_ADD(6, max(max(st_b[0], st_b[1]), max(st_b[2], st_b[3])));
-            GSX_STAT_ADD(7, max(max(st_s[0], st_s[1]), max(st_s[2], st_s[3])));
-#endif
+            // all 64 pixels finished: tested once per 64 candidates, not per Gaussian
+            if (__builtin_amdgcn_ballot_w64(thr < INFINITY) == 0ull) wave_done = true;
         }
     }
     if (inside) {
