@@ -1,0 +1,33 @@
+#!/usr/bin/env bash
+# One-stop measurement of a round on the GPU box (outputs under gpurun_out/<tag>/; copy the summaries into profiles/):
+#   1. bench.py with its default flags (the driver's command)            -> bench.json
+#   2. the same bench under rocprofv3 --kernel-trace --stats              -> kernel_stats.md + bench_under_rocprof.json
+#   3. PMC counters of the bench step, one small group per pass           -> pmc/summary.txt
+#   4. bench.py --scene 5m                                                -> bench_s5m.json
+# Usage: bash tools/profile_round.sh r02
+tag=${1:-r02}
+out=gpurun_out/$tag
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p "$out"
+python bench.py > "$out/bench.json" 2> "$out/bench.err"
+echo "bench rc=$?"
+timeout -k 5 300 rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$out/bench_under_rocprof.json" 2> "$out/kt.err"
+echo "kernel-trace rc=$?"
+python - "$out" <<'PY'
+import csv, glob, sys
+out = sys.argv[1]
+f = glob.glob(out + "/kt/**/*kernel_stats.csv", recursive=True)
+rows = list(csv.DictReader(open(f[0])))
+tot = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
+with open(out + "/kernel_stats.md", "w") as o:
+    o.write("| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n")
+    for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
+        n = r["Name"] if len(r["Name"]) < 110 else r["Name"][:107] + "..."
+        o.write("| `%s` | %s | %.3f | %.1f | %.1f | %.1f | %.1f |\n" % (n, r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
+                                                              float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
+print(open(out + "/kernel_stats.md").read()[:3000])
+PY
+bash tools/pmc_passes.sh "$out/pmc" > "$out/pmc.log" 2>&1
+tail -3 "$out/pmc.log"
+python bench.py --scene 5m --steps 10 --warmup 3 --no-cpu-baseline > "$out/bench_s5m.json" 2> "$out/bench_s5m.err"
+echo "bench 5m rc=$?"
