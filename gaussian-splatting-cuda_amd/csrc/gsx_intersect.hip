@@ -368,31 +368,34 @@ __global__ __launch_bounds__(ISECT_BLOCK) void tile_sort_kernel(uint32_t n_tiles
 // exclusive scan of n counters by one 1024-thread block (n = C*tiles + 1: a few thousand entries; the generic device scan
 // costs three launches for them).  out[i] = sum(in[0..i)), in[n-1] is ignored and out[n-1] = grand total.
 __global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t n, const uint32_t* __restrict__ in, int32_t* __restrict__ out) {
-    __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_carry;
+    // exclusive scan of n - 1 counts, out[n - 1] = total.  Runs in 64 bits: a frame with more than 2^31 - 1 intersections does not
+    // wrap silently — every offset saturates at INT32_MAX and the total is written as -1, which both consumers reject (the fill's
+    // n_isects guard in the C ABI, the shim's TORCH_CHECK): such a scene needs the device-wide sort's int64 scan.
+    __shared__ unsigned long long s_wave[16];
+    __shared__ unsigned long long s_carry;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0u;
+    if (threadIdx.x == 0) s_carry = 0ull;
     __syncthreads();
     for (uint32_t base = 0; base < n; base += 4096u) {
         const uint32_t i0 = base + threadIdx.x * 4u;
-        uint32_t v[4];
+        unsigned long long v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n - 1u) ? in[i0 + k] : 0u;
-        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
-        uint32_t incl = mine;
+        for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n - 1u) ? (unsigned long long)in[i0 + k] : 0ull;
+        const unsigned long long mine = v[0] + v[1] + v[2] + v[3];
+        unsigned long long incl = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o);
+            const unsigned long long t = __shfl_up(incl, o);
             if ((int)lane >= o) incl += t;
         }
         if (lane == 63u) s_wave[wave] = incl;
         __syncthreads();
-        uint32_t wave_base = s_carry;
+        unsigned long long wave_base = s_carry;
         for (uint32_t w = 0; w < wave; ++w) wave_base += s_wave[w];
-        uint32_t run = wave_base + incl - mine;
+        unsigned long long run = wave_base + incl - mine;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (i0 + k < n) out[i0 + k] = (int32_t)run;
+            if (i0 + k < n) out[i0 + k] = (i0 + k == n - 1u && run > 0x7FFFFFFFull) ? -1 : (int32_t)(run > 0x7FFFFFFFull ? 0x7FFFFFFFull : run);
             run += v[k];
         }
         __syncthreads();

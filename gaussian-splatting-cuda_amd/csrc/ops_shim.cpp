@@ -530,6 +530,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
     total_ready.synchronize();
     g_stats.host_syncs++;
     const int64_t n_isects = n_host.data_ptr<int64_t>()[0];
+    TORCH_CHECK(n_isects <= 0x7FFFFFFFll, "intersect_tile: more than 2^31 - 1 intersections (tile offsets are int32, as upstream's isect_offsets)");
     {
         std::lock_guard<std::mutex> lock(hint_mutex);
         int64_t& h = hints[key];

@@ -69,9 +69,12 @@ def load_transforms(path, device="cpu"):
     scene = ColmapScene()
     locs = []
     for uid, frame in enumerate(t.get("frames", [])):
-        if "transform_matrix" not in frame:
-            continue
-        c2w = np.array(frame["transform_matrix"], np.float32).reshape(4, 4).copy()
+        if "transform_matrix" not in frame:   # transforms.cpp:187-195 throws; skipping would also shift the uid <-> image correspondence
+            raise RuntimeError("expected all frames to contain transform_matrix")
+        c2w = np.array(frame["transform_matrix"], np.float32)
+        if c2w.shape != (4, 4):
+            raise RuntimeError("transform_matrix has the wrong dimensions")
+        c2w = c2w.copy()
         c2w[0:3, 1:3] *= -1.0
         w2c = np.linalg.inv(c2w.astype(np.float64)).astype(np.float32) @ fix
         vm = np.eye(4, dtype=np.float32)

@@ -254,6 +254,14 @@ def test_transforms_json_reader(tmp_path):
     torch.manual_seed(8128)
     assert np.array_equal(pts, (torch.rand(10000, 3) * 2.0 - 1.0).numpy())              # the reference's draw (torch seed 8128)
 
+    # a frame without transform_matrix (or with a malformed one) is an error, as upstream (transforms.cpp:187-195): never skipped
+    for mutate in (lambda fr: fr.pop("transform_matrix"), lambda fr: fr.__setitem__("transform_matrix", [[1, 0, 0, 0]] * 3)):
+        bad = json.loads(json.dumps(frames))
+        mutate(bad[1])
+        (tmp_path / "transforms_train.json").write_text(json.dumps({"camera_angle_x": 0.6911, "w": 800, "h": 800, "frames": bad}))
+        with pytest.raises(RuntimeError):
+            io_transforms.load_transforms(str(tmp_path))
+
 
 def test_point_cloud_ply_reader(tmp_path):
     import gsx  # noqa: F401
