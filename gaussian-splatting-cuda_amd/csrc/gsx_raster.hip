@@ -80,10 +80,11 @@ GSX_DEV float pair_alpha(const Staged& s, f3 ray_o, f3 ray_d, f3& gro, f3& grd, 
 template <int KIND, bool HOIST>
 __global__ __launch_bounds__(RB) void raster_fwd_kernel(RasterArgs a, float* __restrict__ render_colors,
                                                         float* __restrict__ render_alphas,
-                                                        int32_t* __restrict__ last_ids) {
+                                                        int32_t* __restrict__ last_ids, const uint8_t* __restrict__ only_tiles) {
     __shared__ Staged s_g[RB];
     const uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y, cid = blockIdx.z;
     const uint32_t tile_id = tile_y * a.tw + tile_x;
+    if (only_tiles != nullptr && !only_tiles[(size_t)cid * a.th * a.tw + tile_id]) return;  // the fast path rendered this tile
     const uint32_t tid = threadIdx.x;
     uint32_t i, j;
     thread_pixel(tid, tile_x, tile_y, i, j);
@@ -162,13 +163,14 @@ __global__ __launch_bounds__(RB) void raster_bwd_kernel(RasterArgs a, const floa
                                                         const float* __restrict__ v_render_alphas,
                                                         float* __restrict__ v_means, float* __restrict__ v_quats,
                                                         float* __restrict__ v_scales, float* __restrict__ v_colors,
-                                                        float* __restrict__ v_opacities) {
+                                                        float* __restrict__ v_opacities, const uint8_t* __restrict__ only_tiles) {
     __shared__ Staged s_g[RB];
     __shared__ float s_acc[RB * NACC];
     __shared__ int32_t s_id[RB];
     __shared__ int32_t s_touched[RB];
     const uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y, cid = blockIdx.z;
     const uint32_t tile_id = tile_y * a.tw + tile_x;
+    if (only_tiles != nullptr && !only_tiles[(size_t)cid * a.th * a.tw + tile_id]) return;  // the fast path handled this tile
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     if (a.masks != nullptr && !a.masks[(size_t)cid * a.th * a.tw + tile_id]) return;  // Bwd.cu:84-86
     uint32_t i, j;
@@ -375,6 +377,7 @@ static int fill_args(RasterArgs& a, uint32_t N, int64_t n_isects, const float* m
     a.cams = *cams;
     a.tile_offsets = tile_offsets; a.flatten_ids = flatten_ids;
     a.packed = nullptr;
+    a.tile_flags = nullptr;
     return GSX_OK;
 }
 
@@ -409,17 +412,21 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_fwd(
     const dim3 grid(a.tw, a.th, a.C), block(RB);
     hipStream_t st = (hipStream_t)stream;
     const bool hoist = cams->shutter == GSX_SHUTTER_GLOBAL;
-    if (hoist && cam_kind(*cams) != CAM_OPENCV_FISHEYE && !force_generic() && workspace != nullptr &&
-        workspace_bytes >= raster_fwd_fast_workspace_bytes(a.C, a.N)) {
-        launch_raster_fwd_fast(cam_kind(*cams), a, renders, alphas, last_ids, workspace, workspace_bytes, st);
-        return check_launch("rasterize_to_pixels_from_world_3dgs_fwd(fast)");
+    const int kind = cam_kind(*cams);
+    const uint8_t* only_tiles = nullptr;
+    // fast path: global shutter; a fisheye additionally needs its (camera, tile) flag plane to fit
+    if (hoist && !force_generic() && workspace != nullptr && workspace_bytes >= raster_fwd_fast_workspace_bytes(a.C, a.N) &&
+        (kind != CAM_OPENCV_FISHEYE || (size_t)a.C * a.tw * a.th <= FAST_FLAG_BYTES)) {
+        only_tiles = launch_raster_fwd_fast(kind, a, renders, alphas, last_ids, workspace, workspace_bytes, st);
+        if (only_tiles == nullptr) return check_launch("rasterize_to_pixels_from_world_3dgs_fwd(fast)");
+        // fisheye: tiles whose list holds a Gaussian without a usable chart were left to the reference-order kernel below
     }
 #define GSX_FWD(KIND)                                                                                                  \
     do {                                                                                                               \
-        if (hoist) hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_fwd_kernel<KIND, true>), grid, block, 0, st, a, renders, alphas, last_ids); \
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_fwd_kernel<KIND, false>), grid, block, 0, st, a, renders, alphas, last_ids);      \
+        if (hoist) hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_fwd_kernel<KIND, true>), grid, block, 0, st, a, renders, alphas, last_ids, only_tiles); \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_fwd_kernel<KIND, false>), grid, block, 0, st, a, renders, alphas, last_ids, only_tiles);      \
     } while (0)
-    switch (cam_kind(*cams)) {
+    switch (kind) {
     case CAM_PERFECT_PINHOLE: GSX_FWD(CAM_PERFECT_PINHOLE); break;
     case CAM_OPENCV_PINHOLE: GSX_FWD(CAM_OPENCV_PINHOLE); break;
     default: GSX_FWD(CAM_OPENCV_FISHEYE); break;
@@ -478,18 +485,22 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd_packed(
     }
     const dim3 grid(a.tw, a.th, a.C), block(RB);
     const bool hoist = cams->shutter == GSX_SHUTTER_GLOBAL;
-    if (hoist && cam_kind(*cams) != CAM_OPENCV_FISHEYE && !force_generic()) {
-        if (launch_raster_bwd_fast(cam_kind(*cams), a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats,
-                                   v_scales, v_colors, v_opacities, workspace, workspace_bytes, (const float4*)packed_records, st))
-            return check_launch("rasterize_to_pixels_from_world_3dgs_bwd(fast)");
+    const int kind = cam_kind(*cams);
+    const uint8_t* only_tiles = nullptr;
+    bool fast_done = false;
+    if (hoist && !force_generic() && (kind != CAM_OPENCV_FISHEYE || (size_t)a.C * a.tw * a.th <= FAST_FLAG_BYTES)) {
+        fast_done = launch_raster_bwd_fast(kind, a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors,
+                                           v_opacities, workspace, workspace_bytes, (const float4*)packed_records, st, &only_tiles);
+        if (fast_done && only_tiles == nullptr) return check_launch("rasterize_to_pixels_from_world_3dgs_bwd(fast)");
+        // fisheye: the gather kernel has written every output element; the reference-order kernel adds the flagged tiles on top
     }
-    zero_outputs();
+    if (!fast_done) zero_outputs();
 #define GSX_BWD(KIND)                                                                                                  \
     do {                                                                                                               \
-        if (hoist) hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_kernel<KIND, true>), grid, block, 0, st, a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors, v_opacities); \
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_kernel<KIND, false>), grid, block, 0, st, a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors, v_opacities);      \
+        if (hoist) hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_kernel<KIND, true>), grid, block, 0, st, a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors, v_opacities, only_tiles); \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_kernel<KIND, false>), grid, block, 0, st, a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors, v_opacities, only_tiles);      \
     } while (0)
-    switch (cam_kind(*cams)) {
+    switch (kind) {
     case CAM_PERFECT_PINHOLE: GSX_BWD(CAM_PERFECT_PINHOLE); break;
     case CAM_OPENCV_PINHOLE: GSX_BWD(CAM_OPENCV_PINHOLE); break;
     default: GSX_BWD(CAM_OPENCV_FISHEYE); break;

@@ -156,7 +156,11 @@ GSX_DEV void make_record(const RawG& r, const CamFrame& cf, const float tb[4], F
 // pack_records_kernel does that once per (camera, Gaussian) into ONE 64 B line; staging a tile then gathers a
 // single line per Gaussian and only adds the tile-dependent footprint (hx, hy).
 //   p0 = (u0, v0, l00, l01)  p1 = (l11, lo, d1, d2)  p2 = (d3, d4, d5, red)  p3 = (green, blue, -, -)
-__global__ __launch_bounds__(256) void pack_records_kernel(RasterArgs a, float4* __restrict__ packed, int32_t* __restrict__ heads) {
+// `bad` (fisheye only): 1 where the Gaussian has no usable (u0, v0) chart — it sits behind the camera plane or more than
+// atan(8) = 83 degrees off the optical axis, where u0 = m_x / m_z loses its digits.  Such a Gaussian is visible in a wide fisheye;
+// the tiles that list one are rendered by the reference-order kernels (tile_flag_kernel below).
+__global__ __launch_bounds__(256) void pack_records_kernel(RasterArgs a, float4* __restrict__ packed, int32_t* __restrict__ heads,
+                                                           uint8_t* __restrict__ bad) {
     const uint32_t n = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
     if (n >= a.N) return;
     const size_t g = (size_t)c * a.N + n;
@@ -175,11 +179,28 @@ __global__ __launch_bounds__(256) void pack_records_kernel(RasterArgs a, float4*
     make_record<false>(raw, cf, tb0, r);
     if (!(r.hx > -INFINITY) && !(r.lo + LOG2_255 > 0.f)) r.lo = -INFINITY;  // never visible (opacity <= 1/255)
     if (!(fabsf(r.l00) < INFINITY)) r.lo = -INFINITY;                       // camera-space z == 0: skipped
+    if (bad) {
+        const f3 dm = raw.mu - cf.c;
+        const float mz = cf.Rc[0][2] * dm.x + cf.Rc[1][2] * dm.y + cf.Rc[2][2] * dm.z;
+        bad[g] = (mz > 0.f && fabsf(r.u0) <= 8.f && fabsf(r.v0) <= 8.f) ? 0 : 1;   // (NaN compares false: bad)
+    }
     float4* o = packed + g * 4;
     o[0] = make_float4(r.u0, r.v0, r.l00, r.l01);
     o[1] = make_float4(r.l11, r.lo, r.d1, r.d2);
     o[2] = make_float4(r.d3, r.d4, r.d5, raw.rgb.x);
     o[3] = make_float4(raw.rgb.y, raw.rgb.z, 0.f, 0.f);
+}
+
+// fisheye: flags[camera, tile] = 1 when the tile's list holds a Gaussian without a usable chart.  One wave per tile.
+__global__ __launch_bounds__(256) void tile_flag_kernel(RasterArgs a, const uint8_t* __restrict__ bad, uint8_t* __restrict__ flags) {
+    const uint32_t n_tiles = a.tw * a.th, t = blockIdx.x * 4u + (threadIdx.x >> 6), cid = blockIdx.y, lane = threadIdx.x & 63u;
+    if (t >= n_tiles) return;
+    const int32_t* toff = a.tile_offsets + (size_t)cid * n_tiles;
+    const int32_t lo = toff[t], hi = (cid == a.C - 1 && t == n_tiles - 1) ? (int32_t)a.n_isects : toff[t + 1];
+    bool any = false;
+    for (int32_t i = lo + (int32_t)lane; i < hi; i += 64) any = any || bad[a.flatten_ids[i]] != 0;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(any);
+    if (lane == 0) flags[(size_t)cid * n_tiles + t] = m != 0ull ? 1 : 0;
 }
 
 // alpha of one (pixel, Gaussian) pair: 16 VALU.  Record layout (== the packed 64 B record):
@@ -191,6 +212,20 @@ GSX_DEV float fast_alpha(float u, float v, float4 r0, float4 r1, float4 r2, floa
     const float t1 = r1.x * dv;
     num2 = fmaf(t0, t0, t1 * t1);
     const float den = fmaf(du, fmaf(r2.x, du, fmaf(r2.y, dv, r1.z)), fmaf(dv, fmaf(r2.z, dv, r1.w), 1.f));
+    rden = __builtin_amdgcn_rcpf(den);
+    return fminf(0.999f, __builtin_amdgcn_exp2f(fmaf(-num2, rden, r1.y)));
+}
+
+// The same for a ray given as an unnormalised direction (u, v, w) instead of (u, v, 1) — fisheye, where rays reach and pass 90 degrees
+// off axis (w <= 0).  With du' = u - w u0, dv' = v - w v0:  (A d) x g = du' B0 + dv' B1 and A d = w h + a0 du' + a1 dv', so the numerator
+// keeps its form and the denominator becomes w (w + d1 du' + d2 dv') + d3 du'^2 + d4 du' dv' + d5 dv'^2; the ratio does not depend
+// on the length of (u, v, w).  19 VALU.
+GSX_DEV float fast_alpha_ray(float u, float v, float w, float ww, float4 r0, float4 r1, float4 r2, float& du, float& dv, float& num2, float& rden) {
+    du = fmaf(-w, r0.x, u); dv = fmaf(-w, r0.y, v);
+    const float t0 = fmaf(r0.w, dv, r0.z * du);
+    const float t1 = r1.x * dv;
+    num2 = fmaf(t0, t0, t1 * t1);
+    const float den = fmaf(du, fmaf(r2.x, du, fmaf(r2.y, dv, r1.z * w)), fmaf(dv, fmaf(r2.z, dv, r1.w * w), ww));
     rden = __builtin_amdgcn_rcpf(den);
     return fminf(0.999f, __builtin_amdgcn_exp2f(fmaf(-num2, rden, r1.y)));
 }
@@ -239,11 +274,23 @@ GSX_DEV bool pixel_uv(const Camera<KIND>& cam, uint32_t i, uint32_t j, float& u,
     return ok;
 }
 
+// fisheye: the pixel's ray as a unit vector (u, v, w), w <= 0 at and beyond 90 degrees; pinholes: (u, v, 1)
+template <int KIND>
+GSX_DEV bool pixel_ray(const Camera<KIND>& cam, uint32_t i, uint32_t j, float& u, float& v, float& w) {
+    if (KIND != CAM_OPENCV_FISHEYE) { w = 1.f; return pixel_uv(cam, i, j, u, v); }
+    f3 d;
+    const bool ok = cam.unproject(f2{(float)j + 0.5f, (float)i + 0.5f}, d);
+    u = d.x; v = d.y; w = d.z;
+    return ok;
+}
+
 // tile bounds in (u,v): min/max over the valid pixels of each wave -> LDS -> whole tile
+// (`wide`: a fisheye pixel whose ray is near or beyond 90 degrees has no (u, v): its wave's and the tile's bounds become infinite,
+// which switches the footprint culling off for them)
 GSX_DEV void uv_bounds(bool valid, float u, float v, uint32_t wave, uint32_t lane, float (*s_bounds)[4], float wb[4],
-                       float tb[4]) {
-    float umin = valid ? u : INFINITY, umax = valid ? u : -INFINITY;
-    float vmin = valid ? v : INFINITY, vmax = valid ? v : -INFINITY;
+                       float tb[4], bool wide = false) {
+    float umin = wide ? -INFINITY : (valid ? u : INFINITY), umax = wide ? INFINITY : (valid ? u : -INFINITY);
+    float vmin = wide ? -INFINITY : (valid ? v : INFINITY), vmax = wide ? INFINITY : (valid ? v : -INFINITY);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         umin = fminf(umin, __shfl_xor(umin, o)); umax = fmaxf(umax, __shfl_xor(umax, o));
@@ -291,12 +338,21 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
             for (int k = 0; k < 3; ++k) render_colors[pix * 3 + k] = bg ? bg[k] : 0.f;
         return;
     }
+    if (KIND == CAM_OPENCV_FISHEYE && a.tile_flags != nullptr && a.tile_flags[(size_t)cid * a.th * a.tw + tile_id]) return;  // generic kernel's tile
     const Camera<KIND> cam(a.cams, cid, a.W, a.H);
-    float u, v;
-    const bool ray_ok = pixel_uv(cam, i, j, u, v);
+    float u, v, w;
+    const bool ray_ok = pixel_ray(cam, i, j, u, v, w);
     bool done = !inside || !ray_ok;
     float wb[4], tb[4];
-    uv_bounds(!done, u, v, wave, lane, s_bounds, wb, tb);
+    if (KIND == CAM_OPENCV_FISHEYE) {
+        const bool wide = !done && w < 0.05f;
+        const float iw = 1.f / fmaxf(w, 0.05f);
+        uv_bounds(!done, u * iw, v * iw, wave, lane, s_bounds, wb, tb, wide);
+    } else {
+        uv_bounds(!done, u, v, wave, lane, s_bounds, wb, tb);
+    }
+    const float ww = w * w;
+    const bool no_cull = KIND == CAM_OPENCV_FISHEYE && !(tb[0] > -INFINITY);
 
     const int32_t* toff = a.tile_offsets + (size_t)cid * a.th * a.tw;
     const int32_t range_start = toff[tile_id];
@@ -322,6 +378,7 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
         if (have) {
             StagedRec sr;
             stage_one(a, tb, g_pre, sr);
+            if (no_cull) { sr.cull.z = INFINITY; sr.cull.w = INFINITY; }
             sr.r1.y -= LOG2_K999; sr.r2.w *= K999; sr.r3.x *= K999; sr.r3.y *= K999;
             s_rec[buf][tid][0] = sr.r0; s_rec[buf][tid][1] = sr.r1; s_rec[buf][tid][2] = sr.r2; s_rec[buf][tid][3] = sr.r3;
             s_cull[buf][tid] = sr.cull;
@@ -348,11 +405,14 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
                 todo &= todo - 1ull;
                 const float4* rp = s_rec[buf][t];
                 const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
-                const float du = u - r0.x, dv = v - r0.y;
+                const float du = KIND == CAM_OPENCV_FISHEYE ? fmaf(-w, r0.x, u) : u - r0.x;   // fisheye: unnormalised ray (u, v, w), see fast_alpha_ray
+                const float dv = KIND == CAM_OPENCV_FISHEYE ? fmaf(-w, r0.y, v) : v - r0.y;
                 const float t0 = fmaf(r0.w, dv, r0.z * du);
                 const float t1 = r1.x * dv;
                 const float num2 = fmaf(t0, t0, t1 * t1);
-                const float den = fmaf(du, fmaf(r2.x, du, fmaf(r2.y, dv, r1.z)), fmaf(dv, fmaf(r2.z, dv, r1.w), 1.f));
+                const float den = KIND == CAM_OPENCV_FISHEYE
+                                      ? fmaf(du, fmaf(r2.x, du, fmaf(r2.y, dv, r1.z * w)), fmaf(dv, fmaf(r2.z, dv, r1.w * w), ww))
+                                      : fmaf(du, fmaf(r2.x, du, fmaf(r2.y, dv, r1.z)), fmaf(dv, fmaf(r2.z, dv, r1.w), 1.f));
                 const float ap = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(fmaf(-num2, __builtin_amdgcn_rcpf(den), r1.y)), 0.f, 1.f);
                 bool take = ap >= thr;                       // alpha >= 1/255 and the pixel is not finished (Fwd.cu:240)
                 float w = take ? ap * T : 0.f;               // alpha T / 0.999
@@ -385,24 +445,39 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
     }
 }
 
-size_t raster_fwd_fast_workspace_bytes(uint32_t C, uint32_t N) { return (size_t)C * N * 64 + 256; }
+// forward workspace, from its 256 B aligned base: packed records [C*N] x 64 B | fisheye: "no chart" bytes [C*N] | tile flags
+static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+size_t raster_fwd_fast_workspace_bytes(uint32_t C, uint32_t N) { return 256 + (size_t)C * N * 64 + align256((size_t)C * N) + FAST_FLAG_BYTES; }
+static uint8_t* ws_bad(const float4* packed, uint32_t C, uint32_t N) { return (uint8_t*)packed + (size_t)C * N * 64; }
+static uint8_t* ws_flags(const float4* packed, uint32_t C, uint32_t N) { return ws_bad(packed, C, N) + align256((size_t)C * N); }
 
-static const float4* pack_into(RasterArgs& a, void* base, hipStream_t st, int32_t* heads = nullptr) {
+// packs the records (and, for a fisheye, flags the tiles the fast kernels must leave to the reference-order kernels)
+static const float4* pack_into(int kind, RasterArgs& a, void* base, hipStream_t st, int32_t* heads = nullptr) {
     float4* packed = (float4*)(((uintptr_t)base + 255) & ~(uintptr_t)255);
-    hipLaunchKernelGGL(pack_records_kernel, dim3((a.N + 255u) / 256u, a.C), dim3(256), 0, st, a, packed, heads);
+    const bool fisheye = kind == CAM_OPENCV_FISHEYE;
+    hipLaunchKernelGGL(pack_records_kernel, dim3((a.N + 255u) / 256u, a.C), dim3(256), 0, st, a, packed, heads, fisheye ? ws_bad(packed, a.C, a.N) : nullptr);
     a.packed = packed;
+    if (fisheye) {
+        uint8_t* flags = ws_flags(packed, a.C, a.N);
+        hipLaunchKernelGGL(tile_flag_kernel, dim3((a.tw * a.th + 3u) / 4u, a.C), dim3(256), 0, st, a, (const uint8_t*)ws_bad(packed, a.C, a.N), flags);
+        a.tile_flags = flags;
+    }
     return packed;
 }
 
-void launch_raster_fwd_fast(int kind, RasterArgs a, float* renders, float* alphas, int32_t* last_ids, void* workspace,
-                            size_t workspace_bytes, hipStream_t st) {
+const uint8_t* launch_raster_fwd_fast(int kind, RasterArgs a, float* renders, float* alphas, int32_t* last_ids, void* workspace,
+                                      size_t workspace_bytes, hipStream_t st) {
+    (void)workspace_bytes;
     const uint32_t n_tiles = a.tw * a.th;
     const dim3 grid(((n_tiles + 7u) / 8u) * 8u, a.C), block(RB);
-    pack_into(a, workspace, st);
+    pack_into(kind, a, workspace, st);
     if (kind == CAM_PERFECT_PINHOLE)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_fwd_fast_kernel<CAM_PERFECT_PINHOLE>), grid, block, 0, st, a, renders, alphas, last_ids);
-    else
+    else if (kind == CAM_OPENCV_PINHOLE)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_fwd_fast_kernel<CAM_OPENCV_PINHOLE>), grid, block, 0, st, a, renders, alphas, last_ids);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_fwd_fast_kernel<CAM_OPENCV_FISHEYE>), grid, block, 0, st, a, renders, alphas, last_ids);
+    return a.tile_flags;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -499,13 +574,22 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
     const bool inside = i < a.H && j < a.W;
     const size_t pix = (size_t)cid * a.H * a.W + (size_t)min(i, a.H - 1) * a.W + min(j, a.W - 1);
     const float* bg = a.backgrounds ? a.backgrounds + cid * 3 : nullptr;
+    if (KIND == CAM_OPENCV_FISHEYE && a.tile_flags != nullptr && a.tile_flags[(size_t)cid * a.th * a.tw + tile_id]) return;  // generic kernel's tile
     const Camera<KIND> cam(a.cams, cid, a.W, a.H);
-    float u, v;
-    const bool ray_ok = pixel_uv(cam, i, j, u, v);
+    float u, v, w;
+    const bool ray_ok = pixel_ray(cam, i, j, u, v, w);
     const bool active = inside && ray_ok;
     if (tid == 0) s_blockmax = -1;
     float wb[4], tb[4];
-    uv_bounds(active, u, v, wave, lane, s_bounds, wb, tb);   // contains a barrier
+    if (KIND == CAM_OPENCV_FISHEYE) {
+        const bool wide = active && w < 0.05f;
+        const float iw = 1.f / fmaxf(w, 0.05f);
+        uv_bounds(active, u * iw, v * iw, wave, lane, s_bounds, wb, tb, wide);   // contains a barrier
+    } else {
+        uv_bounds(active, u, v, wave, lane, s_bounds, wb, tb);   // contains a barrier
+    }
+    const float ww = w * w;
+    const bool no_cull = KIND == CAM_OPENCV_FISHEYE && !(tb[0] > -INFINITY);
 
     const int32_t* toff = a.tile_offsets + (size_t)cid * a.th * a.tw;
     const int32_t range_start = toff[tile_id];
@@ -541,6 +625,7 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
             const int32_t g = a.flatten_ids[chunk_end - (int32_t)tid];
             StagedRec sr;
             stage_one(a, tb, g, sr);
+            if (no_cull) { sr.cull.z = INFINITY; sr.cull.w = INFINITY; }
             s_rec[tid][0] = sr.r0; s_rec[tid][1] = sr.r1; s_rec[tid][2] = sr.r2; s_rec[tid][3] = sr.r3;
             s_cull[tid] = sr.cull;
             s_gid[tid] = g;
@@ -566,7 +651,8 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
                 const float4* rp = s_rec[t];
                 const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
                 float du, dv, num2, rden;
-                const float alpha = fast_alpha(u, v, r0, r1, r2, du, dv, num2, rden);
+                const float alpha = KIND == CAM_OPENCV_FISHEYE ? fast_alpha_ray(u, v, w, ww, r0, r1, r2, du, dv, num2, rden)
+                                                               : fast_alpha(u, v, r0, r1, r2, du, dv, num2, rden);
                 // one comparison feeds the ballot directly (a ballot of `a && b` goes through a VGPR round trip)
                 const float alpha_in = (chunk_end - t <= bin_final) ? alpha : 0.f;
                 const bool valid = alpha_in >= ALPHA_MIN;
@@ -594,6 +680,12 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
                 x[4] = x[7] * du; x[5] = x[7] * dv; x[6] = x[8] * dv;   // (10 products instead of 13 with du^2, du dv, dv^2 formed first)
                 x[9] = bw; x[10] = bw * du; x[11] = bw * dv;
                 x[12] = x[10] * du; x[13] = x[10] * dv; x[14] = x[11] * dv;
+                if (KIND == CAM_OPENCV_FISHEYE) {
+                    // unnormalised rays: du' = u - w u0 has d/du0 = -w and A d = w h + a0 du' + a1 dv', so the moments that multiply
+                    // d/du0, d/dv0 (first-order a) and h (the b family's 1, du', dv') carry the matching powers of w; the gather
+                    // kernel's linear map is unchanged
+                    x[7] *= w; x[8] *= w; x[9] *= ww; x[10] *= w; x[11] *= w;
+                }
                 x[15] = 0.f;
                 const float total = butterfly_reduce16(x);
                 if ((lane & 3u) == 0u) atomicAdd(&s_acc[mom_of_lane][t], total);  // 16 lanes, one moment each
@@ -1085,57 +1177,48 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
 }
 
 size_t raster_bwd_fast_workspace_bytes(uint32_t C, uint32_t N, int64_t n_isects) {
-    // moment records (64 B per intersection) + list heads (4 B per (camera, Gaussian)) + packed records, 256 B aligned
-    return (((size_t)n_isects * 64 + 255) / 256) * 256 + (((size_t)C * N * 4 + 255) / 256) * 256 + raster_fwd_fast_workspace_bytes(C, N);
+    // moment records (64 B per intersection) + list heads (4 B per (camera, Gaussian)) + the forward's layout, 256 B aligned
+    return align256((size_t)n_isects * 64) + align256((size_t)C * N * 4) + raster_fwd_fast_workspace_bytes(C, N);
 }
 
 bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, const int32_t* last_ids,
                             const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats,
                             float* v_scales, float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes,
-                            const float4* packed_from_fwd, hipStream_t st) {
+                            const float4* packed_from_fwd, hipStream_t st, const uint8_t** tile_flags_out) {
+    *tile_flags_out = nullptr;
     if (workspace == nullptr || workspace_bytes < raster_bwd_fast_workspace_bytes(a.C, a.N, a.n_isects)) return false;
     const uint32_t n_tiles = a.tw * a.th;
     const dim3 grid(((n_tiles + 7u) / 8u) * 8u, a.C), block(RB);
     float4* ws_rec = (float4*)workspace;
-    int32_t* ws_head = (int32_t*)((char*)workspace + (((size_t)a.n_isects * 64 + 255) / 256) * 256);
-    if (packed_from_fwd) {  // the forward of the same inputs left its packed records with the caller: only the list heads are reset
+    int32_t* ws_head = (int32_t*)((char*)workspace + align256((size_t)a.n_isects * 64));
+    if (packed_from_fwd) {  // the forward of the same inputs left its packed records (and tile flags) with the caller: only the list heads are reset
         a.packed = packed_from_fwd;
+        if (kind == CAM_OPENCV_FISHEYE) a.tile_flags = ws_flags(packed_from_fwd, a.C, a.N);
         (void)hipMemsetAsync(ws_head, 0xFF, (size_t)a.C * a.N * 4, st);
     } else {
-        pack_into(a, (char*)ws_head + (((size_t)a.C * a.N * 4 + 255) / 256) * 256, st, ws_head);  // also sets every list head to -1
+        pack_into(kind, a, (char*)ws_head + align256((size_t)a.C * a.N * 4), st, ws_head);  // also sets every list head to -1
     }
+    *tile_flags_out = a.tile_flags;
     const dim3 ggrid((a.N + 255u) / 256u), gblock(256);
     // Two backward kernels, same records and gather.  Gaussian-major wins when the projected Gaussians are small next to a 4x4 pixel
     // block's neighbourhood (S-1M: 767 vs 862 us), pixel-major when they cover many blocks (S-5M @4K: 2.47 vs 2.76 ms): DESIGN.md §4.
     // The proxy available without a host read is the mean number of 16x16 tiles per Gaussian; GSX_BWD=pm|gm forces one (tests, tools).
     static const int forced = [] { const char* e = getenv("GSX_BWD"); return !e ? 0 : (std::string(e) == "pm" ? 1 : (std::string(e) == "gm" ? 2 : 0)); }();
-    const bool gaussian_major = forced ? forced == 2 : (double)a.n_isects < 4.5 * (double)a.C * (double)a.N;
+    const bool gaussian_major = kind != CAM_OPENCV_FISHEYE && (forced ? forced == 2 : (double)a.n_isects < 4.5 * (double)a.C * (double)a.N);
+#define GSX_BLEND_BWD(KERNEL, KIND)                                                                                                        \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<KIND>), grid, block, 0, st, a, render_alphas, last_ids, v_render_colors, v_render_alphas, ws_rec, ws_head)
     if (gaussian_major) {
-        if (kind == CAM_PERFECT_PINHOLE)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_gm_kernel<CAM_PERFECT_PINHOLE>), grid, block, 0, st, a, render_alphas, last_ids,
-                               v_render_colors, v_render_alphas, ws_rec, ws_head);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_gm_kernel<CAM_OPENCV_PINHOLE>), grid, block, 0, st, a, render_alphas, last_ids,
-                               v_render_colors, v_render_alphas, ws_rec, ws_head);
-        if (kind == CAM_PERFECT_PINHOLE)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_bwd_gather_kernel<CAM_PERFECT_PINHOLE>), ggrid, gblock, 0, st, a, ws_rec, ws_head, v_means,
-                               v_quats, v_scales, v_colors, v_opacities);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_bwd_gather_kernel<CAM_OPENCV_PINHOLE>), ggrid, gblock, 0, st, a, ws_rec, ws_head, v_means,
-                               v_quats, v_scales, v_colors, v_opacities);
-        return true;
-    }
-    if (kind == CAM_PERFECT_PINHOLE) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_fast_kernel<CAM_PERFECT_PINHOLE>), grid, block, 0, st, a, render_alphas,
-                           last_ids, v_render_colors, v_render_alphas, ws_rec, ws_head);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_bwd_gather_kernel<CAM_PERFECT_PINHOLE>), ggrid, gblock, 0, st, a, ws_rec, ws_head,
-                           v_means, v_quats, v_scales, v_colors, v_opacities);
+        if (kind == CAM_PERFECT_PINHOLE) GSX_BLEND_BWD(raster_bwd_gm_kernel, CAM_PERFECT_PINHOLE);
+        else GSX_BLEND_BWD(raster_bwd_gm_kernel, CAM_OPENCV_PINHOLE);
     } else {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_fast_kernel<CAM_OPENCV_PINHOLE>), grid, block, 0, st, a, render_alphas,
-                           last_ids, v_render_colors, v_render_alphas, ws_rec, ws_head);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_bwd_gather_kernel<CAM_OPENCV_PINHOLE>), ggrid, gblock, 0, st, a, ws_rec, ws_head,
-                           v_means, v_quats, v_scales, v_colors, v_opacities);
+        if (kind == CAM_PERFECT_PINHOLE) GSX_BLEND_BWD(raster_bwd_fast_kernel, CAM_PERFECT_PINHOLE);
+        else if (kind == CAM_OPENCV_PINHOLE) GSX_BLEND_BWD(raster_bwd_fast_kernel, CAM_OPENCV_PINHOLE);
+        else GSX_BLEND_BWD(raster_bwd_fast_kernel, CAM_OPENCV_FISHEYE);
     }
+#undef GSX_BLEND_BWD
+    // the moments -> gradient map only involves the camera pose: one instance serves every camera model
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_bwd_gather_kernel<CAM_PERFECT_PINHOLE>), ggrid, gblock, 0, st, a, ws_rec, ws_head, v_means, v_quats, v_scales,
+                       v_colors, v_opacities);
     return true;
 }
 

@@ -1,5 +1,6 @@
-"""GPU parity for the camera variants of the path: OpenCV-distorted pinhole (fast path), fisheye and rolling
-shutter (generic reference-order path), and C = 2 cameras in one call.  Oracle = oracle/gsx_oracle.cpp."""
+"""GPU parity for the camera variants of the path: OpenCV-distorted pinhole and global-shutter fisheye (fast Delta-form path; a
+fisheye wider than ~165 degrees mixes it with the reference-order kernels tile by tile), rolling shutter (generic reference-order
+path), and C = 2 cameras in one call.  Oracle = oracle/gsx_oracle.cpp."""
 import numpy as np
 import pytest
 import torch
@@ -96,6 +97,40 @@ def test_fisheye(mods):
     o = oracle_pipeline(sc, frag_rel=1e-3, v_render_colors=v_rc, v_render_alphas=v_ra, cam=cam)
     res = _run_gpu(ops, sc, o, ops.CameraModelType.FISHEYE, ops.ShutterType.GLOBAL, None, radial, None, None, v_rc, v_ra)
     _check(*res, o)
+
+
+def _wide_scene(N=3000, size=160, f=45.0, seed=21):
+    """Gaussians all around the optical axis out to 100 degrees, seen by a ~200 degree fisheye (image radius / f = 1.78 rad)."""
+    import math
+    import gsx  # noqa: F401
+    from gsx import scenes
+    g = torch.Generator().manual_seed(seed)
+    theta = torch.rand(N, generator=g) * math.radians(100.0)
+    phi = torch.rand(N, generator=g) * 2 * math.pi
+    dist = 2.0 + torch.rand(N, generator=g)
+    means = torch.stack([torch.sin(theta) * torch.cos(phi), torch.sin(theta) * torch.sin(phi), torch.cos(theta)], 1) * dist[:, None]
+    quats = torch.nn.functional.normalize(torch.randn(N, 4, generator=g), dim=-1)
+    scales = torch.rand(N, 3, generator=g) * 0.05 + 0.01
+    opac = torch.rand(N, generator=g) * 0.5 + 0.3
+    sh = (torch.rand(N, 1, 3, generator=g) - 0.5) * 0.3
+    return dict(means=means, quats=quats, scales=scales, opacities=opac, sh=sh, sh_degree=0, viewmat=torch.eye(4),
+                K=scenes.intrinsics(f, f, size / 2.0, size / 2.0), width=size, height=size, background=torch.tensor([0.05, 0.1, 0.15]))
+
+
+def test_fisheye_wide_field_of_view(mods):
+    """Rays at and beyond 90 degrees (w <= 0 in the Delta-form) and Gaussians without a usable (u0, v0) chart: the tiles that list
+    one of those go to the reference-order kernels, the rest to the fast path, and the frame as a whole must match the oracle."""
+    ops, scenes = mods
+    sc = _wide_scene()
+    radial = np.array([[0.01, -0.002, 0.0, 0.0]], np.float32)
+    v_rc, v_ra = _grads(160)
+    cam = dict(camera_model=oracle.FISHEYE, radial=radial)
+    o = oracle_pipeline(sc, frag_rel=1e-3, v_render_colors=v_rc, v_render_alphas=v_ra, cam=cam)
+    vis = (o["radii"] > 0).all(-1)[0]
+    cos_t = (sc["means"][:, 2] / sc["means"].norm(dim=1)).numpy()
+    assert (vis & (cos_t < 0.12)).sum() > 20 and (vis & (cos_t > 0.5)).sum() > 200   # both regimes are on screen
+    res = _run_gpu(ops, sc, o, ops.CameraModelType.FISHEYE, ops.ShutterType.GLOBAL, None, radial, None, None, v_rc, v_ra)
+    _check(*res, o, min_ok=0.85)
 
 
 @pytest.mark.parametrize("shutter", ["ROLLING_TOP_TO_BOTTOM", "ROLLING_LEFT_TO_RIGHT"])

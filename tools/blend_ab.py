@@ -16,14 +16,18 @@ dev = "cuda:0"
 scene = {"1m": scenes.scene_1m, "5m": scenes.scene_5m}[which]()
 W, H = scene["width"], scene["height"]
 model = scenes.to_splat_data(scene, dev)
-cam = rasterizer.Camera(viewmat=scene["viewmat"].to(dev), K=scene["K"].to(dev), width=W, height=H)
+fisheye = os.environ.get("GSX_AB_CAMERA") == "fisheye"   # the same scene through an equidistant fisheye of the same focal length
+cam_model = ops.CameraModelType.FISHEYE if fisheye else ops.CameraModelType.PINHOLE
+radial = torch.tensor([0.01, -0.002, 0.0, 0.0]) if fisheye else None
+cam = rasterizer.Camera(viewmat=scene["viewmat"].to(dev), K=scene["K"].to(dev), width=W, height=H, camera_model=cam_model, radial=radial)
 with torch.no_grad():
     out = rasterizer.rasterize(cam, model, scene["background"].to(dev))
+radial = None if radial is None else radial.to(dev)
 d = lambda k: scene[k].to(dev)  # noqa: E731
 ut = ops.UnscentedTransformParameters()
 colors, off, fl = out.aux["colors"].contiguous(), out.aux["isect_offsets"], out.aux["flatten_ids"]
 common = (d("means"), d("quats"), d("scales"), colors, d("opacities")[None].contiguous(), d("background")[None].contiguous(), None, W, H, 16,
-          d("viewmat")[None].contiguous(), None, d("K")[None].contiguous(), ops.CameraModelType.PINHOLE, ut, ops.ShutterType.GLOBAL, None, None, None, off, fl)
+          d("viewmat")[None].contiguous(), None, d("K")[None].contiguous(), cam_model, ut, ops.ShutterType.GLOBAL, radial, None, None, off, fl)
 g = torch.Generator(device=dev).manual_seed(0)
 v_rc, v_ra = torch.randn(1, H, W, 3, device=dev, generator=g), torch.randn(1, H, W, 1, device=dev, generator=g)
 
@@ -46,5 +50,5 @@ def timeit(fn):
 t_f, fwd = timeit(lambda: ops.rasterize_to_pixels_from_world_3dgs_fwd(*common, keep_ws=True))
 t_b, bwd = timeit(lambda: ops.rasterize_to_pixels_from_world_3dgs_bwd(*common, fwd[1], fwd[2], v_rc, v_ra, fwd_ws=fwd[3]))
 chk = [float(x.double().abs().sum()) for x in bwd]
-print("%s GSX_BWD=%s n_isects=%d  fwd %.4f ms  bwd %.4f ms  |grads|_1 = %s" % (which, os.environ.get("GSX_BWD", "-"), fl.numel(), t_f, t_b,
+print("%s%s GSX_BWD=%s GSX_RASTER_PATH=%s n_isects=%d  fwd %.4f ms  bwd %.4f ms  |grads|_1 = %s" % (which, " fisheye" if fisheye else "", os.environ.get("GSX_BWD", "-"), os.environ.get("GSX_RASTER_PATH", "-"), fl.numel(), t_f, t_b,
                                                                               " ".join("%.6g" % c for c in chk)))
