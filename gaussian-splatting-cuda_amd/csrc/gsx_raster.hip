@@ -74,6 +74,69 @@ GSX_DEV float pair_alpha(const Staged& s, f3 ray_o, f3 ray_d, f3& gro, f3& grd, 
     return fminf(0.999f, s.r3.x * vis);
 }
 
+// ---- wave-level culling for the reference-order kernels (any camera model, any shutter) ----------------------------------------------
+// alpha >= 1/255 needs |grd_n x gro|^2 <= 2 ln(255 o): the distance from the Gaussian's centre to the ray, measured in the whitened
+// frame M = diag(1/s) R^T, which is at least (Euclidean distance) / s_max.  So a Gaussian whose bounding sphere of radius
+// s_max sqrt(2 ln(255 o)) misses the CONE that bounds the 64 rays of a wave contributes to none of its pixels.  The cone (apex = mean
+// ray origin, axis = mean direction, half angle = largest deviation, plus the spread of the origins for a rolling shutter) is built
+// once per wave; one lane tests one staged Gaussian (~15 VALU), the wave walks the survivors.  Conservative by construction.
+struct WaveCone { f3 apex, axis; float cos_g, sin_g, spread; bool any; };
+
+GSX_DEV float wave_all_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+GSX_DEV float wave_all_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+GSX_DEV float wave_all_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+GSX_DEV WaveCone make_wave_cone(bool active, f3 ray_o, f3 ray_d) {
+    WaveCone c;
+    const float n = wave_all_sum(active ? 1.f : 0.f);
+    c.any = n > 0.f;
+    const float inv = c.any ? 1.f / n : 0.f;
+    c.apex = {wave_all_sum(active ? ray_o.x : 0.f) * inv, wave_all_sum(active ? ray_o.y : 0.f) * inv, wave_all_sum(active ? ray_o.z : 0.f) * inv};
+    f3 ax{wave_all_sum(active ? ray_d.x : 0.f), wave_all_sum(active ? ray_d.y : 0.f), wave_all_sum(active ? ray_d.z : 0.f)};
+    const float l = sqrtf(dot3(ax, ax));
+    if (!(l > 1e-6f)) { c.axis = {0.f, 0.f, 1.f}; c.cos_g = -1.f; c.sin_g = 0.f; c.spread = INFINITY; return c; }  // degenerate bundle: never cull
+    c.axis = ax * (1.f / l);
+    const float dl = sqrtf(dot3(ray_d, ray_d));
+    const float cosd = active ? dot3(ray_d, c.axis) / fmaxf(dl, 1e-20f) : 1.f;
+    c.cos_g = fmaxf(-1.f, wave_all_min(cosd) - 1e-6f);
+    c.sin_g = sqrtf(fmaxf(0.f, 1.f - c.cos_g * c.cos_g));
+    const f3 od = ray_o - c.apex;
+    c.spread = wave_all_max(active ? sqrtf(dot3(od, od)) : 0.f);
+    return c;
+}
+
+// true when the sphere (centre mu, radius rad) may touch the cone
+GSX_DEV bool cone_hits_sphere(const WaveCone& c, f3 mu, float rad) {
+    if (!(rad >= 0.f)) return false;              // opacity <= 1/255: never visible (rad = -1)
+    const f3 v = mu - c.apex;
+    const float along = dot3(v, c.axis);
+    const float perp = sqrtf(fmaxf(0.f, dot3(v, v) - along * along));
+    // distance from the point to the cone's surface along the surface normal (negative inside): perp cos g - along sin g
+    return perp * c.cos_g - along * c.sin_g <= (rad + c.spread) * 1.0001f + 1e-6f;
+}
+
+// (mu, bounding radius) of a staged Gaussian
+GSX_DEV float4 cull_sphere(const RasterArgs& a, int32_t g) {
+    const int32_t gi = (a.C == 1) ? g : (int32_t)((uint32_t)g % a.N);
+    const float smax = fmaxf(fmaxf(a.scales[(size_t)gi * 3], a.scales[(size_t)gi * 3 + 1]), a.scales[(size_t)gi * 3 + 2]);
+    const float o = a.opacities[g];
+    const float t2 = 2.f * __logf(255.f * o);
+    const float rad = (t2 > 0.f) ? smax * sqrtf(t2) * 1.001f : -1.f;
+    return make_float4(a.means[(size_t)gi * 3], a.means[(size_t)gi * 3 + 1], a.means[(size_t)gi * 3 + 2], (rad == rad) ? rad : INFINITY);
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -82,10 +145,11 @@ __global__ __launch_bounds__(RB) void raster_fwd_kernel(RasterArgs a, float* __r
                                                         float* __restrict__ render_alphas,
                                                         int32_t* __restrict__ last_ids, const uint8_t* __restrict__ only_tiles) {
     __shared__ Staged s_g[RB];
+    __shared__ float4 s_sph[RB];
     const uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y, cid = blockIdx.z;
     const uint32_t tile_id = tile_y * a.tw + tile_x;
     if (only_tiles != nullptr && !only_tiles[(size_t)cid * a.th * a.tw + tile_id]) return;  // the fast path rendered this tile
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
     uint32_t i, j;
     thread_pixel(tid, tile_x, tile_y, i, j);
     const bool inside = i < a.H && j < a.W;
@@ -109,6 +173,7 @@ __global__ __launch_bounds__(RB) void raster_fwd_kernel(RasterArgs a, float* __r
         cam_org = {-rt.x, -rt.y, -rt.z};
     }
     bool done = !inside || !ray_ok;
+    const WaveCone cone = make_wave_cone(!done, ray_o, ray_d);
 
     const int32_t* toff = a.tile_offsets + (size_t)cid * a.th * a.tw;
     const int32_t range_start = toff[tile_id];
@@ -123,23 +188,37 @@ __global__ __launch_bounds__(RB) void raster_fwd_kernel(RasterArgs a, float* __r
         const int32_t chunk_start = range_start + RB * b;
         const int32_t idx = chunk_start + (int32_t)tid;
         if (idx < range_end) {
+            const int32_t g = a.flatten_ids[idx];
             Staged s;
-            stage_gaussian<HOIST>(a, a.flatten_ids[idx], cam_org, s);
+            stage_gaussian<HOIST>(a, g, cam_org, s);
             s_g[tid] = s;
+            s_sph[tid] = cull_sphere(a, g);
         }
         __syncthreads();
         const int32_t chunk_size = min(RB, range_end - chunk_start);
-        for (int32_t t = 0; t < chunk_size && !done; ++t) {
-            const Staged s = s_g[t];
-            f3 gro, grd, grd_n, gc; float vis, il;
-            const float alpha = pair_alpha<HOIST>(s, ray_o, ray_d, gro, grd, grd_n, gc, vis, il);
-            if (alpha < ALPHA_MIN) continue;
-            const float next_T = T * (1.f - alpha);
-            if (next_T <= 1e-4f) { done = true; break; }
-            const float w = alpha * T;
-            out_r += s.r3.y * w; out_g += s.r3.z * w; out_b += s.r3.w * w;
-            cur_idx = (uint32_t)(chunk_start + t);
-            T = next_T;
+        for (int32_t sub = 0; sub < chunk_size; sub += 64) {
+            // one candidate per lane against the cone of this wave's rays, then the wave walks the survivors front to back
+            bool hit = false;
+            if (cone.any && sub + (int32_t)lane < chunk_size) {
+                const float4 sp4 = s_sph[sub + lane];
+                hit = cone_hits_sphere(cone, f3{sp4.x, sp4.y, sp4.z}, sp4.w);
+            }
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(hit);
+            while (todo) {
+                const int32_t t = sub + __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                if (done) continue;
+                const Staged s = s_g[t];
+                f3 gro, grd, grd_n, gc; float vis, il;
+                const float alpha = pair_alpha<HOIST>(s, ray_o, ray_d, gro, grd, grd_n, gc, vis, il);
+                if (alpha < ALPHA_MIN) continue;
+                const float next_T = T * (1.f - alpha);
+                if (next_T <= 1e-4f) { done = true; continue; }
+                const float w = alpha * T;
+                out_r += s.r3.y * w; out_g += s.r3.z * w; out_b += s.r3.w * w;
+                cur_idx = (uint32_t)(chunk_start + t);
+                T = next_T;
+            }
         }
     }
     if (inside) {
@@ -163,11 +242,13 @@ __global__ __launch_bounds__(RB) void raster_bwd_kernel(RasterArgs a, const floa
                                                         const float* __restrict__ v_render_alphas,
                                                         float* __restrict__ v_means, float* __restrict__ v_quats,
                                                         float* __restrict__ v_scales, float* __restrict__ v_colors,
-                                                        float* __restrict__ v_opacities, const uint8_t* __restrict__ only_tiles) {
+                                                        float* __restrict__ v_opacities, const uint8_t* __restrict__ only_tiles,
+                                                        float4* __restrict__ grad_rec, int32_t* __restrict__ grad_head) {
     __shared__ Staged s_g[RB];
     __shared__ float s_acc[RB * NACC];
     __shared__ int32_t s_id[RB];
     __shared__ int32_t s_touched[RB];
+    __shared__ float4 s_sph[RB];
     const uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y, cid = blockIdx.z;
     const uint32_t tile_id = tile_y * a.tw + tile_x;
     if (only_tiles != nullptr && !only_tiles[(size_t)cid * a.th * a.tw + tile_id]) return;  // the fast path handled this tile
@@ -190,6 +271,7 @@ __global__ __launch_bounds__(RB) void raster_bwd_kernel(RasterArgs a, const floa
         cam_org = {-rt.x, -rt.y, -rt.z};
     }
     const bool active = inside && ray_ok;
+    const WaveCone cone = make_wave_cone(active, ray_o, ray_d);
 
     const int32_t* toff = a.tile_offsets + (size_t)cid * a.th * a.tw;
     const int32_t range_start = toff[tile_id];
@@ -229,13 +311,23 @@ __global__ __launch_bounds__(RB) void raster_bwd_kernel(RasterArgs a, const floa
             stage_gaussian<HOIST>(a, g, cam_org, s);
             s_g[tid] = s;
             s_id[tid] = g;
+            s_sph[tid] = cull_sphere(a, g);
         }
         s_touched[tid] = 0;
 #pragma unroll
         for (int k = 0; k < NACC; ++k) s_acc[k * RB + tid] = 0.f;
         __syncthreads();
 
-        for (int32_t t = 0; t < chunk_size; ++t) {
+        for (int32_t sub = 0; sub < chunk_size; sub += 64) {
+          bool hit = false;   // (same wave-cone test as the forward)
+          if (cone.any && sub + (int32_t)lane < chunk_size) {
+              const float4 sp4 = s_sph[sub + lane];
+              hit = cone_hits_sphere(cone, f3{sp4.x, sp4.y, sp4.z}, sp4.w);
+          }
+          unsigned long long todo = __builtin_amdgcn_ballot_w64(hit);
+          while (todo) {
+            const int32_t t = sub + __builtin_ctzll(todo);
+            todo &= todo - 1ull;
             const int32_t gidx = chunk_end - t;
             bool valid = active && gidx <= bin_final;
             f3 gro, grd, grd_n, gc; float vis = 0.f, il = 1.f, alpha = 0.f;
@@ -282,13 +374,11 @@ __global__ __launch_bounds__(RB) void raster_bwd_kernel(RasterArgs a, const floa
                 }
                 buf_r += s.r3.y * fac; buf_g += s.r3.z * fac; buf_b += s.r3.w * fac;
             }
-#pragma unroll
-            for (int k = 0; k < NACC; ++k) acc[k] = wave_sum_to_lane63(acc[k]);
-            if (lane == 63u) {
-#pragma unroll
-                for (int k = 0; k < NACC; ++k) atomicAdd(&s_acc[k * RB + t], acc[k]);
-                s_touched[t] = 1;
-            }
+            // 16 sums over the wave in one halving butterfly (~35 VALU instead of 16 x 6 DPP adds): 16 lanes end with one total each
+            const float total = butterfly_reduce16(acc);
+            if ((lane & 3u) == 0u) atomicAdd(&s_acc[butterfly_value_of_lane(lane) * RB + t], total);
+            if (lane == 0u) s_touched[t] = 1;
+          }
         }
         __syncthreads();
 
@@ -299,16 +389,14 @@ __global__ __launch_bounds__(RB) void raster_bwd_kernel(RasterArgs a, const floa
             float A[NACC];
 #pragma unroll
             for (int k = 0; k < NACC; ++k) A[k] = s_acc[k * RB + tid];
-            atomicAdd(&v_colors[(size_t)g * 3], A[0]);
-            atomicAdd(&v_colors[(size_t)g * 3 + 1], A[1]);
-            atomicAdd(&v_colors[(size_t)g * 3 + 2], A[2]);
-            atomicAdd(&v_opacities[g], A[3]);
+            float out[14];   // v_mean 3 | v_quat 4 | v_scale 3 | v_color 3 | v_opacity
+            out[10] = A[0]; out[11] = A[1]; out[12] = A[2]; out[13] = A[3];
             const Staged s = s_g[tid];
             const f3 v_gro{A[4], A[5], A[6]};
             // v_mean = - M^T v_gro
-            atomicAdd(&v_means[(size_t)gi * 3], -(s.r0.x * v_gro.x + s.r1.x * v_gro.y + s.r2.x * v_gro.z));
-            atomicAdd(&v_means[(size_t)gi * 3 + 1], -(s.r0.y * v_gro.x + s.r1.y * v_gro.y + s.r2.y * v_gro.z));
-            atomicAdd(&v_means[(size_t)gi * 3 + 2], -(s.r0.z * v_gro.x + s.r1.z * v_gro.y + s.r2.z * v_gro.z));
+            out[0] = -(s.r0.x * v_gro.x + s.r1.x * v_gro.y + s.r2.x * v_gro.z);
+            out[1] = -(s.r0.y * v_gro.x + s.r1.y * v_gro.y + s.r2.y * v_gro.z);
+            out[2] = -(s.r0.z * v_gro.x + s.r1.z * v_gro.y + s.r2.z * v_gro.z);
             // v_Mt(r,c) = G(r,c) + v_gro_r * omu_c   (Bwd.cu:325-326)
             float vMt[3][3] = {{A[7], A[8], A[9]}, {A[10], A[11], A[12]}, {A[13], A[14], A[15]}};
             const float4 qraw = reinterpret_cast<const float4*>(a.quats)[gi];
@@ -339,15 +427,66 @@ __global__ __launch_bounds__(RB) void raster_bwd_kernel(RasterArgs a, const floa
             const float qn[4] = {w, x, y, z};
             const float dq = vq[0] * qn[0] + vq[1] * qn[1] + vq[2] * qn[2] + vq[3] * qn[3];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) atomicAdd(&v_quats[(size_t)gi * 4 + k], (vq[k] - dq * qn[k]) * inv_norm);
+            for (int k = 0; k < 4; ++k) out[3 + k] = (vq[k] - dq * qn[k]) * inv_norm;
             // v_scale[k] = -(1/s_k)^2 * sum_r R(r,k) * v_M(r,k) = -(is_k)^2 * sum_r R(r,k) * vMt[k][r]
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float sum = R.a[0][k] * vMt[k][0] + R.a[1][k] * vMt[k][1] + R.a[2][k] * vMt[k][2];
-                atomicAdd(&v_scales[(size_t)gi * 3 + k], -isv[k] * isv[k] * sum);
+            for (int k = 0; k < 3; ++k)
+                out[7 + k] = -isv[k] * isv[k] * (R.a[0][k] * vMt[k][0] + R.a[1][k] * vMt[k][1] + R.a[2][k] * vMt[k][2]);
+            if (grad_rec != nullptr) {
+                // No float atomics reach memory: the 14 gradients of this (tile, Gaussian) go into ONE 64 B record at the intersection's
+                // sorted index, chained per (camera, Gaussian) with a returning exchange; gsx_bwd_gather_grads_kernel sums the lists.
+                // (On MI355X device-scope float atomics resolve memory-side: 14 of them per (tile, Gaussian) dominate this kernel.)
+                const int32_t isect = chunk_end - (int32_t)tid;
+                const int32_t prev = atomicExch(&grad_head[g], isect);
+                float4* rec = grad_rec + (size_t)isect * 4;
+                rec[0] = make_float4(out[0], out[1], out[2], out[3]);
+                rec[1] = make_float4(out[4], out[5], out[6], out[7]);
+                rec[2] = make_float4(out[8], out[9], out[10], out[11]);
+                rec[3] = make_float4(out[12], out[13], 0.f, __int_as_float(prev));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) atomicAdd(&v_means[(size_t)gi * 3 + k], out[k]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) atomicAdd(&v_quats[(size_t)gi * 4 + k], out[3 + k]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) atomicAdd(&v_scales[(size_t)gi * 3 + k], out[7 + k]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) atomicAdd(&v_colors[(size_t)g * 3 + k], out[10 + k]);
+                atomicAdd(&v_opacities[g], out[13]);
             }
         }
     }
+}
+
+// Sums the gradient records of every (camera, Gaussian) list built by raster_bwd_kernel in record mode and writes EVERY output
+// element (no pre-zeroing): v_colors / v_opacities per camera, v_means / v_quats / v_scales summed over the cameras.
+__global__ __launch_bounds__(256) void gsx_bwd_gather_grads_kernel(uint32_t C, uint32_t N, const float4* __restrict__ rec,
+                                                                   const int32_t* __restrict__ head, float* __restrict__ v_means,
+                                                                   float* __restrict__ v_quats, float* __restrict__ v_scales,
+                                                                   float* __restrict__ v_colors, float* __restrict__ v_opacities) {
+    const uint32_t gi = blockIdx.x * 256u + threadIdx.x;
+    if (gi >= N) return;
+    float geo[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) geo[k] = 0.f;
+    for (uint32_t c = 0; c < C; ++c) {
+        const size_t g = (size_t)c * N + gi;
+        float col[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int32_t it = head[g]; it >= 0;) {
+            const float4* r = rec + (size_t)it * 4;
+            const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+            geo[0] += r0.x; geo[1] += r0.y; geo[2] += r0.z; geo[3] += r0.w;
+            geo[4] += r1.x; geo[5] += r1.y; geo[6] += r1.z; geo[7] += r1.w;
+            geo[8] += r2.x; geo[9] += r2.y; col[0] += r2.z; col[1] += r2.w;
+            col[2] += r3.x; col[3] += r3.y;
+            it = __float_as_int(r3.w);
+        }
+        v_colors[g * 3] = col[0]; v_colors[g * 3 + 1] = col[1]; v_colors[g * 3 + 2] = col[2];
+        v_opacities[g] = col[3];
+    }
+    v_means[(size_t)gi * 3] = geo[0]; v_means[(size_t)gi * 3 + 1] = geo[1]; v_means[(size_t)gi * 3 + 2] = geo[2];
+    reinterpret_cast<float4*>(v_quats)[gi] = make_float4(geo[3], geo[4], geo[5], geo[6]);
+    v_scales[(size_t)gi * 3] = geo[7]; v_scales[(size_t)gi * 3 + 1] = geo[8]; v_scales[(size_t)gi * 3 + 2] = geo[9];
 }
 
 static int fill_args(RasterArgs& a, uint32_t N, int64_t n_isects, const float* means, const float* quats,
@@ -494,11 +633,22 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd_packed(
         if (fast_done && only_tiles == nullptr) return check_launch("rasterize_to_pixels_from_world_3dgs_bwd(fast)");
         // fisheye: the gather kernel has written every output element; the reference-order kernel adds the flagged tiles on top
     }
-    if (!fast_done) zero_outputs();
+    // Reference-order kernels.  With a workspace and no fast-path results to add to, the per-(tile, Gaussian) gradients travel as
+    // chained 64 B records + one gather pass instead of 14 device-scope float atomics each (rolling shutter, forced generic path).
+    float4* grad_rec = nullptr;
+    int32_t* grad_head = nullptr;
+    const size_t rec_bytes = ((size_t)n_isects * 64 + 255) / 256 * 256;
+    if (!fast_done && workspace != nullptr && workspace_bytes >= rec_bytes + (size_t)a.C * N * 4) {
+        grad_rec = (float4*)workspace;
+        grad_head = (int32_t*)((char*)workspace + rec_bytes);
+        (void)hipMemsetAsync(grad_head, 0xFF, (size_t)a.C * N * 4, st);
+    } else if (!fast_done) {
+        zero_outputs();
+    }
 #define GSX_BWD(KIND)                                                                                                  \
     do {                                                                                                               \
-        if (hoist) hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_kernel<KIND, true>), grid, block, 0, st, a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors, v_opacities, only_tiles); \
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_kernel<KIND, false>), grid, block, 0, st, a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors, v_opacities, only_tiles);      \
+        if (hoist) hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_kernel<KIND, true>), grid, block, 0, st, a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors, v_opacities, only_tiles, grad_rec, grad_head); \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_bwd_kernel<KIND, false>), grid, block, 0, st, a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors, v_opacities, only_tiles, grad_rec, grad_head);      \
     } while (0)
     switch (kind) {
     case CAM_PERFECT_PINHOLE: GSX_BWD(CAM_PERFECT_PINHOLE); break;
@@ -506,6 +656,9 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd_packed(
     default: GSX_BWD(CAM_OPENCV_FISHEYE); break;
     }
 #undef GSX_BWD
+    if (grad_rec != nullptr)
+        hipLaunchKernelGGL(gsx_bwd_gather_grads_kernel, dim3((N + 255u) / 256u), dim3(256), 0, st, a.C, N, (const float4*)grad_rec,
+                           (const int32_t*)grad_head, v_means, v_quats, v_scales, v_colors, v_opacities);
     return check_launch("rasterize_to_pixels_from_world_3dgs_bwd");
 }
 

@@ -23,11 +23,18 @@ cam = rasterizer.Camera(viewmat=scene["viewmat"].to(dev), K=scene["K"].to(dev), 
 with torch.no_grad():
     out = rasterizer.rasterize(cam, model, scene["background"].to(dev))
 radial = None if radial is None else radial.to(dev)
+rolling = os.environ.get("GSX_AB_CAMERA") == "rolling"   # timing only: the global-shutter binning, blended with a rolling shutter
+shutter = ops.ShutterType.ROLLING_TOP_TO_BOTTOM if rolling else ops.ShutterType.GLOBAL
+vm1 = None
+if rolling:
+    vm1 = scene["viewmat"].clone()
+    vm1[0, 3], vm1[1, 3] = 0.01, -0.01
+    vm1 = vm1[None].to(dev).contiguous()
 d = lambda k: scene[k].to(dev)  # noqa: E731
 ut = ops.UnscentedTransformParameters()
 colors, off, fl = out.aux["colors"].contiguous(), out.aux["isect_offsets"], out.aux["flatten_ids"]
 common = (d("means"), d("quats"), d("scales"), colors, d("opacities")[None].contiguous(), d("background")[None].contiguous(), None, W, H, 16,
-          d("viewmat")[None].contiguous(), None, d("K")[None].contiguous(), cam_model, ut, ops.ShutterType.GLOBAL, radial, None, None, off, fl)
+          d("viewmat")[None].contiguous(), vm1, d("K")[None].contiguous(), cam_model, ut, shutter, radial, None, None, off, fl)
 g = torch.Generator(device=dev).manual_seed(0)
 v_rc, v_ra = torch.randn(1, H, W, 3, device=dev, generator=g), torch.randn(1, H, W, 1, device=dev, generator=g)
 
@@ -50,5 +57,5 @@ def timeit(fn):
 t_f, fwd = timeit(lambda: ops.rasterize_to_pixels_from_world_3dgs_fwd(*common, keep_ws=True))
 t_b, bwd = timeit(lambda: ops.rasterize_to_pixels_from_world_3dgs_bwd(*common, fwd[1], fwd[2], v_rc, v_ra, fwd_ws=fwd[3]))
 chk = [float(x.double().abs().sum()) for x in bwd]
-print("%s%s GSX_BWD=%s GSX_RASTER_PATH=%s n_isects=%d  fwd %.4f ms  bwd %.4f ms  |grads|_1 = %s" % (which, " fisheye" if fisheye else "", os.environ.get("GSX_BWD", "-"), os.environ.get("GSX_RASTER_PATH", "-"), fl.numel(), t_f, t_b,
+print("%s%s GSX_BWD=%s GSX_RASTER_PATH=%s n_isects=%d  fwd %.4f ms  bwd %.4f ms  |grads|_1 = %s" % (which, " fisheye" if fisheye else (" rolling-shutter" if rolling else ""), os.environ.get("GSX_BWD", "-"), os.environ.get("GSX_RASTER_PATH", "-"), fl.numel(), t_f, t_b,
                                                                               " ".join("%.6g" % c for c in chk)))
