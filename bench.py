@@ -185,6 +185,8 @@ def main():
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL)")
     ap.add_argument("--unfused", action="store_true", help="reference-style glue (one torch op per activation / SH pre-post step)")
     ap.add_argument("--sparse-allreduce", action="store_true", help="exchange only the gradient rows of Gaussians some camera saw")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1, dense all-reduce: exchange the whole bucket after the backward (default: the "
+                                                             "scaling / rotation / opacity gradients are exchanged under the SH backward)")
     ap.add_argument("--sharded-adam", action="store_true", help="N > 1: reduce-scatter -> Adam on 1/N of the rows -> all-gather of the parameters")
     ap.add_argument("--l1-loss", action="store_true", help="plain torch L1 loss instead of the reference's fused L1 + SSIM loss")
     ap.add_argument("--no-fwd-bwd", action="store_true", help="skip the extra fwd+bwd (no optimizer) timing loop")
@@ -222,6 +224,10 @@ def main():
     timer = OpTimer(ops)
     sinks = bucket.sinks()
     counter = {"i": 0, "isects": []}
+    overlap = world > 1 and sharded is None and not args.sparse_allreduce and not args.unfused and not args.no_overlap
+    early = {"h": None}
+    if overlap:   # parameter order of the bucket: means, sh, scaling_raw, rotation_raw, opacity_raw -> the tail starts at parameter 2
+        sinks["_early_ready"] = lambda: early.__setitem__("h", bucket.all_reduce_mean_tail_async(2))
 
     def step(with_adam=True):
         i = counter["i"]
@@ -244,6 +250,9 @@ def main():
                 if args.sparse_allreduce and not args.unfused:
                     # rows no camera of the step sees are zero on every rank: only the union of the visible rows travels
                     bucket.all_reduce_mean_rows((out.aux["radii_full"] > 0).all(-1))
+                elif overlap:
+                    bucket.all_reduce_mean_head(early["h"])   # means + SH now; scaling / rotation / opacity have been travelling since
+                    early["h"] = None
                 else:
                     bucket.all_reduce_mean()
             if with_adam:
@@ -349,7 +358,8 @@ def main():
                        "n_isects_mean": round(I, 1), "n_isects_min": min(isects_timed), "n_isects_max": max(isects_timed),
                        "cameras_per_step": world,
                        "grad_exchange": ("none" if world == 1 else ("reduce-scatter + sharded Adam + all-gather" if sharded is not None else
-                                         ("all-reduce of visible rows" if args.sparse_allreduce else "dense all-reduce"))),
+                                         ("all-reduce of visible rows" if args.sparse_allreduce else
+                                          ("dense all-reduce, scaling/rotation/opacity exchanged under the SH backward" if overlap else "dense all-reduce")))),
                        "grad_allreduce_bytes": int(getattr(bucket, "last_reduced_bytes", 0)) if world > 1 else 0,
                        "grad_bucket_bytes": bucket.nbytes(),
                        "host_syncs_per_step": round(host_syncs / args.steps, 2),

@@ -38,6 +38,7 @@ class GradBucket:
             off += (p.numel() + align - 1) // align * align
         p0 = self.params[0]
         self.flat = torch.zeros(off, dtype=p0.dtype, device=p0.device)
+        self.offsets = offs
         for p, o in zip(self.params, offs):
             p.grad = self.flat[o:o + p.numel()].view_as(p)
 
@@ -78,6 +79,25 @@ class GradBucket:
         if async_op:
             return _MeanHandle(self.flat)
         self._reduce_mean(self.flat)
+        return None
+
+    # ---- overlapped exchange: the gradients of the late parameters first ------------------------------------------------------------
+    def all_reduce_mean_tail_async(self, first_param):
+        """Starts the mean all-reduce of the bucket from parameter `first_param` to the end and returns a handle (wait() completes it).
+        The render backward produces the scaling / rotation / opacity gradients (the last three parameters: 8 of the 59 floats per
+        Gaussian) BEFORE the SH backward, so their exchange runs under it: rasterize_fused(grad_sinks={..., "_early_ready": callback})."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return None
+        self._tail_from = self.offsets[first_param]
+        return _MeanHandle(self.flat[self._tail_from:])
+
+    def all_reduce_mean_head(self, tail_handle):
+        """Completes the exchange started by all_reduce_mean_tail_async: reduces the head of the bucket, waits for the tail."""
+        if tail_handle is None:
+            return self.all_reduce_mean()
+        self.last_reduced_bytes = self.nbytes()
+        self._reduce_mean(self.flat[:self._tail_from])
+        tail_handle.wait()
         return None
 
     def all_reduce_mean_rows(self, visible, dense_above=0.75):

@@ -90,13 +90,16 @@ def _rows_worker(rank, world, port, out_dir):
     shapes = [(N, 3), (N, 16, 3), (N, 3), (N, 4), (N, 1)]
     visible = torch.rand(N, generator=g) < 0.3                      # this rank's camera sees ~30 % of the Gaussians
     grads = [torch.randn(s, generator=g) * visible.view(-1, *([1] * (len(s) - 1))) for s in shapes]
-    for mode in ("rows", "dense", "rows_fallback"):
+    for mode in ("rows", "dense", "rows_fallback", "tail_head"):
         params = [torch.zeros(s, requires_grad=True) for s in shapes]
         bucket = gdist.GradBucket(params)
         for p, gr in zip(params, grads):
             p.grad.copy_(gr)
         if mode == "dense":
             bucket.all_reduce_mean()
+        elif mode == "tail_head":   # the overlapped exchange: last three parameters first (asynchronously), then the head
+            h = bucket.all_reduce_mean_tail_async(2)
+            bucket.all_reduce_mean_head(h)
         else:
             bucket.all_reduce_mean_rows(visible, dense_above=0.75 if mode == "rows" else 0.1)
         if mode == "rows":
@@ -110,7 +113,7 @@ def test_visible_row_all_reduce_equals_dense(tmp_path):
     world, port = 2, _free_port()
     mp.spawn(_rows_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     dense = np.load(tmp_path / "dense_0.npy")
-    for mode in ("rows", "rows_fallback"):
+    for mode in ("rows", "rows_fallback", "tail_head"):
         for r in range(world):
             got = np.load(tmp_path / ("%s_%d.npy" % (mode, r)))
             assert np.array_equal(got, dense), (mode, r)             # bit-identical to the dense collective on 2 ranks
