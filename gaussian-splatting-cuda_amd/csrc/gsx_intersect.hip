@@ -115,6 +115,7 @@ __global__ __launch_bounds__(ISECT_BLOCK) void isect_offset_kernel(int64_t n_ise
 constexpr uint32_t BIN_NB = 256;          // Gaussian slices (blocks) per camera
 constexpr uint32_t BIN_MAX_TILES = 36864; // 144 KB of LDS counters
 constexpr int TSORT_CAP = 4096;           // keys sorted in LDS per block (32 KB)
+constexpr int TSORT_BIG_CAP = 16384;      // keys sorted in LDS by a 1024-thread block (132 KB): the heavy tiles of dense scenes
 constexpr int TSORT_WAVE_CAP = 1024;      // keys sorted by one wave without block barriers (8 KB); measured faster than a block up to here
 constexpr int BIN_BLOCK = 1024;           // count / scatter: 16 waves share one LDS counter array
 
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(ISECT_BLOCK) void tile_sort_kernel(uint32_t n_tiles
     const int64_t begin = tile_offsets[seg];
     const int n = (int)(tile_offsets[seg + 1] - tile_offsets[seg]);
     if (n <= TSORT_WAVE_CAP || begin + n > capacity) return;  // small segments: tile_sort_wave_kernel
+    if (n > TSORT_CAP && n <= TSORT_BIG_CAP) return;          // heavy segments: tile_sort_big_kernel
     const uint64_t idx_mask = (1ull << idx_bits) - 1ull;
     const int64_t cam_tile = (((int64_t)(seg / n_tiles) << tile_n_bits) | (int64_t)(seg % n_tiles)) << 32;
     const int t = threadIdx.x;
@@ -365,16 +367,51 @@ __global__ __launch_bounds__(ISECT_BLOCK) void tile_sort_kernel(uint32_t n_tiles
     }
 }
 
+// Heavy tiles (4096 < keys <= 16384): one 1024-thread block sorts the whole segment in 132 KB of LDS.  The path below them in
+// tile_sort_kernel (4096-key LDS chunks + rank merges through global memory by ONE 256-thread block) is latency bound: dependent
+// global loads in every binary-search step make a 6 000-key tile cost over a millisecond, and dense scenes have hundreds of such
+// tiles per frame (garden-like stand-in, 185 cameras: 2.35 ms per frame = 47 % of the GPU time of a training iteration went there).
+// Persistent grid: 256 blocks walk the segments with stride 256 (heavy tiles are neighbours in tile order: the stride spreads them
+// over the CUs); a frame without heavy tiles costs 32 offset reads per block.
+__global__ __launch_bounds__(1024) void tile_sort_big_kernel(uint32_t n_segments, uint32_t n_tiles, uint32_t tile_n_bits, uint32_t idx_bits,
+                                                             const int32_t* __restrict__ tile_offsets, const uint64_t* __restrict__ keys,
+                                                             int32_t* __restrict__ flatten_ids, int64_t* __restrict__ isect_ids,
+                                                             int64_t capacity) {
+    extern __shared__ uint64_t s_big[];
+    const int t = threadIdx.x;
+    const uint64_t idx_mask = (1ull << idx_bits) - 1ull;
+    for (uint32_t seg = blockIdx.x; seg < n_segments; seg += gridDim.x) {
+        const int64_t begin = tile_offsets[seg];
+        const int n = (int)(tile_offsets[seg + 1] - tile_offsets[seg]);
+        if (n <= TSORT_CAP || n > TSORT_BIG_CAP || begin + n > capacity) continue;   // (block-uniform)
+        const int m = n <= 8192 ? 8192 : 16384;
+        __syncthreads();   // the previous segment's keys have been read out
+        for (int i = t; i < m; i += 1024) s_big[spad(i)] = i < n ? keys[begin + i] : ~0ull;
+        __syncthreads();
+        if (m == 8192) merge_sort_lds<8, 1024>(s_big, t);
+        else merge_sort_lds<16, 1024>(s_big, t);
+        const int64_t cam_tile = (((int64_t)(seg / n_tiles) << tile_n_bits) | (int64_t)(seg % n_tiles)) << 32;
+        for (int i = t; i < n; i += 1024) {
+            const uint64_t k = s_big[spad(i)];
+            flatten_ids[begin + i] = (int32_t)(k & idx_mask);
+            if (isect_ids) isect_ids[begin + i] = cam_tile | (int64_t)(k >> idx_bits);
+        }
+    }
+}
+
 // exclusive scan of n counters by one 1024-thread block (n = C*tiles + 1: a few thousand entries; the generic device scan
 // costs three launches for them).  out[i] = sum(in[0..i)), in[n-1] is ignored and out[n-1] = grand total.
-__global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t n, const uint32_t* __restrict__ in, int32_t* __restrict__ out) {
+__global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t n, const uint32_t* __restrict__ in, int32_t* __restrict__ out,
+                                                        uint32_t* __restrict__ max_count) {
     // exclusive scan of n - 1 counts, out[n - 1] = total.  Runs in 64 bits: a frame with more than 2^31 - 1 intersections does not
     // wrap silently — every offset saturates at INT32_MAX and the total is written as -1, which both consumers reject (the fill's
     // n_isects guard in the C ABI, the shim's TORCH_CHECK): such a scene needs the device-wide sort's int64 scan.
     __shared__ unsigned long long s_wave[16];
     __shared__ unsigned long long s_carry;
+    __shared__ uint32_t s_max;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0ull;
+    if (threadIdx.x == 0) { s_carry = 0ull; s_max = 0u; }
+    uint32_t my_max = 0u;
     __syncthreads();
     for (uint32_t base = 0; base < n; base += 4096u) {
         const uint32_t i0 = base + threadIdx.x * 4u;
@@ -382,6 +419,8 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t n, const uint32
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n - 1u) ? (unsigned long long)in[i0 + k] : 0ull;
         const unsigned long long mine = v[0] + v[1] + v[2] + v[3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) my_max = max(my_max, (uint32_t)min(v[k], 0xFFFFFFFFull));
         unsigned long long incl = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -401,6 +440,11 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t n, const uint32
         __syncthreads();
         if (threadIdx.x == 1023u) s_carry = run;
         __syncthreads();
+    }
+    if (max_count != nullptr) {   // the largest segment: callers route frames with giant segments to the device-wide sort
+        atomicMax(&s_max, my_max);
+        __syncthreads();
+        if (threadIdx.x == 0) *max_count = s_max;
     }
 }
 
@@ -566,10 +610,13 @@ extern "C" int gsx_intersect_bin_count(uint32_t C, uint32_t N, const float* mean
                        tile_height, tiles_per_gauss, hist);
     hipLaunchKernelGGL(bin_prefix_kernel, dim3((nseg + 31) / 32), dim3(ISECT_BLOCK), 0, st, C, n_tiles, hist, counts);
     // offsets[t] = intersections before (camera, tile) t; offsets[nseg] = n_isects
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, nseg + 1, (const uint32_t*)counts, tile_offsets);
+    // (the largest segment lands in the slack word behind the counts; it travels to the host in the upper half of the pinned word)
+    uint32_t* max_count = (uint32_t*)((char*)workspace + bin_hist_bytes(C, n_tiles) + align_up((size_t)(nseg + 1) * 4, 256));
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, nseg + 1, (const uint32_t*)counts, tile_offsets, max_count);
     if (n_isects_host_pinned) {
-        *n_isects_host_pinned = 0;  // 4 of the 8 bytes are copied
+        *n_isects_host_pinned = 0;  // low 32 bits: n_isects (-1 = more than 2^31 - 1), high 32 bits: keys of the largest (camera, tile) segment
         (void)hipMemcpyAsync(n_isects_host_pinned, tile_offsets + nseg, 4, hipMemcpyDeviceToHost, st);
+        (void)hipMemcpyAsync((char*)n_isects_host_pinned + 4, max_count, 4, hipMemcpyDeviceToHost, st);
     }
     return check_launch("intersect_bin_count");
 }
@@ -610,5 +657,14 @@ extern "C" int gsx_intersect_bin_fill(uint32_t C, uint32_t N, const float* means
                        (const uint64_t*)keys, flatten_ids, isect_ids, n_isects);
     hipLaunchKernelGGL(tile_sort_kernel, dim3(nseg), dim3(ISECT_BLOCK), 0, st, n_tiles, bit_width_u32(n_tiles), idx_bits, tile_offsets, keys, keys_alt,
                        flatten_ids, isect_ids, n_isects);
+    if (n_isects > TSORT_CAP) {   // a segment above 4096 keys needs at least that many intersections
+        const size_t big_lds = (size_t)(TSORT_BIG_CAP + TSORT_BIG_CAP / 32) * 8;
+        static const bool attr_set = [&] {
+            return hipFuncSetAttribute((const void*)tile_sort_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds) == hipSuccess;
+        }();
+        (void)attr_set;
+        hipLaunchKernelGGL(tile_sort_big_kernel, dim3(256), dim3(1024), big_lds, st, nseg, n_tiles, bit_width_u32(n_tiles), idx_bits, tile_offsets,
+                           (const uint64_t*)keys, flatten_ids, isect_ids, n_isects);
+    }
     return check_launch("intersect_bin_fill");
 }

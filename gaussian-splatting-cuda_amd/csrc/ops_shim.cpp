@@ -504,13 +504,16 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
     at::cuda::CUDAEvent total_ready;
     total_ready.record(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
     static std::mutex hint_mutex;
-    static std::map<std::tuple<int, uint32_t, uint32_t, uint32_t, uint32_t>, int64_t> hints;
+    static std::map<std::tuple<int, uint32_t, uint32_t, uint32_t, uint32_t>, std::pair<int64_t, int64_t>> hints;   // (n_isects, largest segment)
     const auto key = std::make_tuple((int)means2d.get_device(), C, N, tile_width, tile_height);
-    int64_t hint = 0;
+    // Per-tile LDS sorts handle segments up to 16384 keys; beyond that one block would sort a segment through global memory (milliseconds
+    // for the 50 k-key tiles of a dense scene), so such frames take the device-wide radix sort instead (same outputs, bit for bit).
+    constexpr int64_t kGiantSegment = 16384;
+    int64_t hint = 0, hint_seg = 0;
     {
         std::lock_guard<std::mutex> lock(hint_mutex);
         auto it = hints.find(key);
-        if (it != hints.end()) hint = it->second;
+        if (it != hints.end()) { hint = it->second.first; hint_seg = it->second.second; }
     }
     at::Tensor flatten_ids, isect_ids;
     auto fill = [&](int64_t capacity) {
@@ -523,22 +526,29 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
                                      want_isect_ids ? isect_ids.data_ptr<int64_t>() : nullptr, fws.data_ptr(), fwb, st), "intersect_tile_binned(fill)");
     };
     int64_t capacity = 0;
-    if (hint > 0 && n_elements) {
+    if (hint > 0 && hint_seg <= kGiantSegment && n_elements) {   // (a scene that had giant segments last time: wait for the count first)
         capacity = std::min<int64_t>(hint + hint / 8 + 4096, 0x7FFFFFFFll);
         fill(capacity);
     }
     total_ready.synchronize();
     g_stats.host_syncs++;
-    const int64_t n_isects = n_host.data_ptr<int64_t>()[0];
+    const uint64_t word = (uint64_t)n_host.data_ptr<int64_t>()[0];
+    const int64_t n_isects = (int64_t)(word & 0xFFFFFFFFull), max_seg = (int64_t)(word >> 32);
     TORCH_CHECK(n_isects <= 0x7FFFFFFFll, "intersect_tile: more than 2^31 - 1 intersections (tile offsets are int32, as upstream's isect_offsets)");
     {
         std::lock_guard<std::mutex> lock(hint_mutex);
-        int64_t& h = hints[key];
-        h = std::max<int64_t>(n_isects, h - h / 50);  // running maximum with a slow decay
+        auto& h = hints[key];
+        h.first = std::max<int64_t>(n_isects, h.first - h.first / 50);  // running maximum with a slow decay
+        h.second = max_seg;
     }
     g_stats.binned_calls++;
     if (capacity > 0 && n_isects > capacity) g_stats.hint_misses++;
     if (capacity == 0 && n_isects > 0) g_stats.hint_cold++;
+    if (max_seg > kGiantSegment && capacity == 0) {   // giant segments and nothing launched yet: the device-wide sort
+        auto r = gsplat::intersect_tile_device_sort(means2d, radii, depths, C, tile_size, tile_width, tile_height, true);
+        at::Tensor off = gsplat::intersect_offset(std::get<1>(r), C, tile_width, tile_height);
+        return std::make_tuple(std::get<0>(r), want_isect_ids ? std::get<1>(r) : at::empty({0}, std::get<1>(r).options()), std::get<2>(r), off);
+    }
     if (capacity > 0 && n_isects <= capacity) {
         flatten_ids = flatten_ids.narrow(0, 0, n_isects);
         if (want_isect_ids) isect_ids = isect_ids.narrow(0, 0, n_isects);

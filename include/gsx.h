@@ -178,7 +178,10 @@ int gsx_add_noise(uint32_t N, const float* raw_opacities, const float* raw_scale
 /* Binned variant of intersect_tile(sort = true) + intersect_offset in one pipeline (same outputs, bit for bit): per-block
  * LDS tile histograms -> per-tile prefix + exclusive scan = isect_offsets -> scatter into tile-major segments -> per-tile LDS
  * sort by (depth bits, flatten index).  No device-wide sort, no global atomics.  tile_offsets has C*tiles + 1 entries (the
- * last one is n_isects, also copied to the pinned host word).  Host protocol as above: bin_count -> sync -> allocate
+ * last one is n_isects; the pinned host word receives n_isects in its low 32 bits — 0xFFFFFFFF when there are more than 2^31 - 1 —
+ * and the key count of the largest (camera, tile) segment in its high 32 bits: segments up to 16384 keys are sorted in LDS, larger
+ * ones by one block through global memory, slowly, so a caller may prefer intersect_tile's device-wide sort for such a frame).
+ * Host protocol as above: bin_count -> sync -> allocate
  * flatten_ids -> bin_fill(count_workspace = the workspace bin_count used).  isect_ids may be NULL (the blend kernels only
  * need flatten_ids + offsets).  bin_fill's `n_isects` is the CAPACITY of flatten_ids / isect_ids / the workspace: a caller
  * that can guess an upper bound may launch bin_fill before the host has read the exact total (nothing beyond the capacity is

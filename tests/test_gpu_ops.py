@@ -276,7 +276,8 @@ def test_blend_with_no_intersections(gsx_mod, raster_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("C,N,W,H,rmax,nq", [(1, 5000, 256, 256, 20, 0), (2, 3000, 200, 120, 40, 16), (1, 30000, 64, 64, 30, 8),
-                                             (3, 1, 33, 17, 5, 0), (1, 100, 1920, 1080, 300, 4)])
+                                             (3, 1, 33, 17, 5, 0), (1, 100, 1920, 1080, 300, 4),
+                                             (1, 20000, 64, 64, 30, 8), (1, 50000, 64, 64, 30, 0), (2, 70000, 64, 48, 30, 0)])
 def test_intersect_tile_binned_equals_sorted_path(C, N, W, H, rmax, nq):
     """The binned pipeline (LDS histograms + per-tile LDS sort, incl. the > 4096-key merge path: case 3) returns bit for bit
     what intersect_tile(sort=True) + intersect_offset return; quantised depths (nq levels) exercise the flatten-index tie break."""
@@ -297,8 +298,14 @@ def test_intersect_tile_binned_equals_sorted_path(C, N, W, H, rmax, nq):
     assert torch.equal(ids, ids2) and torch.equal(flat, flat2)
     _, ids3, flat3, off3 = ops.intersect_tile_binned(means2d, radii, depths, C, 16, tw, th, False)
     assert ids3.numel() == 0 and torch.equal(flat, flat3) and torch.equal(off, off3)
-    if N >= 30000:
-        assert int((off.flatten()[1:] - off.flatten()[:-1]).max()) > 4096   # the merge path ran
+    seg = torch.cat([off.flatten(), torch.tensor([flat.numel()], device=off.device, dtype=off.dtype)])
+    seg = seg[1:] - seg[:-1]
+    if N == 30000:
+        assert int(seg.max()) > 4096                                         # beyond the 4096-key block sort
+    if N in (20000, 50000):
+        assert bool(((seg > 4096) & (seg <= 16384)).any())                   # the heavy-tile kernel (one 1024-thread block, 132 KB of LDS) ran
+    if N == 70000:
+        assert int(seg.max()) > 16384                                        # the chunked merge path behind it ran
 
 
 @pytest.mark.gpu
