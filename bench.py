@@ -187,6 +187,9 @@ def main():
     ap.add_argument("--sparse-allreduce", action="store_true", help="exchange only the gradient rows of Gaussians some camera saw")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1, dense all-reduce: exchange the whole bucket after the backward (default: the "
                                                              "scaling / rotation / opacity gradients are exchanged under the SH backward)")
+    ap.add_argument("--dense-allreduce", action="store_true", help="N > 1: all-reduce the whole 59-float-per-Gaussian bucket (default: the colour-gradient "
+                                                                   "exchange: 3 floats per (camera, Gaussian) are all-gathered, every rank runs the SH backward over all "
+                                                                   "cameras of the step, the other 11 floats are all-reduced meanwhile)")
     ap.add_argument("--sharded-adam", action="store_true", help="N > 1: reduce-scatter -> Adam on 1/N of the rows -> all-gather of the parameters")
     ap.add_argument("--l1-loss", action="store_true", help="plain torch L1 loss instead of the reference's fused L1 + SSIM loss")
     ap.add_argument("--no-fwd-bwd", action="store_true", help="skip the extra fwd+bwd (no optimizer) timing loop")
@@ -211,7 +214,11 @@ def main():
     model = scenes.to_splat_data(scene, dev)
     for p in model.params():
         p.requires_grad_(True)
-    bucket = gdist.GradBucket(model.params())
+    color_xch = world > 1 and not (args.dense_allreduce or args.sparse_allreduce or args.sharded_adam or args.unfused or args.no_overlap)
+    names = ["means", "sh", "scaling_raw", "rotation_raw", "opacity_raw"]
+    if color_xch:   # SH gradient first: everything that is all-reduced (means, scaling, rotation, opacity) is ONE contiguous span behind it
+        names = ["sh", "means", "scaling_raw", "rotation_raw", "opacity_raw"]
+    bucket = gdist.GradBucket([getattr(model, n) for n in names])
     poses = [scene["viewmat"].clone()] if args.fixed_camera else camera_poses(scene)
     cams = [rasterizer.Camera(viewmat=vm.to(dev), K=scene["K"].to(dev), width=W, height=H) for vm in poses]
     bg = scene["background"].to(dev)
@@ -222,9 +229,13 @@ def main():
     sharded = gdist.ShardedAdam(opt, bucket) if (args.sharded_adam and world > 1) else None
 
     timer = OpTimer(ops)
-    sinks = bucket.sinks()
+    sinks = bucket.sinks(tuple(names))
     counter = {"i": 0, "isects": []}
-    overlap = world > 1 and sharded is None and not args.sparse_allreduce and not args.unfused and not args.no_overlap
+    xch = None
+    if color_xch:
+        xch = gdist.ColorGradExchange(bucket, names)
+        sinks["_color_exchange"] = xch
+    overlap = world > 1 and xch is None and sharded is None and not args.sparse_allreduce and not args.unfused and not args.no_overlap
     early = {"h": None}
     if overlap:   # parameter order of the bucket: means, sh, scaling_raw, rotation_raw, opacity_raw -> the tail starts at parameter 2
         sinks["_early_ready"] = lambda: early.__setitem__("h", bucket.all_reduce_mean_tail_async(2))
@@ -233,6 +244,8 @@ def main():
         i = counter["i"]
         counter["i"] += 1
         cam = cams[(i * world + rank) % len(cams)]  # every step, every rank: another camera
+        if xch is not None:   # the step's whole camera batch, in rank order (every rank knows the schedule)
+            xch.begin_step(torch.stack([cams[(i * world + r) % len(cams)].viewmat for r in range(world)]))
         # fused glue: gradients are written straight into the flat bucket (no zero fill, no AccumulateGrad adds)
         if args.unfused:
             bucket.zero_()
@@ -246,7 +259,9 @@ def main():
         if sharded is not None and with_adam:
             sharded.step(1001 + i)  # reduce-scatter -> Adam on this rank's rows -> all-gather of the updated parameters
         else:
-            if world > 1:
+            if xch is not None:
+                xch.finish()   # colours were all-gathered and the SH backward ran over every camera inside backward(); the rest was all-reduced under it
+            elif world > 1:
                 if args.sparse_allreduce and not args.unfused:
                     # rows no camera of the step sees are zero on every rank: only the union of the visible rows travels
                     bucket.all_reduce_mean_rows((out.aux["radii_full"] > 0).all(-1))
@@ -357,10 +372,11 @@ def main():
                        "cameras": "cfg2 pose only" if args.fixed_camera else "%d poses (cfg2 + a 0.4 m orbit around it), a different one every step" % len(cams),
                        "n_isects_mean": round(I, 1), "n_isects_min": min(isects_timed), "n_isects_max": max(isects_timed),
                        "cameras_per_step": world,
-                       "grad_exchange": ("none" if world == 1 else ("reduce-scatter + sharded Adam + all-gather" if sharded is not None else
+                       "grad_exchange": ("none" if world == 1 else ("colour-gradient all-gather (3 floats / camera / Gaussian) + SH backward over all cameras on every rank; "
+                                                                     "all-reduce of the other 11 floats under it" if xch is not None else "reduce-scatter + sharded Adam + all-gather" if sharded is not None else
                                          ("all-reduce of visible rows" if args.sparse_allreduce else
                                           ("dense all-reduce, scaling/rotation/opacity exchanged under the SH backward" if overlap else "dense all-reduce")))),
-                       "grad_allreduce_bytes": int(getattr(bucket, "last_reduced_bytes", 0)) if world > 1 else 0,
+                       "grad_exchange_bytes": int(getattr(bucket, "last_reduced_bytes", 0)) if world > 1 else 0,
                        "grad_bucket_bytes": bucket.nbytes(),
                        "host_syncs_per_step": round(host_syncs / args.steps, 2),
                        "intersect_hint_misses": int(hint_misses), "intersect_cold_calls": int(hint_cold)},

@@ -1162,8 +1162,8 @@ bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, 
     const dim3 ggrid((a.N + 255u) / 256u), gblock(256);
     // Two backward kernels, same records and gather.  Gaussian-major wins when the projected Gaussians are small next to a 4x4 pixel
     // block's neighbourhood (S-1M: 767 vs 862 us), pixel-major when they cover many blocks (S-5M @4K: 2.47 vs 2.76 ms): DESIGN.md §4.
-    // The proxy available without a host read is the mean number of 16x16 tiles per Gaussian; GSX_BWD=pm|gm forces one (tests, tools).
-    static const int forced = [] { const char* e = getenv("GSX_BWD"); return !e ? 0 : (std::string(e) == "pm" ? 1 : (std::string(e) == "gm" ? 2 : 0)); }();
+    // The proxy available without a host read is the mean number of 16x16 tiles per Gaussian; GSX_BWD=pm|gm forces one (tests, tools; read per launch).
+    const int forced = [] { const char* e = getenv("GSX_BWD"); return !e ? 0 : (std::string(e) == "pm" ? 1 : (std::string(e) == "gm" ? 2 : 0)); }();
     const bool gaussian_major = kind != CAM_OPENCV_FISHEYE && (forced ? forced == 2 : (double)a.n_isects < 4.5 * (double)a.C * (double)a.N);
 #define GSX_BLEND_BWD(KERNEL, KIND)                                                                                                        \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<KIND>), grid, block, 0, st, a, render_alphas, last_ids, v_render_colors, v_render_alphas, ws_rec, ws_head)

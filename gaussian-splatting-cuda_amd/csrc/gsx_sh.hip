@@ -364,8 +364,11 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_colors_bwd_kernel(uint32_t C, uin
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t e0 = blockIdx.x * SH_BLOCK + wave * 64u;
     const uint32_t e = e0 + lane;
-    bool any_live = false;
-    if (e < N)
+    // radii == nullptr: "pre-masked" colour gradients (multi-GPU colour exchange, distributed.ColorGradExchange): v_colors [C,N,3] already
+    // carry the visibility and clamp masks of their camera (zero rows where a camera does not see the Gaussian), colors is not read
+    const bool premasked = radii == nullptr;
+    bool any_live = premasked && e < N;
+    if (e < N && !premasked)
         for (uint32_t c = 0; c < C; ++c) {
             const int2 r = reinterpret_cast<const int2*>(radii)[(size_t)c * N + e];
             any_live |= (r.x > 0 && r.y > 0);
@@ -385,12 +388,18 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_colors_bwd_kernel(uint32_t C, uin
         const f3 mu{means[(size_t)e * 3], means[(size_t)e * 3 + 1], means[(size_t)e * 3 + 2]};
         for (uint32_t c = 0; c < C; ++c) {
             const size_t ce = (size_t)c * N + e;
-            const int2 r = reinterpret_cast<const int2*>(radii)[ce];
-            if (!(r.x > 0 && r.y > 0)) continue;
-            // clamp_min(x + 0.5, 0) passes the gradient where the output is positive
-            const float vr = colors[ce * 3] > 0.f ? v_colors[ce * 3] : 0.f;
-            const float vg = colors[ce * 3 + 1] > 0.f ? v_colors[ce * 3 + 1] : 0.f;
-            const float vb = colors[ce * 3 + 2] > 0.f ? v_colors[ce * 3 + 2] : 0.f;
+            float vr, vg, vb;
+            if (premasked) {
+                vr = v_colors[ce * 3]; vg = v_colors[ce * 3 + 1]; vb = v_colors[ce * 3 + 2];
+                if (vr == 0.f && vg == 0.f && vb == 0.f) continue;   // this camera does not see (or clamps) the Gaussian
+            } else {
+                const int2 r = reinterpret_cast<const int2*>(radii)[ce];
+                if (!(r.x > 0 && r.y > 0)) continue;
+                // clamp_min(x + 0.5, 0) passes the gradient where the output is positive
+                vr = colors[ce * 3] > 0.f ? v_colors[ce * 3] : 0.f;
+                vg = colors[ce * 3 + 1] > 0.f ? v_colors[ce * 3 + 1] : 0.f;
+                vb = colors[ce * 3 + 2] > 0.f ? v_colors[ce * 3 + 2] : 0.f;
+            }
             const f3 cp = cam_position(viewmats + c * 16);
             float x = mu.x - cp.x, y = mu.y - cp.y, z = mu.z - cp.z, inorm = 1.f;
             if (DEG >= 1) {
@@ -590,7 +599,8 @@ extern "C" int gsx_sh_colors_bwd(uint32_t degrees_to_use, uint32_t C, uint32_t N
                                  const float* viewmats, const float* coeffs, const int32_t* radii, const float* colors,
                                  const float* v_colors, float* v_coeffs, const float* v_means_in, float* v_means_out, void* stream) {
     if (N == 0 || C == 0) return GSX_OK;
-    if (!means || !viewmats || !coeffs || !radii || !colors || !v_colors || !v_coeffs || !v_means_out) { set_error("sh_colors_bwd: null pointer"); return GSX_ERR_INVALID_ARGUMENT; }
+    if (!means || !viewmats || !coeffs || !v_colors || !v_coeffs || !v_means_out) { set_error("sh_colors_bwd: null pointer"); return GSX_ERR_INVALID_ARGUMENT; }
+    if ((radii == nullptr) != (colors == nullptr)) { set_error("sh_colors_bwd: radii and colors are given together (or neither: pre-masked v_colors)"); return GSX_ERR_INVALID_ARGUMENT; }
     if (degrees_to_use > 4 || (degrees_to_use + 1) * (degrees_to_use + 1) > K) { set_error("sh_colors_bwd: bad degree"); return GSX_ERR_INVALID_ARGUMENT; }
     const size_t lds = (size_t)SH_BLOCK * ((K * 3u) | 1u) * sizeof(float);
     if (lds > 160u * 1024u) { set_error("sh_colors_bwd: K too large for the LDS row tile (K <= 53)"); return GSX_ERR_UNSUPPORTED; }

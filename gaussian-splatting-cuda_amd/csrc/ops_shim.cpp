@@ -404,13 +404,18 @@ at::Tensor sh_colors_fwd(const uint32_t degrees_to_use, const at::Tensor means, 
 }
 
 // writes v_coeffs (into `v_coeffs_out` if given) and v_means_out = v_means_in + d colors/d means (into `v_means_out` if given)
+// radii / colors absent: v_colors [C,N,3] are pre-masked (include/gsx.h), the colour-exchange mode of the multi-GPU step
 std::tuple<at::Tensor, at::Tensor> sh_colors_bwd(const uint32_t degrees_to_use, const at::Tensor means, const at::Tensor viewmats,
-                                                 const at::Tensor coeffs, const at::Tensor radii, const at::Tensor colors,
+                                                 const at::Tensor coeffs, const at::optional<at::Tensor> radii, const at::optional<at::Tensor> colors,
                                                  const at::Tensor v_colors, const at::optional<at::Tensor> v_means_in,
                                                  const at::optional<at::Tensor> v_coeffs_out, const at::optional<at::Tensor> v_means_out) {
     GSX_DEVICE_GUARD(means);
-    GSX_CHECK_INPUT(means); GSX_CHECK_INPUT(viewmats); GSX_CHECK_INPUT(coeffs); GSX_CHECK_INPUT(radii); GSX_CHECK_INPUT(colors); GSX_CHECK_INPUT(v_colors);
+    GSX_CHECK_INPUT(means); GSX_CHECK_INPUT(viewmats); GSX_CHECK_INPUT(coeffs); GSX_CHECK_INPUT(v_colors);
+    const bool premasked = !(radii.has_value() && radii->defined());
+    TORCH_CHECK(premasked == !(colors.has_value() && colors->defined()), "sh_colors_bwd: radii and colors are given together, or neither");
+    if (!premasked) { GSX_CHECK_INPUT(radii.value()); GSX_CHECK_INPUT(colors.value()); }
     const uint32_t C = viewmats.size(0), N = means.size(0), K = coeffs.size(-2);
+    TORCH_CHECK(v_colors.numel() == (int64_t)C * N * 3, "sh_colors_bwd: v_colors must be [C,N,3]");
     at::Tensor vc = (v_coeffs_out.has_value() && v_coeffs_out->defined()) ? v_coeffs_out.value() : at::empty_like(coeffs);
     at::Tensor vm = (v_means_out.has_value() && v_means_out->defined()) ? v_means_out.value() : at::empty_like(means);
     GSX_CHECK_INPUT(vc); GSX_CHECK_INPUT(vm);
@@ -418,7 +423,7 @@ std::tuple<at::Tensor, at::Tensor> sh_colors_bwd(const uint32_t degrees_to_use, 
     const float* vmi = nullptr;
     if (v_means_in.has_value() && v_means_in->defined()) { GSX_CHECK_INPUT(v_means_in.value()); vmi = v_means_in->data_ptr<float>(); }
     check(gsx_sh_colors_bwd(degrees_to_use, C, N, K, means.data_ptr<float>(), viewmats.data_ptr<float>(), coeffs.data_ptr<float>(),
-                            radii.data_ptr<int32_t>(), colors.data_ptr<float>(), v_colors.data_ptr<float>(), vc.data_ptr<float>(), vmi,
+                            premasked ? nullptr : radii->data_ptr<int32_t>(), premasked ? nullptr : colors->data_ptr<float>(), v_colors.data_ptr<float>(), vc.data_ptr<float>(), vmi,
                             vm.data_ptr<float>(), cur_stream()), "sh_colors_bwd");
     return std::make_tuple(vc, vm);
 }

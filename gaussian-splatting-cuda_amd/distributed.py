@@ -240,6 +240,89 @@ class ShardedAdam:
             self._gather_rows(p.data, lo, hi, even)
 
 
+class ColorGradExchange:
+    """Gradient exchange of the camera-sharded step that never moves the SH gradient.
+
+    81 % of the gradient bucket is v_sh [N,K,3] (48 of 59 floats per Gaussian at degree 3), and every rank's v_sh is an outer product:
+    v_sh[g] = basis(direction of camera r to Gaussian g) (x) v_colors_r[g] — K*3 floats built from 3.  So the ranks exchange the THREE
+    colour-gradient floats per (camera, Gaussian) with one all-gather (12 B per Gaussian per rank, every rank sends its slice to its 7
+    peers over its 7 xGMI links at once: the pattern the fully connected node is built for), and every rank runs the fused SH backward
+    over ALL cameras of the step (gsx_sh_colors_bwd, C = world, pre-masked colour gradients): the 192 B SH row of a Gaussian is
+    written once either way, the extra cameras cost 12 B of reads and a basis evaluation each.  The remaining 11 floats per Gaussian
+    (means from the blend, scaling, rotation, opacity) are all-reduced as before, while the SH backward runs.
+        per rank, 1 M Gaussians, 8 GPUs:  dense all-reduce 2 * 7/8 * 236 MB = 413 MB sent  ->  84 MB (all-gather) + 77 MB (all-reduce of 44 MB)
+    Every rank computes v_sh from the same gathered bits in the same camera order, so the replicas stay bit-identical (the dense
+    all-reduce only promises that through the collective).  The mean over the cameras is applied to the colour gradients before
+    they travel (1 / world), the all-reduce averages as GradBucket does.
+
+    Wiring: `sinks = bucket.sinks(); sinks["_color_exchange"] = xch; xch.begin_step(viewmats_all)` before the render's backward;
+    rasterizer.GutRenderFunction.backward then calls xch.sh_backward(...) in place of the local SH backward, and the caller calls
+    xch.finish() before the optimizer reads the gradients."""
+
+    def __init__(self, bucket, names=("means", "sh", "scaling_raw", "rotation_raw", "opacity_raw"), sh_bwd_fn=None):
+        self.bucket, self.names = bucket, list(names)
+        self.sh_bwd_fn = sh_bwd_fn   # tests: a CPU stand-in for ops.sh_colors_bwd (same signature)
+        self._viewmats = None
+        self._pending = []
+        self._buf = self._tmp = None
+        # the spans of the flat bucket that are NOT the SH gradient: one all-reduce per contiguous run (one when sh comes first or last)
+        i_sh = self.names.index("sh")
+        runs, cur = [], None
+        for i, (p, o) in enumerate(zip(bucket.params, bucket.offsets)):
+            if i == i_sh:
+                cur = None
+                continue
+            end = bucket.offsets[i + 1] if i + 1 < len(bucket.offsets) else bucket.flat.numel()
+            if cur is None:
+                cur = [o, end]
+                runs.append(cur)
+            else:
+                cur[1] = end
+        self._runs = [(a, b) for a, b in runs]
+
+    def begin_step(self, viewmats_all):
+        """viewmats_all: [world,4,4] world->camera matrices of the step's cameras, row r = the camera rank r renders (every rank knows
+        the step's batch: the camera schedule is a function of the iteration)."""
+        assert viewmats_all.shape[0] == dist.get_world_size()
+        self._viewmats = viewmats_all.contiguous()
+
+    def sh_backward(self, sh_degree, means, sh, colors, v_colors, v_means_blend, sink_sh, sink_means):
+        """colors / v_colors: [1,N,3] of this rank's camera (post-clamp colours, gradient from the blend); v_means_blend: the blend's
+        gradient w.r.t. the means.  Returns (v_sh, v_means) = the sinks, both complete (mean over the step's cameras) when finish()
+        has returned."""
+        world, rank = dist.get_world_size(), dist.get_rank()
+        n = means.shape[0]
+        if self._buf is None or self._buf.shape[1] != n or self._buf.device != means.device:
+            self._buf = torch.empty(world, n, 3, dtype=means.dtype, device=means.device)
+            self._tmp = torch.empty(n, 3, dtype=means.dtype, device=means.device)
+        mine = self._buf[rank]
+        # clamp_min(x + 0.5, 0) passes the gradient where the colour is positive; a Gaussian the camera does not see has a zero colour
+        # row (sh_colors_fwd) and a zero gradient row (the blend's gather kernel): its row stays zero.  1 / world = mean over the cameras.
+        torch.mul(v_colors.reshape(n, 3), 1.0 / world, out=mine)
+        mine.mul_(colors.reshape(n, 3) > 0)
+        gather = dist.all_gather_into_tensor(self._buf.view(-1), mine.view(-1), async_op=True)   # first: the SH backward waits for it
+        sink_means.copy_(v_means_blend.reshape(sink_means.shape))
+        self._pending = [_MeanHandle(self.bucket.flat[a:b]) for a, b in self._runs]   # means | scaling | rotation | opacity, under the SH backward
+        gather.wait()
+        fn = self.sh_bwd_fn
+        if fn is None:
+            from . import ops
+            fn = ops.sh_colors_bwd
+        fn(sh_degree, means, self._viewmats, sh, None, None, self._buf, None, sink_sh, self._tmp)
+        self.bucket.last_reduced_bytes = self._buf.numel() * 4 + sum(b - a for a, b in self._runs) * 4
+        return sink_sh, sink_means
+
+    def finish(self):
+        """All gradients are complete on the current stream after this: the blend part of the means gradient (averaged over the ranks)
+        plus the direction part the SH backward produced for all cameras."""
+        for h in self._pending:
+            h.wait()
+        if self._pending:
+            i = self.names.index("means")
+            self.bucket.params[i].grad.add_(self._tmp)
+        self._pending = []
+
+
 def shard_cameras(cameras, rank, world):
     """Camera i of the step's batch goes to rank i % world (one camera per GPU when len == world)."""
     return [c for i, c in enumerate(cameras) if i % world == rank]

@@ -312,7 +312,12 @@ class GutRenderFunction(torch.autograd.Function):
                                                  s.get("rotation_raw"), s.get("opacity_raw"))
         if s.get("_early_ready") is not None:
             s["_early_ready"]()
-        v_sh, v_means = ops.sh_colors_bwd(sh_degree, means, viewmat, sh, radii, colors, v_colors, v_means, s.get("sh"), s.get("means"))
+        if s.get("_color_exchange") is not None:
+            # multi-GPU: the ranks exchange the 3 colour-gradient floats per Gaussian and every rank runs the SH backward over all
+            # cameras of the step; the other gradients are all-reduced meanwhile (distributed.ColorGradExchange)
+            v_sh, v_means = s["_color_exchange"].sh_backward(sh_degree, means, sh, colors, v_colors, v_means, s["sh"], s["means"])
+        else:
+            v_sh, v_means = ops.sh_colors_bwd(sh_degree, means, viewmat, sh, radii, colors, v_colors, v_means, s.get("sh"), s.get("means"))
         v_bg = None
         if bg is not None and ctx.needs_input_grad[7]:
             v_bg = (v_renders * (1.0 - alphas)).float().sum(dim=(-3, -2))

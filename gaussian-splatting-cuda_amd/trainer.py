@@ -2,7 +2,8 @@
 (src/training/trainer.cpp:579-800) restricted to what the gut / MCMC configuration executes:
 
     render (rasterize_fused) -> photometric loss (trainer.cpp:103-127) -> backward
-    -> [N > 1 GPUs: all-reduce of the gradient rows some camera of the step saw, mean over the cameras]
+    -> [N > 1 GPUs: all-reduce of the gradient rows some camera of the step saw, mean over the cameras; or (exchange="colors")
+        the colour-gradient exchange: 3 floats per (camera, Gaussian) all-gathered, SH backward over all cameras on every rank]
     -> scale / opacity regularisers (trainer.cpp:132-160; their gradients are added analytically: reg * mean(exp(s)),
        reg * mean(sigmoid(o)); identical on every rank, so added after the reduction)
     -> strategy.post_backward (SH degree schedule, relocation, growth, noise) -> strategy.step (fused Adam + lr decay)
@@ -20,10 +21,11 @@ from .strategy import MCMC, OptimizationParameters
 
 class Trainer:
     def __init__(self, model, cameras, images, params: OptimizationParameters = None, background=None, scene_scale=1.0, seed=0,
-                 sharded_adam=False):
+                 sharded_adam=False, exchange="rows"):
         """cameras: list of rasterizer.Camera; images: list of [3,H,W] ground-truth tensors on the device.
         sharded_adam (world > 1): reduce-scatter -> Adam on this rank's 1/world of the Gaussians -> all-gather of the parameters
-        (distributed.ShardedAdam) instead of all-reduce + replicated Adam."""
+        (distributed.ShardedAdam) instead of all-reduce + replicated Adam.
+        exchange (world > 1, replicated Adam): "rows" = all-reduce of the visible gradient rows; "colors" = distributed.ColorGradExchange."""
         self.model, self.cameras, self.images = model, cameras, images
         self.params = params or OptimizationParameters()
         self.bg = background
@@ -34,6 +36,7 @@ class Trainer:
         gen.manual_seed(seed)
         for p in model.params():
             p.requires_grad_(True)
+        self.exchange = exchange if (self.world > 1 and not sharded_adam) else None
         self.strategy = MCMC(model, self.params, scene_scale, gen)
         self.strategy.on_resize = self._rebuild_bucket
         self._rebuild_bucket(model)
@@ -41,6 +44,13 @@ class Trainer:
         self.last_loss = None
 
     def _rebuild_bucket(self, model):
+        if getattr(self, "exchange", None) == "colors":   # SH gradient first: the all-reduced remainder is one contiguous span
+            names = ["sh", "means", "scaling_raw", "rotation_raw", "opacity_raw"]
+            self.bucket = gdist.GradBucket([getattr(model, n) for n in names])
+            self.sinks = self.bucket.sinks(tuple(names))
+            self.xch = gdist.ColorGradExchange(self.bucket, names)
+            self.sinks["_color_exchange"] = self.xch
+            return
         self.bucket = gdist.GradBucket(model.params())
         self.sinks = self.bucket.sinks()
 
@@ -55,6 +65,8 @@ class Trainer:
 
     def train_step(self, it):
         i = (it * self.world + self.rank) % len(self.cameras)
+        if self.exchange == "colors":   # the step's camera batch in rank order
+            self.xch.begin_step(torch.stack([self.cameras[(it * self.world + r) % len(self.cameras)].viewmat for r in range(self.world)]))
         out = rasterizer.rasterize_fused(self.cameras[i], self.model, self.bg, grad_sinks=self.sinks)
         gt = self.images[i]
         loss = gloss.photometric_loss(out.render_hwc, gt, self.params.lambda_dssim)
@@ -66,7 +78,9 @@ class Trainer:
             self.strategy.post_backward(it, out)
             self.strategy.step(it, optimizer_step=lambda i: self.sharded.step(i, self.bucket))
         else:
-            if self.world > 1:  # only rows some camera of the step saw are non-zero: compacted all-reduce
+            if self.exchange == "colors":
+                self.xch.finish()
+            elif self.world > 1:  # only rows some camera of the step saw are non-zero: compacted all-reduce
                 self.bucket.all_reduce_mean_rows((out.aux["radii_full"] > 0).all(-1))
             self._add_regularisers()  # identical on every rank (functions of the replicated parameters): added after the reduction
             self.strategy.post_backward(it, out)

@@ -240,7 +240,10 @@ int gsx_photometric_loss_bwd(uint32_t C, uint32_t H, uint32_t W, float lambda_ds
  *   gsx_splat_activations_*: splat_data.cpp:267-286  exp / normalize / sigmoid (and their backward) */
 int gsx_sh_colors_fwd(uint32_t degrees_to_use, uint32_t C, uint32_t N, uint32_t K, const float* means,
                       const float* viewmats, const float* coeffs, const int32_t* radii, float* colors, void* stream);
-/* v_coeffs [N,K,3] fully written; v_means_out [N,3] = (v_means_in or 0) + d colors / d means */
+/* v_coeffs [N,K,3] fully written; v_means_out [N,3] = (v_means_in or 0) + d colors / d means.
+ * radii == colors == NULL: v_colors [C,N,3] are "pre-masked" (each camera's rows already carry its visibility and clamp masks, zero
+ * where the camera does not see the Gaussian): the mode of the multi-GPU colour-gradient exchange, where the C cameras of a step were
+ * rendered on C ranks and only these 3 floats per (camera, Gaussian) travel instead of the K*3 SH gradients. */
 int gsx_sh_colors_bwd(uint32_t degrees_to_use, uint32_t C, uint32_t N, uint32_t K, const float* means,
                       const float* viewmats, const float* coeffs, const int32_t* radii, const float* colors,
                       const float* v_colors, float* v_coeffs, const float* v_means_in, float* v_means_out, void* stream);

@@ -172,3 +172,84 @@ def test_sharded_optimizer_step_equals_replicated(tmp_path):
     mp.spawn(_sharded_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for N in (1000, 1001):
         assert np.array_equal(np.load(tmp_path / ("sharded_%d_0.npy" % N)), np.load(tmp_path / ("sharded_%d_1.npy" % N)))
+
+
+# ---- colour-gradient exchange: 3 floats per (camera, Gaussian) travel, every rank runs the SH backward over all cameras -----------
+def _sh_colors_bwd_cpu(sh_degree, means, viewmats, sh, radii, colors, v_colors, v_means_in, v_coeffs_out, v_means_out):
+    """CPU stand-in for ops.sh_colors_bwd in its pre-masked mode (radii = colors = None), on the oracle's SH backward."""
+    from oracle import oracle
+    assert radii is None and colors is None and v_means_in is None
+    C, N = viewmats.shape[0], means.shape[0]
+    vc = np.zeros(tuple(sh.shape), np.float32)
+    vm = np.zeros((N, 3), np.float32)
+    for c in range(C):
+        campos = np.linalg.inv(viewmats[c].numpy().astype(np.float64))[:3, 3].astype(np.float32)
+        dirs = means.detach().numpy() - campos
+        a, b = oracle.sh_bwd(sh_degree, dirs, sh.detach().numpy(), None, v_colors[c].numpy(), True)
+        vc += a
+        vm += b
+    v_coeffs_out.copy_(torch.from_numpy(vc))
+    v_means_out.copy_(torch.from_numpy(vm))
+    return v_coeffs_out, v_means_out
+
+
+def _xch_inputs(rank, N=257, K=16):
+    g = torch.Generator().manual_seed(100 + rank)
+    shared = torch.Generator().manual_seed(7)
+    means = torch.randn(N, 3, generator=shared) + torch.tensor([0.0, 0.0, 5.0])
+    sh = (torch.rand(N, K, 3, generator=shared) - 0.5) * 0.3
+    vm = torch.eye(4)
+    vm[0, 3] = 0.3 * (rank + 1)
+    vm[1, 3] = -0.2 * rank
+    colors = torch.rand(1, N, 3, generator=g) - 0.2            # some channels clamped (<= 0)
+    colors[0, ::7] = 0.0                                       # Gaussians this camera does not see: zero colour row ...
+    v_colors = torch.randn(1, N, 3, generator=g)
+    v_colors[0, ::7] = 0.0                                     # ... and zero gradient row
+    others = [torch.randn(N, 3, generator=g), torch.randn(N, 3, generator=g), torch.randn(N, 4, generator=g), torch.randn(N, 1, generator=g)]
+    return means, sh, vm, colors, v_colors, others   # others: blend's v_means, scaling, rotation, opacity gradients
+
+
+def _worker_xch(rank, world, port, out_dir, sh_first):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import gsx  # noqa: F401
+    from gsx import distributed as gdist
+    gdist.init_from_env(backend="gloo")
+    means, sh, vm, colors, v_colors, others = _xch_inputs(rank)
+    names = ["means", "sh", "scaling_raw", "rotation_raw", "opacity_raw"]
+    shapes = dict(means=(257, 3), sh=(257, 16, 3), scaling_raw=(257, 3), rotation_raw=(257, 4), opacity_raw=(257, 1))
+    if sh_first:
+        names = ["sh", "means", "scaling_raw", "rotation_raw", "opacity_raw"]
+    params = [torch.zeros(shapes[n], requires_grad=True) for n in names]
+    bucket = gdist.GradBucket(params)
+    sinks = bucket.sinks(tuple(names))
+    xch = gdist.ColorGradExchange(bucket, names, sh_bwd_fn=_sh_colors_bwd_cpu)
+    assert len(xch._runs) == (1 if sh_first else 2)
+    vms = [_xch_inputs(r)[2] for r in range(world)]
+    xch.begin_step(torch.stack(vms))
+    # what the render backward does: the other gradients into their sinks, then the exchange in place of the local SH backward
+    sinks["scaling_raw"].copy_(others[1]); sinks["rotation_raw"].copy_(others[2]); sinks["opacity_raw"].copy_(others[3])
+    xch.sh_backward(3, means, sh, colors, v_colors, others[0], sinks["sh"], sinks["means"])
+    xch.finish()
+    np.save(os.path.join(out_dir, "xch_%d.npy" % rank), np.concatenate([sinks[n].numpy().reshape(-1) for n in ["means", "sh", "scaling_raw", "rotation_raw", "opacity_raw"]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sh_first", [False, True])
+def test_color_grad_exchange_equals_dense_all_reduce(tmp_path, sh_first):
+    world, port = 2, _free_port()
+    mp.spawn(_worker_xch, args=(world, port, str(tmp_path), sh_first), nprocs=world, join=True)
+    b0, b1 = np.load(tmp_path / "xch_0.npy"), np.load(tmp_path / "xch_1.npy")
+    assert np.array_equal(b0, b1)   # bit-identical replicas: same gathered bits, same camera order
+    # expectation: every rank's own full gradient (local SH backward of its camera, clamp mask applied), averaged
+    exp = None
+    for r in range(world):
+        means, sh, vm, colors, v_colors, others = _xch_inputs(r)
+        vcm = (v_colors * (colors > 0))[0]
+        vsh, vmn = torch.zeros(257, 16, 3), torch.zeros(257, 3)
+        _sh_colors_bwd_cpu(3, means, vm[None], sh, None, None, vcm[None], None, vsh, vmn)
+        full = np.concatenate([(others[0] + vmn).numpy().reshape(-1), vsh.numpy().reshape(-1), others[1].numpy().reshape(-1),
+                               others[2].numpy().reshape(-1), others[3].numpy().reshape(-1)])
+        exp = full if exp is None else exp + full
+    exp = exp / world
+    np.testing.assert_allclose(b0, exp, rtol=2e-5, atol=2e-6)

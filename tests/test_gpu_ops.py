@@ -225,6 +225,35 @@ def test_blend_backward_vs_oracle(gsx_mod, raster_path):
         assert e < 1e-3, (name, e)
 
 
+@pytest.mark.parametrize("variant", ["pm", "gm"])
+def test_blend_backward_variants_vs_oracle(gsx_mod, variant):
+    """The two backward kernels of the fast path — pixel-major and Gaussian-major (the launcher picks by footprint size) — each forced
+    on an S-1M-like scene (small footprints, ragged tiles) and compared with the oracle."""
+    _, ops, _, scenes = gsx_mod
+    sc = scenes.scene_frustum(20_000, 320, 192, 400.0, (2.0, 10.0), sh_degree=0, seed=7)
+    H, W = sc["height"], sc["width"]
+    rng = np.random.default_rng(1)
+    v_rc = rng.standard_normal((1, H, W, 3)).astype(np.float32)
+    v_ra = rng.standard_normal((1, H, W, 1)).astype(np.float32)
+    o = oracle_pipeline(sc, v_render_colors=v_rc, v_render_alphas=v_ra)
+    b = _blend_inputs(sc, o)
+    old = os.environ.get("GSX_BWD")
+    os.environ["GSX_BWD"] = variant
+    try:
+        grads = ops.rasterize_to_pixels_from_world_3dgs_bwd(
+            b["means"], b["quats"], b["scales"], b["colors"], b["opac"], b["bg"], None, W, H, 16, b["viewmat"], None, b["K"],
+            ops.CameraModelType.PINHOLE, ops.UnscentedTransformParameters(), ops.ShutterType.GLOBAL, None, None, None, b["off"],
+            b["fl"], t(o["alphas"]), t(o["last_ids"]), t(v_rc), t(v_ra))
+    finally:
+        if old is None:
+            os.environ.pop("GSX_BWD", None)
+        else:
+            os.environ["GSX_BWD"] = old
+    for name, g in zip(["v_means", "v_quats", "v_scales", "v_colors", "v_opacities"], grads):
+        e = rel_l2(np32(g), o[name])
+        assert e < 1e-3, (variant, name, e)
+
+
 def test_rasterize_autograd_end_to_end(gsx_mod):
     """gs::training::rasterize mirror: image parity with the oracle pipeline and gradients that flow to every
     raw parameter through the activations."""

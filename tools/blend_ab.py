@@ -59,3 +59,5 @@ t_b, bwd = timeit(lambda: ops.rasterize_to_pixels_from_world_3dgs_bwd(*common, f
 chk = [float(x.double().abs().sum()) for x in bwd]
 print("%s%s GSX_BWD=%s GSX_RASTER_PATH=%s n_isects=%d  fwd %.4f ms  bwd %.4f ms  |grads|_1 = %s" % (which, " fisheye" if fisheye else (" rolling-shutter" if rolling else ""), os.environ.get("GSX_BWD", "-"), os.environ.get("GSX_RASTER_PATH", "-"), fl.numel(), t_f, t_b,
                                                                               " ".join("%.6g" % c for c in chk)))
+if os.environ.get("GSX_AB_SAVE"):   # gradients of this variant, for tools/blend_ab_compare.py
+    torch.save([x.cpu() for x in bwd], os.environ["GSX_AB_SAVE"])
