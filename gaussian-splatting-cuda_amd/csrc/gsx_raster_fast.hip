@@ -16,14 +16,15 @@
 //    the float64 truth than the reference's own fp32 order (tests/test_gpu_ops.py measures both).
 // 2. Sub-tile culling.  Each wave owns an 8x8 quadrant.  alpha >= 1/255 needs
 //    |L d|^2 <= log2(255 o) * den(d); den is convex, so its maximum over the tile is at a corner and the
-//    bounding box of that ellipse in (u,v) is a conservative footprint.  Every wave tests 64 staged
+//    ellipse |L d|^2 <= log2(255 o) * max den is a conservative footprint, tested EXACTLY against the rectangle of the
+//    wave's pixel centres (footprint_hits: minimum of the form over the rectangle).  Every wave tests 64 staged
 //    Gaussians at a time (one per lane) against its quadrant, ballots the survivors and walks only
 //    the set bits, front to back.  A skipped Gaussian has alpha < 1/255 on all 64 pixels, so results are
 //    unchanged (the reference `continue`s on exactly those pairs, Fwd.cu:240).
 // 3. Staging.  pack_records_kernel turns every (camera, Gaussian) into ONE 64 B record (centre, factor L, log2 opacity, the
 //    normalised denominator quadratic, colour) once per launch; a tile gathers one cache line per intersection.  Chunks of
 //    128 Gaussians, records in LDS as AoS float4 x 4 (four wave-uniform ds_read_b128 in the pixel loop) plus a separate
-//    float4 cull plane (u0, v0, hx, hy: conflict-free per-lane reads), double buffered in the forward: the flatten ids of
+//    float4 cull plane (u0, v0, rad2, k2: conflict-free per-lane reads), double buffered in the forward: the flatten ids of
 //    chunk b+1 are in flight while chunk b is composited; one barrier per chunk.  The backward of the same inputs can take
 //    the forward's packed records back (gsx_rasterize_..._bwd_packed).
 // 4. Dispatch.  1-D grid, XCD-aware: block b runs on XCD b % 8, so each XCD is given a contiguous band of
@@ -154,7 +155,7 @@ GSX_DEV void make_record(const RawG& r, const CamFrame& cf, const float tb[4], F
 // scales 12 B, opacities 4 B, colours 12 B): five cache lines gathered for 60 useful bytes, and ~300 VALU to turn
 // them into the 15 camera-space coefficients — all of which depend on (camera, Gaussian) only, not on the tile.
 // pack_records_kernel does that once per (camera, Gaussian) into ONE 64 B line; staging a tile then gathers a
-// single line per Gaussian and only adds the tile-dependent footprint (hx, hy).
+// single line per Gaussian and only adds the tile-dependent footprint (rad2, k2).
 //   p0 = (u0, v0, l00, l01)  p1 = (l11, lo, d1, d2)  p2 = (d3, d4, d5, red)  p3 = (green, blue, -, -)
 // `bad` (fisheye only): 1 where the Gaussian has no usable (u0, v0) chart — it sits behind the camera plane or more than
 // atan(8) = 83 degrees off the optical axis, where u0 = m_x / m_z loses its digits.  Such a Gaussian is visible in a wide fisheye;
@@ -230,10 +231,14 @@ GSX_DEV float fast_alpha_ray(float u, float v, float w, float ww, float4 r0, flo
     return fminf(0.999f, __builtin_amdgcn_exp2f(fmaf(-num2, rden, r1.y)));
 }
 
-// conservative (u,v) footprint half extents of a record for the tile bounds tb (see header comment, item 2)
-GSX_DEV void footprint(float4 r0, float4 r1, float4 r2, const float tb[4], float& hx, float& hy) {
+// Conservative footprint of a record for the tile bounds tb (see header comment, item 2), as an ellipse around (u0, v0):
+//     alpha >= 1/255   =>   N(d) = (l00 du + l01 dv)^2 + (l11 dv)^2  <=  tau2 den(d)  <=  rad2 := tau2 * max over the tile of den
+// (den is convex: its maximum over the tile sits at a corner).  rad2 < 0: never visible (opacity <= 1/255); NaN / +inf: degenerate
+// factor, never culled.  k2 = -l00 l01 / (l01^2 + l11^2) is the slope of the line of minima of N along dv (footprint_hits).
+GSX_DEV void footprint(float4 r0, float4 r1, float4 r2, const float tb[4], float& rad2, float& k2) {
     const float tau2 = r1.y + LOG2_255;
-    hx = -INFINITY; hy = -INFINITY;
+    rad2 = -1.f;
+    k2 = -(r0.z * r0.w) * __builtin_amdgcn_rcpf(fmaf(r0.w, r0.w, r1.x * r1.x));
     if (tau2 > 0.f) {
         float dmax = 0.f;
 #pragma unroll
@@ -241,22 +246,37 @@ GSX_DEV void footprint(float4 r0, float4 r1, float4 r2, const float tb[4], float
             const float du = ((k & 1) ? tb[1] : tb[0]) - r0.x, dv = ((k & 2) ? tb[3] : tb[2]) - r0.y;
             dmax = fmaxf(dmax, 1.f + du * (r1.z + r2.x * du + r2.y * dv) + dv * (r1.w + r2.z * dv));
         }
-        const float rad = sqrtf(tau2 * dmax) * 1.001f + 1e-7f;
-        hy = rad / r1.x;
-        hx = rad * sqrtf(r0.w * r0.w + r1.x * r1.x) / (r0.z * r1.x);
-        if (!(hx == hx) || !(hy == hy)) { hx = INFINITY; hy = INFINITY; }  // degenerate factor: never cull
+        rad2 = fmaf(tau2 * dmax, 1.0021f, 1e-6f);
     }
 }
 
+// Does the footprint ellipse {N(d) <= rad2} of a staged Gaussian reach the rectangle [b0, b1] x [b2, b3] of pixel centres?  EXACT: the
+// minimum of the convex form N over the rectangle, which lies on one of the two sides facing the centre (or is 0 inside): with
+// (xc, yc) the rectangle's point closest to the centre per axis, the minimum over the side dv = yc is at l00 du = clamp(-l01 yc) and
+// the minimum over the side du = xc at dv = clamp(k2 xc).  The bounding-box test this replaces let an ellipse through whenever its BOX
+// touched the rectangle: 23 % of the (Gaussian, 4x4 block) pairs and 15 % of the (Gaussian, 8x8 quadrant) pairs of S-1M, all of them
+// evaluated for nothing (thin ellipses at an angle).  !(min > rad2): a NaN anywhere means "not culled".
+GSX_DEV bool footprint_hits(float4 c, float l00, float l01, float l11, float b0, float b1, float b2, float b3) {
+    const float xa = b0 - c.x, xb = b1 - c.x, ya = b2 - c.y, yb = b3 - c.y;
+    const float xc = __builtin_amdgcn_fmed3f(0.f, xa, xb), yc = __builtin_amdgcn_fmed3f(0.f, ya, yb);
+    const float m = l01 * yc;
+    const float t = __builtin_amdgcn_fmed3f(-m, l00 * xa, l00 * xb) + m, e1 = l11 * yc;
+    const float n1 = fmaf(t, t, e1 * e1);
+    const float ys = __builtin_amdgcn_fmed3f(c.w * xc, ya, yb);
+    const float t2 = fmaf(l01, ys, l00 * xc), e2 = l11 * ys;
+    const float n2 = fmaf(t2, t2, e2 * e2);
+    return !(fminf(n1, n2) > c.z);
+}
+
 // one staged Gaussian: the 64 B record (AoS, read at a wave-uniform index with one base address) + the cull plane entry
-struct StagedRec { float4 r0, r1, r2, r3, cull; };
+struct StagedRec { float4 r0, r1, r2, r3, cull; };   // cull = (u0, v0, rad2, k2): footprint()
 
 GSX_DEV void stage_one(const RasterArgs& a, const float tb[4], int32_t g, StagedRec& o) {
     const float4* p = a.packed + (size_t)g * 4;
     o.r0 = p[0]; o.r1 = p[1]; o.r2 = p[2]; o.r3 = p[3];
-    float hx, hy;
-    footprint(o.r0, o.r1, o.r2, tb, hx, hy);
-    o.cull = make_float4(o.r0.x, o.r0.y, hx, hy);
+    float rad2, k2;
+    footprint(o.r0, o.r1, o.r2, tb, rad2, k2);
+    o.cull = make_float4(o.r0.x, o.r0.y, rad2, k2);
 }
 
 // per-thread pixel set-up shared by forward and backward: undistorted normalised coordinates (u,v)
@@ -320,7 +340,7 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
                                                              float* __restrict__ render_alphas,
                                                              int32_t* __restrict__ last_ids) {
     __shared__ float4 s_rec[2][FCH][4];   // AoS records, double buffered
-    __shared__ float4 s_cull[2][FCH];     // (u0, v0, hx, hy): per-lane cull reads are conflict-free on this plane
+    __shared__ float4 s_cull[2][FCH];     // (u0, v0, rad2, k2): per-lane cull reads are conflict-free on this plane
     __shared__ float s_bounds[4][4];
     __shared__ int s_wdone[2][4];
     const uint32_t cid = blockIdx.y;
@@ -378,7 +398,7 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
         if (have) {
             StagedRec sr;
             stage_one(a, tb, g_pre, sr);
-            if (no_cull) { sr.cull.z = INFINITY; sr.cull.w = INFINITY; }
+            if (no_cull) sr.cull.z = INFINITY;
             sr.r1.y -= LOG2_K999; sr.r2.w *= K999; sr.r3.x *= K999; sr.r3.y *= K999;
             s_rec[buf][tid][0] = sr.r0; s_rec[buf][tid][1] = sr.r1; s_rec[buf][tid][2] = sr.r2; s_rec[buf][tid][3] = sr.r3;
             s_cull[buf][tid] = sr.cull;
@@ -395,7 +415,8 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
             bool hit = false;
             if (sub + (int32_t)lane < chunk_size) {
                 const float4 c = s_cull[buf][sub + lane];
-                hit = (c.x + c.z >= wb[0]) && (c.x - c.z <= wb[1]) && (c.y + c.w >= wb[2]) && (c.y - c.w <= wb[3]);
+                const float4 q0 = s_rec[buf][sub + lane][0], q1 = s_rec[buf][sub + lane][1];   // (.., .., l00, l01), (l11, ..)
+                hit = footprint_hits(c, q0.z, q0.w, q1.x, wb[0], wb[1], wb[2], wb[3]);
             }
             unsigned long long todo = __builtin_amdgcn_ballot_w64(hit);
             GSX_STAT_ADD(1, min(64, chunk_size - sub));
@@ -585,7 +606,7 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
             const int32_t g = a.flatten_ids[chunk_end - (int32_t)tid];
             StagedRec sr;
             stage_one(a, tb, g, sr);
-            if (no_cull) { sr.cull.z = INFINITY; sr.cull.w = INFINITY; }
+            if (no_cull) sr.cull.z = INFINITY;
             s_rec[tid][0] = sr.r0; s_rec[tid][1] = sr.r1; s_rec[tid][2] = sr.r2; s_rec[tid][3] = sr.r3;
             s_cull[tid] = sr.cull;
             s_gid[tid] = g;
@@ -601,7 +622,8 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
             bool hit = false;
             if (sub + (int32_t)lane < chunk_size && chunk_end - (sub + (int32_t)lane) <= wave_last) {
                 const float4 c = s_cull[sub + lane];
-                hit = (c.x + c.z >= wb[0]) && (c.x - c.z <= wb[1]) && (c.y + c.w >= wb[2]) && (c.y - c.w <= wb[3]);
+                const float4 q0 = s_rec[sub + lane][0], q1 = s_rec[sub + lane][1];   // (.., .., l00, l01), (l11, ..)
+                hit = footprint_hits(c, q0.z, q0.w, q1.x, wb[0], wb[1], wb[2], wb[3]);
             }
             unsigned long long todo = __builtin_amdgcn_ballot_w64(hit);
             unsigned long long touched = 0ull;
@@ -769,7 +791,7 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gm_kernel(RasterA
                                                                           const float* __restrict__ v_render_colors,
                                                                           const float* __restrict__ v_render_alphas,
                                                                           float4* __restrict__ ws_rec, int32_t* __restrict__ ws_head) {
-    // record planes: 0 u0, 1 v0, 2 l00, 3 l01, 4 l11, 5 lo, 6 d1, 7 d2, 8 d3, 9 d4, 10 d5, 11 red, 12 green, 13 blue, 14 hx, 15 hy
+    // record planes: 0 u0, 1 v0, 2 l00, 3 l01, 4 l11, 5 lo, 6 d1, 7 d2, 8 d3, 9 d4, 10 d5, 11 red, 12 green, 13 blue, 14 rad2, 15 k2 (footprint())
     __shared__ float s_rec[16][GS];
     __shared__ float s_acc[15][GS];
     __shared__ int32_t s_gid[GS];
@@ -863,15 +885,15 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gm_kernel(RasterA
         for (int32_t c0 = 0; c0 < chunk_size; c0 += 64) {
             const int32_t c = c0 + (int32_t)lane;
             const bool in = c < chunk_size;
-            const float cu = s_rec[0][c & (GS - 1)], cv_ = s_rec[1][c & (GS - 1)], chx = s_rec[14][c & (GS - 1)], chy = s_rec[15][c & (GS - 1)];
+            const float4 cc = make_float4(s_rec[0][c & (GS - 1)], s_rec[1][c & (GS - 1)], s_rec[14][c & (GS - 1)], s_rec[15][c & (GS - 1)]);
+            const float c00 = s_rec[2][c & (GS - 1)], c01 = s_rec[3][c & (GS - 1)], c11 = s_rec[4][c & (GS - 1)];
             const int32_t idx = chunk_end - c;
             bool any = false;
 #pragma unroll
             for (int sb = 0; sb < 5; ++sb) {
                 bool hit = any;   // k = 4: the union of the four blocks
                 if (sb < 4) {
-                    hit = in && idx <= sb_last[sb] && (cu + chx >= sbb[sb][0]) && (cu - chx <= sbb[sb][1]) && (cv_ + chy >= sbb[sb][2]) &&
-                          (cv_ - chy <= sbb[sb][3]);
+                    hit = in && idx <= sb_last[sb] && footprint_hits(cc, c00, c01, c11, sbb[sb][0], sbb[sb][1], sbb[sb][2], sbb[sb][3]);
                     any = any || hit;
                 }
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
