@@ -690,53 +690,88 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward, Gaussian-major ("GM") variant: lanes = Gaussians, loop over pixels
+// backward, Gaussian-major ("GQ"): lanes = Gaussians, loop over pixels
 // ------------------------------------------------------------------------------------------------
 // raster_bwd_fast_kernel above evaluates one Gaussian per step on the 64 pixels of a quadrant and pays, per step, a 16-value
-// reduction over the wave (the butterfly, ~35 VALU) plus an LDS atomic — and 71 % of the lanes carry no weight, because a thin
-// ellipse covers a fraction of an 8x8 block.  This kernel transposes the loop: the tile's Gaussians are binned per 4x4 pixel block
-// (the footprint of a thin ellipse fits a 4x4 block much better: 42 % useful lanes), 64 Gaussians of a block's list sit on the 64
-// lanes, and the wave walks the 16 pixels of the block.  Per pixel every lane evaluates ITS Gaussian; the back-to-front recurrences
+// reduction over the wave (the butterfly, ~35 VALU) plus an LDS atomic — and 65-70 % of the lanes carry no weight, because a thin
+// ellipse covers a fraction of an 8x8 block.  The Gaussian-major kernel transposes the loop: the tile's Gaussians are binned per
+// 4x4 pixel block (the footprint of a thin ellipse fits a 4x4 block much better), Gaussians of a block's list sit on the lanes and
+// the wave walks the block's pixels.  Per pixel every lane evaluates ITS Gaussian; the back-to-front recurrences
 //     T_j = T_in * prod_{i<=j} 1/(1-alpha_i)            tbuf_j = tbuf_in - sum_{i<j} (c_i . v) alpha_i T_i
-// become one multiplicative and one additive DPP scan over the lanes (6 instructions each), and the 15 moments of a Gaussian are
-// summed over the pixels in the lane's own registers: no cross-lane reduction at all.  After the 16 pixels the lane adds its
-// partial moments to the tile's LDS accumulator (15 ds_add_f32 per 64 Gaussians x 16 pixels, instead of one per Gaussian x 64
-// pixels).  The per-pixel state (u, v, upstream gradient, T, tbuf, last id) lives in LDS and is read with a wave-uniform address
-// (broadcast, no VALU); the last lane writes the carries back for the block's next batch.
-// Moment records / list heads / the gather kernel are those of the pixel-major kernel (same 15 moments, same layout).
-// Measured and simulated numbers: DESIGN.md §4.
+// become one multiplicative and one additive DPP scan over the lanes, and the 15 moments of a Gaussian are summed over the pixels in
+// the lane's own registers.  Moment records / list heads / the gather kernel are those of the pixel-major kernel (same 15 moments,
+// same layout).  First version (round 2, removed again): 64 Gaussians per batch on the 64 lanes, four row passes per block, scans of
+// six steps — 0.72 ms at S-1M against 0.86 pixel-major, batches 73 % full.  Measured and simulated numbers: DESIGN.md §4.
 constexpr int GS = 256;   // Gaussians per super-chunk (one per thread at staging time)
 
-// Inclusive scans of FOUR independent values (the four pixels of a row of the 4x4 block) over the 64 lanes: Hillis-Steele inside each
-// row of 16 lanes (row_shr 1, 2, 4, 8), then the row totals travel with row_bcast:15 (lane 15 of rows 0 / 2 -> rows 1 / 3) and
-// row_bcast:31 (lane 31 -> rows 2, 3).  Written as DPP instructions with dst == src1 and bound_ctrl:0: a lane whose source lies
-// outside its row (or whose row is masked off) is not written and keeps its value — the identity of the scan — which is what a
-// multiplicative scan needs (through __builtin_amdgcn_update_dpp the compiler materialises the identity 1.0 and emits v_mov +
-// v_mov_dpp + v_mul per step).  Four values per step: the three other DPPs are the wait states a VALU write needs before a DPP
-// read of the same register (no s_nop inside the chain).
-#define GSX_SCAN4_STEP(OP, CTRL) OP " %0, %0, %0 " CTRL "\n\t" OP " %1, %1, %1 " CTRL "\n\t" OP " %2, %2, %2 " CTRL "\n\t" OP " %3, %3, %3 " CTRL "\n\t"
-#define GSX_SCAN4(OP)                                                     \
-    asm volatile("s_nop 1\n\t"                                            \
-                 GSX_SCAN4_STEP(OP, "row_shr:1 row_mask:0xf bank_mask:0xf")   \
-                 GSX_SCAN4_STEP(OP, "row_shr:2 row_mask:0xf bank_mask:0xf")   \
-                 GSX_SCAN4_STEP(OP, "row_shr:4 row_mask:0xf bank_mask:0xf")   \
-                 GSX_SCAN4_STEP(OP, "row_shr:8 row_mask:0xf bank_mask:0xf")   \
-                 GSX_SCAN4_STEP(OP, "row_bcast:15 row_mask:0xa bank_mask:0xf") \
-                 GSX_SCAN4_STEP(OP, "row_bcast:31 row_mask:0xc bank_mask:0xf") \
-                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]))
-GSX_DEV void wave_scan4_mul(float (&x)[4]) { GSX_SCAN4("v_mul_f32_dpp"); }
-GSX_DEV void wave_scan4_add(float (&x)[4]) { GSX_SCAN4("v_add_f32_dpp"); }
-#undef GSX_SCAN4
-#undef GSX_SCAN4_STEP
-
-// One row (4 pixels) of a 4x4 block for the 64 Gaussians of a batch (raster_bwd_gm_kernel).  CLAMP = false when no Gaussian of the
-// batch can reach alpha 0.999 (opacity < 0.999: alpha = o exp(-s) stays below it), which drops the clamp and its gradient mask.
 struct GmLaneRec { float u0, v0, l00, l01, l11, lo, d1, d2, d3, d4, d5, cr, cg, cb; int32_t idx; };
 struct GmRowPix { float T[4], tb[4], vr[4], vg[4], vb[4]; int32_t binf[4]; };
 
+// pixel owned by thread `tid` in the Gaussian-major kernel: wave = 8x8 quadrant, DPP row (16 lanes) = 4x4 block of the quadrant
+GSX_DEV void thread_pixel_gm(uint32_t tid, uint32_t tile_x, uint32_t tile_y, uint32_t& i, uint32_t& j) {
+    const uint32_t wave = tid >> 6, sb = (tid >> 4) & 3u, p = tid & 15u;
+    j = tile_x * TILE + (wave & 1u) * 8u + (sb & 1u) * 4u + (p & 3u);
+    i = tile_y * TILE + (wave >> 1) * 8u + (sb >> 1) * 4u + (p >> 2);
+}
+
+#ifndef GSX_GM_WAVES
+#define GSX_GM_WAVES 4
+#endif
+
+// ---- batch quantum 16: lanes = 16 Gaussians x the 4 pixel rows of a 4x4 block --------------------------------------------------
+// With 64 Gaussians of a block's list on the 64 lanes, a (wave, block) that sees ~35-57 Gaussians per super-chunk (S-1M) runs its
+// batch 73 % full.  Here a DPP row (16 lanes) holds 16 Gaussians of the
+// list and the wave's four DPP rows are the block's four pixel ROWS: one pass of the (same) 4-pixel body covers the whole 4x4 block
+// for 16 Gaussians, lists are consumed 16 at a time (fill ~0.9) and both scans stay inside a DPP row (row_shr 1/2/4/8: four steps
+// instead of six, no row_bcast).  What it costs: the per-pixel inputs differ between the rows, so they live in VGPRs (loaded once
+// per (wave, block, super-chunk)) instead of SGPRs; the carries T / tbuf travel from lane 15 of each row to the row's next pass with
+// a ds_swizzle broadcast (LDS crossbar, no VALU); and the four rows' partial moments of a Gaussian are summed with the first two
+// stages of the halving butterfly (v_permlane32_swap, v_permlane16_swap: 24 VALU per pass) before ONE lock-protected read-add-write
+// of four values per lane.  Super-chunks are balanced (a tile with 412 Gaussians stages 2 x 206, not 256 + 156).
+#define GSX_SCANR_STEP(OP, CTRL) OP " %0, %0, %0 " CTRL "\n\t" OP " %1, %1, %1 " CTRL "\n\t" OP " %2, %2, %2 " CTRL "\n\t" OP " %3, %3, %3 " CTRL "\n\t"
+#define GSX_SCANR(OP)                                                      \
+    asm volatile("s_nop 1\n\t"                                             \
+                 GSX_SCANR_STEP(OP, "row_shr:1 row_mask:0xf bank_mask:0xf")    \
+                 GSX_SCANR_STEP(OP, "row_shr:2 row_mask:0xf bank_mask:0xf")    \
+                 GSX_SCANR_STEP(OP, "row_shr:4 row_mask:0xf bank_mask:0xf")    \
+                 GSX_SCANR_STEP(OP, "row_shr:8 row_mask:0xf bank_mask:0xf")    \
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]))
+GSX_DEV void row_scan4_mul(float (&x)[4]) { GSX_SCANR("v_mul_f32_dpp"); }
+GSX_DEV void row_scan4_add(float (&x)[4]) { GSX_SCANR("v_add_f32_dpp"); }
+#undef GSX_SCANR
+#undef GSX_SCANR_STEP
+
+// lane 15 of every DPP row -> all 16 lanes of that row (ds_swizzle bit mode: lane' = (lane & 0x10) | 0x0f inside each half)
+GSX_DEV float row_last(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x01F0)); }
+
+// Sums x[0..15] over the four DPP rows (lanes l, l+16, l+32, l+48).  Afterwards z[j] of a lane in row r is the total of value
+// 4 j + {0,2,1,3}[r] for the lane's column (the first two stages of butterfly_reduce16).
+GSX_DEV void rows_reduce16(float (&x)[16], float (&z)[4]) {
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\t"
+                 "v_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7\n\t"
+                 "v_permlane32_swap_b32 %8, %9\n\tv_permlane32_swap_b32 %10, %11\n\t"
+                 "v_permlane32_swap_b32 %12, %13\n\tv_permlane32_swap_b32 %14, %15\n\t"
+                 "s_nop 1"
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]),
+                   "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+    float y[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[j] = x[2 * j] + x[2 * j + 1];
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+                 "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\t"
+                 "s_nop 1"
+                 : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) z[j] = y[2 * j] + y[2 * j + 1];
+}
+
+// One row (4 pixels) of a 4x4 block for the 16 Gaussians of a DPP row.  CLAMP = false when no Gaussian of the pass can reach alpha
+// 0.999 (opacity < 0.999: alpha = o exp(-s) stays below it), which drops the clamp and its gradient mask.
 template <bool CLAMP>
-GSX_DEV void gm_row(const GmLaneRec& g, const GmRowPix& px, const float (&du)[4], const float (&dv)[4], const float (&num2)[4],
-                    const float (&rden)[4], float (&acc)[15], float (&T_out)[4], float (&tb_out)[4]) {
+GSX_DEV void gq_row(const GmLaneRec& g, const GmRowPix& px, const float (&du)[4], const float (&dv)[4], const float (&num2)[4],
+                    const float (&rden)[4], float (&acc)[16], float (&T_out)[4], float (&tb_out)[4]) {
     float al[4], ra[4], P[4];
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
@@ -746,7 +781,7 @@ GSX_DEV void gm_row(const GmLaneRec& g, const GmRowPix& px, const float (&du)[4]
         al[h] = valid ? alpha : 0.f;
         P[h] = ra[h] = __builtin_amdgcn_rcpf(1.f - al[h]);
     }
-    wave_scan4_mul(P);
+    row_scan4_mul(P);
     float T[4], fac[4], cv[4], e[4], S[4];
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
@@ -755,7 +790,9 @@ GSX_DEV void gm_row(const GmLaneRec& g, const GmRowPix& px, const float (&du)[4]
         cv[h] = fmaf(g.cb, px.vb[h], fmaf(g.cg, px.vg[h], g.cr * px.vr[h]));
         S[h] = e[h] = cv[h] * fac[h];
     }
-    wave_scan4_add(S);
+    row_scan4_add(S);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         const float tbuf = (px.tb[h] + e[h]) - S[h];             // tail - v . (colour accumulated behind this Gaussian)
@@ -774,31 +811,19 @@ GSX_DEV void gm_row(const GmLaneRec& g, const GmRowPix& px, const float (&du)[4]
     }
 }
 
-// pixel owned by thread `tid` in the GM kernel: wave = 8x8 quadrant, DPP row (16 lanes) = 4x4 block of the quadrant
-GSX_DEV void thread_pixel_gm(uint32_t tid, uint32_t tile_x, uint32_t tile_y, uint32_t& i, uint32_t& j) {
-    const uint32_t wave = tid >> 6, sb = (tid >> 4) & 3u, p = tid & 15u;
-    j = tile_x * TILE + (wave & 1u) * 8u + (sb & 1u) * 4u + (p & 3u);
-    i = tile_y * TILE + (wave >> 1) * 8u + (sb >> 1) * 4u + (p >> 2);
-}
-
-#ifndef GSX_GM_WAVES
-#define GSX_GM_WAVES 4
-#endif
-
 template <int KIND>
-__global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gm_kernel(RasterArgs a, const float* __restrict__ render_alphas,
+__global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterArgs a, const float* __restrict__ render_alphas,
                                                                           const int32_t* __restrict__ last_ids,
                                                                           const float* __restrict__ v_render_colors,
                                                                           const float* __restrict__ v_render_alphas,
                                                                           float4* __restrict__ ws_rec, int32_t* __restrict__ ws_head) {
     // record planes: 0 u0, 1 v0, 2 l00, 3 l01, 4 l11, 5 lo, 6 d1, 7 d2, 8 d3, 9 d4, 10 d5, 11 red, 12 green, 13 blue, 14 rad2, 15 k2 (footprint())
     __shared__ float s_rec[16][GS];
-    __shared__ float s_acc[15][GS];
+    __shared__ float s_acc[16][GS];          // plane 15 is the butterfly's padding value (always 0)
     __shared__ int32_t s_gid[GS];
     __shared__ uint32_t s_touched[GS / 32];
-    __shared__ uint8_t s_list[20][GS];   // [wave * 5 + k]: slots of the super-chunk whose footprint touches 4x4 block k (k < 4) / the 8x8 quadrant (k = 4)
-    __shared__ float s_T[RB], s_tbuf[RB];   // per pixel: the two loop-carried quantities of the back-to-front recurrence (two b32 planes: a
-                                            // wave-uniform ds_read_b32 costs 4.9 LDS cycles, a ds_read_b64 16.5: tools/lds_probe.hip)
+    __shared__ uint8_t s_list[16][GS];       // [wave * 4 + k]: slots of the super-chunk whose footprint reaches 4x4 block k of the wave's quadrant
+    __shared__ float s_T[RB], s_tbuf[RB];    // per pixel: the two loop-carried quantities of the back-to-front recurrence, between super-chunks
     __shared__ uint32_t s_lock;
     __shared__ float4 s_uvb[KIND == CAM_PERFECT_PINHOLE ? 1 : RB];   // distorted cameras: per pixel (u, v, last id, -)
     __shared__ float s_bounds[4][4];
@@ -858,12 +883,20 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gm_kernel(RasterA
     __syncthreads();
     const int32_t block_last = min(s_blockmax, range_end - 1);
     if (block_last < range_start) return;
-    const int32_t n_super = (block_last - range_start + GS) / GS;
+    const int32_t n_total = block_last - range_start + 1;
+    const int32_t n_super = (n_total + GS - 1) / GS;
+    const int32_t per_super = (n_total + n_super - 1) / n_super;   // balanced super-chunks (<= GS)
+
+    const uint32_t prow = lane >> 4, pcol = lane & 15u;            // this lane's pixel row of the block / its Gaussian column of the batch
+    const float su = 1.f / cam.fx, sv = 1.f / cam.fy;
+    const float prow_f = (float)prow;
+    // plane of value z[j] after rows_reduce16: 4 j + {0,2,1,3}[row]
+    const uint32_t zplane0 = (prow == 1u) ? 2u : (prow == 2u ? 1u : prow);
 
     for (int32_t sc = 0; sc < n_super; ++sc) {
         __syncthreads();  // previous super-chunk's records are written, LDS planes are free
-        const int32_t chunk_end = block_last - GS * sc;  // inclusive; slot t holds sorted index chunk_end - t (back to front)
-        const int32_t chunk_size = min(GS, chunk_end + 1 - range_start);
+        const int32_t chunk_end = block_last - per_super * sc;  // inclusive; slot t holds sorted index chunk_end - t (back to front)
+        const int32_t chunk_size = min(per_super, chunk_end + 1 - range_start);
         if ((int32_t)tid < chunk_size) {
             const int32_t g = a.flatten_ids[chunk_end - (int32_t)tid];
             StagedRec sr;
@@ -875,155 +908,126 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gm_kernel(RasterA
             s_gid[tid] = g;
         }
 #pragma unroll
-        for (int k = 0; k < 15; ++k) s_acc[k][tid] = 0.f;
+        for (int k = 0; k < 16; ++k) s_acc[k][tid] = 0.f;
         if (tid < GS / 32) s_touched[tid] = 0u;
         __syncthreads();
 
         if (wave == 0) { GSX_STAT_ADD(10, 1); GSX_STAT_ADD(11, chunk_size); }
         // ---- bin the super-chunk's Gaussians into the lists of this wave's four 4x4 blocks (back-to-front order is kept) ----
-        uint32_t cnt[5] = {0u, 0u, 0u, 0u, 0u};
+        uint32_t cnt[4] = {0u, 0u, 0u, 0u};
         for (int32_t c0 = 0; c0 < chunk_size; c0 += 64) {
             const int32_t c = c0 + (int32_t)lane;
             const bool in = c < chunk_size;
             const float4 cc = make_float4(s_rec[0][c & (GS - 1)], s_rec[1][c & (GS - 1)], s_rec[14][c & (GS - 1)], s_rec[15][c & (GS - 1)]);
             const float c00 = s_rec[2][c & (GS - 1)], c01 = s_rec[3][c & (GS - 1)], c11 = s_rec[4][c & (GS - 1)];
             const int32_t idx = chunk_end - c;
-            bool any = false;
 #pragma unroll
-            for (int sb = 0; sb < 5; ++sb) {
-                bool hit = any;   // k = 4: the union of the four blocks
-                if (sb < 4) {
-                    hit = in && idx <= sb_last[sb] && footprint_hits(cc, c00, c01, c11, sbb[sb][0], sbb[sb][1], sbb[sb][2], sbb[sb][3]);
-                    any = any || hit;
-                }
+            for (int sb = 0; sb < 4; ++sb) {
+                const bool hit = in && idx <= sb_last[sb] && footprint_hits(cc, c00, c01, c11, sbb[sb][0], sbb[sb][1], sbb[sb][2], sbb[sb][3]);
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
                 if (hit) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    s_list[wave * 5 + sb][cnt[sb] + rank] = (uint8_t)c;
+                    s_list[wave * 4 + sb][cnt[sb] + rank] = (uint8_t)c;
                 }
                 cnt[sb] += (uint32_t)__popcll(m);
             }
         }
         __builtin_amdgcn_wave_barrier();
 
-        // ---- batches of 64 Gaussians: per 4x4 block (16 pixels per batch) or, when the footprints are large, per quadrant ----
-        // Thin small ellipses touch few 4x4 blocks: one list per block keeps the lanes busy.  A Gaussian that covers most of the
-        // quadrant would sit in all four lists (four record loads, four flushes, four partly filled batches): then ONE batch per
-        // 64 Gaussians of the quadrant's list walks all 64 pixels and flushes once.  Both costs are known exactly from the list
-        // lengths (pixel rows to process), so every wave picks the cheaper one for every super-chunk.
-        const uint32_t rows4 = 4u * (((cnt[0] + 63u) >> 6) + ((cnt[1] + 63u) >> 6) + ((cnt[2] + 63u) >> 6) + ((cnt[3] + 63u) >> 6));
-        const uint32_t rows8 = 16u * ((cnt[4] + 63u) >> 6);
-        const bool per_quadrant = rows8 <= rows4;
-        GSX_STAT_ADD(12, per_quadrant ? 1 : 0); GSX_STAT_ADD(13, per_quadrant ? rows8 : rows4);
-        const float su = 1.f / cam.fx, sv = 1.f / cam.fy;
-        const int n_units = per_quadrant ? 1 : 4;
 #pragma unroll 1
-        for (int unit = 0; unit < n_units; ++unit) {
-            const int list_id = per_quadrant ? 4 : unit;
-            const uint32_t n_list = cnt[list_id];
-            GSX_STAT_ADD(8, n_list); GSX_STAT_ADD(9, (n_list + 63u) / 64u);
-            const uint8_t* list = s_list[wave * 5 + list_id];
+        for (int sb = 0; sb < 4; ++sb) {
+            const uint32_t n_list = cnt[sb];
+            if (n_list == 0u) continue;
+            GSX_STAT_ADD(8, n_list); GSX_STAT_ADD(9, (n_list + 15u) / 16u);
+            const uint8_t* list = s_list[wave * 4 + sb];
+            // ---- this lane's four pixels: row `prow` of block sb, columns 0..3 (inputs in VGPRs for the whole list) ----
+            const uint32_t bx = tile_x * TILE + (uwave & 1u) * 8u + ((uint32_t)sb & 1u) * 4u, by = tile_y * TILE + (uwave >> 1) * 8u + ((uint32_t)sb >> 1) * 4u;
+            const uint32_t y = by + prow;
+            const uint32_t cbase = wave * 64u + (uint32_t)sb * 16u + prow * 4u;   // carries / s_uvb index of this lane's first pixel
+            GmRowPix px;
+            float pu[4], pv[4];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const uint32_t x = bx + (uint32_t)h;
+                const size_t gp = (size_t)cid * a.H * a.W + (size_t)min(y, a.H - 1) * a.W + min(x, a.W - 1);
+                px.vr[h] = v_render_colors[gp * 3]; px.vg[h] = v_render_colors[gp * 3 + 1]; px.vb[h] = v_render_colors[gp * 3 + 2];
+                px.T[h] = s_T[cbase + h]; px.tb[h] = s_tbuf[cbase + h];
+                if (KIND == CAM_PERFECT_PINHOLE) {
+                    px.binf[h] = (y < a.H && x < a.W) ? last_ids[gp] : -1;
+                } else {
+                    const float4 q = s_uvb[cbase + h];
+                    px.binf[h] = __float_as_int(q.z);
+                    pu[h] = q.x; pv[h] = q.y;
+                }
+            }
+            const float bu = ((float)bx + 0.5f - cam.cx) * su;                       // perfect pinhole: u of the block's column 0
+            const float pvr = fmaf(prow_f, sv, ((float)by + 0.5f - cam.cy) * sv);    //                  v of this lane's row
 #pragma unroll 1
-            for (uint32_t b0 = 0; b0 < n_list; b0 += 64) {
-                const bool have = b0 + lane < n_list;
-                const uint32_t slot = have ? (uint32_t)list[b0 + lane] : 0u;
+            for (uint32_t b0 = 0; b0 < n_list; b0 += 16) {
+                const bool have = b0 + pcol < n_list;
+                const uint32_t slot = have ? (uint32_t)list[b0 + pcol] : 0u;
                 GmLaneRec g;
                 g.idx = chunk_end - (int32_t)slot;
                 g.u0 = s_rec[0][slot]; g.v0 = s_rec[1][slot]; g.l00 = s_rec[2][slot]; g.l01 = s_rec[3][slot]; g.l11 = s_rec[4][slot];
                 g.lo = have ? s_rec[5][slot] : -INFINITY;   // idle lanes: alpha = 0
                 g.d1 = s_rec[6][slot]; g.d2 = s_rec[7][slot]; g.d3 = s_rec[8][slot]; g.d4 = s_rec[9][slot]; g.d5 = s_rec[10][slot];
                 g.cr = s_rec[11][slot]; g.cg = s_rec[12][slot]; g.cb = s_rec[13][slot];
-                float acc[15];
-#pragma unroll
-                for (int k = 0; k < 15; ++k) acc[k] = 0.f;
-                // no lane of the batch can reach the alpha clamp (log2 opacity below log2 0.999): the cheaper row body
                 const bool clamp = __builtin_amdgcn_ballot_w64(g.lo > -0.0015f) != 0ull;
-                const int sb_first = per_quadrant ? 0 : unit, sb_end = per_quadrant ? 4 : unit + 1;
-#pragma unroll 1
-                for (int sb = sb_first; sb < sb_end; ++sb) {
-                    float* carry_T = &s_T[wave * 64 + sb * 16];
-                    float* carry_b = &s_tbuf[wave * 64 + sb * 16];
-                    const float4* uvb = &s_uvb[KIND == CAM_PERFECT_PINHOLE ? 0 : wave * 64 + sb * 16];
-                    // origin of the 4x4 block (wave-uniform): pixel (bx + px, by + py)
-                    const uint32_t bx = tile_x * TILE + (uwave & 1u) * 8u + ((uint32_t)sb & 1u) * 4u, by = tile_y * TILE + (uwave >> 1) * 8u + ((uint32_t)sb >> 1) * 4u;
-                    const float bu = ((float)bx + 0.5f - cam.cx) * su, bv = ((float)by + 0.5f - cam.cy) * sv;   // perfect pinhole: (u, v) of its pixel (0, 0)
-                    float duc[4];   // perfect pinhole: du of the block's four columns (dv is constant along a row)
+                float du[4], dv[4], num2[4], rden[4];
+                if (KIND == CAM_PERFECT_PINHOLE) {
+                    const float dvr = pvr - g.v0, du0 = bu - g.u0;
+                    const float t1 = g.l11 * dvr, t1sq = t1 * t1, t0r = g.l01 * dvr;
+                    const float Ar = fmaf(dvr, fmaf(g.d5, dvr, g.d2), 1.f), Br = fmaf(g.d4, dvr, g.d1);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) duc[c] = fmaf((float)c, su, bu - g.u0);
-                    const float dv00 = bv - g.v0;
-#pragma unroll 1
-                    for (int row = 0; row < 4; ++row) {
-                        GmRowPix px;
-                        float du[4], dv[4], num2[4], rden[4];
-                        const uint32_t y = by + (uint32_t)row;
+                    for (int h = 0; h < 4; ++h) {
+                        du[h] = fmaf((float)h, su, du0); dv[h] = dvr;
+                        const float t0 = fmaf(g.l00, du[h], t0r);
+                        num2[h] = fmaf(t0, t0, t1sq);
+                        rden[h] = __builtin_amdgcn_rcpf(fmaf(du[h], fmaf(g.d3, du[h], Br), Ar));
+                    }
+                } else {
 #pragma unroll
-                        for (int h = 0; h < 4; ++h) {
-                            const int pp = row * 4 + h;
-                            px.T[h] = carry_T[pp]; px.tb[h] = carry_b[pp];            // wave-uniform addresses: LDS broadcast
-                            // read-only per-pixel inputs: wave-uniform addresses into the global tensors
-                            const uint32_t x = bx + (uint32_t)h;
-                            const size_t gp = (size_t)cid * a.H * a.W + (size_t)min(y, a.H - 1) * a.W + min(x, a.W - 1);
-                            px.vr[h] = v_render_colors[gp * 3]; px.vg[h] = v_render_colors[gp * 3 + 1]; px.vb[h] = v_render_colors[gp * 3 + 2];
-                            if (KIND == CAM_PERFECT_PINHOLE) {
-                                px.binf[h] = (y < a.H && x < a.W) ? last_ids[gp] : -1;
-                            } else {
-                                const float4 q = uvb[pp];
-                                px.binf[h] = __float_as_int(q.z);
-                                du[h] = q.x - g.u0; dv[h] = q.y - g.v0;
-                            }
-                        }
-                        if (KIND == CAM_PERFECT_PINHOLE) {
-                            // separable pixel grid: everything that depends on the row only is hoisted out of the four pixels
-                            const float dvr = fmaf((float)row, sv, dv00);
-                            const float t1 = g.l11 * dvr, t1sq = t1 * t1, t0r = g.l01 * dvr;
-                            const float Ar = fmaf(dvr, fmaf(g.d5, dvr, g.d2), 1.f), Br = fmaf(g.d4, dvr, g.d1);
-#pragma unroll
-                            for (int h = 0; h < 4; ++h) {
-                                du[h] = duc[h]; dv[h] = dvr;
-                                const float t0 = fmaf(g.l00, du[h], t0r);
-                                num2[h] = fmaf(t0, t0, t1sq);
-                                rden[h] = __builtin_amdgcn_rcpf(fmaf(du[h], fmaf(g.d3, du[h], Br), Ar));
-                            }
-                        } else {
-#pragma unroll
-                            for (int h = 0; h < 4; ++h) {
-                                const float t0 = fmaf(g.l01, dv[h], g.l00 * du[h]);
-                                const float t1 = g.l11 * dv[h];
-                                num2[h] = fmaf(t0, t0, t1 * t1);
-                                rden[h] = __builtin_amdgcn_rcpf(fmaf(du[h], fmaf(g.d3, du[h], fmaf(g.d4, dv[h], g.d1)), fmaf(dv[h], fmaf(g.d5, dv[h], g.d2), 1.f)));
-                            }
-                        }
-                        float T_out[4], tb_out[4];
-                        if (clamp) gm_row<true>(g, px, du, dv, num2, rden, acc, T_out, tb_out);
-                        else gm_row<false>(g, px, du, dv, num2, rden, acc, T_out, tb_out);
-                        if (lane == 63u) {   // carries for this block's next batch
-#pragma unroll
-                            for (int h = 0; h < 4; ++h) { carry_T[row * 4 + h] = T_out[h]; carry_b[row * 4 + h] = tb_out[h]; }
-                        }
+                    for (int h = 0; h < 4; ++h) {
+                        du[h] = pu[h] - g.u0; dv[h] = pv[h] - g.v0;
+                        const float t0 = fmaf(g.l01, dv[h], g.l00 * du[h]);
+                        const float t1 = g.l11 * dv[h];
+                        num2[h] = fmaf(t0, t0, t1 * t1);
+                        rden[h] = __builtin_amdgcn_rcpf(fmaf(du[h], fmaf(g.d3, du[h], fmaf(g.d4, dv[h], g.d1)), fmaf(dv[h], fmaf(g.d5, dv[h], g.d2), 1.f)));
                     }
                 }
-                // Partial moments -> the tile's accumulator.  The slots of one batch are distinct, so inside a wave a plain
-                // read-add-write is race free; the four waves of the tile exclude each other with a wave-level lock.  (ds_add_f32
-                // is serialised by the LDS at ~3 cycles per active lane — 192 cycles per wave64 instruction, tools/lds_probe.hip —
-                // which made a 15-atomic flush cost more than the batch's arithmetic; integer LDS atomics run at 4 cycles.)
+                float acc[16], T_out[4], tb_out[4];
+                if (clamp) gq_row<true>(g, px, du, dv, num2, rden, acc, T_out, tb_out);
+                else gq_row<false>(g, px, du, dv, num2, rden, acc, T_out, tb_out);
+                // carries for this row's next pass: the values behind the row's last Gaussian
+#pragma unroll
+                for (int h = 0; h < 4; ++h) { px.T[h] = row_last(T_out[h]); px.tb[h] = row_last(tb_out[h]); }
+                // the four pixel rows' partial moments of each Gaussian -> one total per (Gaussian, moment), four moments per lane
+                float z[4];
+                rows_reduce16(acc, z);
+                // -> the tile's accumulator: inside the wave every (moment, slot) has one owner lane; the four waves exclude each other
                 if (lane == 0u) {
                     uint32_t expected = 0u;
                     while (!__hip_atomic_compare_exchange_strong(&s_lock, &expected, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
                         expected = 0u;
-                        __builtin_amdgcn_s_sleep(2);
+                        __builtin_amdgcn_s_sleep(1);
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 if (have) {
-                    float cur[15];
+                    float cur[4];
 #pragma unroll
-                    for (int k = 0; k < 15; ++k) cur[k] = s_acc[k][slot];
+                    for (int jz = 0; jz < 4; ++jz) cur[jz] = s_acc[4 * jz + zplane0][slot];
 #pragma unroll
-                    for (int k = 0; k < 15; ++k) s_acc[k][slot] = cur[k] + acc[k];
-                    atomicOr(&s_touched[slot >> 5], 1u << (slot & 31u));
+                    for (int jz = 0; jz < 4; ++jz) s_acc[4 * jz + zplane0][slot] = cur[jz] + z[jz];
+                    if (prow == 0u) atomicOr(&s_touched[slot >> 5], 1u << (slot & 31u));
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0u) __hip_atomic_store(&s_lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            // carries of the block's pixels for the next super-chunk (every lane of a row holds the row's values)
+            if (pcol == 0u) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) { s_T[cbase + h] = px.T[h]; s_tbuf[cbase + h] = px.tb[h]; }
             }
         }
         __syncthreads();
@@ -1182,16 +1186,15 @@ bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, 
     }
     *tile_flags_out = a.tile_flags;
     const dim3 ggrid((a.N + 255u) / 256u), gblock(256);
-    // Two backward kernels, same records and gather.  Gaussian-major wins when the projected Gaussians are small next to a 4x4 pixel
-    // block's neighbourhood (S-1M: 767 vs 862 us), pixel-major when they cover many blocks (S-5M @4K: 2.47 vs 2.76 ms): DESIGN.md §4.
-    // The proxy available without a host read is the mean number of 16x16 tiles per Gaussian; GSX_BWD=pm|gm forces one (tests, tools; read per launch).
-    const int forced = [] { const char* e = getenv("GSX_BWD"); return !e ? 0 : (std::string(e) == "pm" ? 1 : (std::string(e) == "gm" ? 2 : 0)); }();
-    const bool gaussian_major = kind != CAM_OPENCV_FISHEYE && (forced ? forced == 2 : (double)a.n_isects < 4.5 * (double)a.C * (double)a.N);
+    // Two backward kernels, same records and gather: Gaussian-major (global-shutter pinholes; S-1M 0.54 vs 0.86 ms, S-5M @4K 1.9 vs 2.5 ms,
+    // garden stand-in 248 vs 226 it/s) and pixel-major (fisheye: its moments are dz-weighted; GSX_BWD=pm forces it: tests, tools).
+    const bool force_pm = [] { const char* e = getenv("GSX_BWD"); return e && std::string(e) == "pm"; }();   // read per launch: the tests switch it
+    const bool gaussian_major = kind != CAM_OPENCV_FISHEYE && !force_pm;
 #define GSX_BLEND_BWD(KERNEL, KIND)                                                                                                        \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<KIND>), grid, block, 0, st, a, render_alphas, last_ids, v_render_colors, v_render_alphas, ws_rec, ws_head)
     if (gaussian_major) {
-        if (kind == CAM_PERFECT_PINHOLE) GSX_BLEND_BWD(raster_bwd_gm_kernel, CAM_PERFECT_PINHOLE);
-        else GSX_BLEND_BWD(raster_bwd_gm_kernel, CAM_OPENCV_PINHOLE);
+        if (kind == CAM_PERFECT_PINHOLE) GSX_BLEND_BWD(raster_bwd_gq_kernel, CAM_PERFECT_PINHOLE);
+        else GSX_BLEND_BWD(raster_bwd_gq_kernel, CAM_OPENCV_PINHOLE);
     } else {
         if (kind == CAM_PERFECT_PINHOLE) GSX_BLEND_BWD(raster_bwd_fast_kernel, CAM_PERFECT_PINHOLE);
         else if (kind == CAM_OPENCV_PINHOLE) GSX_BLEND_BWD(raster_bwd_fast_kernel, CAM_OPENCV_PINHOLE);

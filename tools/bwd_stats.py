@@ -1,5 +1,5 @@
 """Debug tool: build libgsx with -DGSX_STATS into gpurun_out/, run the blend forward + backward of S-1M (or S-5M) once and print the
-work counters of the Gaussian-major backward kernel.  Run on the GPU box: python tools/bwd_stats.py [1m|5m]"""
+work counters of the Gaussian-major backward kernel (raster_bwd_gq_kernel).  Run on the GPU box: python tools/bwd_stats.py [1m|5m]"""
 import ctypes
 import os
 import subprocess
@@ -27,10 +27,9 @@ def main():
     runpy.run_path(os.path.join(ROOT, "tools", "blend_ab.py"), run_name="__main__")   # 3 warm-up + 1 timed launch of each op = 4 launches
     lib.gsx_debug_read_stats(buf, 1)
     n = 4.0
-    print("per launch: list entries (4x4 block, Gaussian) %.3fM  batches %.1fK -> pixel iterations %.3fM  super-chunks %.1fK  staged %.3fM" %
-          (buf[8] / n / 1e6, buf[9] / n / 1e3, buf[9] / n * 16 / 1e6, buf[10] / n / 1e3, buf[11] / n / 1e6))
-    print("batch fill %.3f   per-quadrant (wave, super-chunk) units %.1fK of %.1fK   pixel rows %.3fM (= %.3fM pixel iterations)" %
-          (buf[8] / max(1, buf[9] * 64), buf[12] / n / 1e3, 4 * buf[10] / n / 1e3, buf[13] / n / 1e6, 4 * buf[13] / n / 1e6))
+    print("per launch: list entries (4x4 block, Gaussian) %.3fM  passes of 16 Gaussians x 16 pixels %.1fK (= %.3fM lane-pixel slots)  super-chunks %.1fK  staged %.3fM" %
+          (buf[8] / n / 1e6, buf[9] / n / 1e3, buf[9] / n * 256 / 1e6, buf[10] / n / 1e3, buf[11] / n / 1e6))
+    print("pass fill %.3f" % (buf[8] / max(1, buf[9] * 16)))
 
 
 if __name__ == "__main__":
