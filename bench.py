@@ -4,8 +4,8 @@ rasterizer at 1 M Gaussians / SH degree 3 / 1920x1080 (configs[1], "S-1M"), on N
 
 A step = one TRAINING ITERATION of the hot path over one camera per rank (the "train iters/s" of BASELINE's metric):
     activations -> projection_ut -> SH colours (+0.5, clamp) -> intersect_tile (+sort) -> intersect_offset -> blend fwd
-    -> photometric loss (0.8 L1 + 0.2 (1 - SSIM)) -> blend bwd -> SH bwd -> activation Jacobians
-    [-> gradient all-reduce when N > 1] -> fused Adam on all six parameter groups
+    -> photometric loss (0.8 L1 + 0.2 (1 - SSIM)) -> blend bwd -> SH bwd (+ the SH tensor's Adam step in the same launch) -> activation Jacobians
+    [-> gradient exchange when N > 1] -> fused Adam on the other parameter groups
 The camera changes EVERY step (8 poses on a 0.4 m orbit around the cfg2 pose, pose 0 = cfg2 itself), so n_isects differs from
 step to step and intersect_tile's capacity hint is not trivially right; hint misses and host synchronisations per step are
 reported.  The second half of BASELINE's metric, fwd+bwd ms/frame (no optimizer), is measured in a separate loop (`fwd_bwd`).
@@ -13,8 +13,9 @@ Default: the fused glue kernels of rasterize_fused (gradients written straight i
 --unfused runs the reference-style chain of torch ops around the seven gsplat operators.
 Inputs are resident in HBM before the timed region.  N > 1: launched by torch.distributed.run, one rank per
 GPU over RCCL; every rank renders its own camera of the step's batch (cameras on a small orbit around the
-cfg2 pose so per-GPU work stays fixed: weak scaling) and the per-Gaussian gradients (59 fp32 / Gaussian, one
-flat bucket) are all-reduced after backward.
+cfg2 pose so per-GPU work stays fixed: weak scaling); the gradient exchange is the colour-gradient exchange of
+distributed.ColorGradExchange (3 floats per (camera, Gaussian) all-gathered, SH backward over all cameras on every rank, the other
+11 floats per Gaussian all-reduced under it) unless --dense-allreduce / --sparse-allreduce / --sharded-adam pick another one.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, live HIP-event
 timing) and `cpu_baseline` (the CPU oracle timed on one full frame of the same workload, ~10 s on 8 cores).
@@ -45,6 +46,8 @@ def algorithmic_bytes(N, C, I, P, tiles, deg, K):  # noqa: E741  (SURVEY.md §8d
         # fused variants: means instead of dirs, radii (8 B) instead of the mask; bwd also reads colours and v_means
         "sh_colors_fwd": N * C * (12 + 12 * nb + 8 + 12),
         "sh_colors_bwd": N * C * (12 + 12 * nb + 8 + 12 + 12 + 12 * K + 24),
+        # fused with the SH tensor's Adam step: parameter, two moments read and written (72 K B) instead of the gradient written
+        "sh_colors_bwd_adam": N * C * (12 + 8 + 12 + 12 + 24) + N * 72 * K,
         "splat_activations_fwd": N * (40 + 44),
         "splat_activations_bwd": N * (40 + 44 + 40),
         "intersect_tile": 20 * N * C + 12 * N * C + (28 * N * C + 12 * I) + 144 * I,
@@ -68,7 +71,7 @@ class OpTimer:
         self.ops = ops_mod
         self.names = ["projection_ut_3dgs_fused", "spherical_harmonics_fwd", "spherical_harmonics_bwd", "intersect_tile",
                       "intersect_offset", "rasterize_to_pixels_from_world_3dgs_fwd", "rasterize_to_pixels_from_world_3dgs_bwd",
-                      "sh_colors_fwd", "sh_colors_bwd", "splat_activations_fwd", "splat_activations_bwd",
+                      "sh_colors_fwd", "sh_colors_bwd", "sh_colors_bwd_adam", "splat_activations_fwd", "splat_activations_bwd",
                       "photometric_loss_fwd", "photometric_loss_bwd", "intersect_tile_binned", "adam_step", "adam_step_split"]
         self.orig = {n: getattr(ops_mod, n) for n in self.names}
         self.events = {n: [] for n in self.names}
@@ -191,6 +194,8 @@ def main():
                                                                    "exchange: 3 floats per (camera, Gaussian) are all-gathered, every rank runs the SH backward over all "
                                                                    "cameras of the step, the other 11 floats are all-reduced meanwhile)")
     ap.add_argument("--sharded-adam", action="store_true", help="N > 1: reduce-scatter -> Adam on 1/N of the rows -> all-gather of the parameters")
+    ap.add_argument("--unfused-adam", action="store_true", help="write the SH gradient and step the SH groups with the separate Adam launch (default: "
+                                                                "the SH backward applies the SH tensor's Adam step where it produces the gradient)")
     ap.add_argument("--l1-loss", action="store_true", help="plain torch L1 loss instead of the reference's fused L1 + SSIM loss")
     ap.add_argument("--no-fwd-bwd", action="store_true", help="skip the extra fwd+bwd (no optimizer) timing loop")
     ap.add_argument("--fixed-camera", action="store_true", help="the cfg2 camera on every step (default: 8 poses around it, one per step)")
@@ -228,6 +233,8 @@ def main():
     opt = optim.FusedAdam.for_splat_data(model)  # reference learning rates (include/core/parameters.hpp:19-23)
     sharded = gdist.ShardedAdam(opt, bucket) if (args.sharded_adam and world > 1) else None
 
+    # fused SH backward + Adam: with the dense exchanges (all-reduce variants / sharded Adam) the SH gradient has to exist as a tensor
+    sh_adam_ok = not args.unfused_adam and not args.unfused and sharded is None and (world == 1 or color_xch)
     timer = OpTimer(ops)
     sinks = bucket.sinks(tuple(names))
     counter = {"i": 0, "isects": []}
@@ -244,6 +251,10 @@ def main():
         i = counter["i"]
         counter["i"] += 1
         cam = cams[(i * world + rank) % len(cams)]  # every step, every rank: another camera
+        # the SH tensor's Adam step rides on the SH backward (no 192 MB gradient round trip); the other groups are stepped below
+        fused_sh = with_adam and sh_adam_ok
+        sinks["_sh_adam"] = opt.begin_fused_sh_step(1001 + i) if fused_sh else None
+        fused_sh = sinks["_sh_adam"] is not None
         if xch is not None:   # the step's whole camera batch, in rank order (every rank knows the schedule)
             xch.begin_step(torch.stack([cams[(i * world + r) % len(cams)].viewmat for r in range(world)]))
         # fused glue: gradients are written straight into the flat bucket (no zero fill, no AccumulateGrad adds)
@@ -271,7 +282,7 @@ def main():
                 else:
                     bucket.all_reduce_mean()
             if with_adam:
-                opt.step(1001 + i)  # past the shN warm-up (fused_adam.cpp:66-70): all six groups are updated
+                opt.step(1001 + i, skip_sh=fused_sh)  # past the shN warm-up (fused_adam.cpp:66-70): all six groups are updated
         counter["isects"].append(out.n_isects)
 
     def timed(n, with_adam):
@@ -345,8 +356,9 @@ def main():
         n_adam_steps = max(1, min(args.steps, 8))
         if adam_ms > 0:
             ms = adam_ms / n_adam_steps
-            gbs = 28 * n_params / (ms * 1e-3) / 1e9  # p, m, v read + written, g read
-            kernels["fused_adam (6 groups)"] = {"ms": round(ms, 4), "algorithmic_bytes": 28 * n_params, "GBps": round(gbs, 1),
+            n_adam = n_params - (model.sh.numel() if sh_adam_ok else 0)   # the SH tensor is stepped inside sh_colors_bwd_adam
+            gbs = 28 * n_adam / (ms * 1e-3) / 1e9  # p, m, v read + written, g read
+            kernels["fused_adam (%s)" % ("4 groups: means, scaling, rotation, opacity" if sh_adam_ok else "6 groups")] = {"ms": round(ms, 4), "algorithmic_bytes": 28 * n_adam, "GBps": round(gbs, 1),
                                                 "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
         blend = [n for n in all_ms if n.startswith("rasterize_to_pixels")]
         dom = max(blend or list(all_ms), key=lambda n: all_ms[n])

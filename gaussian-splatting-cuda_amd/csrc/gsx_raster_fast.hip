@@ -769,7 +769,9 @@ GSX_DEV void rows_reduce16(float (&x)[16], float (&z)[4]) {
 
 // One row (4 pixels) of a 4x4 block for the 16 Gaussians of a DPP row.  CLAMP = false when no Gaussian of the pass can reach alpha
 // 0.999 (opacity < 0.999: alpha = o exp(-s) stays below it), which drops the clamp and its gradient mask.
-template <bool CLAMP>
+// ROWDV: dv is the same for the lane's four pixels (perfect pinhole: a lane's pixels are one image row), so the dv factors of the
+// moments are applied once per pass to three sums per weight instead of per pixel (12 instead of 19 accumulation VALU per pixel).
+template <bool CLAMP, bool ROWDV>
 GSX_DEV void gq_row(const GmLaneRec& g, const GmRowPix& px, const float (&du)[4], const float (&dv)[4], const float (&num2)[4],
                     const float (&rden)[4], float (&acc)[16], float (&T_out)[4], float (&tb_out)[4]) {
     float al[4], ra[4], P[4];
@@ -803,11 +805,22 @@ GSX_DEV void gq_row(const GmLaneRec& g, const GmRowPix& px, const float (&du)[4]
         const float bw = aw * (num2[h] * rden[h]);
         acc[0] = fmaf(fac[h], px.vr[h], acc[0]); acc[1] = fmaf(fac[h], px.vg[h], acc[1]); acc[2] = fmaf(fac[h], px.vb[h], acc[2]);
         acc[3] += av;
-        const float x7 = aw * du[h], x8 = aw * dv[h], x10 = bw * du[h], x11 = bw * dv[h];
-        acc[4] = fmaf(x7, du[h], acc[4]); acc[5] = fmaf(x7, dv[h], acc[5]); acc[6] = fmaf(x8, dv[h], acc[6]);
-        acc[7] += x7; acc[8] += x8; acc[9] += bw; acc[10] += x10; acc[11] += x11;
-        acc[12] = fmaf(x10, du[h], acc[12]); acc[13] = fmaf(x10, dv[h], acc[13]); acc[14] = fmaf(x11, dv[h], acc[14]);
+        if (ROWDV) {   // acc[6] / acc[8] / acc[11] collect sum aw, sum aw (again), sum bw here; the dv factors follow below
+            const float x7 = aw * du[h], x10 = bw * du[h];
+            acc[4] = fmaf(x7, du[h], acc[4]); acc[7] += x7; acc[8] += aw;
+            acc[9] += bw; acc[10] += x10; acc[12] = fmaf(x10, du[h], acc[12]);
+        } else {
+            const float x7 = aw * du[h], x8 = aw * dv[h], x10 = bw * du[h], x11 = bw * dv[h];
+            acc[4] = fmaf(x7, du[h], acc[4]); acc[5] = fmaf(x7, dv[h], acc[5]); acc[6] = fmaf(x8, dv[h], acc[6]);
+            acc[7] += x7; acc[8] += x8; acc[9] += bw; acc[10] += x10; acc[11] += x11;
+            acc[12] = fmaf(x10, du[h], acc[12]); acc[13] = fmaf(x10, dv[h], acc[13]); acc[14] = fmaf(x11, dv[h], acc[14]);
+        }
         T_out[h] = T[h]; tb_out[h] = tbuf - e[h];
+    }
+    if (ROWDV) {
+        const float d = dv[0], a0 = acc[8] * d, b0 = acc[9] * d;   // sum aw dv, sum bw dv
+        acc[5] = acc[7] * d; acc[6] = a0 * d; acc[8] = a0;
+        acc[11] = b0; acc[13] = acc[10] * d; acc[14] = b0 * d;
     }
 }
 
@@ -819,9 +832,8 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
                                                                           float4* __restrict__ ws_rec, int32_t* __restrict__ ws_head) {
     // record planes: 0 u0, 1 v0, 2 l00, 3 l01, 4 l11, 5 lo, 6 d1, 7 d2, 8 d3, 9 d4, 10 d5, 11 red, 12 green, 13 blue, 14 rad2, 15 k2 (footprint())
     __shared__ float s_rec[16][GS];
-    __shared__ float s_acc[16][GS];          // plane 15 is the butterfly's padding value (always 0)
+    __shared__ float s_acc[16][GS];          // plane 15 (the butterfly's padding value) counts the passes that listed the slot: > 0 = touched
     __shared__ int32_t s_gid[GS];
-    __shared__ uint32_t s_touched[GS / 32];
     __shared__ uint8_t s_list[16][GS];       // [wave * 4 + k]: slots of the super-chunk whose footprint reaches 4x4 block k of the wave's quadrant
     __shared__ float s_T[RB], s_tbuf[RB];    // per pixel: the two loop-carried quantities of the back-to-front recurrence, between super-chunks
     __shared__ uint32_t s_lock;
@@ -909,7 +921,6 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) s_acc[k][tid] = 0.f;
-        if (tid < GS / 32) s_touched[tid] = 0u;
         __syncthreads();
 
         if (wave == 0) { GSX_STAT_ADD(10, 1); GSX_STAT_ADD(11, chunk_size); }
@@ -996,8 +1007,9 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
                     }
                 }
                 float acc[16], T_out[4], tb_out[4];
-                if (clamp) gq_row<true>(g, px, du, dv, num2, rden, acc, T_out, tb_out);
-                else gq_row<false>(g, px, du, dv, num2, rden, acc, T_out, tb_out);
+                if (clamp) gq_row<true, KIND == CAM_PERFECT_PINHOLE>(g, px, du, dv, num2, rden, acc, T_out, tb_out);
+                else gq_row<false, KIND == CAM_PERFECT_PINHOLE>(g, px, du, dv, num2, rden, acc, T_out, tb_out);
+                acc[15] = 1.f;   // "listed" marker (summed like a moment: no separate LDS atomic)
                 // carries for this row's next pass: the values behind the row's last Gaussian
 #pragma unroll
                 for (int h = 0; h < 4; ++h) { px.T[h] = row_last(T_out[h]); px.tb[h] = row_last(tb_out[h]); }
@@ -1019,7 +1031,6 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
                     for (int jz = 0; jz < 4; ++jz) cur[jz] = s_acc[4 * jz + zplane0][slot];
 #pragma unroll
                     for (int jz = 0; jz < 4; ++jz) s_acc[4 * jz + zplane0][slot] = cur[jz] + z[jz];
-                    if (prow == 0u) atomicOr(&s_touched[slot >> 5], 1u << (slot & 31u));
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0u) __hip_atomic_store(&s_lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1033,7 +1044,7 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
         __syncthreads();
 
         // one thread per touched Gaussian of the super-chunk: 64 B moment record at its sorted index, chained per Gaussian
-        if ((int32_t)tid < chunk_size && ((s_touched[tid >> 5] >> (tid & 31u)) & 1u)) {
+        if ((int32_t)tid < chunk_size && s_acc[15][tid] > 0.f) {
             const int32_t isect = chunk_end - (int32_t)tid;
             const int32_t prev = atomicExch(&ws_head[s_gid[tid]], isect);
             float4* rec = ws_rec + (size_t)isect * 4;

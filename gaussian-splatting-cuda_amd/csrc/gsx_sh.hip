@@ -344,18 +344,28 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_colors_fwd_kernel(uint32_t C, uin
     }
 }
 
+// Adam state and step of the SH tensor for the fused "SH backward + optimizer" launch (gsx_sh_colors_bwd_adam): the two column blocks
+// sh0 (first 3 floats of a row) / shN keep their own step size and enable flag, as gsx_adam_step_split.
+struct ShAdam {
+    float* exp_avg; float* exp_avg_sq;
+    float step0, stepN; int do0, doN;      // step = lr * bias_correction1_rcp
+    float beta1, beta2, eps, bc2_sqrt_rcp;
+};
+
 // v_coeffs [N,K,3] is fully written (sum over cameras); v_means_inout [N,3] += d(colors)/d(means).
-template <int DEG>
+// ADAM: the gradient rows are not written; the wave's coalesced pass over its rows applies the Adam step to coeffs / exp_avg / exp_avg_sq
+// in place instead (coeffs is then an in/out argument: `coeffs_rw`), which saves the 192 MB write + read of the SH gradient at 1 M Gaussians.
+template <int DEG, bool ADAM>
 __global__ __launch_bounds__(SH_BLOCK) void sh_colors_bwd_kernel(uint32_t C, uint32_t N, uint32_t K,
                                                                  const float* __restrict__ means,
                                                                  const float* __restrict__ viewmats,
-                                                                 const float* __restrict__ coeffs,
+                                                                 const float* coeffs,
                                                                  const int32_t* __restrict__ radii,
                                                                  const float* __restrict__ colors,
                                                                  const float* __restrict__ v_colors,
-                                                                 float* __restrict__ v_coeffs,
+                                                                 float* v_coeffs,
                                                                  const float* __restrict__ v_means_in,
-                                                                 float* __restrict__ v_means_out) {
+                                                                 float* __restrict__ v_means_out, ShAdam ad) {
     constexpr int NB = (DEG + 1) * (DEG + 1);
     constexpr uint32_t NB3 = NB * 3;
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];
@@ -436,6 +446,44 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_colors_bwd_kernel(uint32_t C, uin
         if ((K3 & 3u) == 0u) {
             const uint32_t q_per_row = K3 >> 2, total = rows * q_per_row;
             constexpr int B = 6;  // LDS reads of a batch overlap; the stores are fire-and-forget
+            if (ADAM) {
+                // the same coalesced pass, as an optimizer step: gradient from the tile, parameter / moments streamed (the parameter rows
+                // were read a moment ago by this wave: the re-read is served by L2 / Infinity Cache)
+                float4* pp = reinterpret_cast<float4*>(dst);   // dst == coeffs rows of this wave
+                float4* pm = reinterpret_cast<float4*>(ad.exp_avg + (size_t)e0 * K3);
+                float4* pv = reinterpret_cast<float4*>(ad.exp_avg_sq + (size_t)e0 * K3);
+                constexpr int BA = 3;
+                for (uint32_t j0 = lane; j0 < total; j0 += 64 * BA) {
+                    float4 g[BA], p[BA], m[BA], v[BA];
+                    uint32_t col[BA];
+#pragma unroll
+                    for (int b = 0; b < BA; ++b) {
+                        const uint32_t j = min(j0 + 64u * b, total - 1u);
+                        const uint32_t er = j / q_per_row, rr = (j - er * q_per_row) << 2;
+                        const float* sp = tile + er * LS + rr;
+                        g[b] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                        col[b] = rr;
+                        p[b] = pp[j]; m[b] = pm[j]; v[b] = pv[j];
+                    }
+#pragma unroll
+                    for (int b = 0; b < BA; ++b) {
+                        if (j0 + 64u * b >= total) continue;
+#define GSX_SH_ADAM1(F, J)                                                                                   \
+                        {                                                                                    \
+                            const bool a0 = col[b] + J < 3u;                                                 \
+                            if (a0 ? ad.do0 : ad.doN) {                                                      \
+                                m[b].F = ad.beta1 * m[b].F + (1.0f - ad.beta1) * g[b].F;                     \
+                                v[b].F = ad.beta2 * v[b].F + (1.0f - ad.beta2) * g[b].F * g[b].F;            \
+                                p[b].F -= (a0 ? ad.step0 : ad.stepN) * m[b].F / (sqrtf(v[b].F) * ad.bc2_sqrt_rcp + ad.eps); \
+                            }                                                                                \
+                        }
+                        GSX_SH_ADAM1(x, 0) GSX_SH_ADAM1(y, 1) GSX_SH_ADAM1(z, 2) GSX_SH_ADAM1(w, 3)
+#undef GSX_SH_ADAM1
+                        const uint32_t j = j0 + 64u * b;
+                        pp[j] = p[b]; pm[j] = m[b]; pv[j] = v[b];
+                    }
+                }
+            } else
             for (uint32_t j0 = lane; j0 < total; j0 += 64 * B) {
                 float4 v[B];
 #pragma unroll
@@ -606,10 +654,37 @@ extern "C" int gsx_sh_colors_bwd(uint32_t degrees_to_use, uint32_t C, uint32_t N
     if (lds > 160u * 1024u) { set_error("sh_colors_bwd: K too large for the LDS row tile (K <= 53)"); return GSX_ERR_UNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((N + SH_BLOCK - 1) / SH_BLOCK), block(SH_BLOCK);
-#define GSX_L(D) hipLaunchKernelGGL(HIP_KERNEL_NAME(sh_colors_bwd_kernel<D>), grid, block, lds, st, C, N, K, means, viewmats, coeffs, radii, colors, v_colors, v_coeffs, v_means_in, v_means_out)
+#define GSX_L(D) hipLaunchKernelGGL(HIP_KERNEL_NAME(sh_colors_bwd_kernel<D, false>), grid, block, lds, st, C, N, K, means, viewmats, coeffs, radii, colors, v_colors, v_coeffs, v_means_in, v_means_out, ShAdam{})
     switch (degrees_to_use) { case 0: GSX_L(0); break; case 1: GSX_L(1); break; case 2: GSX_L(2); break; case 3: GSX_L(3); break; default: GSX_L(4); break; }
 #undef GSX_L
     return check_launch("sh_colors_bwd");
+}
+
+// gsx_sh_colors_bwd fused with the Adam step of the SH tensor (the sh0 / shN groups of src/training/optimizers/fused_adam.cpp:20-96, same
+// arithmetic as gsx_adam_step_split): coeffs [N,K,3], exp_avg, exp_avg_sq are updated in place, the SH gradient is never materialised.
+// K * 3 must be a multiple of 4 (K = 4, 16: degrees 1 and 3); step_* = lr * bias_correction1_rcp; do_* = 0 leaves that block untouched.
+extern "C" int gsx_sh_colors_bwd_adam(uint32_t degrees_to_use, uint32_t C, uint32_t N, uint32_t K, const float* means,
+                                      const float* viewmats, float* coeffs, const int32_t* radii, const float* colors,
+                                      const float* v_colors, const float* v_means_in, float* v_means_out, float* exp_avg,
+                                      float* exp_avg_sq, float step_sh0, float step_shN, int do_sh0, int do_shN, float beta1, float beta2,
+                                      float eps, float bias_correction2_sqrt_rcp, void* stream) {
+    if (N == 0 || C == 0) return GSX_OK;
+    if (!means || !viewmats || !coeffs || !v_colors || !v_means_out || !exp_avg || !exp_avg_sq) { set_error("sh_colors_bwd_adam: null pointer"); return GSX_ERR_INVALID_ARGUMENT; }
+    if ((radii == nullptr) != (colors == nullptr)) { set_error("sh_colors_bwd_adam: radii and colors are given together (or neither: pre-masked v_colors)"); return GSX_ERR_INVALID_ARGUMENT; }
+    if (degrees_to_use > 4 || (degrees_to_use + 1) * (degrees_to_use + 1) > K) { set_error("sh_colors_bwd_adam: bad degree"); return GSX_ERR_INVALID_ARGUMENT; }
+    if ((K * 3u) % 4u != 0u || ((((uintptr_t)coeffs | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15u) != 0)) {
+        set_error("sh_colors_bwd_adam: K * 3 must be a multiple of 4 and the arrays 16-byte aligned");
+        return GSX_ERR_UNSUPPORTED;
+    }
+    const size_t lds = (size_t)SH_BLOCK * ((K * 3u) | 1u) * sizeof(float);
+    if (lds > 160u * 1024u) { set_error("sh_colors_bwd_adam: K too large for the LDS row tile (K <= 53)"); return GSX_ERR_UNSUPPORTED; }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((N + SH_BLOCK - 1) / SH_BLOCK), block(SH_BLOCK);
+    const ShAdam ad{exp_avg, exp_avg_sq, step_sh0, step_shN, do_sh0, do_shN, beta1, beta2, eps, bias_correction2_sqrt_rcp};
+#define GSX_L(D) hipLaunchKernelGGL(HIP_KERNEL_NAME(sh_colors_bwd_kernel<D, true>), grid, block, lds, st, C, N, K, means, viewmats, coeffs, radii, colors, v_colors, coeffs, v_means_in, v_means_out, ad)
+    switch (degrees_to_use) { case 0: GSX_L(0); break; case 1: GSX_L(1); break; case 2: GSX_L(2); break; case 3: GSX_L(3); break; default: GSX_L(4); break; }
+#undef GSX_L
+    return check_launch("sh_colors_bwd_adam");
 }
 
 extern "C" int gsx_splat_activations_fwd(uint32_t N, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,

@@ -428,6 +428,32 @@ std::tuple<at::Tensor, at::Tensor> sh_colors_bwd(const uint32_t degrees_to_use, 
     return std::make_tuple(vc, vm);
 }
 
+// SH backward + Adam step of the SH tensor in one launch (include/gsx.h): coeffs / exp_avg / exp_avg_sq are updated in place; returns v_means
+at::Tensor sh_colors_bwd_adam(const uint32_t degrees_to_use, const at::Tensor means, const at::Tensor viewmats, at::Tensor coeffs,
+                              const at::optional<at::Tensor> radii, const at::optional<at::Tensor> colors, const at::Tensor v_colors,
+                              const at::optional<at::Tensor> v_means_in, const at::optional<at::Tensor> v_means_out, at::Tensor exp_avg,
+                              at::Tensor exp_avg_sq, double step_sh0, double step_shN, bool do_sh0, bool do_shN, double beta1, double beta2,
+                              double eps, double bc2_sqrt_rcp) {
+    GSX_DEVICE_GUARD(means);
+    GSX_CHECK_INPUT(means); GSX_CHECK_INPUT(viewmats); GSX_CHECK_INPUT(coeffs); GSX_CHECK_INPUT(v_colors); GSX_CHECK_INPUT(exp_avg); GSX_CHECK_INPUT(exp_avg_sq);
+    const bool premasked = !(radii.has_value() && radii->defined());
+    TORCH_CHECK(premasked == !(colors.has_value() && colors->defined()), "sh_colors_bwd_adam: radii and colors are given together, or neither");
+    if (!premasked) { GSX_CHECK_INPUT(radii.value()); GSX_CHECK_INPUT(colors.value()); }
+    const uint32_t C = viewmats.size(0), N = means.size(0), K = coeffs.size(-2);
+    TORCH_CHECK(v_colors.numel() == (int64_t)C * N * 3, "sh_colors_bwd_adam: v_colors must be [C,N,3]");
+    TORCH_CHECK(exp_avg.numel() == coeffs.numel() && exp_avg_sq.numel() == coeffs.numel(), "sh_colors_bwd_adam: moments must match coeffs");
+    at::Tensor vm = (v_means_out.has_value() && v_means_out->defined()) ? v_means_out.value() : at::empty_like(means);
+    GSX_CHECK_INPUT(vm);
+    const float* vmi = nullptr;
+    if (v_means_in.has_value() && v_means_in->defined()) { GSX_CHECK_INPUT(v_means_in.value()); vmi = v_means_in->data_ptr<float>(); }
+    check(gsx_sh_colors_bwd_adam(degrees_to_use, C, N, K, means.data_ptr<float>(), viewmats.data_ptr<float>(), coeffs.data_ptr<float>(),
+                                 premasked ? nullptr : radii->data_ptr<int32_t>(), premasked ? nullptr : colors->data_ptr<float>(),
+                                 v_colors.data_ptr<float>(), vmi, vm.data_ptr<float>(), exp_avg.data_ptr<float>(), exp_avg_sq.data_ptr<float>(),
+                                 (float)step_sh0, (float)step_shN, do_sh0 ? 1 : 0, do_shN ? 1 : 0, (float)beta1, (float)beta2, (float)eps,
+                                 (float)bc2_sqrt_rcp, cur_stream()), "sh_colors_bwd_adam");
+    return vm;
+}
+
 std::tuple<at::Tensor, at::Tensor, at::Tensor> splat_activations_fwd(const at::Tensor scaling_raw, const at::Tensor rotation_raw,
                                                                      const at::Tensor opacity_raw) {
     GSX_DEVICE_GUARD(scaling_raw);
@@ -767,6 +793,7 @@ PYBIND11_MODULE(_gsx_ops, m) {
     });
     m.def("sh_colors_fwd", &gsx_ext::sh_colors_fwd);
     m.def("sh_colors_bwd", &gsx_ext::sh_colors_bwd);
+    m.def("sh_colors_bwd_adam", &gsx_ext::sh_colors_bwd_adam);
     m.def("splat_activations_fwd", &gsx_ext::splat_activations_fwd);
     m.def("splat_activations_bwd", &gsx_ext::splat_activations_bwd);
     m.def("intersect_tile_binned", &gsx_ext::intersect_tile_binned);

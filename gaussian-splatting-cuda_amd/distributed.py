@@ -286,7 +286,7 @@ class ColorGradExchange:
         assert viewmats_all.shape[0] == dist.get_world_size()
         self._viewmats = viewmats_all.contiguous()
 
-    def sh_backward(self, sh_degree, means, sh, colors, v_colors, v_means_blend, sink_sh, sink_means):
+    def sh_backward(self, sh_degree, means, sh, colors, v_colors, v_means_blend, sink_sh, sink_means, sh_adam=None):
         """colors / v_colors: [1,N,3] of this rank's camera (post-clamp colours, gradient from the blend); v_means_blend: the blend's
         gradient w.r.t. the means.  Returns (v_sh, v_means) = the sinks, both complete (mean over the step's cameras) when finish()
         has returned."""
@@ -305,10 +305,16 @@ class ColorGradExchange:
         self._pending = [_MeanHandle(self.bucket.flat[a:b]) for a, b in self._runs]   # means | scaling | rotation | opacity, under the SH backward
         gather.wait()
         fn = self.sh_bwd_fn
-        if fn is None:
+        if sh_adam is not None and fn is None:
+            # the SH gradient is complete on every rank inside this kernel, so the Adam step of the SH tensor is applied right there
+            # (optim.FusedAdam.begin_fused_sh_step): every rank performs the identical update on identical bits
             from . import ops
-            fn = ops.sh_colors_bwd
-        fn(sh_degree, means, self._viewmats, sh, None, None, self._buf, None, sink_sh, self._tmp)
+            ops.sh_colors_bwd_adam(sh_degree, means, self._viewmats, sh, None, None, self._buf, None, self._tmp, *sh_adam)
+        else:
+            if fn is None:
+                from . import ops
+                fn = ops.sh_colors_bwd
+            fn(sh_degree, means, self._viewmats, sh, None, None, self._buf, None, sink_sh, self._tmp)
         self.bucket.last_reduced_bytes = self._buf.numel() * 4 + sum(b - a for a, b in self._runs) * 4
         return sink_sh, sink_means
 

@@ -47,6 +47,7 @@ abi_version = _C.abi_version
 # fused glue ops (extensions beyond Ops.h; include/gsx.h "fused glue")
 sh_colors_fwd = _C.sh_colors_fwd
 sh_colors_bwd = _C.sh_colors_bwd
+sh_colors_bwd_adam = _C.sh_colors_bwd_adam
 splat_activations_fwd = _C.splat_activations_fwd
 splat_activations_bwd = _C.splat_activations_bwd
 adam_step = _C.adam_step

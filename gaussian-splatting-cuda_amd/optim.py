@@ -83,10 +83,33 @@ class FusedAdam:
                 st["exp_avg_sq"] = st["exp_avg_sq"].index_select(0, indices)
 
     # ---- step ------------------------------------------------------------------------------------------------------------
+    def begin_fused_sh_step(self, iteration):
+        """The SH groups' share of step(iteration), handed to the render backward: the fused kernel gsx_sh_colors_bwd_adam applies it
+        where the SH gradient is produced (the 192 MB gradient is then never written or re-read).  Advances the sh0 / shN step counters
+        exactly as step() would and returns the kernel's arguments; the following step(iteration, skip_sh=True) updates the other groups.
+        Returns None when the split launch does not apply (K * 3 not a multiple of 4): call step() as usual then."""
+        sh = self.model.sh
+        if not ((sh.shape[1] * 3) % 4 == 0 and sh.shape[1] > 1):
+            return None
+        b1, b2 = self.betas
+        args = {}
+        for i, grp in enumerate(self.groups, start=1):
+            name = grp["name"]
+            if name not in ("sh0", "shN"):
+                continue
+            self.state["step:" + name] = t = self.step_count(name) + 1
+            skip = i == 3 and (iteration <= 1000 or (self.skip_sh_steps and iteration % 2 != 0 and iteration <= 25000))
+            args[name] = (not skip, grp["lr"] / (1.0 - math.pow(b1, t)), 1.0 / math.sqrt(1.0 - math.pow(b2, t)))
+        assert args["sh0"][2] == args["shN"][2], "sh0 / shN step counters diverged"
+        st = self._moments("sh0")
+        # positional tail of ops.sh_colors_bwd_adam: exp_avg, exp_avg_sq, step_sh0, step_shN, do_sh0, do_shN, beta1, beta2, eps, bc2_sqrt_rcp
+        return (st["exp_avg"], st["exp_avg_sq"], args["sh0"][1], args["shN"][1], args["sh0"][0], args["shN"][0], b1, b2, self.eps, args["sh0"][2])
+
     @torch.no_grad()
-    def step(self, iteration, rows=None):
+    def step(self, iteration, rows=None, skip_sh=False):
         """One Adam step of every group.  rows=(lo, hi) restricts the update to that block of Gaussians (distributed.ShardedAdam:
-        the other blocks are updated by the other ranks); step counters and bias corrections advance as for a full step."""
+        the other blocks are updated by the other ranks); step counters and bias corrections advance as for a full step.
+        skip_sh: the sh0 / shN groups were stepped by the fused render backward (begin_fused_sh_step)."""
         b1, b2 = self.betas
         sh = self.model.sh
         sh_grad = sh.grad
@@ -97,7 +120,7 @@ class FusedAdam:
             name = grp["name"]
             p = self._param(name)
             grad = sh_grad if name in ("sh0", "shN") else p.grad
-            if grad is None or (name == "shN" and sh.shape[1] == 1):
+            if grad is None or (name == "shN" and sh.shape[1] == 1) or (skip_sh and name in ("sh0", "shN")):
                 continue
             self.state["step:" + name] = t = self.step_count(name) + 1
             skip = i == 3 and (iteration <= 1000 or (self.skip_sh_steps and iteration % 2 != 0 and iteration <= 25000))

@@ -315,7 +315,13 @@ class GutRenderFunction(torch.autograd.Function):
         if s.get("_color_exchange") is not None:
             # multi-GPU: the ranks exchange the 3 colour-gradient floats per Gaussian and every rank runs the SH backward over all
             # cameras of the step; the other gradients are all-reduced meanwhile (distributed.ColorGradExchange)
-            v_sh, v_means = s["_color_exchange"].sh_backward(sh_degree, means, sh, colors, v_colors, v_means, s["sh"], s["means"])
+            v_sh, v_means = s["_color_exchange"].sh_backward(sh_degree, means, sh, colors, v_colors, v_means, s["sh"], s["means"],
+                                                             sh_adam=s.get("_sh_adam"))
+        elif s.get("_sh_adam") is not None:
+            # SH backward fused with the Adam step of the SH tensor (optim.FusedAdam.begin_fused_sh_step): sh and its moments are updated
+            # in place by the kernel that produces the gradient; the gradient itself is not written (the "sh" sink keeps its old content)
+            v_sh = s.get("sh")
+            v_means = ops.sh_colors_bwd_adam(sh_degree, means, viewmat, sh, radii, colors, v_colors, v_means, s.get("means"), *s["_sh_adam"])
         else:
             v_sh, v_means = ops.sh_colors_bwd(sh_degree, means, viewmat, sh, radii, colors, v_colors, v_means, s.get("sh"), s.get("means"))
         v_bg = None

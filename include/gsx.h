@@ -247,6 +247,15 @@ int gsx_sh_colors_fwd(uint32_t degrees_to_use, uint32_t C, uint32_t N, uint32_t 
 int gsx_sh_colors_bwd(uint32_t degrees_to_use, uint32_t C, uint32_t N, uint32_t K, const float* means,
                       const float* viewmats, const float* coeffs, const int32_t* radii, const float* colors,
                       const float* v_colors, float* v_coeffs, const float* v_means_in, float* v_means_out, void* stream);
+/* gsx_sh_colors_bwd fused with the Adam step of the SH tensor (groups sh0 = first 3 floats of a row / shN = the rest of
+ * src/training/optimizers/fused_adam.cpp:20-96; arithmetic of gsx_adam_step_split): coeffs, exp_avg, exp_avg_sq [N,K,3] are updated in
+ * place and the SH gradient is never written (1 M Gaussians: 576 MB of HBM traffic less per training iteration).  K * 3 % 4 == 0.
+ * step_* = lr * bias_correction1_rcp of the group; do_* = 0 leaves the group's block untouched (the shN warm-up quirk). */
+int gsx_sh_colors_bwd_adam(uint32_t degrees_to_use, uint32_t C, uint32_t N, uint32_t K, const float* means,
+                           const float* viewmats, float* coeffs, const int32_t* radii, const float* colors,
+                           const float* v_colors, const float* v_means_in, float* v_means_out, float* exp_avg,
+                           float* exp_avg_sq, float step_sh0, float step_shN, int do_sh0, int do_shN, float beta1, float beta2,
+                           float eps, float bias_correction2_sqrt_rcp, void* stream);
 int gsx_splat_activations_fwd(uint32_t N, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
                               float* scales, float* quats, float* opacities, void* stream);
 int gsx_splat_activations_bwd(uint32_t N, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,

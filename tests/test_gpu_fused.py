@@ -110,3 +110,43 @@ def test_fused_ops_vs_torch(mods):
     gs, gr, go = ops.splat_activations_bwd(sr, rr, orw, vs, vq, vo, None, None, None)
     assert torch.allclose(gs, sr2.grad, rtol=1e-5, atol=1e-7) and torch.allclose(gr, rr2.grad, rtol=1e-4, atol=1e-6)
     assert torch.allclose(go, or2.grad, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("iteration,deg", [(1500, 3), (500, 3), (1500, 1)])
+def test_sh_backward_fused_with_adam_equals_separate_step(mods, iteration, deg):
+    """Training steps through rasterize_fused with the SH tensor's Adam step applied inside the SH backward (gsx_sh_colors_bwd_adam,
+    optim.FusedAdam.begin_fused_sh_step) against the same steps with the SH gradient written and optimizer.step() over all six groups:
+    parameters, moments and step counters must agree — including the shN warm-up quirk (iteration <= 1000: shN untouched, counter
+    advances) and the rows beyond the active degree (zero gradient, still stepped)."""
+    distributed, ops, rasterizer, scenes = mods
+    from gsx import optim
+    sc, cam = _setup(scenes, rasterizer, deg)
+    bg = sc["background"].to(DEV)
+    target = torch.rand(1, 112, 160, 3, generator=torch.Generator().manual_seed(5)).to(DEV)
+    results = []
+    for fused in (False, True):
+        model = scenes.to_splat_data(dict(sc), DEV)
+        for p in model.params():
+            p.requires_grad_(True)
+        bucket = distributed.GradBucket(model.params())
+        sinks = bucket.sinks()
+        opt = optim.FusedAdam.for_splat_data(model)
+        for it in range(iteration, iteration + 3):
+            sinks["_sh_adam"] = opt.begin_fused_sh_step(it) if fused else None
+            assert (sinks["_sh_adam"] is not None) == fused
+            out = rasterizer.rasterize_fused(cam, model, bg, grad_sinks=sinks)
+            ((out.render_hwc - target) ** 2).mean().backward()
+            opt.step(it, skip_sh=fused)
+        torch.cuda.synchronize()
+        st = opt.state["sh"]
+        results.append(dict(sh=model.sh.detach().clone(), means=model.means.detach().clone(), m=st["exp_avg"].clone(), v=st["exp_avg_sq"].clone(),
+                            steps=(opt.step_count("sh0"), opt.step_count("shN"), opt.step_count("means"))))
+    a, b = results
+    assert a["steps"] == b["steps"] == (3, 3, 3)
+    for k in ("sh", "m", "v", "means"):
+        assert torch.isfinite(b[k]).all()
+        # same arithmetic in two kernels (FMA contraction may differ): a few ulp on the update, relative to the tensor's scale
+        assert float((a[k] - b[k]).abs().max()) <= 2e-6 * float(a[k].abs().max()) + 1e-12, k
+    if iteration <= 1000:   # shN frozen: its block is untouched in both
+        assert torch.equal(b["sh"][:, 1:], scenes.to_splat_data(dict(sc), DEV).sh[:, 1:])
+    assert float((b["sh"][:, :1] - scenes.to_splat_data(dict(sc), DEV).sh[:, :1]).abs().max()) > 0
