@@ -72,7 +72,7 @@ class OpTimer:
         self.names = ["projection_ut_3dgs_fused", "spherical_harmonics_fwd", "spherical_harmonics_bwd", "intersect_tile",
                       "intersect_offset", "rasterize_to_pixels_from_world_3dgs_fwd", "rasterize_to_pixels_from_world_3dgs_bwd",
                       "sh_colors_fwd", "sh_colors_bwd", "sh_colors_bwd_adam", "splat_activations_fwd", "splat_activations_bwd",
-                      "photometric_loss_fwd", "photometric_loss_bwd", "intersect_tile_binned", "adam_step", "adam_step_split"]
+                      "photometric_loss_fwd", "photometric_loss_bwd", "intersect_tile_binned", "adam_step", "adam_step_split", "adam_step_multi"]
         self.orig = {n: getattr(ops_mod, n) for n in self.names}
         self.events = {n: [] for n in self.names}
         self.enabled = False
@@ -346,9 +346,9 @@ def main():
         K = (deg + 1) ** 2
         ab = algorithmic_bytes(N, 1, I, P, tiles, deg, K)
         n_params = sum(p.numel() for p in model.params())
-        ab["adam_step"] = ab["adam_step_split"] = None  # priced together below
+        ab["adam_step"] = ab["adam_step_split"] = ab["adam_step_multi"] = None  # priced together below
         kernels = {}
-        adam_ms = sum(all_ms.pop(n, 0.0) * len(timer.events.get(n, [])) for n in ("adam_step", "adam_step_split"))
+        adam_ms = sum(all_ms.pop(n, 0.0) * len(timer.events.get(n, [])) for n in ("adam_step", "adam_step_split", "adam_step_multi"))
         for n, ms in all_ms.items():
             gbs = ab[n] / (ms * 1e-3) / 1e9
             kernels[n] = {"ms": round(ms, 4), "algorithmic_bytes": int(ab[n]), "GBps": round(gbs, 1),

@@ -6,6 +6,7 @@
 #include <algorithm>
 
 #include "gsx_device.hpp"
+#include "../../include/gsx.h"
 
 namespace gsx {
 
@@ -74,9 +75,75 @@ __global__ __launch_bounds__(256) void adam_step_split_kernel(uint64_t n4, uint3
     }
 }
 
+// Several dense tensors in ONE launch (the means / scaling / rotation / opacity groups of a training step: four launches of 3-16 MB
+// each left the chip half idle between them).  Block b works on tensor t with blk_begin[t] <= b < blk_begin[t + 1].
+struct AdamMulti {
+    float* param[GSX_ADAM_MULTI_MAX]; float* exp_avg[GSX_ADAM_MULTI_MAX]; float* exp_avg_sq[GSX_ADAM_MULTI_MAX]; const float* grad[GSX_ADAM_MULTI_MAX];
+    uint64_t n[GSX_ADAM_MULTI_MAX];
+    float step[GSX_ADAM_MULTI_MAX], bc2[GSX_ADAM_MULTI_MAX];
+    uint32_t blk_begin[GSX_ADAM_MULTI_MAX + 1];
+    uint32_t count;
+};
+
+__global__ __launch_bounds__(256) void adam_step_multi_kernel(AdamMulti a, float beta1, float beta2, float eps) {
+    uint32_t t = 0;
+    while (t + 1 < a.count && blockIdx.x >= a.blk_begin[t + 1]) ++t;
+    const uint32_t nb = a.blk_begin[t + 1] - a.blk_begin[t], b = blockIdx.x - a.blk_begin[t];
+    float* __restrict__ P = a.param[t]; float* __restrict__ M = a.exp_avg[t]; float* __restrict__ V = a.exp_avg_sq[t];
+    const float* __restrict__ G = a.grad[t];
+    const float step_size = a.step[t], bc2 = a.bc2[t];
+    const uint64_t n = a.n[t], n4 = n / 4;
+    const bool vec = ((((uintptr_t)P | (uintptr_t)M | (uintptr_t)V | (uintptr_t)G) & 15u) == 0);
+#define GSX_ADAM1(p, m, v, g)                                  \
+    m = beta1 * m + (1.0f - beta1) * g;                        \
+    v = beta2 * v + (1.0f - beta2) * g * g;                    \
+    p -= step_size * m / (sqrtf(v) * bc2 + eps);
+    if (vec) {
+        for (uint64_t i = (uint64_t)b * 256u + threadIdx.x; i < n4; i += (uint64_t)nb * 256u) {
+            const float4 g = reinterpret_cast<const float4*>(G)[i];
+            float4 m = reinterpret_cast<float4*>(M)[i], v = reinterpret_cast<float4*>(V)[i], p = reinterpret_cast<float4*>(P)[i];
+            GSX_ADAM1(p.x, m.x, v.x, g.x) GSX_ADAM1(p.y, m.y, v.y, g.y) GSX_ADAM1(p.z, m.z, v.z, g.z) GSX_ADAM1(p.w, m.w, v.w, g.w)
+            reinterpret_cast<float4*>(P)[i] = p; reinterpret_cast<float4*>(M)[i] = m; reinterpret_cast<float4*>(V)[i] = v;
+        }
+    }
+    for (uint64_t i = (vec ? n4 * 4 : 0) + (uint64_t)b * 256u + threadIdx.x; i < n; i += (uint64_t)nb * 256u) {   // tail (or everything, unaligned)
+        const float g = G[i];
+        float m = M[i], v = V[i], p = P[i];
+        GSX_ADAM1(p, m, v, g)
+        P[i] = p; M[i] = m; V[i] = v;
+    }
+#undef GSX_ADAM1
+}
+
 }  // namespace gsx
 
 using namespace gsx;
+
+extern "C" int gsx_adam_step_multi(uint32_t count, float* const* param, float* const* exp_avg, float* const* exp_avg_sq,
+                                   const float* const* grad, const uint64_t* n, const float* lr, const float* bias_correction1_rcp,
+                                   const float* bias_correction2_sqrt_rcp, float beta1, float beta2, float eps, void* stream) {
+    if (count == 0) return GSX_OK;
+    if (count > GSX_ADAM_MULTI_MAX || !param || !exp_avg || !exp_avg_sq || !grad || !n || !lr || !bias_correction1_rcp || !bias_correction2_sqrt_rcp) {
+        set_error("adam_step_multi: null argument or more than GSX_ADAM_MULTI_MAX tensors");
+        return GSX_ERR_INVALID_ARGUMENT;
+    }
+    AdamMulti a;
+    a.count = 0;
+    uint32_t blocks = 0;
+    for (uint32_t t = 0; t < count; ++t) {
+        if (n[t] == 0) continue;
+        if (!param[t] || !exp_avg[t] || !exp_avg_sq[t] || !grad[t]) { set_error("adam_step_multi: null tensor"); return GSX_ERR_INVALID_ARGUMENT; }
+        const uint32_t k = a.count++;
+        a.param[k] = param[t]; a.exp_avg[k] = exp_avg[t]; a.exp_avg_sq[k] = exp_avg_sq[t]; a.grad[k] = grad[t];
+        a.n[k] = n[t]; a.step[k] = lr[t] * bias_correction1_rcp[t]; a.bc2[k] = bias_correction2_sqrt_rcp[t];
+        a.blk_begin[k] = blocks;
+        blocks += (uint32_t)std::min<uint64_t>((n[t] / 4 + 255) / 256 + 1, 8192u);   // blocks in proportion to the tensor's size
+    }
+    if (a.count == 0) return GSX_OK;
+    a.blk_begin[a.count] = blocks;
+    hipLaunchKernelGGL(adam_step_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, beta1, beta2, eps);
+    return check_launch("adam_step_multi");
+}
 
 extern "C" int gsx_adam_step_split(uint64_t rows, uint32_t cols, uint32_t split, float* param, float* exp_avg, float* exp_avg_sq,
                                    const float* grad, float lr_a, float lr_b, int step_a, int step_b, float beta1, float beta2, float eps,

@@ -658,6 +658,26 @@ at::Tensor photometric_loss_bwd(const at::Tensor& render, const at::Tensor& gt, 
 }
 
 // fused Adam step on a parameter (or a row-strided view of one: dims after the first must be dense)
+// several dense parameter groups in one launch (include/gsx.h: gsx_adam_step_multi); lrs / bias corrections per tensor
+void adam_step_multi(std::vector<at::Tensor> params, std::vector<at::Tensor> exp_avgs, std::vector<at::Tensor> exp_avg_sqs,
+                     std::vector<at::Tensor> grads, std::vector<double> lrs, std::vector<double> bc1_rcps, std::vector<double> bc2_sqrt_rcps,
+                     double beta1, double beta2, double eps) {
+    const size_t k = params.size();
+    TORCH_CHECK(k > 0 && k <= GSX_ADAM_MULTI_MAX && exp_avgs.size() == k && exp_avg_sqs.size() == k && grads.size() == k && lrs.size() == k &&
+                bc1_rcps.size() == k && bc2_sqrt_rcps.size() == k, "adam_step_multi: 1..", GSX_ADAM_MULTI_MAX, " tensors, equally long lists");
+    GSX_DEVICE_GUARD(params[0]);
+    float* p[GSX_ADAM_MULTI_MAX]; float* m[GSX_ADAM_MULTI_MAX]; float* v[GSX_ADAM_MULTI_MAX]; const float* g[GSX_ADAM_MULTI_MAX];
+    uint64_t n[GSX_ADAM_MULTI_MAX]; float lr[GSX_ADAM_MULTI_MAX], b1[GSX_ADAM_MULTI_MAX], b2[GSX_ADAM_MULTI_MAX];
+    for (size_t i = 0; i < k; ++i) {
+        GSX_CHECK_INPUT(params[i]); GSX_CHECK_INPUT(exp_avgs[i]); GSX_CHECK_INPUT(exp_avg_sqs[i]); GSX_CHECK_INPUT(grads[i]);
+        TORCH_CHECK(params[i].numel() == grads[i].numel() && params[i].numel() == exp_avgs[i].numel() && params[i].numel() == exp_avg_sqs[i].numel(),
+                    "adam_step_multi: shape mismatch in tensor ", i);
+        p[i] = params[i].data_ptr<float>(); m[i] = exp_avgs[i].data_ptr<float>(); v[i] = exp_avg_sqs[i].data_ptr<float>(); g[i] = grads[i].data_ptr<float>();
+        n[i] = (uint64_t)params[i].numel(); lr[i] = (float)lrs[i]; b1[i] = (float)bc1_rcps[i]; b2[i] = (float)bc2_sqrt_rcps[i];
+    }
+    check(gsx_adam_step_multi((uint32_t)k, p, m, v, g, n, lr, b1, b2, (float)beta1, (float)beta2, (float)eps, cur_stream()), "adam_step_multi");
+}
+
 void adam_step(at::Tensor param, at::Tensor exp_avg, at::Tensor exp_avg_sq, const at::Tensor grad, double lr, double beta1,
                double beta2, double eps, double bias_correction1_rcp, double bias_correction2_sqrt_rcp) {
     GSX_DEVICE_GUARD(param);
@@ -802,6 +822,7 @@ PYBIND11_MODULE(_gsx_ops, m) {
         return gsplat::intersect_tile_device_sort(means2d, radii, depths, C, tile_size, tile_width, tile_height, sort);
     });
     m.def("adam_step", &gsx_ext::adam_step);
+    m.def("adam_step_multi", &gsx_ext::adam_step_multi);
     m.def("adam_step_wrapper", [](at::Tensor param, at::Tensor exp_avg, at::Tensor exp_avg_sq, const at::Tensor grad, float lr, float beta1, float beta2,
                                   float eps, float bc1_rcp, float bc2_sqrt_rcp) {  // the reference's signature (adam_api.h:11-21)
         fast_gs::optimizer::adam_step_wrapper(param, exp_avg, exp_avg_sq, grad, lr, beta1, beta2, eps, bc1_rcp, bc2_sqrt_rcp);

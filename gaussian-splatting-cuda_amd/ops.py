@@ -51,6 +51,7 @@ sh_colors_bwd_adam = _C.sh_colors_bwd_adam
 splat_activations_fwd = _C.splat_activations_fwd
 splat_activations_bwd = _C.splat_activations_bwd
 adam_step = _C.adam_step
+adam_step_multi = _C.adam_step_multi
 adam_step_wrapper = _C.adam_step_wrapper
 intersect_tile_binned = _C.intersect_tile_binned
 intersect_tile_device_sort = _C.intersect_tile_device_sort

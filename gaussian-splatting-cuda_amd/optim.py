@@ -115,7 +115,7 @@ class FusedAdam:
         sh_grad = sh.grad
         r = (lambda t: t) if rows is None else (lambda t: t[rows[0]:rows[1]])
         split_ok = (sh.shape[1] * 3) % 4 == 0 and sh.shape[1] > 1
-        do_sh = {}
+        do_sh, dense = {}, []
         for i, grp in enumerate(self.groups, start=1):
             name = grp["name"]
             p = self._param(name)
@@ -132,7 +132,14 @@ class FusedAdam:
             if skip:
                 continue
             st = self._moments(name)
-            ops.adam_step(r(p.data), r(st["exp_avg"]), r(st["exp_avg_sq"]), r(grad), grp["lr"], b1, b2, self.eps, bc1_rcp, bc2_sqrt_rcp)
+            dense.append((r(p.data), r(st["exp_avg"]), r(st["exp_avg_sq"]), r(grad), grp["lr"], bc1_rcp, bc2_sqrt_rcp))
+        if dense and all(t.is_contiguous() for d in dense for t in d[:4]):
+            # the dense groups (means, scaling, rotation, opacity) in ONE launch: four launches of 4-16 MB each leave the chip half idle
+            cols = list(zip(*dense))
+            ops.adam_step_multi(list(cols[0]), list(cols[1]), list(cols[2]), list(cols[3]), list(cols[4]), list(cols[5]), list(cols[6]), b1, b2, self.eps)
+        else:
+            for d in dense:
+                ops.adam_step(d[0], d[1], d[2], d[3], d[4], b1, b2, self.eps, d[5], d[6])
         if do_sh:
             a = do_sh.get("sh0", (False, 0.0, 1.0, 1.0))
             b = do_sh.get("shN", (False, 0.0, a[2], a[3]))

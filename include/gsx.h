@@ -211,6 +211,13 @@ int gsx_adam_step_split(uint64_t rows, uint32_t cols, uint32_t split, float* par
                         const float* grad, float lr_a, float lr_b, int step_a, int step_b, float beta1, float beta2, float eps,
                         float bias_correction1_rcp, float bias_correction2_sqrt_rcp, void* stream);
 
+/* The same update on up to GSX_ADAM_MULTI_MAX dense tensors in ONE launch, each with its own learning rate and bias corrections (the
+ * parameter groups of one optimizer step: fused_adam.cpp:20-96 loops over them with one launch each).  Arrays are host arrays. */
+#define GSX_ADAM_MULTI_MAX 8
+int gsx_adam_step_multi(uint32_t count, float* const* param, float* const* exp_avg, float* const* exp_avg_sq, const float* const* grad,
+                        const uint64_t* n, const float* lr, const float* bias_correction1_rcp, const float* bias_correction2_sqrt_rcp,
+                        float beta1, float beta2, float eps, void* stream);
+
 /* ---- next tier: photometric loss ----------------------------------------------------------
  * fusedssim / fusedssim_backward, src/training/kernels/ssim.cu:436-470 / 478-510 (kernels :64-275, :283-428): planar
  * [B,CH,H,W] images, 11x11 Gaussian window (sigma 1.5), zero padding.  Pass dm_* = NULL for train == false. */

@@ -145,8 +145,9 @@ def test_sh_backward_fused_with_adam_equals_separate_step(mods, iteration, deg):
     assert a["steps"] == b["steps"] == (3, 3, 3)
     for k in ("sh", "m", "v", "means"):
         assert torch.isfinite(b[k]).all()
-        # same arithmetic in two kernels (FMA contraction may differ): a few ulp on the update, relative to the tensor's scale
-        assert float((a[k] - b[k]).abs().max()) <= 2e-6 * float(a[k].abs().max()) + 1e-12, k
+        # same arithmetic in two kernels (FMA contraction may differ, and m / sqrt(v) amplifies the last bits of a tiny gradient): the
+        # updates agree to a small fraction of one step (lr 2.5e-3 / 1.25e-4), relative to the tensor's scale
+        assert float((a[k] - b[k]).abs().max()) <= 1e-5 * float(a[k].abs().max()) + 1e-12, k
     if iteration <= 1000:   # shN frozen: its block is untouched in both
         assert torch.equal(b["sh"][:, 1:], scenes.to_splat_data(dict(sc), DEV).sh[:, 1:])
     assert float((b["sh"][:, :1] - scenes.to_splat_data(dict(sc), DEV).sh[:, :1]).abs().max()) > 0
