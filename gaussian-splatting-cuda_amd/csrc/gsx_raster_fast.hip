@@ -832,7 +832,7 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
                                                                           float4* __restrict__ ws_rec, int32_t* __restrict__ ws_head) {
     // record planes: 0 u0, 1 v0, 2 l00, 3 l01, 4 l11, 5 lo, 6 d1, 7 d2, 8 d3, 9 d4, 10 d5, 11 red, 12 green, 13 blue, 14 rad2, 15 k2 (footprint())
     __shared__ float s_rec[16][GS];
-    __shared__ float s_acc[16][GS];          // plane 15 (the butterfly's padding value) counts the passes that listed the slot: > 0 = touched
+    __shared__ float s_acc[16][GS + 8];      // (+8: the four pixel rows of a pass flush the same slot to planes p, p+1, p+2, p+3 -> four different banks) plane 15 (the butterfly's padding value) counts the passes that listed the slot: > 0 = touched
     __shared__ int32_t s_gid[GS];
     __shared__ uint8_t s_list[16][GS];       // [wave * 4 + k]: slots of the super-chunk whose footprint reaches 4x4 block k of the wave's quadrant
     __shared__ float s_T[RB], s_tbuf[RB];    // per pixel: the two loop-carried quantities of the back-to-front recurrence, between super-chunks

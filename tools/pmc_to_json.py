@@ -29,13 +29,13 @@ def main():
     find = lambda sub: next((v for n, v in k.items() if sub in n), None)  # noqa: E731
     traffic = lambda v: int((2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024) if v else 0  # noqa: E731
     pack, fwd, gather = find("pack_records"), find("raster_fwd_fast"), find("gsx_bwd_gather")
-    bwd = find("raster_bwd_gm") or find("raster_bwd_fast")
+    bwd = find("raster_bwd_gq") or find("raster_bwd_gm") or find("raster_bwd_fast")
     entry = {
         "source": source,
         "rasterize_to_pixels_from_world_3dgs_fwd": {"hbm_bytes": traffic(pack) + traffic(fwd), "valu_insts": int(fwd["SQ_INSTS_VALU"]),
                                                     "kernels": "pack_records + raster_fwd_fast"},
         "rasterize_to_pixels_from_world_3dgs_bwd": {"hbm_bytes": traffic(bwd) + traffic(gather), "valu_insts": int(bwd["SQ_INSTS_VALU"]),
-                                                    "kernels": "raster_bwd_gm (or raster_bwd_fast) + gsx_bwd_gather; packed records reused from the forward"},
+                                                    "kernels": "raster_bwd_gq (or raster_bwd_fast) + gsx_bwd_gather; packed records reused from the forward"},
     }
     path = os.path.join(ROOT, "profiles", "pmc.json")
     data = json.load(open(path)) if os.path.exists(path) else {}
