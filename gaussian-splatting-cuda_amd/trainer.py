@@ -21,11 +21,14 @@ from .strategy import MCMC, OptimizationParameters
 
 class Trainer:
     def __init__(self, model, cameras, images, params: OptimizationParameters = None, background=None, scene_scale=1.0, seed=0,
-                 sharded_adam=False, exchange="rows"):
+                 sharded_adam=False, exchange="rows", fused_sh_adam=True):
         """cameras: list of rasterizer.Camera; images: list of [3,H,W] ground-truth tensors on the device.
         sharded_adam (world > 1): reduce-scatter -> Adam on this rank's 1/world of the Gaussians -> all-gather of the parameters
         (distributed.ShardedAdam) instead of all-reduce + replicated Adam.
-        exchange (world > 1, replicated Adam): "rows" = all-reduce of the visible gradient rows; "colors" = distributed.ColorGradExchange."""
+        exchange (world > 1, replicated Adam): "rows" = all-reduce of the visible gradient rows; "colors" = distributed.ColorGradExchange.
+        fused_sh_adam: on iterations without densification the SH tensor's Adam step is applied inside the SH backward
+        (gsx_sh_colors_bwd_adam: the SH gradient is never written); needs the complete SH gradient on this rank, i.e. one GPU or the
+        colour exchange.  Refine iterations keep the separate step: relocation / growth run between backward and optimizer there."""
         self.model, self.cameras, self.images = model, cameras, images
         self.params = params or OptimizationParameters()
         self.bg = background
@@ -37,6 +40,7 @@ class Trainer:
         for p in model.params():
             p.requires_grad_(True)
         self.exchange = exchange if (self.world > 1 and not sharded_adam) else None
+        self.fused_sh_adam = fused_sh_adam and not sharded_adam and (self.world == 1 or self.exchange == "colors")
         self.strategy = MCMC(model, self.params, scene_scale, gen)
         self.strategy.on_resize = self._rebuild_bucket
         self._rebuild_bucket(model)
@@ -67,6 +71,9 @@ class Trainer:
         i = (it * self.world + self.rank) % len(self.cameras)
         if self.exchange == "colors":   # the step's camera batch in rank order
             self.xch.begin_step(torch.stack([self.cameras[(it * self.world + r) % len(self.cameras)].viewmat for r in range(self.world)]))
+        fuse = self.fused_sh_adam and it < self.params.iterations and not self.strategy.is_refining(it)
+        self.sinks["_sh_adam"] = self.strategy.optimizer.begin_fused_sh_step(it) if fuse else None
+        fuse = self.sinks["_sh_adam"] is not None
         out = rasterizer.rasterize_fused(self.cameras[i], self.model, self.bg, grad_sinks=self.sinks)
         gt = self.images[i]
         loss = gloss.photometric_loss(out.render_hwc, gt, self.params.lambda_dssim)
@@ -84,7 +91,7 @@ class Trainer:
                 self.bucket.all_reduce_mean_rows((out.aux["radii_full"] > 0).all(-1))
             self._add_regularisers()  # identical on every rank (functions of the replicated parameters): added after the reduction
             self.strategy.post_backward(it, out)
-            self.strategy.step(it)
+            self.strategy.step(it, optimizer_step=(lambda k: self.strategy.optimizer.step(k, skip_sh=True)) if fuse else None)
         self.last_loss = loss.detach()
         return self.last_loss
 
