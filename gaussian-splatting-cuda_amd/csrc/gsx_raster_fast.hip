@@ -771,8 +771,10 @@ GSX_DEV void rows_reduce16(float (&x)[16], float (&z)[4]) {
 // 0.999 (opacity < 0.999: alpha = o exp(-s) stays below it), which drops the clamp and its gradient mask.
 // ROWDV: dv is the same for the lane's four pixels (perfect pinhole: a lane's pixels are one image row), so the dv factors of the
 // moments are applied once per pass to three sums per weight instead of per pixel (12 instead of 19 accumulation VALU per pixel).
-template <bool CLAMP, bool ROWDV>
-GSX_DEV void gq_row(const GmLaneRec& g, const GmRowPix& px, const float (&du)[4], const float (&dv)[4], const float (&num2)[4],
+// FISH: unnormalised rays (u, v, w): du' = u - w u0 has d/du0 = -w and A d = w h + a0 du' + a1 dv', so the moments that multiply d/du0,
+// d/dv0 (first-order a) and h (the b family's 1, du', dv') carry the matching powers of the pixel's w (as in raster_bwd_fast_kernel).
+template <bool CLAMP, bool ROWDV, bool FISH>
+GSX_DEV void gq_row(const GmLaneRec& g, const GmRowPix& px, const float (&du)[4], const float (&dv)[4], const float (&pw)[4], const float (&num2)[4],
                     const float (&rden)[4], float (&acc)[16], float (&T_out)[4], float (&tb_out)[4]) {
     float al[4], ra[4], P[4];
 #pragma unroll
@@ -812,7 +814,12 @@ GSX_DEV void gq_row(const GmLaneRec& g, const GmRowPix& px, const float (&du)[4]
         } else {
             const float x7 = aw * du[h], x8 = aw * dv[h], x10 = bw * du[h], x11 = bw * dv[h];
             acc[4] = fmaf(x7, du[h], acc[4]); acc[5] = fmaf(x7, dv[h], acc[5]); acc[6] = fmaf(x8, dv[h], acc[6]);
-            acc[7] += x7; acc[8] += x8; acc[9] += bw; acc[10] += x10; acc[11] += x11;
+            if (FISH) {
+                acc[7] = fmaf(x7, pw[h], acc[7]); acc[8] = fmaf(x8, pw[h], acc[8]); acc[9] = fmaf(bw, pw[h] * pw[h], acc[9]);
+                acc[10] = fmaf(x10, pw[h], acc[10]); acc[11] = fmaf(x11, pw[h], acc[11]);
+            } else {
+                acc[7] += x7; acc[8] += x8; acc[9] += bw; acc[10] += x10; acc[11] += x11;
+            }
             acc[12] = fmaf(x10, du[h], acc[12]); acc[13] = fmaf(x10, dv[h], acc[13]); acc[14] = fmaf(x11, dv[h], acc[14]);
         }
         T_out[h] = T[h]; tb_out[h] = tbuf - e[h];
@@ -837,7 +844,7 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
     __shared__ uint8_t s_list[16][GS];       // [wave * 4 + k]: slots of the super-chunk whose footprint reaches 4x4 block k of the wave's quadrant
     __shared__ float s_T[RB], s_tbuf[RB];    // per pixel: the two loop-carried quantities of the back-to-front recurrence, between super-chunks
     __shared__ uint32_t s_lock;
-    __shared__ float4 s_uvb[KIND == CAM_PERFECT_PINHOLE ? 1 : RB];   // distorted cameras: per pixel (u, v, last id, -)
+    __shared__ float4 s_uvb[KIND == CAM_PERFECT_PINHOLE ? 1 : RB];   // distorted cameras: per pixel (u, v, last id, w) (w = 1 unless fisheye)
     __shared__ float s_bounds[4][4];
     __shared__ int32_t s_blockmax;
     const uint32_t cid = blockIdx.y;
@@ -852,13 +859,20 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
     const bool inside = i < a.H && j < a.W;
     const size_t pix = (size_t)cid * a.H * a.W + (size_t)min(i, a.H - 1) * a.W + min(j, a.W - 1);
     const float* bg = a.backgrounds ? a.backgrounds + cid * 3 : nullptr;
+    if (KIND == CAM_OPENCV_FISHEYE && a.tile_flags != nullptr && a.tile_flags[(size_t)cid * a.th * a.tw + tile_id]) return;  // generic kernel's tile
     const Camera<KIND> cam(a.cams, cid, a.W, a.H);
-    float u, v;
-    const bool ray_ok = pixel_uv(cam, i, j, u, v);
+    float u, v, w;
+    const bool ray_ok = pixel_ray(cam, i, j, u, v, w);
     const bool active = inside && ray_ok;
     if (tid == 0) { s_blockmax = -1; s_lock = 0u; }
     float wb[4], tb[4];
-    uv_bounds(active, u, v, wave, lane, s_bounds, wb, tb);   // contains a barrier
+    // footprints live in the chart (u / w, v / w); a fisheye pixel near or beyond 90 degrees has none: its block's / wave's / tile's bounds
+    // become infinite, which switches the culling off for them
+    const bool wide = KIND == CAM_OPENCV_FISHEYE && active && w < 0.05f;
+    const float iw = KIND == CAM_OPENCV_FISHEYE ? 1.f / fmaxf(w, 0.05f) : 1.f;
+    const float uc = u * iw, vc = v * iw;
+    uv_bounds(active, uc, vc, wave, lane, s_bounds, wb, tb, wide);   // contains a barrier
+    const bool no_cull = KIND == CAM_OPENCV_FISHEYE && !(tb[0] > -INFINITY);
 
     const int32_t* toff = a.tile_offsets + (size_t)cid * a.th * a.tw;
     const int32_t range_start = toff[tile_id];
@@ -869,10 +883,11 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
         float tail = v_render_alphas ? v_render_alphas[pix] : 0.f;   // T_final * (v_alpha_out - bg . v_out)   (Bwd.cu:307-316)
         if (bg) tail -= bg[0] * v_render_colors[pix * 3] + bg[1] * v_render_colors[pix * 3 + 1] + bg[2] * v_render_colors[pix * 3 + 2];
         s_T[tid] = T_final; s_tbuf[tid] = tail * T_final;
-        if (KIND != CAM_PERFECT_PINHOLE) s_uvb[tid] = make_float4(u, v, __int_as_float(active ? last_ids[pix] : -1), 0.f);
+        if (KIND != CAM_PERFECT_PINHOLE) s_uvb[tid] = make_float4(u, v, __int_as_float(active ? last_ids[pix] : -1), w);
     }
     // bounds and last id of this lane's 4x4 block (row of 16 lanes), then as wave-uniform scalars per block
-    float bu0 = active ? u : INFINITY, bu1 = active ? u : -INFINITY, bv0 = active ? v : INFINITY, bv1 = active ? v : -INFINITY;
+    float bu0 = wide ? -INFINITY : (active ? uc : INFINITY), bu1 = wide ? INFINITY : (active ? uc : -INFINITY);
+    float bv0 = wide ? -INFINITY : (active ? vc : INFINITY), bv1 = wide ? INFINITY : (active ? vc : -INFINITY);
     int32_t blast = active ? last_ids[pix] : -1;
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) {
@@ -916,7 +931,7 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
             s_rec[0][tid] = sr.r0.x; s_rec[1][tid] = sr.r0.y; s_rec[2][tid] = sr.r0.z; s_rec[3][tid] = sr.r0.w;
             s_rec[4][tid] = sr.r1.x; s_rec[5][tid] = sr.r1.y; s_rec[6][tid] = sr.r1.z; s_rec[7][tid] = sr.r1.w;
             s_rec[8][tid] = sr.r2.x; s_rec[9][tid] = sr.r2.y; s_rec[10][tid] = sr.r2.z; s_rec[11][tid] = sr.r2.w;
-            s_rec[12][tid] = sr.r3.x; s_rec[13][tid] = sr.r3.y; s_rec[14][tid] = sr.cull.z; s_rec[15][tid] = sr.cull.w;
+            s_rec[12][tid] = sr.r3.x; s_rec[13][tid] = sr.r3.y; s_rec[14][tid] = no_cull ? INFINITY : sr.cull.z; s_rec[15][tid] = sr.cull.w;
             s_gid[tid] = g;
         }
 #pragma unroll
@@ -956,7 +971,7 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
             const uint32_t y = by + prow;
             const uint32_t cbase = wave * 64u + (uint32_t)sb * 16u + prow * 4u;   // carries / s_uvb index of this lane's first pixel
             GmRowPix px;
-            float pu[4], pv[4];
+            float pu[4], pv[4], pw[4];
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 const uint32_t x = bx + (uint32_t)h;
@@ -968,7 +983,7 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
                 } else {
                     const float4 q = s_uvb[cbase + h];
                     px.binf[h] = __float_as_int(q.z);
-                    pu[h] = q.x; pv[h] = q.y;
+                    pu[h] = q.x; pv[h] = q.y; pw[h] = q.w;
                 }
             }
             const float bu = ((float)bx + 0.5f - cam.cx) * su;                       // perfect pinhole: u of the block's column 0
@@ -996,6 +1011,16 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
                         num2[h] = fmaf(t0, t0, t1sq);
                         rden[h] = __builtin_amdgcn_rcpf(fmaf(du[h], fmaf(g.d3, du[h], Br), Ar));
                     }
+                } else if (KIND == CAM_OPENCV_FISHEYE) {   // unnormalised rays (u, v, w): fast_alpha_ray
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        du[h] = fmaf(-pw[h], g.u0, pu[h]); dv[h] = fmaf(-pw[h], g.v0, pv[h]);
+                        const float t0 = fmaf(g.l01, dv[h], g.l00 * du[h]);
+                        const float t1 = g.l11 * dv[h];
+                        num2[h] = fmaf(t0, t0, t1 * t1);
+                        rden[h] = __builtin_amdgcn_rcpf(fmaf(du[h], fmaf(g.d3, du[h], fmaf(g.d4, dv[h], g.d1 * pw[h])),
+                                                             fmaf(dv[h], fmaf(g.d5, dv[h], g.d2 * pw[h]), pw[h] * pw[h])));
+                    }
                 } else {
 #pragma unroll
                     for (int h = 0; h < 4; ++h) {
@@ -1007,8 +1032,8 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
                     }
                 }
                 float acc[16], T_out[4], tb_out[4];
-                if (clamp) gq_row<true, KIND == CAM_PERFECT_PINHOLE>(g, px, du, dv, num2, rden, acc, T_out, tb_out);
-                else gq_row<false, KIND == CAM_PERFECT_PINHOLE>(g, px, du, dv, num2, rden, acc, T_out, tb_out);
+                if (clamp) gq_row<true, KIND == CAM_PERFECT_PINHOLE, KIND == CAM_OPENCV_FISHEYE>(g, px, du, dv, pw, num2, rden, acc, T_out, tb_out);
+                else gq_row<false, KIND == CAM_PERFECT_PINHOLE, KIND == CAM_OPENCV_FISHEYE>(g, px, du, dv, pw, num2, rden, acc, T_out, tb_out);
                 acc[15] = 1.f;   // "listed" marker (summed like a moment: no separate LDS atomic)
                 // carries for this row's next pass: the values behind the row's last Gaussian
 #pragma unroll
@@ -1197,15 +1222,16 @@ bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, 
     }
     *tile_flags_out = a.tile_flags;
     const dim3 ggrid((a.N + 255u) / 256u), gblock(256);
-    // Two backward kernels, same records and gather: Gaussian-major (global-shutter pinholes; S-1M 0.54 vs 0.86 ms, S-5M @4K 1.9 vs 2.5 ms,
-    // garden stand-in 248 vs 226 it/s) and pixel-major (fisheye: its moments are dz-weighted; GSX_BWD=pm forces it: tests, tools).
+    // Two backward kernels, same records and gather: Gaussian-major (the default; S-1M 0.49 vs 0.86 ms, S-5M @4K 1.9 vs 2.5 ms, garden
+    // stand-in 248 vs 226 it/s) and pixel-major (GSX_BWD=pm forces it: tests, tools).
     const bool force_pm = [] { const char* e = getenv("GSX_BWD"); return e && std::string(e) == "pm"; }();   // read per launch: the tests switch it
-    const bool gaussian_major = kind != CAM_OPENCV_FISHEYE && !force_pm;
+    const bool gaussian_major = !force_pm;
 #define GSX_BLEND_BWD(KERNEL, KIND)                                                                                                        \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<KIND>), grid, block, 0, st, a, render_alphas, last_ids, v_render_colors, v_render_alphas, ws_rec, ws_head)
     if (gaussian_major) {
         if (kind == CAM_PERFECT_PINHOLE) GSX_BLEND_BWD(raster_bwd_gq_kernel, CAM_PERFECT_PINHOLE);
-        else GSX_BLEND_BWD(raster_bwd_gq_kernel, CAM_OPENCV_PINHOLE);
+        else if (kind == CAM_OPENCV_PINHOLE) GSX_BLEND_BWD(raster_bwd_gq_kernel, CAM_OPENCV_PINHOLE);
+        else GSX_BLEND_BWD(raster_bwd_gq_kernel, CAM_OPENCV_FISHEYE);
     } else {
         if (kind == CAM_PERFECT_PINHOLE) GSX_BLEND_BWD(raster_bwd_fast_kernel, CAM_PERFECT_PINHOLE);
         else if (kind == CAM_OPENCV_PINHOLE) GSX_BLEND_BWD(raster_bwd_fast_kernel, CAM_OPENCV_PINHOLE);
