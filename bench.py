@@ -373,7 +373,8 @@ def main():
                     "5m": "S-5M (BASELINE configs[4]): 5M random Gaussians, SH deg 3, 3840x2160, one camera per GPU per iteration",
                     "small": "S-small (BASELINE configs[0]): 10k Gaussians, SH deg 0, 256x256"}[args.scene]
         result = {
-            "metric": "train iters/s (render + loss + backward + Adam), 1M Gaussians @1080p SH3; fwd+bwd ms/frame in `fwd_bwd`",
+            "metric": "train iters/s (render + loss + backward + Adam), %s; fwd+bwd ms/frame in `fwd_bwd`" %
+                      {"1m": "1M Gaussians @1080p SH3", "5m": "5M Gaussians @4K SH3", "small": "10k Gaussians @256x256 SH0"}[args.scene],
             "value": round(world * args.steps / elapsed, 4),
             "unit": "iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
