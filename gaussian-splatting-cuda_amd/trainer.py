@@ -21,11 +21,12 @@ from .strategy import MCMC, OptimizationParameters
 
 class Trainer:
     def __init__(self, model, cameras, images, params: OptimizationParameters = None, background=None, scene_scale=1.0, seed=0,
-                 sharded_adam=False, exchange="rows", fused_sh_adam=True):
+                 sharded_adam=False, exchange="colors", fused_sh_adam=True):
         """cameras: list of rasterizer.Camera; images: list of [3,H,W] ground-truth tensors on the device.
         sharded_adam (world > 1): reduce-scatter -> Adam on this rank's 1/world of the Gaussians -> all-gather of the parameters
         (distributed.ShardedAdam) instead of all-reduce + replicated Adam.
-        exchange (world > 1, replicated Adam): "rows" = all-reduce of the visible gradient rows; "colors" = distributed.ColorGradExchange.
+        exchange (world > 1, replicated Adam): "colors" = distributed.ColorGradExchange (default: 2.6x fewer bytes than the dense bucket, no
+        host sync); "rows" = all-reduce of the gradient rows some camera of the step saw (one host sync for the row count).
         fused_sh_adam: on iterations without densification the SH tensor's Adam step is applied inside the SH backward
         (gsx_sh_colors_bwd_adam: the SH gradient is never written); needs the complete SH gradient on this rank, i.e. one GPU or the
         colour exchange.  Refine iterations keep the separate step: relocation / growth run between backward and optimizer there."""

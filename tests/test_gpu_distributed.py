@@ -1,5 +1,5 @@
 """The world > 1 branch of the training step on real kernels: two ranks (both on GPU 0, gloo — RCCL refuses two ranks on one device)
-run Trainer.train_step through relocation and growth with (a) the compacted all-reduce + replicated Adam and (b) reduce-scatter ->
+run Trainer.train_step through relocation and growth with (a) the colour-gradient exchange + replicated Adam (the default), (c) the compacted row all-reduce and (b) reduce-scatter ->
 sharded Adam -> all-gather, and must end with bit-identical replicas; (a) and (b) must agree with each other to rounding."""
 import os
 import socket
@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, sharded, exchange="rows"):
+def _worker(rank, world, port, out_dir, sharded, exchange="colors"):
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     import gsx  # noqa: F401
@@ -42,7 +42,7 @@ def _worker(rank, world, port, out_dir, sharded, exchange="rows"):
         model.opacity_raw[:50] = -10.0                # dead Gaussians: relocation has work to do
     prm = parameters.OptimizationParameters(iterations=200, start_refine=10, refine_every=10, stop_refine=100, max_cap=2400, sh_degree_interval=1000)
     tr = trainer.Trainer(model, cams, images, prm, bg, seed=3, sharded_adam=sharded, exchange=exchange)
-    tag = "x" if exchange == "colors" else str(int(sharded))
+    tag = "rows" if exchange == "rows" else str(int(sharded))
     for it in range(1, 46):
         tr.train_step(it)
     torch.cuda.synchronize()
@@ -70,9 +70,10 @@ def test_two_rank_color_exchange_matches_row_all_reduce(tmp_path):
     exchanges sum the same terms in a different order; 45 Adam steps amplify the last bits, hence 1e-3 on the parameter norm)."""
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), False, "colors"), nprocs=world, join=True)
-    a, b = np.load(tmp_path / "params_x_0.npy"), np.load(tmp_path / "params_x_1.npy")
+    a, b = np.load(tmp_path / "params_0_0.npy"), np.load(tmp_path / "params_0_1.npy")
     assert a.shape == b.shape and np.array_equal(a, b) and np.isfinite(a).all()
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), False, "rows"), nprocs=world, join=True)
-    r = np.load(tmp_path / "params_0_0.npy")
+    r, r1 = np.load(tmp_path / "params_rows_0.npy"), np.load(tmp_path / "params_rows_1.npy")
+    assert np.array_equal(r, r1)
     assert r.shape == a.shape
     assert np.linalg.norm(a - r) / np.linalg.norm(r) < 1e-3
