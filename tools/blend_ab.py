@@ -1,5 +1,6 @@
 """Times the two blend ops in isolation (HIP events, median of n launches) on S-1M or S-5M: the A/B harness for kernel variants
-selected by environment switches (GSX_BWD=pm|gm, ...), one process per variant.   python tools/blend_ab.py [1m|5m] [n]"""
+selected by environment switches (GSX_BWD=pm = pixel-major backward, GSX_RASTER_PATH=generic, GSX_AB_CAMERA=fisheye|rolling), one process per variant;
+GSX_AB_SAVE=path keeps the gradients for tools/blend_ab_compare.py.   python tools/blend_ab.py [1m|5m] [n]"""
 import os
 import sys
 
