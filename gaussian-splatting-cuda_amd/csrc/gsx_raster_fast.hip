@@ -702,7 +702,10 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
 // the lane's own registers.  Moment records / list heads / the gather kernel are those of the pixel-major kernel (same 15 moments,
 // same layout).  First version (round 2, removed again): 64 Gaussians per batch on the 64 lanes, four row passes per block, scans of
 // six steps — 0.72 ms at S-1M against 0.86 pixel-major, batches 73 % full.  Measured and simulated numbers: DESIGN.md §4.
-constexpr int GS = 256;   // Gaussians per super-chunk (one per thread at staging time)
+#ifndef GSX_GS
+#define GSX_GS 256
+#endif
+constexpr int GS = GSX_GS;   // Gaussians per super-chunk (one per thread at staging time; <= 256: list entries are bytes)
 
 struct GmLaneRec { float u0, v0, l00, l01, l11, lo, d1, d2, d3, d4, d5, cr, cg, cb; int32_t idx; };
 struct GmRowPix { float T[4], tb[4], vr[4], vg[4], vb[4]; int32_t binf[4]; };
@@ -716,6 +719,9 @@ GSX_DEV void thread_pixel_gm(uint32_t tid, uint32_t tile_x, uint32_t tile_y, uin
 
 #ifndef GSX_GM_WAVES
 #define GSX_GM_WAVES 4
+#endif
+#ifndef GSX_GQ_SLEEP
+#define GSX_GQ_SLEEP 1   // s_sleep argument while waiting for the tile's flush lock
 #endif
 
 // ---- batch quantum 16: lanes = 16 Gaussians x the 4 pixel rows of a 4x4 block --------------------------------------------------
@@ -1046,7 +1052,7 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
                     uint32_t expected = 0u;
                     while (!__hip_atomic_compare_exchange_strong(&s_lock, &expected, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
                         expected = 0u;
-                        __builtin_amdgcn_s_sleep(1);
+                        __builtin_amdgcn_s_sleep(GSX_GQ_SLEEP);
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
