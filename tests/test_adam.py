@@ -137,3 +137,31 @@ def test_fused_adam_matches_torch_adam_over_iterations(K):
     assert (got_sh[:, :1] - ref_sh0.detach()).abs().max() < 1e-5 and (got_sh[:, 1:] - ref_shN.detach()).abs().max() < 1e-6
     for a, b in zip(params[2:], ref[2:]):
         assert (a.detach().cpu().double() - b.detach()).abs().max() < 1e-4
+
+
+def test_begin_fused_sh_step_bookkeeping():
+    """optim.FusedAdam.begin_fused_sh_step hands the sh0 / shN groups' step to the render backward: step counters advance exactly as in
+    step(), the shN block is disabled during the first 1000 iterations (fused_adam.cpp:66-70) while its counter advances, the step sizes
+    carry the bias correction of the advanced count; K * 3 not a multiple of 4 falls back (None).  No kernel runs: CPU tensors."""
+    import math
+
+    import gsx  # noqa: F401
+    from gsx import optim, rasterizer
+
+    def model(K):
+        n = 5
+        return rasterizer.SplatData(means=torch.zeros(n, 3), sh=torch.zeros(n, K, 3), scaling_raw=torch.zeros(n, 3), rotation_raw=torch.zeros(n, 4),
+                                    opacity_raw=torch.zeros(n, 1), active_sh_degree=0)
+    opt = optim.FusedAdam.for_splat_data(model(16))
+    a = opt.begin_fused_sh_step(10)
+    exp_avg, exp_avg_sq, step0, stepN, do0, doN, b1, b2, eps, bc2 = a
+    assert exp_avg.shape == (5, 16, 3) and exp_avg_sq.shape == (5, 16, 3)
+    assert do0 is True and doN is False                       # shN warm-up: untouched ...
+    assert opt.step_count("sh0") == 1 and opt.step_count("shN") == 1   # ... while its counter advances
+    assert abs(step0 - 0.0025 / (1 - 0.9)) < 1e-12 and abs(stepN - 0.000125 / (1 - 0.9)) < 1e-12
+    assert abs(bc2 - 1 / math.sqrt(1 - 0.999)) < 1e-9 and (b1, b2, eps) == (0.9, 0.999, 1e-15)
+    a = opt.begin_fused_sh_step(1500)
+    assert a[4] is True and a[5] is True and opt.step_count("shN") == 2
+    assert abs(a[2] - 0.0025 / (1 - 0.9 ** 2)) < 1e-12
+    assert opt.step_count("means") == 0                       # the other groups are stepped by step(skip_sh=True)
+    assert optim.FusedAdam.for_splat_data(model(9)).begin_fused_sh_step(1500) is None   # 27 floats per row: no 16 B vectors
