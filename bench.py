@@ -49,6 +49,7 @@ def algorithmic_bytes(N, C, I, P, tiles, deg, K):  # noqa: E741  (SURVEY.md §8d
         # fused with the SH tensor's Adam step: parameter, two moments read and written (72 K B) instead of the gradient written
         "sh_colors_bwd_adam": N * C * (12 + 8 + 12 + 12 + 24) + N * 72 * K,
         "splat_activations_fwd": N * (40 + 44),
+        "splat_activations_projection_ut": N * (12 + 40 + 44) + 32 * N * C,   # raw parameters in, activated copies + the projection's outputs out
         "splat_activations_bwd": N * (40 + 44 + 40),
         "intersect_tile": 20 * N * C + 12 * N * C + (28 * N * C + 12 * I) + 144 * I,
         "intersect_offset": 8 * I + 4 * tiles,
@@ -71,7 +72,7 @@ class OpTimer:
         self.ops = ops_mod
         self.names = ["projection_ut_3dgs_fused", "spherical_harmonics_fwd", "spherical_harmonics_bwd", "intersect_tile",
                       "intersect_offset", "rasterize_to_pixels_from_world_3dgs_fwd", "rasterize_to_pixels_from_world_3dgs_bwd",
-                      "sh_colors_fwd", "sh_colors_bwd", "sh_colors_bwd_adam", "splat_activations_fwd", "splat_activations_bwd",
+                      "sh_colors_fwd", "sh_colors_bwd", "sh_colors_bwd_adam", "splat_activations_fwd", "splat_activations_projection_ut", "splat_activations_bwd",
                       "photometric_loss_fwd", "photometric_loss_bwd", "intersect_tile_binned", "adam_step", "adam_step_split", "adam_step_multi"]
         self.orig = {n: getattr(ops_mod, n) for n in self.names}
         self.events = {n: [] for n in self.names}

@@ -454,6 +454,33 @@ at::Tensor sh_colors_bwd_adam(const uint32_t degrees_to_use, const at::Tensor me
     return vm;
 }
 
+// activations + UT projection of ONE camera in one launch (include/gsx.h): returns scales, quats, opacities, radii, means2d, depths, conics
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> splat_activations_projection_ut(
+    const at::Tensor means, const at::Tensor scaling_raw, const at::Tensor rotation_raw, const at::Tensor opacity_raw, const at::Tensor viewmats0,
+    const at::Tensor Ks, const uint32_t image_width, const uint32_t image_height, const float eps2d, const float near_plane, const float far_plane,
+    const float radius_clip, const gsplat::CameraModelType camera_model, const UnscentedTransformParameters ut_params,
+    const at::optional<at::Tensor> radial_coeffs, const at::optional<at::Tensor> tangential_coeffs, const at::optional<at::Tensor> thin_prism_coeffs) {
+    GSX_DEVICE_GUARD(means);
+    GSX_CHECK_INPUT(means); GSX_CHECK_INPUT(scaling_raw); GSX_CHECK_INPUT(rotation_raw); GSX_CHECK_INPUT(opacity_raw);
+    TORCH_CHECK(means.scalar_type() == at::kFloat, "float32 only");
+    const uint32_t N = means.size(0), C = Ks.size(0);
+    TORCH_CHECK(C == 1, "splat_activations_projection_ut: one camera per call");
+    const gsx_cameras cams = make_cams(viewmats0, at::nullopt, Ks, camera_model, ShutterType::GLOBAL, radial_coeffs, tangential_coeffs, thin_prism_coeffs, C);
+    const gsx_ut_params ut = make_ut(ut_params);
+    at::Tensor scales = at::empty_like(scaling_raw), quats = at::empty_like(rotation_raw);
+    at::Tensor opac = at::empty({(int64_t)N}, means.options());
+    at::Tensor radii = at::empty({C, N, 2}, means.options().dtype(at::kInt));
+    at::Tensor means2d = at::empty({C, N, 2}, means.options());
+    at::Tensor depths = at::empty({C, N}, means.options());
+    at::Tensor conics = at::empty({C, N, 3}, means.options());
+    check(gsx_splat_activations_projection_ut(N, means.data_ptr<float>(), rotation_raw.data_ptr<float>(), scaling_raw.data_ptr<float>(),
+                                              opacity_raw.data_ptr<float>(), &cams, image_width, image_height, eps2d, near_plane, far_plane,
+                                              radius_clip, &ut, scales.data_ptr<float>(), quats.data_ptr<float>(), opac.data_ptr<float>(),
+                                              radii.data_ptr<int32_t>(), means2d.data_ptr<float>(), depths.data_ptr<float>(),
+                                              conics.data_ptr<float>(), cur_stream()), "splat_activations_projection_ut");
+    return std::make_tuple(scales, quats, opac, radii, means2d, depths, conics);
+}
+
 std::tuple<at::Tensor, at::Tensor, at::Tensor> splat_activations_fwd(const at::Tensor scaling_raw, const at::Tensor rotation_raw,
                                                                      const at::Tensor opacity_raw) {
     GSX_DEVICE_GUARD(scaling_raw);
@@ -815,6 +842,7 @@ PYBIND11_MODULE(_gsx_ops, m) {
     m.def("sh_colors_bwd", &gsx_ext::sh_colors_bwd);
     m.def("sh_colors_bwd_adam", &gsx_ext::sh_colors_bwd_adam);
     m.def("splat_activations_fwd", &gsx_ext::splat_activations_fwd);
+    m.def("splat_activations_projection_ut", &gsx_ext::splat_activations_projection_ut);
     m.def("splat_activations_bwd", &gsx_ext::splat_activations_bwd);
     m.def("intersect_tile_binned", &gsx_ext::intersect_tile_binned);
     m.def("intersect_tile_device_sort", [](const at::Tensor means2d, const at::Tensor radii, const at::Tensor depths, uint32_t C, uint32_t tile_size,

@@ -49,6 +49,7 @@ sh_colors_fwd = _C.sh_colors_fwd
 sh_colors_bwd = _C.sh_colors_bwd
 sh_colors_bwd_adam = _C.sh_colors_bwd_adam
 splat_activations_fwd = _C.splat_activations_fwd
+splat_activations_projection_ut = _C.splat_activations_projection_ut
 splat_activations_bwd = _C.splat_activations_bwd
 adam_step = _C.adam_step
 adam_step_multi = _C.adam_step_multi

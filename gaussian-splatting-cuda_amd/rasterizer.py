@@ -268,12 +268,15 @@ class GutRenderFunction(torch.autograd.Function):
         ut = ops.UnscentedTransformParameters()
         means_c, sh_c = means.contiguous(), sh.contiguous()
         sr, rr, orw = scaling_raw.contiguous(), rotation_raw.contiguous(), opacity_raw.reshape(-1).contiguous()
-        scales, quats, opac = ops.splat_activations_fwd(sr, rr, orw)
-        if scaling_modifier != 1.0:
+        if scaling_modifier == 1.0:   # activations and projection in one launch (bit-identical to the two calls below)
+            scales, quats, opac, radii, means2d, depths, conics = ops.splat_activations_projection_ut(
+                means_c, sr, rr, orw, viewmat, K, width, height, EPS2D, NEAR_PLANE, FAR_PLANE, RADIUS_CLIP, camera_model, ut, radial, tangential, None)
+        else:
+            scales, quats, opac = ops.splat_activations_fwd(sr, rr, orw)
             scales = scales * scaling_modifier
-        radii, means2d, depths, conics, _ = ops.projection_ut_3dgs_fused(
-            means_c, quats, scales, opac, viewmat, None, K, width, height, EPS2D, NEAR_PLANE, FAR_PLANE, RADIUS_CLIP, False,
-            camera_model, ut, ops.ShutterType.GLOBAL, radial, tangential, None)
+            radii, means2d, depths, conics, _ = ops.projection_ut_3dgs_fused(
+                means_c, quats, scales, opac, viewmat, None, K, width, height, EPS2D, NEAR_PLANE, FAR_PLANE, RADIUS_CLIP, False,
+                camera_model, ut, ops.ShutterType.GLOBAL, radial, tangential, None)
         colors = ops.sh_colors_fwd(sh_degree, means_c, viewmat, sh_c, radii)
         tw, th = (width + TILE_SIZE - 1) // TILE_SIZE, (height + TILE_SIZE - 1) // TILE_SIZE
         # binned pipeline: flatten_ids + isect_offsets in one go (bit-identical to intersect_tile + intersect_offset, no isect_ids)

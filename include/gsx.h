@@ -263,6 +263,13 @@ int gsx_sh_colors_bwd_adam(uint32_t degrees_to_use, uint32_t C, uint32_t N, uint
                            const float* v_colors, const float* v_means_in, float* v_means_out, float* exp_avg,
                            float* exp_avg_sq, float step_sh0, float step_shN, int do_sh0, int do_shN, float beta1, float beta2,
                            float eps, float bias_correction2_sqrt_rcp, void* stream);
+/* gsx_splat_activations_fwd followed by gsx_projection_ut_3dgs_fused (one camera) in ONE launch: raw parameters in, the activated
+ * copies (scales, quats, opacities) and the projection (radii, means2d, depths, conics) out; bit-identical to the two calls. */
+int gsx_splat_activations_projection_ut(uint32_t N, const float* means, const float* rotation_raw, const float* scaling_raw,
+                                        const float* opacity_raw, const gsx_cameras* cams, uint32_t image_width,
+                                        uint32_t image_height, float eps2d, float near_plane, float far_plane, float radius_clip,
+                                        const gsx_ut_params* ut, float* scales, float* quats, float* opacities, int32_t* radii,
+                                        float* means2d, float* depths, float* conics, void* stream);
 int gsx_splat_activations_fwd(uint32_t N, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
                               float* scales, float* quats, float* opacities, void* stream);
 int gsx_splat_activations_bwd(uint32_t N, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,

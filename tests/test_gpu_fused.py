@@ -151,3 +151,25 @@ def test_sh_backward_fused_with_adam_equals_separate_step(mods, iteration, deg):
     if iteration <= 1000:   # shN frozen: its block is untouched in both
         assert torch.equal(b["sh"][:, 1:], scenes.to_splat_data(dict(sc), DEV).sh[:, 1:])
     assert float((b["sh"][:, :1] - scenes.to_splat_data(dict(sc), DEV).sh[:, :1]).abs().max()) > 0
+
+
+def test_activations_projection_in_one_launch_is_bit_identical(mods):
+    """gsx_splat_activations_projection_ut == gsx_splat_activations_fwd followed by gsx_projection_ut_3dgs_fused, bit for bit (every
+    output, incl. the culled Gaussians' radii), for a perfect pinhole and a distorted one."""
+    distributed, ops, rasterizer, scenes = mods
+    sc, cam = _setup(scenes, rasterizer, 3)
+    model = scenes.to_splat_data(dict(sc), DEV)
+    ut = ops.UnscentedTransformParameters()
+    vm, K = cam.world_view_transform().contiguous(), cam.K_batched().contiguous()
+    sr, rr, orw = model.scaling_raw.contiguous(), model.rotation_raw.contiguous(), model.opacity_raw.reshape(-1).contiguous()
+    for radial in (None, torch.tensor([0.05, -0.01, 0.0, 0.0, 0.0, 0.0], device=DEV)):
+        s1, q1, o1 = ops.splat_activations_fwd(sr, rr, orw)
+        r1, m1, d1, c1, _ = ops.projection_ut_3dgs_fused(model.means, q1, s1, o1, vm, None, K, 160, 112, 0.3, 0.01, 10000.0, 0.0, False,
+                                                        ops.CameraModelType.PINHOLE, ut, ops.ShutterType.GLOBAL, radial, None, None)
+        s2, q2, o2, r2, m2, d2, c2 = ops.splat_activations_projection_ut(model.means, sr, rr, orw, vm, K, 160, 112, 0.3, 0.01, 10000.0, 0.0,
+                                                                       ops.CameraModelType.PINHOLE, ut, radial, None, None)
+        assert torch.equal(s1, s2) and torch.equal(q1, q2) and torch.equal(o1, o2) and torch.equal(r1, r2)
+        vis = (r1 > 0).all(-1)
+        assert int(vis.sum()) > 1000
+        for a, b in ((m1, m2), (d1, d2), (c1, c2)):   # outputs of culled Gaussians are not written by either
+            assert torch.equal(a[vis], b[vis])
