@@ -1,6 +1,6 @@
 """Times the two blend ops in isolation (HIP events, median of n launches) on S-1M or S-5M: the A/B harness for kernel variants
 selected by environment switches (GSX_BWD=pm = pixel-major backward, GSX_RASTER_PATH=generic, GSX_AB_CAMERA=fisheye|rolling), one process per variant;
-GSX_AB_SAVE=path keeps the gradients for tools/blend_ab_compare.py.   python tools/blend_ab.py [1m|5m] [n]"""
+GSX_AB_SAVE=path keeps the gradients for tools/blend_ab_compare.py.   python tools/blend_ab.py [1m|5m|dense] [n]"""
 import os
 import sys
 
@@ -14,7 +14,11 @@ from gsx import ops, rasterizer, scenes  # noqa: E402
 which = sys.argv[1] if len(sys.argv) > 1 else "1m"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = "cuda:0"
-scene = {"1m": scenes.scene_1m, "5m": scenes.scene_5m}[which]()
+if which == "dense":   # saturated tiles: high opacity, large footprints, early termination everywhere (the regime of a trained real capture)
+    scene = scenes.scene_frustum(300_000, 640, 360, 300.0, (2.0, 6.0), scale_range=(0.01, 0.08), sh_degree=0, seed=3)
+    scene["opacities"] = torch.rand(300_000, generator=torch.Generator().manual_seed(4)) * 0.3 + 0.69
+else:
+    scene = {"1m": scenes.scene_1m, "5m": scenes.scene_5m}[which]()
 W, H = scene["width"], scene["height"]
 model = scenes.to_splat_data(scene, dev)
 fisheye = os.environ.get("GSX_AB_CAMERA") == "fisheye"   # the same scene through an equidistant fisheye of the same focal length

@@ -1,5 +1,5 @@
 """Debug tool: build libgsx with -DGSX_STATS into gpurun_out/, run the S-1M forward once and print the
-culling / early-exit counters of the fast blend kernel.  Run on the GPU box: python tools/fwd_stats.py"""
+culling / early-exit counters of the fast blend kernel.  Run on the GPU box: python tools/fwd_stats.py [1m|5m]"""
 import ctypes
 import os
 import subprocess
@@ -23,12 +23,12 @@ def main():
     import gsx  # noqa: F401
     from gsx import rasterizer, scenes
     dev = "cuda:0"
-    scene = scenes.scene_1m()
+    scene = {"1m": scenes.scene_1m, "5m": scenes.scene_5m}[sys.argv[1] if len(sys.argv) > 1 else "1m"]()
     model = scenes.to_splat_data(scene, dev)
     cam = rasterizer.Camera(viewmat=scene["viewmat"].to(dev), K=scene["K"].to(dev), width=scene["width"], height=scene["height"])
     with torch.no_grad():
         o = rasterizer.rasterize(cam, model, scene["background"].to(dev))
-    buf = (ctypes.c_ulonglong * 8)()
+    buf = (ctypes.c_ulonglong * 16)()   # gsx_debug_read_stats copies all 16 counters
     lib.gsx_debug_read_stats(buf, 1)
     names = ["wave-Gaussian evaluations", "cull candidates (wave x Gaussian)", "evaluations with >=1 contributing lane",
              "contributing (pixel,Gaussian) pairs", "survivors skipped by wave early-exit",
