@@ -14,6 +14,7 @@
 // exactly like CUB's SortPairs upstream.  The scan is rocPRIM's single-pass decoupled look-back.
 // The per-tile offsets are a lower_bound per tile (8 160 tiles @1080p) instead of the reference's
 // one-thread-per-intersection boundary detection with serial gap filling; same output.
+#include <algorithm>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -307,61 +308,25 @@ __global__ __launch_bounds__(256) void tile_sort_wave_kernel(uint32_t n_segments
 }
 
 __global__ __launch_bounds__(ISECT_BLOCK) void tile_sort_kernel(uint32_t n_tiles, uint32_t tile_n_bits, uint32_t idx_bits,
-                                                                const int32_t* __restrict__ tile_offsets, uint64_t* __restrict__ keys,
-                                                                uint64_t* __restrict__ keys_alt, int32_t* __restrict__ flatten_ids,
-                                                                int64_t* __restrict__ isect_ids, int64_t capacity) {
+                                                                const int32_t* __restrict__ tile_offsets, const uint64_t* __restrict__ keys,
+                                                                int32_t* __restrict__ flatten_ids, int64_t* __restrict__ isect_ids,
+                                                                int64_t capacity) {
     __shared__ uint64_t s_keys[TSORT_CAP + TSORT_CAP / 32];
     const uint32_t seg = blockIdx.x;
     const int64_t begin = tile_offsets[seg];
     const int n = (int)(tile_offsets[seg + 1] - tile_offsets[seg]);
     if (n <= TSORT_WAVE_CAP || begin + n > capacity) return;  // small segments: tile_sort_wave_kernel
-    if (n > TSORT_CAP && n <= TSORT_BIG_CAP) return;          // heavy segments: tile_sort_big_kernel
+    if (n > TSORT_CAP) return;                                // heavy / giant segments: tile_sort_big_kernel, giant_* kernels
     const uint64_t idx_mask = (1ull << idx_bits) - 1ull;
     const int64_t cam_tile = (((int64_t)(seg / n_tiles) << tile_n_bits) | (int64_t)(seg % n_tiles)) << 32;
     const int t = threadIdx.x;
-    if (n <= TSORT_CAP) {
-        const int m = n <= 2048 ? 2048 : 4096;
-        for (int i = t; i < m; i += ISECT_BLOCK) s_keys[spad(i)] = i < n ? keys[begin + i] : ~0ull;
-        __syncthreads();
-        if (m == 2048) merge_sort_lds<8, ISECT_BLOCK>(s_keys, t);
-        else merge_sort_lds<16, ISECT_BLOCK>(s_keys, t);
-        for (int i = t; i < n; i += ISECT_BLOCK) {
-            const uint64_t k = s_keys[spad(i)];
-            flatten_ids[begin + i] = (int32_t)(k & idx_mask);
-            if (isect_ids) isect_ids[begin + i] = cam_tile | (int64_t)(k >> idx_bits);
-        }
-        return;
-    }
-    // large segment: LDS-sorted chunks of TSORT_CAP keys, then rank merges ping-ponging between the two key buffers
-    uint64_t* src = keys + begin;
-    uint64_t* dst = keys_alt + begin;
-    for (int c0 = 0; c0 < n; c0 += TSORT_CAP) {
-        const int cn = min(TSORT_CAP, n - c0);
-        for (int i = t; i < TSORT_CAP; i += ISECT_BLOCK) s_keys[spad(i)] = i < cn ? src[c0 + i] : ~0ull;
-        __syncthreads();
-        merge_sort_lds<16, ISECT_BLOCK>(s_keys, t);
-        for (int i = t; i < cn; i += ISECT_BLOCK) src[c0 + i] = s_keys[spad(i)];
-        __syncthreads();
-    }
-    for (int run = TSORT_CAP; run < n; run <<= 1) {
-        for (int i = threadIdx.x; i < n; i += ISECT_BLOCK) {
-            const int pair0 = (i / (2 * run)) * (2 * run);          // start of this pair of runs
-            const int mid = min(pair0 + run, n), end = min(pair0 + 2 * run, n);
-            const uint64_t k = src[i];
-            const bool in_a = i < mid;
-            int lo = in_a ? mid : pair0, hi = in_a ? end : mid;     // the other run: count its keys below k (keys are unique)
-            const int other0 = lo;
-            while (lo < hi) {
-                const int md = (lo + hi) >> 1;
-                if (src[md] < k) lo = md + 1; else hi = md;
-            }
-            dst[pair0 + (in_a ? (i - pair0) : (i - mid)) + (lo - other0)] = k;
-        }
-        __syncthreads();
-        uint64_t* t = src; src = dst; dst = t;
-    }
-    for (int i = threadIdx.x; i < n; i += ISECT_BLOCK) {
-        const uint64_t k = src[i];
+    const int m = n <= 2048 ? 2048 : 4096;
+    for (int i = t; i < m; i += ISECT_BLOCK) s_keys[spad(i)] = i < n ? keys[begin + i] : ~0ull;
+    __syncthreads();
+    if (m == 2048) merge_sort_lds<8, ISECT_BLOCK>(s_keys, t);
+    else merge_sort_lds<16, ISECT_BLOCK>(s_keys, t);
+    for (int i = t; i < n; i += ISECT_BLOCK) {
+        const uint64_t k = s_keys[spad(i)];
         flatten_ids[begin + i] = (int32_t)(k & idx_mask);
         if (isect_ids) isect_ids[begin + i] = cam_tile | (int64_t)(k >> idx_bits);
     }
@@ -396,6 +361,143 @@ __global__ __launch_bounds__(1024) void tile_sort_big_kernel(uint32_t n_segments
             flatten_ids[begin + i] = (int32_t)(k & idx_mask);
             if (isect_ids) isect_ids[begin + i] = cam_tile | (int64_t)(k >> idx_bits);
         }
+    }
+}
+
+// Giant segments (more than TSORT_BIG_CAP keys: the densest tiles of a garden-like scene hold 20 000 .. 60 000 keys, and nearly
+// every frame of such a scene has a few).  They are sorted by many blocks: the segment is cut into chunks of TSORT_BIG_CAP keys,
+// every chunk is sorted in LDS (giant_chunk_sort_kernel), then ceil(log2(chunks)) merge passes ping-pong between the two key
+// buffers (giant_merge_kernel).  A merge pass is parallel over WINDOWS of TSORT_BIG_CAP output keys: the block finds the merge-path
+// split of its window's two diagonals by a 64-way search (one wave per diagonal: three dependent global loads for a 262 144-key
+// run instead of eighteen), stages the two input pieces in LDS, and merges them there exactly as merge_sort_lds does.  The last
+// pass of a segment writes flatten_ids / isect_ids directly.  Keys are unique (they carry the Gaussian index), so the result is
+// THE sorted order: bit-identical to the device-wide radix sort.
+// giant_list_kernel enumerates the (segment, chunk) pairs once; chunk c of a segment is also window c of each of its passes.
+GSX_DEV int ceil_log2_i(int v) { int p = 0; while ((1 << p) < v) ++p; return p; }
+
+__global__ __launch_bounds__(1024) void giant_list_kernel(uint32_t n_segments, const int32_t* __restrict__ tile_offsets, int64_t capacity,
+                                                          int4* __restrict__ list, uint32_t* __restrict__ count) {
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0u;
+    __syncthreads();
+    for (uint32_t seg = threadIdx.x; seg < n_segments; seg += 1024u) {
+        const int begin = tile_offsets[seg];
+        const int n = tile_offsets[seg + 1] - begin;
+        if (n <= TSORT_BIG_CAP || (int64_t)begin + n > capacity) continue;
+        const int k = (n + TSORT_BIG_CAP - 1) / TSORT_BIG_CAP;
+        const uint32_t base = atomicAdd(&s_n, (uint32_t)k);
+        for (int c = 0; c < k; ++c) list[base + c] = make_int4(begin, n, c, (int)seg);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *count = s_n;
+}
+
+__global__ __launch_bounds__(1024) void giant_chunk_sort_kernel(const int4* __restrict__ list, const uint32_t* __restrict__ count,
+                                                                uint64_t* __restrict__ keys) {
+    extern __shared__ uint64_t s_big[];
+    const int t = threadIdx.x;
+    const uint32_t cnt = *count;
+    for (uint32_t w = blockIdx.x; w < cnt; w += gridDim.x) {
+        const int4 d = list[w];
+        const int c0 = d.z * TSORT_BIG_CAP, cn = min(TSORT_BIG_CAP, d.y - c0);
+        uint64_t* chunk = keys + (int64_t)d.x + c0;
+        const int m = cn <= 8192 ? 8192 : 16384;
+        __syncthreads();   // the previous chunk has been stored
+        for (int i = t; i < m; i += 1024) s_big[spad(i)] = i < cn ? chunk[i] : ~0ull;
+        __syncthreads();
+        if (m == 8192) merge_sort_lds<8, 1024>(s_big, t);
+        else merge_sort_lds<16, 1024>(s_big, t);
+        for (int i = t; i < cn; i += 1024) chunk[i] = s_big[spad(i)];
+    }
+}
+
+// merge-path split of diagonal d of two sorted runs in global memory, searched by a whole wave: number of outputs among the first d
+// that come from A (A wins ties; there are none).  All 64 lanes must call it together.
+GSX_DEV int merge_split_wave(const uint64_t* __restrict__ A, int la, const uint64_t* __restrict__ B, int lb, int d, int lane) {
+    int lo = max(0, d - lb), hi = min(d, la);
+    while (lo < hi) {
+        const int64_t span = hi - lo;
+        const int mid = lo + (int)(span * (lane + 1) / 65);   // non-decreasing in the lane, inside [lo, hi)
+        const bool below = A[mid] <= B[d - 1 - mid];          // true for the first `cnt` lanes, false after
+        const int cnt = __popcll(__ballot(below));
+        const int last_true = lo + (int)(span * cnt / 65), first_false = lo + (int)(span * (cnt + 1) / 65);
+        const int nlo = cnt > 0 ? last_true + 1 : lo, nhi = cnt < 64 ? first_false : hi;
+        lo = nlo;
+        hi = nhi;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(1024) void giant_merge_kernel(const int4* __restrict__ list, const uint32_t* __restrict__ count, int pass,
+                                                           const uint64_t* __restrict__ src_buf, uint64_t* __restrict__ dst_buf, uint32_t n_tiles,
+                                                           uint32_t tile_n_bits, uint32_t idx_bits, int32_t* __restrict__ flatten_ids,
+                                                           int64_t* __restrict__ isect_ids) {
+    extern __shared__ uint64_t s_big[];
+    __shared__ int s_split[2];
+    constexpr int E = TSORT_BIG_CAP / 1024;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint64_t idx_mask = (1ull << idx_bits) - 1ull;
+    const uint32_t cnt = *count;
+    for (uint32_t w = blockIdx.x; w < cnt; w += gridDim.x) {
+        const int4 d = list[w];
+        const int n = d.y;
+        const int passes = ceil_log2_i((n + TSORT_BIG_CAP - 1) / TSORT_BIG_CAP);
+        if (pass >= passes) continue;   // (block-uniform) this segment is finished
+        const bool last = pass == passes - 1;
+        const uint32_t run = (uint32_t)TSORT_BIG_CAP << pass;             // pass < 17: run <= 2^30
+        const uint32_t o = (uint32_t)d.z * TSORT_BIG_CAP;
+        const uint32_t pair0 = o & ~(2u * run - 1u);
+        const int la = (int)min(run, (uint32_t)n - pair0), lb = (int)min(run, (uint32_t)n - pair0 - (uint32_t)la);
+        const int d0 = (int)(o - pair0), d1 = min(d0 + TSORT_BIG_CAP, la + lb);
+        const uint64_t* A = src_buf + (int64_t)d.x + pair0;
+        const uint64_t* B = A + la;
+        if (wave < 2) {
+            const int dd = wave == 0 ? d0 : d1;
+            const int a = merge_split_wave(A, la, B, lb, dd, lane);
+            if (lane == 0) s_split[wave] = a;
+        }
+        __syncthreads();   // (also: the previous window has been stored)
+        const int a0 = s_split[0], a1 = s_split[1];
+        const int na = a1 - a0, b0 = d0 - a0, W = d1 - d0, nb = W - na;
+        for (int i = t; i < W; i += 1024) s_big[spad(i)] = i < na ? A[a0 + i] : B[b0 + (i - na)];
+        __syncthreads();
+        uint64_t r[E];
+        {
+            const int ot = t * E;   // this thread's first output inside the window
+            int lo = max(0, min(ot, W) - nb), hi = min(min(ot, W), na);
+            const int dt = min(ot, W);
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_big[spad(mid)] <= s_big[spad(na + dt - 1 - mid)]) lo = mid + 1; else hi = mid;
+            }
+            int ai = lo, bi = dt - lo;
+            uint64_t a = ai < na ? s_big[spad(ai)] : ~0ull, b = bi < nb ? s_big[spad(na + bi)] : ~0ull;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const bool ta = a <= b;
+                r[e] = ta ? a : b;
+                const int nxt = ta ? ++ai : ++bi;
+                const uint64_t v = nxt < (ta ? na : nb) ? s_big[spad((ta ? 0 : na) + nxt)] : ~0ull;
+                a = ta ? v : a;
+                b = ta ? b : v;
+            }
+        }
+        __syncthreads();   // every thread has finished reading the staged runs
+#pragma unroll
+        for (int e = 0; e < E; ++e) s_big[spad(t * E + e)] = r[e];
+        __syncthreads();
+        const int64_t out0 = (int64_t)d.x + pair0 + d0;
+        if (last) {
+            const int64_t cam_tile = (((int64_t)((uint32_t)d.w / n_tiles) << tile_n_bits) | (int64_t)((uint32_t)d.w % n_tiles)) << 32;
+            for (int i = t; i < W; i += 1024) {
+                const uint64_t k = s_big[spad(i)];
+                flatten_ids[out0 + i] = (int32_t)(k & idx_mask);
+                if (isect_ids) isect_ids[out0 + i] = cam_tile | (int64_t)(k >> idx_bits);
+            }
+        } else {
+            for (int i = t; i < W; i += 1024) dst_buf[out0 + i] = s_big[spad(i)];
+        }
+        __syncthreads();
     }
 }
 
@@ -621,17 +723,20 @@ extern "C" int gsx_intersect_bin_count(uint32_t C, uint32_t N, const float* mean
     return check_launch("intersect_bin_count");
 }
 
+// (segment, chunk) list of the giant segments: sum of ceil(n_s / 16384) over segments with n_s > 16384 is below n_isects / 8192
+static size_t giant_list_bytes(int64_t n_isects) { return align_up(((size_t)n_isects / (TSORT_BIG_CAP / 2) + 2) * sizeof(int4), 256); }
+
 extern "C" size_t gsx_intersect_bin_fill_workspace_bytes(uint32_t C, uint32_t tile_width, uint32_t tile_height, int64_t n_isects) {
     (void)C; (void)tile_width; (void)tile_height;
     if (n_isects <= 0) return 256;
-    return 2 * align_up((size_t)n_isects * 8, 256) + 256;
+    return 2 * align_up((size_t)n_isects * 8, 256) + giant_list_bytes(n_isects) + 256;
 }
 
 // `count_workspace` is the workspace gsx_intersect_bin_count filled (its per-block prefixes are consumed here).
 extern "C" int gsx_intersect_bin_fill(uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, const float* depths,
                                       uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, const int32_t* tile_offsets,
-                                      int64_t n_isects, const void* count_workspace, int32_t* flatten_ids, int64_t* isect_ids, void* workspace,
-                                      size_t workspace_bytes, void* stream) {
+                                      int64_t n_isects, int64_t max_segment, const void* count_workspace, int32_t* flatten_ids,
+                                      int64_t* isect_ids, void* workspace, size_t workspace_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (n_isects <= 0) return GSX_OK;
     if (n_isects > 0x7FFFFFFFll) { set_error("intersect_bin_fill: n_isects must fit int32"); return GSX_ERR_INVALID_ARGUMENT; }
@@ -655,8 +760,8 @@ extern "C" int gsx_intersect_bin_fill(uint32_t C, uint32_t N, const float* means
                        tile_width, tile_height, idx_bits, tile_offsets, (const uint32_t*)count_workspace, keys, (uint32_t)n_isects);
     hipLaunchKernelGGL(tile_sort_wave_kernel, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, n_tiles, bit_width_u32(n_tiles), idx_bits, tile_offsets,
                        (const uint64_t*)keys, flatten_ids, isect_ids, n_isects);
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(nseg), dim3(ISECT_BLOCK), 0, st, n_tiles, bit_width_u32(n_tiles), idx_bits, tile_offsets, keys, keys_alt,
-                       flatten_ids, isect_ids, n_isects);
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(nseg), dim3(ISECT_BLOCK), 0, st, n_tiles, bit_width_u32(n_tiles), idx_bits, tile_offsets,
+                       (const uint64_t*)keys, flatten_ids, isect_ids, n_isects);
     if (n_isects > TSORT_CAP) {   // a segment above 4096 keys needs at least that many intersections
         const size_t big_lds = (size_t)(TSORT_BIG_CAP + TSORT_BIG_CAP / 32) * 8;
         static const bool attr_set = [&] {
@@ -665,6 +770,29 @@ extern "C" int gsx_intersect_bin_fill(uint32_t C, uint32_t N, const float* means
         (void)attr_set;
         hipLaunchKernelGGL(tile_sort_big_kernel, dim3(256), dim3(1024), big_lds, st, nseg, n_tiles, bit_width_u32(n_tiles), idx_bits, tile_offsets,
                            (const uint64_t*)keys, flatten_ids, isect_ids, n_isects);
+    }
+    // giant segments (above 16384 keys): chunk sorts + merge passes by many blocks; the number of passes follows from the caller's
+    // bound on the largest segment (unknown: every intersection could sit in one tile)
+    const int64_t seg_bound = std::min<int64_t>(max_segment > 0 ? max_segment : n_isects, n_isects);
+    if (seg_bound > TSORT_BIG_CAP) {
+        const size_t big_lds = (size_t)(TSORT_BIG_CAP + TSORT_BIG_CAP / 32) * 8;
+        static const bool attr_set = [&] {
+            return hipFuncSetAttribute((const void*)giant_chunk_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)giant_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds) == hipSuccess;
+        }();
+        (void)attr_set;
+        int4* list = (int4*)((char*)workspace + 2 * align_up((size_t)n_isects * 8, 256));
+        uint32_t* list_count = (uint32_t*)((char*)list + giant_list_bytes(n_isects));
+        const int64_t chunks = (seg_bound + TSORT_BIG_CAP - 1) / TSORT_BIG_CAP;
+        int passes = 0;
+        while ((1ll << passes) < chunks) ++passes;
+        const uint32_t grid = 256;   // one block per CU (132 KB of LDS each); the blocks walk the list with that stride
+        hipLaunchKernelGGL(giant_list_kernel, dim3(1), dim3(1024), 0, st, nseg, tile_offsets, n_isects, list, list_count);
+        hipLaunchKernelGGL(giant_chunk_sort_kernel, dim3(grid), dim3(1024), big_lds, st, (const int4*)list, (const uint32_t*)list_count, keys);
+        for (int p = 0; p < passes; ++p)
+            hipLaunchKernelGGL(giant_merge_kernel, dim3(grid), dim3(1024), big_lds, st, (const int4*)list, (const uint32_t*)list_count, p,
+                               (const uint64_t*)((p & 1) ? keys_alt : keys), (p & 1) ? keys : keys_alt, n_tiles, bit_width_u32(n_tiles), idx_bits,
+                               flatten_ids, isect_ids);
     }
     return check_launch("intersect_bin_fill");
 }

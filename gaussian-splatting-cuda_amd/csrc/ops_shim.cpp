@@ -564,9 +564,8 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
     static std::mutex hint_mutex;
     static std::map<std::tuple<int, uint32_t, uint32_t, uint32_t, uint32_t>, std::pair<int64_t, int64_t>> hints;   // (n_isects, largest segment)
     const auto key = std::make_tuple((int)means2d.get_device(), C, N, tile_width, tile_height);
-    // Per-tile LDS sorts handle segments up to 16384 keys; beyond that one block would sort a segment through global memory (milliseconds
-    // for the 50 k-key tiles of a dense scene), so such frames take the device-wide radix sort instead (same outputs, bit for bit).
-    constexpr int64_t kGiantSegment = 16384;
+    // The hint also carries the largest (camera, tile) segment of the last call: it fixes how many merge passes the optimistic fill
+    // launches for segments above 16384 keys (none for most scenes).  A frame whose largest segment outgrows the bound is refilled.
     int64_t hint = 0, hint_seg = 0;
     {
         std::lock_guard<std::mutex> lock(hint_mutex);
@@ -574,19 +573,20 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
         if (it != hints.end()) { hint = it->second.first; hint_seg = it->second.second; }
     }
     at::Tensor flatten_ids, isect_ids;
-    auto fill = [&](int64_t capacity) {
+    auto fill = [&](int64_t capacity, int64_t seg_bound) {
         flatten_ids = at::empty({capacity}, depths.options().dtype(at::kInt));
         isect_ids = at::empty({want_isect_ids ? capacity : 0}, depths.options().dtype(at::kLong));
         const size_t fwb = gsx_intersect_bin_fill_workspace_bytes(C, tile_width, tile_height, capacity);
         at::Tensor fws = at::empty({(int64_t)fwb}, depths.options().dtype(at::kByte));
         check(gsx_intersect_bin_fill(C, N, means2d.data_ptr<float>(), radii.data_ptr<int32_t>(), depths.data_ptr<float>(), tile_size, tile_width,
-                                     tile_height, offsets.data_ptr<int32_t>(), capacity, cws.data_ptr(), flatten_ids.data_ptr<int32_t>(),
+                                     tile_height, offsets.data_ptr<int32_t>(), capacity, seg_bound, cws.data_ptr(), flatten_ids.data_ptr<int32_t>(),
                                      want_isect_ids ? isect_ids.data_ptr<int64_t>() : nullptr, fws.data_ptr(), fwb, st), "intersect_tile_binned(fill)");
     };
-    int64_t capacity = 0;
-    if (hint > 0 && hint_seg <= kGiantSegment && n_elements) {   // (a scene that had giant segments last time: wait for the count first)
+    int64_t capacity = 0, seg_bound = 0;
+    if (hint > 0 && n_elements) {
         capacity = std::min<int64_t>(hint + hint / 8 + 4096, 0x7FFFFFFFll);
-        fill(capacity);
+        seg_bound = std::max<int64_t>(hint_seg + hint_seg / 4, 16384);   // (16384: no giant-segment launches at all)
+        fill(capacity, seg_bound);
     }
     total_ready.synchronize();
     g_stats.host_syncs++;
@@ -597,21 +597,16 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
         std::lock_guard<std::mutex> lock(hint_mutex);
         auto& h = hints[key];
         h.first = std::max<int64_t>(n_isects, h.first - h.first / 50);  // running maximum with a slow decay
-        h.second = max_seg;
+        h.second = std::max<int64_t>(max_seg, h.second - h.second / 50);
     }
     g_stats.binned_calls++;
-    if (capacity > 0 && n_isects > capacity) g_stats.hint_misses++;
+    if (capacity > 0 && (n_isects > capacity || max_seg > seg_bound)) g_stats.hint_misses++;
     if (capacity == 0 && n_isects > 0) g_stats.hint_cold++;
-    if (max_seg > kGiantSegment && capacity == 0) {   // giant segments and nothing launched yet: the device-wide sort
-        auto r = gsplat::intersect_tile_device_sort(means2d, radii, depths, C, tile_size, tile_width, tile_height, true);
-        at::Tensor off = gsplat::intersect_offset(std::get<1>(r), C, tile_width, tile_height);
-        return std::make_tuple(std::get<0>(r), want_isect_ids ? std::get<1>(r) : at::empty({0}, std::get<1>(r).options()), std::get<2>(r), off);
-    }
-    if (capacity > 0 && n_isects <= capacity) {
+    if (capacity > 0 && n_isects <= capacity && max_seg <= seg_bound) {
         flatten_ids = flatten_ids.narrow(0, 0, n_isects);
         if (want_isect_ids) isect_ids = isect_ids.narrow(0, 0, n_isects);
     } else if (n_isects > 0) {
-        fill(n_isects);
+        fill(n_isects, std::max<int64_t>(max_seg, 1));
     } else {
         flatten_ids = at::empty({0}, depths.options().dtype(at::kInt));
         isect_ids = at::empty({0}, depths.options().dtype(at::kLong));

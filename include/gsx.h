@@ -179,8 +179,11 @@ int gsx_add_noise(uint32_t N, const float* raw_opacities, const float* raw_scale
  * LDS tile histograms -> per-tile prefix + exclusive scan = isect_offsets -> scatter into tile-major segments -> per-tile LDS
  * sort by (depth bits, flatten index).  No device-wide sort, no global atomics.  tile_offsets has C*tiles + 1 entries (the
  * last one is n_isects; the pinned host word receives n_isects in its low 32 bits — 0xFFFFFFFF when there are more than 2^31 - 1 —
- * and the key count of the largest (camera, tile) segment in its high 32 bits: segments up to 16384 keys are sorted in LDS, larger
- * ones by one block through global memory, slowly, so a caller may prefer intersect_tile's device-wide sort for such a frame).
+ * and the key count of the largest (camera, tile) segment in its high 32 bits: segments up to 16384 keys are sorted in LDS by one
+ * block or wave, larger ones as LDS-sorted 16384-key chunks plus ceil(log2(chunks)) merge-path passes by many blocks).
+ * bin_fill's `max_segment` is an upper bound of that largest segment (it fixes the number of merge passes that are launched);
+ * 0 = unknown (as many passes as n_isects could need: a few empty launches).  If a segment is larger than the stated bound its
+ * part of flatten_ids / isect_ids is not written: re-run bin_fill with the value bin_count reported.
  * Host protocol as above: bin_count -> sync -> allocate
  * flatten_ids -> bin_fill(count_workspace = the workspace bin_count used).  isect_ids may be NULL (the blend kernels only
  * need flatten_ids + offsets).  bin_fill's `n_isects` is the CAPACITY of flatten_ids / isect_ids / the workspace: a caller
@@ -194,8 +197,8 @@ int gsx_intersect_bin_count(uint32_t C, uint32_t N, const float* means2d, const 
 size_t gsx_intersect_bin_fill_workspace_bytes(uint32_t C, uint32_t tile_width, uint32_t tile_height, int64_t n_isects);
 int gsx_intersect_bin_fill(uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, const float* depths,
                            uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, const int32_t* tile_offsets,
-                           int64_t n_isects, const void* count_workspace, int32_t* flatten_ids, int64_t* isect_ids, void* workspace,
-                           size_t workspace_bytes, void* stream);
+                           int64_t n_isects, int64_t max_segment, const void* count_workspace, int32_t* flatten_ids, int64_t* isect_ids,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- next tier: fused Adam step -------------------------------------------------------
  * fast_gs::optimizer::adam_step_wrapper, fastgs/optimizer/include/adam_kernels.cuh:13-38:

@@ -79,7 +79,7 @@ def test_argument_validation_of_the_next_tier_entry_points():
     off = (c.c_int32 * 16)()
     assert lib.gsx_intersect_bin_count(u32(1), u32(8), buf, off, u32(16), u32(480), u32(270), None, off, None, buf, c.c_size_t(1 << 30), None) == -2
     assert lib.gsx_intersect_bin_count(u32(1), u32(8), buf, off, u32(16), u32(2), u32(2), None, off, None, buf, c.c_size_t(8), None) == -3
-    assert lib.gsx_intersect_bin_fill(u32(1), u32(8), buf, off, buf, u32(16), u32(2), u32(2), off, c.c_int64(0), buf, off, None, None, c.c_size_t(0), None) == 0
+    assert lib.gsx_intersect_bin_fill(u32(1), u32(8), buf, off, buf, u32(16), u32(2), u32(2), off, c.c_int64(0), c.c_int64(0), buf, off, None, None, c.c_size_t(0), None) == 0
     assert lib.gsx_intersect_bin_fill_workspace_bytes(u32(1), u32(2), u32(2), c.c_int64(100)) >= 2 * 100 * 8
     # blend workspaces
     assert lib.gsx_rasterize_fwd_packed_records(None, c.c_size_t(0), u32(1), u32(8)) is None

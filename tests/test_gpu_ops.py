@@ -306,7 +306,8 @@ def test_blend_with_no_intersections(gsx_mod, raster_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("C,N,W,H,rmax,nq", [(1, 5000, 256, 256, 20, 0), (2, 3000, 200, 120, 40, 16), (1, 30000, 64, 64, 30, 8),
                                              (3, 1, 33, 17, 5, 0), (1, 100, 1920, 1080, 300, 4),
-                                             (1, 20000, 64, 64, 30, 8), (1, 50000, 64, 64, 30, 0), (2, 70000, 64, 48, 30, 0)])
+                                             (1, 20000, 64, 64, 30, 8), (1, 50000, 64, 64, 30, 0), (2, 70000, 64, 48, 30, 0),
+                                             (1, 700000, 64, 64, 30, 0), (1, 150000, 64, 64, 30, 4)])
 def test_intersect_tile_binned_equals_sorted_path(C, N, W, H, rmax, nq):
     """The binned pipeline (LDS histograms + per-tile LDS sort, incl. the > 4096-key merge path: case 3) returns bit for bit
     what intersect_tile(sort=True) + intersect_offset return; quantised depths (nq levels) exercise the flatten-index tie break."""
@@ -334,7 +335,11 @@ def test_intersect_tile_binned_equals_sorted_path(C, N, W, H, rmax, nq):
     if N in (20000, 50000):
         assert bool(((seg > 4096) & (seg <= 16384)).any())                   # the heavy-tile kernel (one 1024-thread block, 132 KB of LDS) ran
     if N == 70000:
-        assert int(seg.max()) > 16384                                        # the chunked merge path behind it ran
+        assert int(seg.max()) > 16384                                        # giant segments: LDS-sorted chunks + merge-path passes
+    if N == 700000:
+        assert int(seg.max()) > 8 * 16384 and int(seg.min()) > 16384         # four merge passes, run counts that are not powers of two
+    if N == 150000:
+        assert int(seg.max()) > 2 * 16384                                    # ties in depth across chunk borders
 
 
 @pytest.mark.gpu
@@ -358,3 +363,27 @@ def test_intersect_tile_binned_optimistic_capacity_overflow():
         assert torch.equal(ids, ids2) and torch.equal(flat, flat2) and torch.equal(off, off2) and torch.equal(tpg, tpg2)
         sizes.append(flat.numel())
     assert sizes[1] > 1.3 * sizes[0]
+
+
+@pytest.mark.gpu
+def test_intersect_tile_binned_segment_bound_outgrown():
+    """The optimistic fill launches as many merge passes as the largest segment of the previous call needs.  Second call: the tiles
+    grow past 16384 keys (no passes were launched: the fill is repeated); third call: small again, the passes find nothing to do."""
+    import gsx  # noqa: F401
+    from gsx import ops
+    C, N, W, H = 1, 60000, 64, 64
+    g = torch.Generator().manual_seed(11)
+    means2d = (torch.rand(C, N, 2, generator=g) * torch.tensor([W, H])).cuda()
+    depths = (torch.rand(C, N, generator=g) * 5 + 0.2).cuda()
+    base = torch.randint(1, 8, (C, N, 2), generator=g, dtype=torch.int32)
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    largest = []
+    for scale in (1, 3, 5, 1):
+        radii = (base * scale).cuda()
+        tpg, ids, flat = ops.intersect_tile_device_sort(means2d, radii, depths, C, 16, tw, th, True)
+        off = ops.intersect_offset(ids, C, tw, th)
+        tpg2, ids2, flat2, off2 = ops.intersect_tile_binned(means2d, radii, depths, C, 16, tw, th, True)
+        assert torch.equal(ids, ids2) and torch.equal(flat, flat2) and torch.equal(off, off2) and torch.equal(tpg, tpg2)
+        seg = torch.cat([off.flatten(), torch.tensor([flat.numel()], device=off.device, dtype=off.dtype)])
+        largest.append(int((seg[1:] - seg[:-1]).max()))
+    assert largest[0] <= 16384 < largest[1] and largest[2] > 1.3 * largest[1] and largest[3] == largest[0]
