@@ -64,11 +64,8 @@ def ring_cameras(dev):
     return cams
 
 
-def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    iters = int(args[0]) if args else 4000
-    out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
-    dev = "cuda:0"
+def setup(dev="cuda:0"):
+    """Hidden scene -> ground-truth images -> SfM-like initial model -> Trainer with the 'default' preset (MCMC)."""
     bg = torch.zeros(3, device=dev)
     gt = hidden_scene(dev)
     cams = ring_cameras(dev)
@@ -84,6 +81,14 @@ def main():
     model, scene_scale = io_colmap.init_model_from_pointcloud(pts, rgb, (0.0, 0.0, 0.0), sh_degree=3, init_scaling=params.init_scaling,
                                                              init_opacity=params.init_opacity, device=dev)
     tr = trainer.Trainer(model, cams, images, params, bg, scene_scale=scene_scale, seed=0)
+    return tr, model, cams, images, bg, params
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    iters = int(args[0]) if args else 4000
+    out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+    tr, model, cams, images, bg, params = setup()
     eval_idx = list(range(0, N_CAMS, 8))
     ev = lambda: metrics.evaluate(model, [cams[i] for i in eval_idx], [images[i] for i in eval_idx], bg)  # noqa: E731
     before = ev()

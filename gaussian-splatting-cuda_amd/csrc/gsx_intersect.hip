@@ -119,6 +119,7 @@ constexpr int TSORT_CAP = 4096;           // keys sorted in LDS per block (32 KB
 constexpr int TSORT_BIG_CAP = 16384;      // keys sorted in LDS by a 1024-thread block (132 KB): the heavy tiles of dense scenes
 constexpr int TSORT_WAVE_CAP = 1024;      // keys sorted by one wave without block barriers (8 KB); measured faster than a block up to here
 constexpr int BIN_BLOCK = 1024;           // count / scatter: 16 waves share one LDS counter array
+constexpr uint32_t BIN_WIDE = 16;         // count / scatter: tile rectangles above this many tiles are walked by the whole wave
 
 __global__ __launch_bounds__(BIN_BLOCK) void bin_count_kernel(uint32_t N, uint32_t per_block, const float* __restrict__ means2d,
                                                                 const int32_t* __restrict__ radii, float tile_size, uint32_t tw,
@@ -129,16 +130,25 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_count_kernel(uint32_t N, uint32
     for (uint32_t t = threadIdx.x; t < n_tiles; t += BIN_BLOCK) s_hist[t] = 0u;
     __syncthreads();
     const uint32_t n0 = b * per_block, n1 = min(N, n0 + per_block);
-    for (uint32_t n = n0 + threadIdx.x; n < n1; n += BIN_BLOCK) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t base = n0; base < n1; base += BIN_BLOCK) {   // (wave-uniform trip count: the wide rectangles below are shared by the wave)
+        const uint32_t n = base + threadIdx.x;
         const size_t idx = (size_t)c * N + n;
-        uint32_t x0, y0, x1, y1;
-        int32_t cnt = 0;
-        if (tile_rect(means2d, radii, idx, tile_size, tw, th, x0, y0, x1, y1)) {
-            cnt = (int32_t)((y1 - y0) * (x1 - x0));
+        uint32_t x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+        const bool hit = n < n1 && tile_rect(means2d, radii, idx, tile_size, tw, th, x0, y0, x1, y1);
+        const uint32_t cnt = hit ? (y1 - y0) * (x1 - x0) : 0u;
+        if (cnt != 0u && cnt <= BIN_WIDE)
             for (uint32_t i = y0; i < y1; ++i)
                 for (uint32_t j = x0; j < x1; ++j) atomicAdd(&s_hist[i * tw + j], 1u);
+        // a rectangle of more than BIN_WIDE tiles is walked by all 64 lanes (one thread looping over the 4 000 tiles of a
+        // screen-filling Gaussian held its whole block for hundreds of microseconds)
+        for (uint64_t wide = __ballot(cnt > BIN_WIDE); wide != 0ull; wide &= wide - 1ull) {
+            const int src = __builtin_ctzll(wide);
+            const uint32_t wx0 = __builtin_amdgcn_readlane(x0, src), wy0 = __builtin_amdgcn_readlane(y0, src);
+            const uint32_t ww = __builtin_amdgcn_readlane(x1, src) - wx0, total = __builtin_amdgcn_readlane(cnt, src);
+            for (uint32_t k = lane; k < total; k += 64u) atomicAdd(&s_hist[(wy0 + k / ww) * tw + wx0 + k % ww], 1u);
         }
-        if (tiles_per_gauss) tiles_per_gauss[idx] = cnt;
+        if (tiles_per_gauss && n < n1) tiles_per_gauss[idx] = (int32_t)cnt;
     }
     __syncthreads();
     uint32_t* out = block_hist + ((size_t)c * BIN_NB + b) * n_tiles;
@@ -194,16 +204,31 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_scatter_kernel(uint32_t N, uint
     for (uint32_t t = threadIdx.x; t < n_tiles; t += BIN_BLOCK) s_cur[t] = (uint32_t)off[t] + pre[t];
     __syncthreads();
     const uint32_t n0 = b * per_block, n1 = min(N, n0 + per_block);
-    for (uint32_t n = n0 + threadIdx.x; n < n1; n += BIN_BLOCK) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t base = n0; base < n1; base += BIN_BLOCK) {
+        const uint32_t n = base + threadIdx.x;
         const size_t idx = (size_t)c * N + n;
-        uint32_t x0, y0, x1, y1;
-        if (!tile_rect(means2d, radii, idx, tile_size, tw, th, x0, y0, x1, y1)) continue;
-        const uint64_t key = ((uint64_t)__float_as_uint(depths[idx]) << idx_bits) | (uint64_t)idx;
-        for (uint32_t i = y0; i < y1; ++i)
-            for (uint32_t j = x0; j < x1; ++j) {
-                const uint32_t pos = atomicAdd(&s_cur[i * tw + j], 1u);
-                if (pos < capacity) keys[pos] = key;  // capacity < n_isects only when an optimistic caller under-estimated: it re-runs
+        uint32_t x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+        const bool hit = n < n1 && tile_rect(means2d, radii, idx, tile_size, tw, th, x0, y0, x1, y1);
+        const uint32_t cnt = hit ? (y1 - y0) * (x1 - x0) : 0u;
+        const uint64_t key = hit ? ((uint64_t)__float_as_uint(depths[idx]) << idx_bits) | (uint64_t)idx : 0ull;
+        if (cnt != 0u && cnt <= BIN_WIDE)
+            for (uint32_t i = y0; i < y1; ++i)
+                for (uint32_t j = x0; j < x1; ++j) {
+                    const uint32_t pos = atomicAdd(&s_cur[i * tw + j], 1u);
+                    if (pos < capacity) keys[pos] = key;  // capacity < n_isects only when an optimistic caller under-estimated: it re-runs
+                }
+        for (uint64_t wide = __ballot(cnt > BIN_WIDE); wide != 0ull; wide &= wide - 1ull) {   // wide rectangles: all 64 lanes (see bin_count_kernel)
+            const int src = __builtin_ctzll(wide);
+            const uint32_t wx0 = __builtin_amdgcn_readlane(x0, src), wy0 = __builtin_amdgcn_readlane(y0, src);
+            const uint32_t ww = __builtin_amdgcn_readlane(x1, src) - wx0, total = __builtin_amdgcn_readlane(cnt, src);
+            const uint64_t wkey = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), src) << 32) |
+                                  (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, src);   // (readlane returns int)
+            for (uint32_t k = lane; k < total; k += 64u) {
+                const uint32_t pos = atomicAdd(&s_cur[(wy0 + k / ww) * tw + wx0 + k % ww], 1u);
+                if (pos < capacity) keys[pos] = wkey;
             }
+        }
     }
 }
 
