@@ -191,11 +191,13 @@ __global__ __launch_bounds__(ISECT_BLOCK) void bin_prefix_kernel(uint32_t C, uin
     if (grp == 0) tile_counts[g] = total;
 }
 
+// K = uint64_t: keys (depth bits << idx_bits | flatten index); K = uint32_t: the Gaussian's rank (ranked variant), read from `ranks`.
+template <typename K>
 __global__ __launch_bounds__(BIN_BLOCK) void bin_scatter_kernel(uint32_t N, uint32_t per_block, const float* __restrict__ means2d,
                                                                   const int32_t* __restrict__ radii, const float* __restrict__ depths,
-                                                                  float tile_size, uint32_t tw, uint32_t th, uint32_t idx_bits,
-                                                                  const int32_t* __restrict__ tile_offsets,
-                                                                  const uint32_t* __restrict__ block_hist, uint64_t* __restrict__ keys,
+                                                                  const uint32_t* __restrict__ ranks, float tile_size, uint32_t tw, uint32_t th,
+                                                                  uint32_t idx_bits, const int32_t* __restrict__ tile_offsets,
+                                                                  const uint32_t* __restrict__ block_hist, K* __restrict__ keys,
                                                                   uint32_t capacity) {
     extern __shared__ uint32_t s_cur[];
     const uint32_t n_tiles = tw * th, c = blockIdx.y, b = blockIdx.x;
@@ -211,12 +213,13 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_scatter_kernel(uint32_t N, uint
         uint32_t x0 = 0, y0 = 0, x1 = 0, y1 = 0;
         const bool hit = n < n1 && tile_rect(means2d, radii, idx, tile_size, tw, th, x0, y0, x1, y1);
         const uint32_t cnt = hit ? (y1 - y0) * (x1 - x0) : 0u;
-        const uint64_t key = hit ? ((uint64_t)__float_as_uint(depths[idx]) << idx_bits) | (uint64_t)idx : 0ull;
+        uint64_t key = 0ull;   // (held in 64 bits either way: the wide path broadcasts both halves)
+        if (hit) key = sizeof(K) == 8 ? ((uint64_t)__float_as_uint(depths[idx]) << idx_bits) | (uint64_t)idx : (uint64_t)ranks[idx];
         if (cnt != 0u && cnt <= BIN_WIDE)
             for (uint32_t i = y0; i < y1; ++i)
                 for (uint32_t j = x0; j < x1; ++j) {
                     const uint32_t pos = atomicAdd(&s_cur[i * tw + j], 1u);
-                    if (pos < capacity) keys[pos] = key;  // capacity < n_isects only when an optimistic caller under-estimated: it re-runs
+                    if (pos < capacity) keys[pos] = (K)key;  // capacity < n_isects only when an optimistic caller under-estimated: it re-runs
                 }
         for (uint64_t wide = __ballot(cnt > BIN_WIDE); wide != 0ull; wide &= wide - 1ull) {   // wide rectangles: all 64 lanes (see bin_count_kernel)
             const int src = __builtin_ctzll(wide);
@@ -224,9 +227,16 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_scatter_kernel(uint32_t N, uint
             const uint32_t ww = __builtin_amdgcn_readlane(x1, src) - wx0, total = __builtin_amdgcn_readlane(cnt, src);
             const uint64_t wkey = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), src) << 32) |
                                   (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, src);   // (readlane returns int)
-            for (uint32_t k = lane; k < total; k += 64u) {
-                const uint32_t pos = atomicAdd(&s_cur[(wy0 + k / ww) * tw + wx0 + k % ww], 1u);
-                if (pos < capacity) keys[pos] = wkey;
+            for (uint32_t k0 = lane; k0 < total; k0 += 256u) {   // four returning LDS atomics in flight per lane
+                uint32_t pos[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t k = k0 + 64u * u;
+                    pos[u] = k < total ? atomicAdd(&s_cur[(wy0 + k / ww) * tw + wx0 + k % ww], 1u) : 0xFFFFFFFFu;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u)
+                    if (pos[u] < capacity) keys[pos[u]] = (K)wkey;   // (capacity <= 2^31 - 1)
             }
         }
     }
@@ -240,6 +250,8 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_scatter_kernel(uint32_t N, uint
 // the merge cursors of neighbouring lanes about E/2 apart: without the pad, lanes 32/E (or 64/E) apart hit the same banks
 // (8 B keys, 64 banks x 4 B) — 72 % of the LDS cycles of this kernel were bank-conflict cycles at E = 8..16.
 GSX_DEV int spad(int i) { return i + (i >> 5); }
+// (4-byte keys — the ranked variant below — : one pad key after every 64, the same two-bank shift)
+template <typename K> GSX_DEV int spad_of(int i) { return sizeof(K) == 8 ? i + (i >> 5) : i + (i >> 6); }
 
 template <int NT>
 GSX_DEV void group_sync() {
@@ -250,11 +262,12 @@ GSX_DEV void group_sync() {
 // Sort NT * E keys in LDS with NT threads (NT = 64: one wave, no barrier; NT = 256: a block).  Thread t first sorts keys
 // [t E, (t+1) E) in registers, then log2(NT) merge passes: it finds the merge-path split of its E outputs by binary search and
 // merges them sequentially.
-template <int E, int NT>
-GSX_DEV void merge_sort_lds(uint64_t* s, int t) {
-    uint64_t r[E];
+template <int E, int NT, typename K = uint64_t>
+GSX_DEV void merge_sort_lds(K* s, int t) {
+    constexpr K kMax = ~(K)0;
+    K r[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) r[e] = s[spad(t * E + e)];
+    for (int e = 0; e < E; ++e) r[e] = s[spad_of<K>(t * E + e)];
     // Batcher's odd-even merge sort network on the thread's own keys (E a power of two: 1 / 5 / 19 / 63 compare-exchanges for
     // E = 2 / 4 / 8 / 16; all indices are compile-time constants after unrolling)
 #pragma unroll
@@ -266,12 +279,12 @@ GSX_DEV void merge_sort_lds(uint64_t* s, int t) {
 #pragma unroll
                 for (int i = 0; i < k; ++i)
                     if (i + j + k < E && (i + j) / (2 * p) == (i + j + k) / (2 * p)) {
-                        const uint64_t x = r[i + j], y = r[i + j + k];
+                        const K x = r[i + j], y = r[i + j + k];
                         r[i + j] = x < y ? x : y;
                         r[i + j + k] = x < y ? y : x;
                     }
 #pragma unroll
-    for (int e = 0; e < E; ++e) s[spad(t * E + e)] = r[e];
+    for (int e = 0; e < E; ++e) s[spad_of<K>(t * E + e)] = r[e];
     group_sync<NT>();
     for (int run = E; run < NT * E; run <<= 1) {
         const int o = t * E;
@@ -281,79 +294,109 @@ GSX_DEV void merge_sort_lds(uint64_t* s, int t) {
         int lo = max(0, d - run), hi = min(d, run);
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if (s[spad(A + mid)] <= s[spad(B + d - 1 - mid)]) lo = mid + 1; else hi = mid;
+            if (s[spad_of<K>(A + mid)] <= s[spad_of<K>(B + d - 1 - mid)]) lo = mid + 1; else hi = mid;
         }
         int ai = lo, bi = d - lo;
-        uint64_t a = ai < run ? s[spad(A + ai)] : ~0ull, b = bi < run ? s[spad(B + bi)] : ~0ull;
+        K a = ai < run ? s[spad_of<K>(A + ai)] : kMax, b = bi < run ? s[spad_of<K>(B + bi)] : kMax;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const bool ta = a <= b;
             r[e] = ta ? a : b;
             const int nxt = ta ? ++ai : ++bi;
-            const uint64_t v = nxt < run ? s[spad((ta ? A : B) + nxt)] : ~0ull;
+            const K v = nxt < run ? s[spad_of<K>((ta ? A : B) + nxt)] : kMax;
             a = ta ? v : a;
             b = ta ? b : v;
         }
         group_sync<NT>();  // every thread has finished reading this pass
 #pragma unroll
-        for (int e = 0; e < E; ++e) s[spad(t * E + e)] = r[e];
+        for (int e = 0; e < E; ++e) s[spad_of<K>(t * E + e)] = r[e];
         group_sync<NT>();
     }
 }
 
-__global__ __launch_bounds__(256) void tile_sort_wave_kernel(uint32_t n_segments, uint32_t n_tiles, uint32_t tile_n_bits, uint32_t idx_bits,
-                                                             const int32_t* __restrict__ tile_offsets, const uint64_t* __restrict__ keys,
+// What a sorted key stands for.  KeyDepthIdx: (depth bits << idx_bits) | flatten index, 8 bytes — self-contained.  KeyRank: the
+// position of the Gaussian in the frame-wide (depth bits, flatten index) order, 4 bytes — see "ranked variant" further down.
+struct KeyDepthIdx {
+    using T = uint64_t;
+    static constexpr bool kDeferred = false;   // the sort kernels write flatten_ids / isect_ids themselves
+    uint32_t idx_bits;
+    GSX_DEV int32_t id(T k) const { return (int32_t)(k & ((1ull << idx_bits) - 1ull)); }
+    GSX_DEV int64_t depth_bits(T k, int32_t) const { return (int64_t)(k >> idx_bits); }
+};
+struct KeyRank {
+    using T = uint32_t;
+    static constexpr bool kDeferred = true;    // the sort kernels leave sorted ranks in place; ranked_finalize_kernel turns them into ids
+    const uint32_t* __restrict__ order;   // rank -> flatten index
+    const float* __restrict__ depths;
+    GSX_DEV int32_t id(T k) const { return (int32_t)order[k]; }
+    GSX_DEV int64_t depth_bits(T, int32_t id) const { return (int64_t)__float_as_uint(depths[id]); }
+};
+
+template <class KT>
+__global__ __launch_bounds__(256) void tile_sort_wave_kernel(uint32_t n_segments, uint32_t n_tiles, uint32_t tile_n_bits, KT kt,
+                                                             const int32_t* __restrict__ tile_offsets, const typename KT::T* __restrict__ keys,
                                                              int32_t* __restrict__ flatten_ids, int64_t* __restrict__ isect_ids,
                                                              int64_t capacity) {
-    __shared__ uint64_t s_all[4][TSORT_WAVE_CAP + TSORT_WAVE_CAP / 32];
+    using K = typename KT::T;
+    __shared__ K s_all[4][TSORT_WAVE_CAP + TSORT_WAVE_CAP / 32];
     const uint32_t seg = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (seg >= n_segments) return;
     const int64_t begin = tile_offsets[seg];
     const int n = (int)(tile_offsets[seg + 1] - tile_offsets[seg]);
     if (n <= 0 || n > TSORT_WAVE_CAP || begin + n > capacity) return;
-    uint64_t* s_keys = s_all[threadIdx.x >> 6];
+    K* s_keys = s_all[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
     int m = 128;
     while (m < n) m <<= 1;
-    for (int i = lane; i < m; i += 64) s_keys[spad(i)] = i < n ? keys[begin + i] : ~0ull;
+    for (int i = lane; i < m; i += 64) s_keys[spad_of<K>(i)] = i < n ? keys[begin + i] : ~(K)0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     switch (m) {
-    case 128: merge_sort_lds<2, 64>(s_keys, lane); break;
-    case 256: merge_sort_lds<4, 64>(s_keys, lane); break;
-    case 512: merge_sort_lds<8, 64>(s_keys, lane); break;
-    default: merge_sort_lds<16, 64>(s_keys, lane); break;
+    case 128: merge_sort_lds<2, 64, K>(s_keys, lane); break;
+    case 256: merge_sort_lds<4, 64, K>(s_keys, lane); break;
+    case 512: merge_sort_lds<8, 64, K>(s_keys, lane); break;
+    default: merge_sort_lds<16, 64, K>(s_keys, lane); break;
     }
-    const uint64_t idx_mask = (1ull << idx_bits) - 1ull;
     const int64_t cam_tile = (((int64_t)(seg / n_tiles) << tile_n_bits) | (int64_t)(seg % n_tiles)) << 32;
     for (int i = lane; i < n; i += 64) {
-        const uint64_t k = s_keys[spad(i)];
-        flatten_ids[begin + i] = (int32_t)(k & idx_mask);
-        if (isect_ids) isect_ids[begin + i] = cam_tile | (int64_t)(k >> idx_bits);
+        const K k = s_keys[spad_of<K>(i)];
+        if (KT::kDeferred) {
+            const_cast<K*>(keys)[begin + i] = k;   // (the whole segment was read before the sort)
+        } else {
+            const int32_t id = kt.id(k);
+            flatten_ids[begin + i] = id;
+            if (isect_ids) isect_ids[begin + i] = cam_tile | kt.depth_bits(k, id);
+        }
     }
 }
 
-__global__ __launch_bounds__(ISECT_BLOCK) void tile_sort_kernel(uint32_t n_tiles, uint32_t tile_n_bits, uint32_t idx_bits,
-                                                                const int32_t* __restrict__ tile_offsets, const uint64_t* __restrict__ keys,
+template <class KT>
+__global__ __launch_bounds__(ISECT_BLOCK) void tile_sort_kernel(uint32_t n_tiles, uint32_t tile_n_bits, KT kt,
+                                                                const int32_t* __restrict__ tile_offsets, const typename KT::T* __restrict__ keys,
                                                                 int32_t* __restrict__ flatten_ids, int64_t* __restrict__ isect_ids,
                                                                 int64_t capacity) {
-    __shared__ uint64_t s_keys[TSORT_CAP + TSORT_CAP / 32];
+    using K = typename KT::T;
+    __shared__ K s_keys[TSORT_CAP + TSORT_CAP / 32];
     const uint32_t seg = blockIdx.x;
     const int64_t begin = tile_offsets[seg];
     const int n = (int)(tile_offsets[seg + 1] - tile_offsets[seg]);
     if (n <= TSORT_WAVE_CAP || begin + n > capacity) return;  // small segments: tile_sort_wave_kernel
-    if (n > TSORT_CAP) return;                                // heavy / giant segments: tile_sort_big_kernel, giant_* kernels
-    const uint64_t idx_mask = (1ull << idx_bits) - 1ull;
+    if (n > TSORT_CAP) return;                                // heavy / giant segments: tile_sort_big_kernel + giant_*, or tile_sort_bitmap_kernel
     const int64_t cam_tile = (((int64_t)(seg / n_tiles) << tile_n_bits) | (int64_t)(seg % n_tiles)) << 32;
     const int t = threadIdx.x;
     const int m = n <= 2048 ? 2048 : 4096;
-    for (int i = t; i < m; i += ISECT_BLOCK) s_keys[spad(i)] = i < n ? keys[begin + i] : ~0ull;
+    for (int i = t; i < m; i += ISECT_BLOCK) s_keys[spad_of<K>(i)] = i < n ? keys[begin + i] : ~(K)0;
     __syncthreads();
-    if (m == 2048) merge_sort_lds<8, ISECT_BLOCK>(s_keys, t);
-    else merge_sort_lds<16, ISECT_BLOCK>(s_keys, t);
+    if (m == 2048) merge_sort_lds<8, ISECT_BLOCK, K>(s_keys, t);
+    else merge_sort_lds<16, ISECT_BLOCK, K>(s_keys, t);
     for (int i = t; i < n; i += ISECT_BLOCK) {
-        const uint64_t k = s_keys[spad(i)];
-        flatten_ids[begin + i] = (int32_t)(k & idx_mask);
-        if (isect_ids) isect_ids[begin + i] = cam_tile | (int64_t)(k >> idx_bits);
+        const K k = s_keys[spad_of<K>(i)];
+        if (KT::kDeferred) {
+            const_cast<K*>(keys)[begin + i] = k;
+        } else {
+            const int32_t id = kt.id(k);
+            flatten_ids[begin + i] = id;
+            if (isect_ids) isect_ids[begin + i] = cam_tile | kt.depth_bits(k, id);
+        }
     }
 }
 
@@ -523,6 +566,137 @@ __global__ __launch_bounds__(1024) void giant_merge_kernel(const int4* __restric
             for (int i = t; i < W; i += 1024) dst_buf[out0 + i] = s_big[spad(i)];
         }
         __syncthreads();
+    }
+}
+
+// ---- ranked variant: for frames whose tiles are heavy (a trained garden-like scene: 37 M intersections over 4 293 tiles, 60 % of
+// them in tiles above 16 384 keys) the per-tile LDS merge sorts are LDS-bandwidth bound (~64 us per 16 384 64-bit keys per CU).
+// Here the frame's Gaussians are first ranked ONCE by (depth bits, flatten index) — a stable 32-bit radix sort of C*N pairs, about
+// 50 us at 1 M — and the per-tile keys are those ranks: unique integers below C*N.  A tile above 4096 keys is then sorted by
+// writing its ranks into a C*N-bit bitmap in LDS (128 KB at 1 M) and reading the set bits back in order: no comparison, no merge
+// passes, any segment size (tile_sort_bitmap_kernel, ~5 us + 3 ps per key per CU).  Lighter tiles take the merge sorts above with
+// 4-byte keys.  flatten_ids = order[rank]; the result is the same total order, bit for bit.
+__global__ __launch_bounds__(ISECT_BLOCK) void rank_keys_kernel(uint32_t total, const int32_t* __restrict__ radii, const float* __restrict__ depths,
+                                                                uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint32_t i = blockIdx.x * ISECT_BLOCK + threadIdx.x;
+    if (i >= total) return;
+    const int2 r = reinterpret_cast<const int2*>(radii)[i];
+    keys[i] = (r.x > 0 && r.y > 0) ? __float_as_uint(depths[i]) : 0xFFFFFFFFu;   // (culled Gaussians: behind every visible one)
+    vals[i] = i;
+}
+
+__global__ __launch_bounds__(ISECT_BLOCK) void rank_invert_kernel(uint32_t total, const uint32_t* __restrict__ order, uint32_t* __restrict__ ranks) {
+    const uint32_t r = blockIdx.x * ISECT_BLOCK + threadIdx.x;
+    if (r < total) ranks[order[r]] = r;
+}
+
+// inclusive prefix sum over the 64 lanes with DPP row operations (no LDS traffic: six adds)
+GSX_DEV uint32_t wave_incl_scan_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// Persistent grid, one 1024-thread block per CU; dynamic LDS: n_words (a multiple of 4096) 32-bit words of bitmap, then 16 staging
+// rows of BITMAP_STAGE ranks (one per wave).  The sorted ranks overwrite the segment's keys in place (every key has been read by
+// then); ranked_finalize_kernel turns them into flatten_ids afterwards, at full-chip parallelism — a gather inside this kernel's
+// emission loop put one global-load latency into each of a wave's 32 dependent steps.
+constexpr uint32_t BITMAP_STAGE = 480;
+__global__ __launch_bounds__(1024) void tile_sort_bitmap_kernel(uint32_t n_segments, uint32_t n_words, const int32_t* __restrict__ tile_offsets,
+                                                                uint32_t* __restrict__ keys, int64_t capacity) {
+    extern __shared__ uint32_t s_bits[];
+    __shared__ uint32_t s_wave_total[16];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t per_wave = n_words / 16u;   // (a multiple of 256)
+    uint32_t* stage = s_bits + n_words + wave * BITMAP_STAGE;
+    for (uint32_t seg = blockIdx.x; seg < n_segments; seg += gridDim.x) {
+        const int64_t begin = tile_offsets[seg];
+        const int n = (int)(tile_offsets[seg + 1] - tile_offsets[seg]);
+        if (n <= TSORT_CAP || begin + n > capacity) continue;   // (block-uniform)
+        uint32_t* seg_keys = keys + begin;
+        __syncthreads();   // the previous segment has been read out
+        for (uint32_t i = t; i < n_words / 4u; i += 1024u) reinterpret_cast<uint4*>(s_bits)[i] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        for (int i0 = (int)t; i0 < n; i0 += 8 * 1024) {   // eight loads in flight per thread
+            uint32_t r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r[u] = i0 + u * 1024 < n ? seg_keys[i0 + u * 1024] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (r[u] != 0xFFFFFFFFu) atomicOr(&s_bits[r[u] >> 5], 1u << (r[u] & 31u));
+        }
+        __syncthreads();
+        // every wave owns a contiguous range of words: its population count, then the block-wide exclusive prefix over the waves
+        uint32_t mine = 0u;
+        for (uint32_t w = wave * per_wave + lane; w < (wave + 1u) * per_wave; w += 64u) mine += (uint32_t)__popc(s_bits[w]);
+        mine = wave_incl_scan_u32(mine);
+        if (lane == 63u) s_wave_total[wave] = mine;
+        __syncthreads();
+        uint32_t pos = 0u;
+        for (uint32_t w = 0; w < wave; ++w) pos += s_wave_total[w];
+        // emission, 256 words (4 per lane, lane-major within each 64-word group) per step
+        for (uint32_t w0 = wave * per_wave; w0 < (wave + 1u) * per_wave; w0 += 256u) {
+            uint32_t word[4], cnt[4], incl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                word[u] = s_bits[w0 + 64u * u + lane];
+                cnt[u] = (uint32_t)__popc(word[u]);
+            }
+            const uint32_t s01 = wave_incl_scan_u32(cnt[0] | (cnt[1] << 16)), s23 = wave_incl_scan_u32(cnt[2] | (cnt[3] << 16));   // (<= 2048 each)
+            incl[0] = s01 & 0xFFFFu; incl[1] = s01 >> 16; incl[2] = s23 & 0xFFFFu; incl[3] = s23 >> 16;
+            const uint32_t t01 = (uint32_t)__builtin_amdgcn_readlane((int)s01, 63), t23 = (uint32_t)__builtin_amdgcn_readlane((int)s23, 63);
+            const uint32_t base[4] = {0u, t01 & 0xFFFFu, (t01 & 0xFFFFu) + (t01 >> 16), (t01 & 0xFFFFu) + (t01 >> 16) + (t23 & 0xFFFFu)};
+            const uint32_t tot = base[3] + (t23 >> 16);
+            if (tot <= BITMAP_STAGE) {   // (wave-uniform) ranks to the wave's staging row in order, then 64 consecutive outputs per store
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    uint32_t j = base[u] + incl[u] - cnt[u], bits = word[u];
+                    const uint32_t rank0 = (w0 + 64u * u + lane) << 5;
+                    while (bits != 0u) {
+                        stage[j++] = rank0 + (uint32_t)__builtin_ctz(bits);
+                        bits &= bits - 1u;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                for (uint32_t i = lane; i < tot; i += 64u) seg_keys[pos + i] = stage[i];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            } else {   // more than 480 of the step's 8192 bits set (a tile holding > 6 % of the frame's Gaussians): every lane writes its own runs
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    uint32_t out = pos + base[u] + incl[u] - cnt[u], bits = word[u];
+                    const uint32_t rank0 = (w0 + 64u * u + lane) << 5;
+                    while (bits != 0u) {
+                        seg_keys[out++] = rank0 + (uint32_t)__builtin_ctz(bits);
+                        bits &= bits - 1u;
+                    }
+                }
+            }
+            pos += tot;
+        }
+    }
+}
+
+// sorted ranks -> flatten_ids (and isect_ids on request: the segment of a position by binary search over the offsets)
+__global__ __launch_bounds__(ISECT_BLOCK) void ranked_finalize_kernel(int64_t capacity, uint32_t n_segments, uint32_t n_tiles, uint32_t tile_n_bits,
+                                                                      const int32_t* __restrict__ tile_offsets, const uint32_t* __restrict__ sorted,
+                                                                      KeyRank kt, int32_t* __restrict__ flatten_ids, int64_t* __restrict__ isect_ids) {
+    const int64_t p = (int64_t)blockIdx.x * ISECT_BLOCK + threadIdx.x;
+    if (p >= capacity || p >= (int64_t)tile_offsets[n_segments]) return;
+    const uint32_t r = sorted[p];
+    const int32_t id = kt.id(r);
+    flatten_ids[p] = id;
+    if (isect_ids) {
+        uint32_t lo = 0, hi = n_segments;   // last segment whose offset is <= p
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((int64_t)tile_offsets[mid] <= p) lo = mid; else hi = mid;
+        }
+        const int64_t cam_tile = (((int64_t)(lo / n_tiles) << tile_n_bits) | (int64_t)(lo % n_tiles)) << 32;
+        isect_ids[p] = cam_tile | kt.depth_bits(r, id);
     }
 }
 
@@ -780,12 +954,14 @@ extern "C" int gsx_intersect_bin_fill(uint32_t C, uint32_t N, const float* means
     uint64_t* keys_alt = (uint64_t*)((char*)workspace + align_up((size_t)n_isects * 8, 256));
     const uint32_t per_block = (N + BIN_NB - 1) / BIN_NB;
     const size_t lds = (size_t)n_tiles * 4;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)bin_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(BIN_NB, C), dim3(BIN_BLOCK), lds, st, N, per_block, means2d, radii, depths, (float)tile_size,
-                       tile_width, tile_height, idx_bits, tile_offsets, (const uint32_t*)count_workspace, keys, (uint32_t)n_isects);
-    hipLaunchKernelGGL(tile_sort_wave_kernel, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, n_tiles, bit_width_u32(n_tiles), idx_bits, tile_offsets,
-                       (const uint64_t*)keys, flatten_ids, isect_ids, n_isects);
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(nseg), dim3(ISECT_BLOCK), 0, st, n_tiles, bit_width_u32(n_tiles), idx_bits, tile_offsets,
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)bin_scatter_kernel<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(bin_scatter_kernel<uint64_t>, dim3(BIN_NB, C), dim3(BIN_BLOCK), lds, st, N, per_block, means2d, radii, depths,
+                       (const uint32_t*)nullptr, (float)tile_size, tile_width, tile_height, idx_bits, tile_offsets, (const uint32_t*)count_workspace,
+                       keys, (uint32_t)n_isects);
+    const KeyDepthIdx kt{idx_bits};
+    hipLaunchKernelGGL(tile_sort_wave_kernel<KeyDepthIdx>, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, n_tiles, bit_width_u32(n_tiles), kt,
+                       tile_offsets, (const uint64_t*)keys, flatten_ids, isect_ids, n_isects);
+    hipLaunchKernelGGL(tile_sort_kernel<KeyDepthIdx>, dim3(nseg), dim3(ISECT_BLOCK), 0, st, n_tiles, bit_width_u32(n_tiles), kt, tile_offsets,
                        (const uint64_t*)keys, flatten_ids, isect_ids, n_isects);
     if (n_isects > TSORT_CAP) {   // a segment above 4096 keys needs at least that many intersections
         const size_t big_lds = (size_t)(TSORT_BIG_CAP + TSORT_BIG_CAP / 32) * 8;
@@ -820,4 +996,103 @@ extern "C" int gsx_intersect_bin_fill(uint32_t C, uint32_t N, const float* means
                                flatten_ids, isect_ids);
     }
     return check_launch("intersect_bin_fill");
+}
+
+// ---- ranked variant (see tile_sort_bitmap_kernel): C ABI ------------------------------------------------------------------
+static constexpr uint32_t RANK_MAX_WORDS = 32768;   // 128 KB of LDS bitmap (+ 30 KB of staging rows): 1 048 576 Gaussians, all cameras together
+static uint32_t rank_words(uint32_t total) { return (uint32_t)align_up((size_t)(total + 31u) / 32u, 4096); }   // 16 waves x steps of 256 words
+
+extern "C" int gsx_intersect_ranked_supported(uint32_t C, uint32_t N) {
+    return (uint64_t)C * N > 0 && (uint64_t)C * N <= (uint64_t)RANK_MAX_WORDS * 32u ? 1 : 0;
+}
+
+// merge_sort_limit = 0: rocPRIM's default sorts up to 1 M items with a block sort + 10 merge passes (21 launches, 150 us at 1 M);
+// the Onesweep radix path is one histogram + four digit passes
+using RankSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+
+static size_t rank_sort_temp_bytes(uint32_t total) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs<RankSortConfig>(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                    (size_t)total, 0u, 32u, 0, false);
+    return align_up(bytes, 256);
+}
+
+extern "C" size_t gsx_intersect_depth_ranks_workspace_bytes(uint32_t C, uint32_t N) {
+    const uint32_t total = C * N;
+    return 3 * align_up((size_t)total * 4, 256) + rank_sort_temp_bytes(total) + 256;
+}
+
+extern "C" int gsx_intersect_depth_ranks(uint32_t C, uint32_t N, const int32_t* radii, const float* depths, uint32_t* ranks, uint32_t* order,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!gsx_intersect_ranked_supported(C, N)) { set_error("intersect_depth_ranks: C*N must be in [1, 1048576]"); return GSX_ERR_UNSUPPORTED; }
+    if (!radii || !depths || !ranks || !order) { set_error("intersect_depth_ranks: null pointer"); return GSX_ERR_INVALID_ARGUMENT; }
+    if (!workspace || workspace_bytes < gsx_intersect_depth_ranks_workspace_bytes(C, N)) {
+        set_error("intersect_depth_ranks: workspace too small");
+        return GSX_ERR_WORKSPACE_TOO_SMALL;
+    }
+    const uint32_t total = C * N;
+    const size_t stride = align_up((size_t)total * 4, 256);
+    uint32_t* keys_in = (uint32_t*)workspace;
+    uint32_t* keys_out = (uint32_t*)((char*)workspace + stride);
+    uint32_t* vals_in = (uint32_t*)((char*)workspace + 2 * stride);
+    void* temp = (char*)workspace + 3 * stride;
+    size_t temp_bytes = rank_sort_temp_bytes(total);
+    const uint32_t grid = (total + ISECT_BLOCK - 1) / ISECT_BLOCK;
+    hipLaunchKernelGGL(rank_keys_kernel, dim3(grid), dim3(ISECT_BLOCK), 0, st, total, radii, depths, keys_in, vals_in);
+    // stable LSD radix sort over the 32 depth bits: equal depths keep ascending flatten index, as the 64-bit keys' low bits do
+    if (rocprim::radix_sort_pairs<RankSortConfig>(temp, temp_bytes, (const uint32_t*)keys_in, keys_out, (const uint32_t*)vals_in, order, (size_t)total, 0u, 32u, st,
+                                  false) != hipSuccess) {
+        set_error("intersect_depth_ranks: radix sort failed");
+        return GSX_ERR_LAUNCH_FAILED;
+    }
+    hipLaunchKernelGGL(rank_invert_kernel, dim3(grid), dim3(ISECT_BLOCK), 0, st, total, (const uint32_t*)order, ranks);
+    return check_launch("intersect_depth_ranks");
+}
+
+extern "C" size_t gsx_intersect_bin_fill_ranked_workspace_bytes(int64_t n_isects) {
+    return n_isects <= 0 ? 256 : align_up((size_t)n_isects * 4, 256) + 256;
+}
+
+extern "C" int gsx_intersect_bin_fill_ranked(uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, const float* depths,
+                                             uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, const int32_t* tile_offsets,
+                                             int64_t n_isects, const void* count_workspace, const uint32_t* ranks, const uint32_t* order,
+                                             int32_t* flatten_ids, int64_t* isect_ids, void* workspace, size_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n_isects <= 0) return GSX_OK;
+    if (n_isects > 0x7FFFFFFFll) { set_error("intersect_bin_fill_ranked: n_isects must fit int32"); return GSX_ERR_INVALID_ARGUMENT; }
+    if (!means2d || !radii || !depths || !tile_offsets || !count_workspace || !ranks || !order || !flatten_ids || tile_size == 0) {
+        set_error("intersect_bin_fill_ranked: null pointer / zero tile size");
+        return GSX_ERR_INVALID_ARGUMENT;
+    }
+    if (!gsx_intersect_bin_supported(tile_width, tile_height) || !gsx_intersect_ranked_supported(C, N)) {
+        set_error("intersect_bin_fill_ranked: more than 36864 tiles per camera or more than 1048576 Gaussians");
+        return GSX_ERR_UNSUPPORTED;
+    }
+    if (!workspace || workspace_bytes < gsx_intersect_bin_fill_ranked_workspace_bytes(n_isects)) {
+        set_error("intersect_bin_fill_ranked: workspace too small");
+        return GSX_ERR_WORKSPACE_TOO_SMALL;
+    }
+    const uint32_t total = C * N, n_tiles = tile_width * tile_height, nseg = C * n_tiles;
+    uint32_t* keys = (uint32_t*)workspace;
+    const uint32_t per_block = (N + BIN_NB - 1) / BIN_NB;
+    const size_t lds = (size_t)n_tiles * 4;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)bin_scatter_kernel<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(bin_scatter_kernel<uint32_t>, dim3(BIN_NB, C), dim3(BIN_BLOCK), lds, st, N, per_block, means2d, radii, depths, ranks,
+                       (float)tile_size, tile_width, tile_height, 0u, tile_offsets, (const uint32_t*)count_workspace, keys, (uint32_t)n_isects);
+    const KeyRank kt{order, depths};
+    hipLaunchKernelGGL(tile_sort_wave_kernel<KeyRank>, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, n_tiles, bit_width_u32(n_tiles), kt, tile_offsets,
+                       (const uint32_t*)keys, flatten_ids, isect_ids, n_isects);
+    hipLaunchKernelGGL(tile_sort_kernel<KeyRank>, dim3(nseg), dim3(ISECT_BLOCK), 0, st, n_tiles, bit_width_u32(n_tiles), kt, tile_offsets,
+                       (const uint32_t*)keys, flatten_ids, isect_ids, n_isects);
+    if (n_isects > TSORT_CAP) {
+        const uint32_t n_words = rank_words(total);
+        const size_t bitmap_lds = (size_t)n_words * 4 + (size_t)16 * BITMAP_STAGE * 4;
+        if (bitmap_lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)tile_sort_bitmap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bitmap_lds);
+        hipLaunchKernelGGL(tile_sort_bitmap_kernel, dim3(256), dim3(1024), bitmap_lds, st, nseg, n_words, tile_offsets, keys, n_isects);
+    }
+    hipLaunchKernelGGL(ranked_finalize_kernel, dim3((uint32_t)((n_isects + ISECT_BLOCK - 1) / ISECT_BLOCK)), dim3(ISECT_BLOCK), 0, st, n_isects, nseg,
+                       n_tiles, bit_width_u32(n_tiles), tile_offsets, (const uint32_t*)keys, kt, flatten_ids, isect_ids);
+    return check_launch("intersect_bin_fill_ranked");
 }

@@ -17,6 +17,7 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
@@ -82,7 +83,7 @@ static thread_local at::Tensor* g_fwd_ws_out = nullptr;
 static thread_local const at::Tensor* g_fwd_ws_in = nullptr;
 
 // counters for bench.py (host synchronisations and capacity-hint outcomes of intersect_tile); never read by the ops themselves
-struct ShimStats { std::atomic<int64_t> host_syncs{0}, binned_calls{0}, hint_misses{0}, hint_cold{0}; };
+struct ShimStats { std::atomic<int64_t> host_syncs{0}, binned_calls{0}, hint_misses{0}, hint_cold{0}, ranked_calls{0}; };
 static ShimStats g_stats;
 
 namespace gsx_ext {
@@ -572,10 +573,38 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
         auto it = hints.find(key);
         if (it != hints.end()) { hint = it->second.first; hint_seg = it->second.second; }
     }
+    // Frames with heavy tiles (last call: a tile above 4096 keys and at least kRankedMeanKeys keys per tile on average) take the ranked
+    // fill: one frame-wide depth ranking (~50 us), then 4-byte keys and bitmap sorts for the heavy tiles.  Same outputs bit for bit,
+    // so the choice — like the capacity hint — only affects speed.  GSX_INTERSECT_FILL=ranked|keys forces one or the other.
+    constexpr int64_t kRankedMeanKeys = 2500;
+    const int64_t nseg_all = (int64_t)C * tile_width * tile_height;
+    bool ranked = hint_seg > 4096 && hint >= kRankedMeanKeys * nseg_all;
+    if (const char* e = std::getenv("GSX_INTERSECT_FILL")) ranked = std::strcmp(e, "ranked") == 0 ? true : (std::strcmp(e, "keys") == 0 ? false : ranked);
+    ranked = ranked && n_elements && gsx_intersect_ranked_supported(C, N);
+    at::Tensor ranks, order;
+    if (ranked) {
+        ranks = at::empty({(int64_t)n_elements}, depths.options().dtype(at::kInt));
+        order = at::empty({(int64_t)n_elements}, depths.options().dtype(at::kInt));
+        const size_t rwb = gsx_intersect_depth_ranks_workspace_bytes(C, N);
+        at::Tensor rws = at::empty({(int64_t)rwb}, depths.options().dtype(at::kByte));
+        check(gsx_intersect_depth_ranks(C, N, radii.data_ptr<int32_t>(), depths.data_ptr<float>(), (uint32_t*)ranks.data_ptr<int32_t>(),
+                                        (uint32_t*)order.data_ptr<int32_t>(), rws.data_ptr(), rwb, st), "intersect_tile_binned(ranks)");
+        g_stats.ranked_calls++;
+    }
     at::Tensor flatten_ids, isect_ids;
     auto fill = [&](int64_t capacity, int64_t seg_bound) {
         flatten_ids = at::empty({capacity}, depths.options().dtype(at::kInt));
         isect_ids = at::empty({want_isect_ids ? capacity : 0}, depths.options().dtype(at::kLong));
+        if (ranked) {
+            const size_t fwb = gsx_intersect_bin_fill_ranked_workspace_bytes(capacity);
+            at::Tensor fws = at::empty({(int64_t)fwb}, depths.options().dtype(at::kByte));
+            check(gsx_intersect_bin_fill_ranked(C, N, means2d.data_ptr<float>(), radii.data_ptr<int32_t>(), depths.data_ptr<float>(), tile_size,
+                                                tile_width, tile_height, offsets.data_ptr<int32_t>(), capacity, cws.data_ptr(),
+                                                (const uint32_t*)ranks.data_ptr<int32_t>(), (const uint32_t*)order.data_ptr<int32_t>(),
+                                                flatten_ids.data_ptr<int32_t>(), want_isect_ids ? isect_ids.data_ptr<int64_t>() : nullptr,
+                                                fws.data_ptr(), fwb, st), "intersect_tile_binned(ranked fill)");
+            return;
+        }
         const size_t fwb = gsx_intersect_bin_fill_workspace_bytes(C, tile_width, tile_height, capacity);
         at::Tensor fws = at::empty({(int64_t)fwb}, depths.options().dtype(at::kByte));
         check(gsx_intersect_bin_fill(C, N, means2d.data_ptr<float>(), radii.data_ptr<int32_t>(), depths.data_ptr<float>(), tile_size, tile_width,
@@ -600,9 +629,10 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
         h.second = std::max<int64_t>(max_seg, h.second - h.second / 50);
     }
     g_stats.binned_calls++;
-    if (capacity > 0 && (n_isects > capacity || max_seg > seg_bound)) g_stats.hint_misses++;
+    const bool seg_ok = ranked || max_seg <= seg_bound;   // (the ranked fill has no merge passes to run short of)
+    if (capacity > 0 && (n_isects > capacity || !seg_ok)) g_stats.hint_misses++;
     if (capacity == 0 && n_isects > 0) g_stats.hint_cold++;
-    if (capacity > 0 && n_isects <= capacity && max_seg <= seg_bound) {
+    if (capacity > 0 && n_isects <= capacity && seg_ok) {
         flatten_ids = flatten_ids.narrow(0, 0, n_isects);
         if (want_isect_ids) isect_ids = isect_ids.narrow(0, 0, n_isects);
     } else if (n_isects > 0) {
@@ -831,6 +861,11 @@ PYBIND11_MODULE(_gsx_ops, m) {
     m.def("shim_stats", [](bool reset) {  // (host_syncs, binned intersect calls, capacity-hint misses, cold calls without a hint)
         auto r = std::make_tuple((int64_t)g_stats.host_syncs, (int64_t)g_stats.binned_calls, (int64_t)g_stats.hint_misses, (int64_t)g_stats.hint_cold);
         if (reset) { g_stats.host_syncs = 0; g_stats.binned_calls = 0; g_stats.hint_misses = 0; g_stats.hint_cold = 0; }
+        return r;
+    });
+    m.def("shim_ranked_calls", [](bool reset) {  // binned intersect calls that took the ranked fill (heavy tiles)
+        const int64_t r = g_stats.ranked_calls;
+        if (reset) g_stats.ranked_calls = 0;
         return r;
     });
     m.def("sh_colors_fwd", &gsx_ext::sh_colors_fwd);

@@ -62,3 +62,4 @@ fusedssim_backward = _C.fusedssim_backward
 photometric_loss_fwd = _C.photometric_loss_fwd
 photometric_loss_bwd = _C.photometric_loss_bwd
 shim_stats = _C.shim_stats
+shim_ranked_calls = _C.shim_ranked_calls

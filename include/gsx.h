@@ -200,6 +200,24 @@ int gsx_intersect_bin_fill(uint32_t C, uint32_t N, const float* means2d, const i
                            int64_t n_isects, int64_t max_segment, const void* count_workspace, int32_t* flatten_ids, int64_t* isect_ids,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* Ranked variant of the fill for frames with heavy tiles (same outputs, bit for bit; same reference interface).  The Gaussians of
+ * the frame are ranked once by (depth bits, flatten index) — gsx_intersect_depth_ranks: ranks[c*N + n] = position in that order,
+ * order[rank] = flatten index; culled Gaussians rank last — and the per-tile keys are these 4-byte ranks.  A tile above 4096 keys
+ * is sorted by setting its ranks in a C*N-bit bitmap in LDS and reading it back in order (no merge passes, any segment size);
+ * lighter tiles use the same LDS merge sorts as bin_fill with half the bytes.  Pays off when most intersections sit in tiles above
+ * 4096 keys (a trained dense scene); needs C*N <= 1 048 576 (128 KB of bitmap): gsx_intersect_ranked_supported.
+ * Protocol: bin_count -> depth_ranks (any time before) -> bin_fill_ranked(count_workspace, ranks, order); `n_isects` is the
+ * capacity of the outputs exactly as in bin_fill. */
+int gsx_intersect_ranked_supported(uint32_t C, uint32_t N);
+size_t gsx_intersect_depth_ranks_workspace_bytes(uint32_t C, uint32_t N);
+int gsx_intersect_depth_ranks(uint32_t C, uint32_t N, const int32_t* radii, const float* depths, uint32_t* ranks, uint32_t* order,
+                              void* workspace, size_t workspace_bytes, void* stream);
+size_t gsx_intersect_bin_fill_ranked_workspace_bytes(int64_t n_isects);
+int gsx_intersect_bin_fill_ranked(uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, const float* depths,
+                                  uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, const int32_t* tile_offsets,
+                                  int64_t n_isects, const void* count_workspace, const uint32_t* ranks, const uint32_t* order,
+                                  int32_t* flatten_ids, int64_t* isect_ids, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- next tier: fused Adam step -------------------------------------------------------
  * fast_gs::optimizer::adam_step_wrapper, fastgs/optimizer/include/adam_kernels.cuh:13-38:
  *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr * bc1_rcp * m / (sqrt(v) * bc2_sqrt_rcp + eps)

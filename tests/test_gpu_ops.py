@@ -308,11 +308,16 @@ def test_blend_with_no_intersections(gsx_mod, raster_path):
                                              (3, 1, 33, 17, 5, 0), (1, 100, 1920, 1080, 300, 4),
                                              (1, 20000, 64, 64, 30, 8), (1, 50000, 64, 64, 30, 0), (2, 70000, 64, 48, 30, 0),
                                              (1, 700000, 64, 64, 30, 0), (1, 150000, 64, 64, 30, 4)])
-def test_intersect_tile_binned_equals_sorted_path(C, N, W, H, rmax, nq):
+@pytest.mark.parametrize("fill", ["keys", "ranked"])
+def test_intersect_tile_binned_equals_sorted_path(C, N, W, H, rmax, nq, fill, monkeypatch):
     """The binned pipeline (LDS histograms + per-tile LDS sort, incl. the > 4096-key merge path: case 3) returns bit for bit
-    what intersect_tile(sort=True) + intersect_offset return; quantised depths (nq levels) exercise the flatten-index tie break."""
+    what intersect_tile(sort=True) + intersect_offset return; quantised depths (nq levels) exercise the flatten-index tie break.
+    fill = "keys": 64-bit (depth, index) keys, LDS merge sorts, chunk + merge passes for giant segments; "ranked": frame-wide depth
+    ranks as 4-byte keys, bitmap sort for tiles above 4096 keys (the shim picks one by the previous frame's statistics)."""
     import gsx  # noqa: F401
     from gsx import ops
+    monkeypatch.setenv("GSX_INTERSECT_FILL", fill)
+    ops.shim_ranked_calls(True)
     g = torch.Generator().manual_seed(C * 1000 + N)
     means2d = torch.rand(C, N, 2, generator=g) * torch.tensor([W * 1.2, H * 1.2]) - torch.tensor([W * 0.1, H * 0.1])
     radii = torch.randint(0, rmax, (C, N, 2), generator=g, dtype=torch.int32)      # zeros = culled
@@ -330,6 +335,7 @@ def test_intersect_tile_binned_equals_sorted_path(C, N, W, H, rmax, nq):
     assert ids3.numel() == 0 and torch.equal(flat, flat3) and torch.equal(off, off3)
     seg = torch.cat([off.flatten(), torch.tensor([flat.numel()], device=off.device, dtype=off.dtype)])
     seg = seg[1:] - seg[:-1]
+    assert ops.shim_ranked_calls(True) == (2 if fill == "ranked" else 0)
     if N == 30000:
         assert int(seg.max()) > 4096                                         # beyond the 4096-key block sort
     if N in (20000, 50000):

@@ -39,19 +39,21 @@ def main():
             model.opacity_raw.reshape(-1).contiguous(), cam.viewmat[None], cam.K[None], cam.width, cam.height, rasterizer.EPS2D,
             rasterizer.NEAR_PLANE, rasterizer.FAR_PLANE, rasterizer.RADIUS_CLIP, ops.CameraModelType.PINHOLE, ut, None, None, None)
     tw, th = (cam.width + 15) // 16, (cam.height + 15) // 16
-    for _ in range(3):
-        _, _, flat, off = ops.intersect_tile_binned(means2d, radii, depths, 1, 16, tw, th, False)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        ops.intersect_tile_binned(means2d, radii, depths, 1, 16, tw, th, False)
-    e1.record()
-    torch.cuda.synchronize()
+    for fill in ("keys", "ranked"):
+        os.environ["GSX_INTERSECT_FILL"] = fill
+        for _ in range(3):
+            _, _, flat, off = ops.intersect_tile_binned(means2d, radii, depths, 1, 16, tw, th, False)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.intersect_tile_binned(means2d, radii, depths, 1, 16, tw, th, False)
+        e1.record()
+        torch.cuda.synchronize()
+        print("fill=%-6s N %d  visible %d  n_isects %d  tiles %d  intersect_tile_binned %.3f ms" % (
+            fill, n, int((radii > 0).all(-1).sum()), flat.numel(), off.numel(), e0.elapsed_time(e1) / reps))
     seg = torch.cat([off.flatten(), torch.tensor([flat.numel()], device=dev, dtype=off.dtype)])
     seg = (seg[1:] - seg[:-1]).cpu()
-    print("N %d  visible %d  n_isects %d  tiles %d  intersect_tile_binned %.3f ms" % (n, int((radii > 0).all(-1).sum()), flat.numel(), seg.numel(),
-                                                                                    e0.elapsed_time(e1) / reps))
     edges = [0, 1, 1025, 4097, 8193, 16385, 32769, 65537, 1 << 30]
     for lo, hi in zip(edges[:-1], edges[1:]):
         m = (seg >= lo) & (seg < hi)
