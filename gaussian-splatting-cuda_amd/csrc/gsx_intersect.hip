@@ -15,6 +15,7 @@
 // The per-tile offsets are a lower_bound per tile (8 160 tiles @1080p) instead of the reference's
 // one-thread-per-intersection boundary detection with serial gap filling; same output.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(ISECT_BLOCK) void isect_offset_kernel(int64_t n_ise
 //               (camera|tile) << 32 | depth bits.  Keys are unique, so the result is exactly the stable sort upstream.
 // No global atomics anywhere (device-scope atomics resolve at the memory side on MI355X: ~14 G/s measured, 0.24 ms for the
 // 3.4 M increments of a naive tile counter).  Tile grids above 36 K tiles per camera (LDS) use the device-wide sort instead.
-constexpr uint32_t BIN_NB = 256;          // Gaussian slices (blocks) per camera
+constexpr uint32_t BIN_NB_MAX = 1024;     // Gaussian slices (blocks) per camera: bin_nb() below, a multiple of 32
 constexpr uint32_t BIN_MAX_TILES = 36864; // 144 KB of LDS counters
 constexpr int TSORT_CAP = 4096;           // keys sorted in LDS per block (32 KB)
 constexpr int TSORT_BIG_CAP = 16384;      // keys sorted in LDS by a 1024-thread block (132 KB): the heavy tiles of dense scenes
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_count_kernel(uint32_t N, uint32
                                                                 const int32_t* __restrict__ radii, float tile_size, uint32_t tw,
                                                                 uint32_t th, int32_t* __restrict__ tiles_per_gauss,
                                                                 uint32_t* __restrict__ block_hist) {
+    const uint32_t BIN_NB = gridDim.x;
     extern __shared__ uint32_t s_hist[];
     const uint32_t n_tiles = tw * th, c = blockIdx.y, b = blockIdx.x;
     for (uint32_t t = threadIdx.x; t < n_tiles; t += BIN_BLOCK) s_hist[t] = 0u;
@@ -158,10 +160,10 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_count_kernel(uint32_t N, uint32
 // block_hist[c][b][t] -> exclusive prefix over b; tile_counts[c*n_tiles + t] = total.
 // 32 tiles x 8 groups of 32 blocks per workgroup: every thread keeps its 32 counts in registers, the 8 group sums of a tile meet
 // in LDS (8 160 tiles alone would be 32 workgroups of strictly serial 256-step columns).
-__global__ __launch_bounds__(ISECT_BLOCK) void bin_prefix_kernel(uint32_t C, uint32_t n_tiles, uint32_t* __restrict__ block_hist,
+__global__ __launch_bounds__(BIN_NB_MAX) void bin_prefix_kernel(uint32_t C, uint32_t n_tiles, uint32_t* __restrict__ block_hist,
                                                                  uint32_t* __restrict__ tile_counts) {
-    static_assert(BIN_NB == 256 && ISECT_BLOCK == 256, "layout below assumes 8 groups of 32 blocks");
-    __shared__ uint32_t s_sum[8][32];
+    const uint32_t BIN_NB = blockDim.x;   // BIN_NB / 32 groups of 32 slices, one thread per (tile, group)
+    __shared__ uint32_t s_sum[BIN_NB_MAX / 32][32];
     const uint32_t tl = threadIdx.x & 31u, grp = threadIdx.x >> 5;
     const uint32_t g = blockIdx.x * 32u + tl;
     const bool ok = g < C * n_tiles;
@@ -176,8 +178,7 @@ __global__ __launch_bounds__(ISECT_BLOCK) void bin_prefix_kernel(uint32_t C, uin
     s_sum[grp][tl] = sum;
     __syncthreads();
     uint32_t run = 0, total = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 8; ++k) {
+    for (uint32_t k = 0; k < BIN_NB / 32; ++k) {
         const uint32_t sv = s_sum[k][tl];
         run += k < grp ? sv : 0u;
         total += sv;
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_scatter_kernel(uint32_t N, uint
                                                                   const uint32_t* __restrict__ block_hist, K* __restrict__ keys,
                                                                   uint32_t capacity) {
     extern __shared__ uint32_t s_cur[];
+    const uint32_t BIN_NB = gridDim.x;
     const uint32_t n_tiles = tw * th, c = blockIdx.y, b = blockIdx.x;
     const uint32_t* pre = block_hist + ((size_t)c * BIN_NB + b) * n_tiles;
     const int32_t* off = tile_offsets + (size_t)c * n_tiles;
@@ -872,7 +874,16 @@ extern "C" int gsx_intersect_offset(int64_t n_isects, const int64_t* isect_ids, 
 
 
 // ---- binned path C ABI -----------------------------------------------------------------------------------------------------
-static size_t bin_hist_bytes(uint32_t C, uint32_t n_tiles) { return align_up((size_t)C * BIN_NB * n_tiles * 4, 256); }
+// Slices per camera: 256 (one 1024-thread block per CU); GSX_BIN_NB overrides it for experiments (a multiple of 32 up to 1024; read once).
+static uint32_t bin_nb() {
+    static const uint32_t nb = [] {
+        const char* e = getenv("GSX_BIN_NB");
+        const long v = e ? atol(e) : 256;
+        return (v >= 32 && v <= (long)BIN_NB_MAX && v % 32 == 0) ? (uint32_t)v : 256u;
+    }();
+    return nb;
+}
+static size_t bin_hist_bytes(uint32_t C, uint32_t n_tiles) { return align_up((size_t)C * bin_nb() * n_tiles * 4, 256); }
 
 extern "C" int gsx_intersect_bin_supported(uint32_t tile_width, uint32_t tile_height) {
     return (uint64_t)tile_width * tile_height <= BIN_MAX_TILES;
@@ -904,12 +915,12 @@ extern "C" int gsx_intersect_bin_count(uint32_t C, uint32_t N, const float* mean
     }
     uint32_t* hist = (uint32_t*)workspace;
     uint32_t* counts = (uint32_t*)((char*)workspace + bin_hist_bytes(C, n_tiles));
-    const uint32_t per_block = (N + BIN_NB - 1) / BIN_NB;
+    const uint32_t per_block = (N + bin_nb() - 1) / bin_nb();
     const size_t lds = (size_t)n_tiles * 4;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(bin_count_kernel, dim3(BIN_NB, C), dim3(BIN_BLOCK), lds, st, N, per_block, means2d, radii, (float)tile_size, tile_width,
+    hipLaunchKernelGGL(bin_count_kernel, dim3(bin_nb(), C), dim3(BIN_BLOCK), lds, st, N, per_block, means2d, radii, (float)tile_size, tile_width,
                        tile_height, tiles_per_gauss, hist);
-    hipLaunchKernelGGL(bin_prefix_kernel, dim3((nseg + 31) / 32), dim3(ISECT_BLOCK), 0, st, C, n_tiles, hist, counts);
+    hipLaunchKernelGGL(bin_prefix_kernel, dim3((nseg + 31) / 32), dim3(bin_nb()), 0, st, C, n_tiles, hist, counts);
     // offsets[t] = intersections before (camera, tile) t; offsets[nseg] = n_isects
     // (the largest segment lands in the slack word behind the counts; it travels to the host in the upper half of the pinned word)
     uint32_t* max_count = (uint32_t*)((char*)workspace + bin_hist_bytes(C, n_tiles) + align_up((size_t)(nseg + 1) * 4, 256));
@@ -952,10 +963,10 @@ extern "C" int gsx_intersect_bin_fill(uint32_t C, uint32_t N, const float* means
     const uint32_t idx_bits = total > 1 ? bit_width_u32(total - 1) : 1;
     uint64_t* keys = (uint64_t*)workspace;
     uint64_t* keys_alt = (uint64_t*)((char*)workspace + align_up((size_t)n_isects * 8, 256));
-    const uint32_t per_block = (N + BIN_NB - 1) / BIN_NB;
+    const uint32_t per_block = (N + bin_nb() - 1) / bin_nb();
     const size_t lds = (size_t)n_tiles * 4;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)bin_scatter_kernel<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(bin_scatter_kernel<uint64_t>, dim3(BIN_NB, C), dim3(BIN_BLOCK), lds, st, N, per_block, means2d, radii, depths,
+    hipLaunchKernelGGL(bin_scatter_kernel<uint64_t>, dim3(bin_nb(), C), dim3(BIN_BLOCK), lds, st, N, per_block, means2d, radii, depths,
                        (const uint32_t*)nullptr, (float)tile_size, tile_width, tile_height, idx_bits, tile_offsets, (const uint32_t*)count_workspace,
                        keys, (uint32_t)n_isects);
     const KeyDepthIdx kt{idx_bits};
@@ -1075,10 +1086,10 @@ extern "C" int gsx_intersect_bin_fill_ranked(uint32_t C, uint32_t N, const float
     }
     const uint32_t total = C * N, n_tiles = tile_width * tile_height, nseg = C * n_tiles;
     uint32_t* keys = (uint32_t*)workspace;
-    const uint32_t per_block = (N + BIN_NB - 1) / BIN_NB;
+    const uint32_t per_block = (N + bin_nb() - 1) / bin_nb();
     const size_t lds = (size_t)n_tiles * 4;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)bin_scatter_kernel<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(bin_scatter_kernel<uint32_t>, dim3(BIN_NB, C), dim3(BIN_BLOCK), lds, st, N, per_block, means2d, radii, depths, ranks,
+    hipLaunchKernelGGL(bin_scatter_kernel<uint32_t>, dim3(bin_nb(), C), dim3(BIN_BLOCK), lds, st, N, per_block, means2d, radii, depths, ranks,
                        (float)tile_size, tile_width, tile_height, 0u, tile_offsets, (const uint32_t*)count_workspace, keys, (uint32_t)n_isects);
     const KeyRank kt{order, depths};
     hipLaunchKernelGGL(tile_sort_wave_kernel<KeyRank>, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, n_tiles, bit_width_u32(n_tiles), kt, tile_offsets,
