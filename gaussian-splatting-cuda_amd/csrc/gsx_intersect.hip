@@ -336,7 +336,7 @@ struct KeyRank {
 
 template <class KT>
 __global__ __launch_bounds__(256) void tile_sort_wave_kernel(uint32_t n_segments, uint32_t n_tiles, uint32_t tile_n_bits, KT kt,
-                                                             const int32_t* __restrict__ tile_offsets, const typename KT::T* __restrict__ keys,
+                                                             const int32_t* __restrict__ tile_offsets, typename KT::T* __restrict__ keys,
                                                              int32_t* __restrict__ flatten_ids, int64_t* __restrict__ isect_ids,
                                                              int64_t capacity) {
     using K = typename KT::T;
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void tile_sort_wave_kernel(uint32_t n_segments
     for (int i = lane; i < n; i += 64) {
         const K k = s_keys[spad_of<K>(i)];
         if (KT::kDeferred) {
-            const_cast<K*>(keys)[begin + i] = k;   // (the whole segment was read before the sort)
+            keys[begin + i] = k;   // in place: the whole segment was read before the sort
         } else {
             const int32_t id = kt.id(k);
             flatten_ids[begin + i] = id;
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void tile_sort_wave_kernel(uint32_t n_segments
 
 template <class KT>
 __global__ __launch_bounds__(ISECT_BLOCK) void tile_sort_kernel(uint32_t n_tiles, uint32_t tile_n_bits, KT kt,
-                                                                const int32_t* __restrict__ tile_offsets, const typename KT::T* __restrict__ keys,
+                                                                const int32_t* __restrict__ tile_offsets, typename KT::T* __restrict__ keys,
                                                                 int32_t* __restrict__ flatten_ids, int64_t* __restrict__ isect_ids,
                                                                 int64_t capacity) {
     using K = typename KT::T;
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(ISECT_BLOCK) void tile_sort_kernel(uint32_t n_tiles
     for (int i = t; i < n; i += ISECT_BLOCK) {
         const K k = s_keys[spad_of<K>(i)];
         if (KT::kDeferred) {
-            const_cast<K*>(keys)[begin + i] = k;
+            keys[begin + i] = k;
         } else {
             const int32_t id = kt.id(k);
             flatten_ids[begin + i] = id;
@@ -971,9 +971,9 @@ extern "C" int gsx_intersect_bin_fill(uint32_t C, uint32_t N, const float* means
                        keys, (uint32_t)n_isects);
     const KeyDepthIdx kt{idx_bits};
     hipLaunchKernelGGL(tile_sort_wave_kernel<KeyDepthIdx>, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, n_tiles, bit_width_u32(n_tiles), kt,
-                       tile_offsets, (const uint64_t*)keys, flatten_ids, isect_ids, n_isects);
+                       tile_offsets, keys, flatten_ids, isect_ids, n_isects);
     hipLaunchKernelGGL(tile_sort_kernel<KeyDepthIdx>, dim3(nseg), dim3(ISECT_BLOCK), 0, st, n_tiles, bit_width_u32(n_tiles), kt, tile_offsets,
-                       (const uint64_t*)keys, flatten_ids, isect_ids, n_isects);
+                       keys, flatten_ids, isect_ids, n_isects);
     if (n_isects > TSORT_CAP) {   // a segment above 4096 keys needs at least that many intersections
         const size_t big_lds = (size_t)(TSORT_BIG_CAP + TSORT_BIG_CAP / 32) * 8;
         static const bool attr_set = [&] {
@@ -1093,9 +1093,9 @@ extern "C" int gsx_intersect_bin_fill_ranked(uint32_t C, uint32_t N, const float
                        (float)tile_size, tile_width, tile_height, 0u, tile_offsets, (const uint32_t*)count_workspace, keys, (uint32_t)n_isects);
     const KeyRank kt{order, depths};
     hipLaunchKernelGGL(tile_sort_wave_kernel<KeyRank>, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, n_tiles, bit_width_u32(n_tiles), kt, tile_offsets,
-                       (const uint32_t*)keys, flatten_ids, isect_ids, n_isects);
+                       keys, flatten_ids, isect_ids, n_isects);
     hipLaunchKernelGGL(tile_sort_kernel<KeyRank>, dim3(nseg), dim3(ISECT_BLOCK), 0, st, n_tiles, bit_width_u32(n_tiles), kt, tile_offsets,
-                       (const uint32_t*)keys, flatten_ids, isect_ids, n_isects);
+                       keys, flatten_ids, isect_ids, n_isects);
     if (n_isects > TSORT_CAP) {
         const uint32_t n_words = rank_words(total);
         const size_t bitmap_lds = (size_t)n_words * 4 + (size_t)16 * BITMAP_STAGE * 4;
