@@ -329,7 +329,20 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
     at::Tensor v_scales = at::empty_like(scales);
     at::Tensor v_colors = at::empty_like(colors);
     at::Tensor v_opacities = at::empty_like(opacities);
-    const size_t wsb = gsx_rasterize_bwd_workspace_bytes(C, N, flatten_ids.size(0));
+    // The workspace holds 64 B per intersection: 1.5 .. 1.8 GB at S-5M @4K, a different size for every camera.  Requests of ever-changing
+    // sizes make the caching allocator split and re-grow its largest blocks (each growth is a hipMalloc of gigabytes inside the training
+    // step), so the request is sized by the running maximum of n_isects for this problem shape — the same size call after call.
+    int64_t isects_cap = flatten_ids.size(0);
+    {
+        static std::mutex cap_mutex;
+        static std::map<std::tuple<int, uint32_t, uint32_t, uint32_t, uint32_t>, int64_t> caps;
+        std::lock_guard<std::mutex> lock(cap_mutex);
+        if (caps.size() > 4096) caps.clear();
+        int64_t& cap = caps[std::make_tuple((int)means.get_device(), C, N, image_width, image_height)];
+        if (isects_cap > cap || isects_cap < cap / 4) cap = isects_cap + isects_cap / 8;   // grows with 12 % head room; a much lighter scene starts over
+        isects_cap = cap;
+    }
+    const size_t wsb = gsx_rasterize_bwd_workspace_bytes(C, N, isects_cap);
     at::Tensor ws = at::empty({(int64_t)wsb}, means.options().dtype(at::kByte));  // caching allocator, like CUB temp storage upstream
     const void* packed = (g_fwd_ws_in && g_fwd_ws_in->defined())
                              ? gsx_rasterize_fwd_packed_records(g_fwd_ws_in->data_ptr(), (size_t)g_fwd_ws_in->numel(), C, N) : nullptr;
@@ -558,7 +571,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
     // Intersect.cpp:76).  To keep the GPU busy meanwhile, the fill is launched optimistically into buffers sized from a capacity
     // hint; the host then waits only for the 4-byte copy, not for the fill.  If the guess was too small the fill is repeated with
     // the exact size.  The hint is the ONLY state the shim keeps between calls: a process-wide map {(device, C, N, tile grid) ->
-    // recent maximum of n_isects}, mutex protected, decaying 2 % per call so that one outlier view does not pin memory for ever.
+    // recent maxima of n_isects and of the largest tile segment}, mutex protected, decaying 2 % per call so that one outlier view does not pin memory for ever.
     // It never changes a result (the outputs are narrowed to the exact length); it only decides whether the fill runs once or twice.
     at::cuda::CUDAEvent total_ready;
     total_ready.record(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
@@ -567,11 +580,20 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
     const auto key = std::make_tuple((int)means2d.get_device(), C, N, tile_width, tile_height);
     // The hint also carries the largest (camera, tile) segment of the last call: it fixes how many merge passes the optimistic fill
     // launches for segments above 16384 keys (none for most scenes).  A frame whose largest segment outgrows the bound is refilled.
+    // A model that grows (densification changes N every few hundred iterations) would start cold after every resize: the entry with
+    // N = 0 holds the last call of the same (device, C, tile grid) at any N and stands in, scaled by the ratio of the Gaussian counts.
+    const auto key_any = std::make_tuple((int)means2d.get_device(), C, 0u, tile_width, tile_height);
+    static std::map<std::tuple<int, uint32_t, uint32_t, uint32_t, uint32_t>, uint32_t> last_n;
     int64_t hint = 0, hint_seg = 0;
     {
         std::lock_guard<std::mutex> lock(hint_mutex);
         auto it = hints.find(key);
-        if (it != hints.end()) { hint = it->second.first; hint_seg = it->second.second; }
+        if (it != hints.end()) {
+            hint = it->second.first; hint_seg = it->second.second;
+        } else if ((it = hints.find(key_any)) != hints.end() && last_n[key_any] > 0) {
+            const double grow = std::min(2.0, std::max(1.0, (double)N / (double)last_n[key_any]));
+            hint = (int64_t)((double)it->second.first * grow); hint_seg = (int64_t)((double)it->second.second * grow);
+        }
     }
     // Frames with heavy tiles (last call: a tile above 4096 keys and at least kRankedMeanKeys keys per tile on average) take the ranked
     // fill: one frame-wide depth ranking (~50 us), then 4-byte keys and bitmap sorts for the heavy tiles.  Same outputs bit for bit,
@@ -627,6 +649,9 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
         auto& h = hints[key];
         h.first = std::max<int64_t>(n_isects, h.first - h.first / 50);  // running maximum with a slow decay
         h.second = std::max<int64_t>(max_seg, h.second - h.second / 50);
+        hints[key_any] = std::make_pair(n_isects, max_seg);
+        last_n[key_any] = N;
+        if (hints.size() > 4096) hints.clear();   // (a long run that resizes thousands of times: start over rather than grow without bound)
     }
     g_stats.binned_calls++;
     const bool seg_ok = ranked || max_seg <= seg_bound;   // (the ranked fill has no merge passes to run short of)

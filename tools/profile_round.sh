@@ -4,6 +4,7 @@
 #   2. the same bench under rocprofv3 --kernel-trace --stats              -> kernel_stats.md + bench_under_rocprof.json
 #   3. PMC counters of the bench step, one small group per pass           -> pmc/summary.txt
 #   4. bench.py --scene 5m                                                -> bench_s5m.json
+#   5. examples/train_garden_standin.py 4000 (twice)                      -> garden_standin.json
 # Usage: bash tools/profile_round.sh r02
 tag=${1:-r02}
 out=gpurun_out/$tag
@@ -27,7 +28,13 @@ with open(out + "/kernel_stats.md", "w") as o:
                                                               float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
 print(open(out + "/kernel_stats.md").read()[:3000])
 PY
-bash tools/pmc_passes.sh "$out/pmc" > "$out/pmc.log" 2>&1
-tail -3 "$out/pmc.log"
+if [ -z "$SKIP_PMC" ]; then   # SKIP_PMC=1: the blend kernels did not change since the last counter passes
+  bash tools/pmc_passes.sh "$out/pmc" > "$out/pmc.log" 2>&1
+  tail -3 "$out/pmc.log"
+fi
 python bench.py --scene 5m --steps 10 --warmup 3 --no-cpu-baseline > "$out/bench_s5m.json" 2> "$out/bench_s5m.err"
 echo "bench 5m rc=$?"
+# 5. the BASELINE configs[2] stand-in, twice (the first run on a fresh box is cold)                       -> garden_standin{_cold,}.json
+timeout 150 python examples/train_garden_standin.py 4000 --json "$out/garden_standin_cold.json" > /dev/null 2> "$out/garden.err"
+timeout 150 python examples/train_garden_standin.py 4000 --json "$out/garden_standin.json" > /dev/null 2>> "$out/garden.err"
+echo "garden rc=$?"; cut -c 200-420 "$out/garden_standin.json"
