@@ -109,9 +109,11 @@ __global__ __launch_bounds__(ISECT_BLOCK) void isect_offset_kernel(int64_t n_ise
 //   3. scan     exclusive scan of the C*tiles totals = the reference's isect_offsets (+ the grand total = n_isects);
 //   4. scatter  the same blocks reload (tile offset + block prefix) as LDS cursors, claim slots with returning LDS atomics and
 //               write 64-bit keys (depth bits << idx_bits | flatten index) into their tile's segment — unordered inside it;
-//   5. sort     one wave per tile (up to 1024 keys; a 256-thread block up to 4096): merge sort of the segment in LDS (segments
-//               above 4096 keys: LDS-sorted chunks, then rank merges through the two key buffers), then flatten_ids = low bits, isect_ids (on request) =
-//               (camera|tile) << 32 | depth bits.  Keys are unique, so the result is exactly the stable sort upstream.
+//   5. sort     one wave per tile (up to 1024 keys; a 256-thread block up to 4096; a 1024-thread block with 132 KB of LDS up to
+//               16384): merge sort of the segment in LDS; larger segments: 16384-key LDS-sorted chunks + merge-path passes by many
+//               blocks (giant_* kernels).  Then flatten_ids = low bits, isect_ids (on request) = (camera|tile) << 32 | depth bits.
+//               Keys are unique, so the result is exactly the stable sort upstream.
+//      Frames with heavy tiles: the ranked variant (4-byte depth ranks as keys, bitmap sort for tiles above 4096 keys), further down.
 // No global atomics anywhere (device-scope atomics resolve at the memory side on MI355X: ~14 G/s measured, 0.24 ms for the
 // 3.4 M increments of a naive tile counter).  Tile grids above 36 K tiles per camera (LDS) use the device-wide sort instead.
 constexpr uint32_t BIN_NB_MAX = 1024;     // Gaussian slices (blocks) per camera: bin_nb() below, a multiple of 32
@@ -402,10 +404,10 @@ __global__ __launch_bounds__(ISECT_BLOCK) void tile_sort_kernel(uint32_t n_tiles
     }
 }
 
-// Heavy tiles (4096 < keys <= 16384): one 1024-thread block sorts the whole segment in 132 KB of LDS.  The path below them in
-// tile_sort_kernel (4096-key LDS chunks + rank merges through global memory by ONE 256-thread block) is latency bound: dependent
-// global loads in every binary-search step make a 6 000-key tile cost over a millisecond, and dense scenes have hundreds of such
-// tiles per frame (garden-like stand-in, 185 cameras: 2.35 ms per frame = 47 % of the GPU time of a training iteration went there).
+// Heavy tiles (4096 < keys <= 16384): one 1024-thread block sorts the whole segment in 132 KB of LDS.  (Their first implementation —
+// 4096-key LDS chunks + rank merges through global memory by ONE 256-thread block — was latency bound: dependent global loads in
+// every binary-search step made a 6 000-key tile cost over a millisecond, and dense scenes have hundreds of such tiles per frame:
+// garden-like stand-in, 185 cameras: 2.35 ms per frame = 47 % of the GPU time of a training iteration went there.)
 // Persistent grid: 256 blocks walk the segments with stride 256 (heavy tiles are neighbours in tile order: the stride spreads them
 // over the CUs); a frame without heavy tiles costs 32 offset reads per block.
 __global__ __launch_bounds__(1024) void tile_sort_big_kernel(uint32_t n_segments, uint32_t n_tiles, uint32_t tile_n_bits, uint32_t idx_bits,
