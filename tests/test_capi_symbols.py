@@ -81,6 +81,18 @@ def test_argument_validation_of_the_next_tier_entry_points():
     assert lib.gsx_intersect_bin_count(u32(1), u32(8), buf, off, u32(16), u32(2), u32(2), None, off, None, buf, c.c_size_t(8), None) == -3
     assert lib.gsx_intersect_bin_fill(u32(1), u32(8), buf, off, buf, u32(16), u32(2), u32(2), off, c.c_int64(0), c.c_int64(0), buf, off, None, None, c.c_size_t(0), None) == 0
     assert lib.gsx_intersect_bin_fill_workspace_bytes(u32(1), u32(2), u32(2), c.c_int64(100)) >= 2 * 100 * 8
+    # ranked variant: bitmap capacity, argument checks (no launch happens without valid pointers)
+    assert lib.gsx_intersect_ranked_supported(u32(1), u32(1 << 20)) == 1 and lib.gsx_intersect_ranked_supported(u32(2), u32(1 << 19)) == 1
+    assert lib.gsx_intersect_ranked_supported(u32(1), u32((1 << 20) + 1)) == 0 and lib.gsx_intersect_ranked_supported(u32(0), u32(5)) == 0
+    assert lib.gsx_intersect_depth_ranks_workspace_bytes(u32(1), u32(1000)) >= 3 * 1000 * 4
+    assert lib.gsx_intersect_depth_ranks(u32(1), u32((1 << 20) + 1), off, buf, off, off, buf, c.c_size_t(1 << 30), None) == -2
+    assert lib.gsx_intersect_depth_ranks(u32(1), u32(8), None, buf, off, off, buf, c.c_size_t(1 << 30), None) == -1
+    assert lib.gsx_intersect_depth_ranks(u32(1), u32(8), off, buf, off, off, buf, c.c_size_t(8), None) == -3
+    assert lib.gsx_intersect_bin_fill_ranked_workspace_bytes(c.c_int64(100)) >= 100 * 4
+    assert lib.gsx_intersect_bin_fill_ranked(u32(1), u32(8), buf, off, buf, u32(16), u32(2), u32(2), off, c.c_int64(0), buf, off, off, off, None, None,
+                                             c.c_size_t(0), None) == 0     # nothing to fill
+    assert lib.gsx_intersect_bin_fill_ranked(u32(1), u32(8), buf, off, buf, u32(16), u32(2), u32(2), off, c.c_int64(5), buf, None, off, off, None, buf,
+                                             c.c_size_t(1 << 20), None) == -1    # ranks missing
     # blend workspaces
     assert lib.gsx_rasterize_fwd_packed_records(None, c.c_size_t(0), u32(1), u32(8)) is None
     assert lib.gsx_rasterize_bwd_workspace_bytes(u32(1), u32(1000), c.c_int64(5000)) >= 5000 * 64 + 1000 * 4 + 1000 * 64
