@@ -11,7 +11,8 @@ step to step and intersect_tile's capacity hint is not trivially right; hint mis
 reported.  The second half of BASELINE's metric, fwd+bwd ms/frame (no optimizer), is measured in a separate loop (`fwd_bwd`).
 Default: the fused glue kernels of rasterize_fused (gradients written straight into the flat all-reduce bucket);
 --unfused runs the reference-style chain of torch ops around the seven gsplat operators.
-Inputs are resident in HBM before the timed region.  N > 1: launched by torch.distributed.run, one rank per
+Inputs are resident in HBM before the timed region.  N > 1: launched by torch.distributed.run (a bare `python bench.py --gpus N`
+re-executes itself under it), one rank per
 GPU over RCCL; every rank renders its own camera of the step's batch (cameras on a small orbit around the
 cfg2 pose so per-GPU work stays fixed: weak scaling); the gradient exchange is the colour-gradient exchange of
 distributed.ColorGradExchange (3 floats per (camera, Gaussian) all-gathered, SH backward over all cameras on every rank, the other
@@ -179,6 +180,18 @@ def load_pmc(workload_key):
 VALU_PEAK_LANE_OPS = 78.6e12  # fp32 vector lane-operations / s: 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz (157.3 TFLOP/s / 2)
 
 
+def self_launch_command(n, argv, port=None):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): the command this process replaces itself
+    with — the launch line of the contract, one rank per GPU under torch.distributed.run, rendezvous on 127.0.0.1."""
+    if port is None:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,18 +213,40 @@ def main():
     ap.add_argument("--l1-loss", action="store_true", help="plain torch L1 loss instead of the reference's fused L1 + SSIM loss")
     ap.add_argument("--no-fwd-bwd", action="store_true", help="skip the extra fwd+bwd (no optimizer) timing loop")
     ap.add_argument("--fixed-camera", action="store_true", help="the cfg2 camera on every step (default: 8 poses around it, one per step)")
+    ap.add_argument("--repeats", type=int, default=1, help="R > 1: time R x K steps and report the MEDIAN K-step time (sub-3 %% claims need it; "
+                                                           "the contract's single K-step region is R = 1)")
+    ap.add_argument("--launch-check", action="store_true", help="initialise the process group, report rank / world / backend and exit "
+                                                                "(tests the N > 1 launch logic without touching a GPU)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become `python -m torch.distributed.run --nproc-per-node N bench.py ...` (one rank per GPU)
+        cmd = self_launch_command(args.gpus, sys.argv[1:])
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.stdout.flush()
+        os.execv(cmd[0], cmd)
 
     import gsx  # noqa: F401
     from gsx import distributed as gdist
     from gsx import loss as gloss
     from gsx import ops, optim, rasterizer, scenes
 
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     if os.environ.get("GSX_BENCH_ALL_RANKS_ON_DEVICE0"):  # functional test of the N>1 code path on a 1-GPU box (gloo)
         os.environ["LOCAL_RANK"] = "0"
+    if args.launch_check:
+        rank, local_rank, world = gdist.init_from_env(args.backend or ("nccl" if torch.cuda.is_available() else "gloo"))
+        assert world == max(1, args.gpus), "--gpus must equal WORLD_SIZE"
+        if world > 1:
+            tt = torch.ones(1) if dist.get_backend() == "gloo" else torch.ones(1, device="cuda:%d" % local_rank)
+            dist.all_reduce(tt)
+            assert int(tt.item()) == world
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "backend": dist.get_backend() if world > 1 else None}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     rank, local_rank, world = gdist.init_from_env(args.backend)
-    assert world == max(1, args.gpus), "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
+    assert world == max(1, args.gpus), "--gpus must equal WORLD_SIZE (torch.distributed.run sets it; a bare `python bench.py --gpus N` launches itself)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -324,7 +359,8 @@ def main():
     # in a separate pass after the timed region.
     timer.enabled = True
     timer.only = {"rasterize_to_pixels_from_world_3dgs_fwd", "rasterize_to_pixels_from_world_3dgs_bwd"}
-    elapsed = timed(args.steps, True)
+    elapsed_all = [timed(args.steps, True) for _ in range(max(1, args.repeats))]
+    elapsed = sorted(elapsed_all)[len(elapsed_all) // 2]   # R = 1: the contract's single region; R > 1: the median region
     timer.enabled = False
     host_syncs, binned_calls, hint_misses, hint_cold = ops.shim_stats(True)
     isects_timed = list(counter["isects"])
@@ -385,15 +421,16 @@ def main():
             "config": {"workload": workload, "n_gaussians": N, "width": W, "height": H, "sh_degree": deg,
                        "cameras": "cfg2 pose only" if args.fixed_camera else "%d poses (cfg2 + a 0.4 m orbit around it), a different one every step" % len(cams),
                        "n_isects_mean": round(I, 1), "n_isects_min": min(isects_timed), "n_isects_max": max(isects_timed),
-                       "cameras_per_step": world,
+                       "cameras_per_step": world, "ranks": world, "backend": (dist.get_backend() if world > 1 else None),
                        "grad_exchange": ("none" if world == 1 else ("colour-gradient all-gather (3 floats / camera / Gaussian) + SH backward over all cameras on every rank; "
                                                                      "all-reduce of the other 11 floats under it" if xch is not None else "reduce-scatter + sharded Adam + all-gather" if sharded is not None else
                                          ("all-reduce of visible rows" if args.sparse_allreduce else
                                           ("dense all-reduce, scaling/rotation/opacity exchanged under the SH backward" if overlap else "dense all-reduce")))),
                        "grad_exchange_bytes": int(getattr(bucket, "last_reduced_bytes", 0)) if world > 1 else 0,
                        "grad_bucket_bytes": bucket.nbytes(),
-                       "host_syncs_per_step": round(host_syncs / args.steps, 2),
+                       "host_syncs_per_step": round(host_syncs / (args.steps * len(elapsed_all)), 2),
                        "intersect_hint_misses": int(hint_misses), "intersect_cold_calls": int(hint_cold)},
+            "repeats": {"R": len(elapsed_all), "ms_per_step_each": [round(e / args.steps * 1e3, 4) for e in elapsed_all], "reported": "median"},
             "gaussians_x_pixels_per_s": round(world * N * P / (elapsed / args.steps), 1),
             "pairs_per_s_fwd": round(256.0 * I / (all_ms.get("rasterize_to_pixels_from_world_3dgs_fwd", float("nan")) * 1e-3), 1),
             "roofline": roofline,

@@ -39,6 +39,13 @@ namespace {
     TORCH_CHECK((x).is_cuda(), #x " must be a CUDA tensor");   \
     const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(at::device_of(x))
 
+// the shim was compiled against include/gsx.h: refuse to run on a libgsx.so with another ABI (a stale library silently shifts arguments)
+const bool abi_checked = [] {
+    TORCH_CHECK(gsx_abi_version() == GSX_ABI_VERSION, "libgsx.so has ABI version ", gsx_abi_version(), ", this shim was built against ", GSX_ABI_VERSION,
+                " (include/gsx.h): rebuild both");
+    return true;
+}();
+
 inline void* cur_stream() { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream(); }
 inline void check(int rc, const char* op) { TORCH_CHECK(rc == GSX_OK, op, " failed (", rc, "): ", gsx_last_error()); }
 

@@ -23,7 +23,12 @@
 extern "C" {
 #endif
 
-#define GSX_ABI_VERSION 1
+/* ABI history (gsx_abi_version() returns the value the library was built with; a host compares it with the header it compiled against):
+ *   1  round 1.
+ *   2  gsx_intersect_bin_fill gained the positional `max_segment` argument; the pinned host word written by gsx_intersect_bin_count holds
+ *      n_isects in its low 32 bits (0xFFFFFFFF on overflow) and the largest tile segment in its high 32 bits; gsx_sh_colors_bwd accepts
+ *      NULL radii / colors; ranked fill entry points added. */
+#define GSX_ABI_VERSION 2
 
 typedef enum gsx_status {
     GSX_OK = 0,
