@@ -172,9 +172,15 @@ def load_pmc(workload_key):
     if not os.path.exists(path):
         return {}
     try:
-        return json.load(open(path)).get(workload_key, {})
+        entry = json.load(open(path)).get(workload_key, {})
     except Exception:  # noqa: BLE001
         return {}
+    from gsx import build as gbuild
+    if entry and entry.get("blend_kernel_hash") != gbuild.blend_kernel_hash():
+        # the blend kernels changed since the counter passes: the committed figures describe other code
+        return {"stale": "profiles/pmc.json was measured on blend sources %s, this tree is %s: re-run tools/pmc_passes.sh + tools/pmc_to_json.py"
+                         % (entry.get("blend_kernel_hash"), gbuild.blend_kernel_hash())}
+    return entry
 
 
 VALU_PEAK_LANE_OPS = 78.6e12  # fp32 vector lane-operations / s: 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz (157.3 TFLOP/s / 2)
@@ -405,7 +411,7 @@ def main():
         roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": kernels[dom]["frac_hbm"], "traffic": pm.get("hbm_bytes"),
                     "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"], "avg_launch_ms": kernels[dom]["ms"],
-                    "traffic_source": pmc.get("source") if pm.get("hbm_bytes") else None}
+                    "traffic_source": (pmc.get("source") if pm.get("hbm_bytes") else pmc.get("stale"))}
         workload = {"1m": "S-1M (BASELINE configs[1]): 1M random Gaussians, SH deg 3, 1920x1080, one camera per GPU per iteration",
                     "5m": "S-5M (BASELINE configs[4]): 5M random Gaussians, SH deg 3, 3840x2160, one camera per GPU per iteration",
                     "small": "S-small (BASELINE configs[0]): 10k Gaussians, SH deg 0, 256x256"}[args.scene]

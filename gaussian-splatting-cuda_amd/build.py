@@ -20,6 +20,17 @@ HIP_SOURCES = ["gsx_capi.hip", "gsx_sh.hip", "gsx_projection.hip", "gsx_intersec
 HIP_HEADERS = ["gsx_device.hpp", "gsx_raster_common.hpp"]
 
 
+def blend_kernel_hash():
+    """sha256 over the sources the blend kernels are compiled from (+ the compile flags): the committed counter-derived figures of
+    profiles/pmc.json carry the hash they were measured with, and bench.py reports them only while it still matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gsx_raster_fast.hip", "gsx_raster_common.hpp", "gsx_device.hpp"):
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(("-O3 -fno-slp-vectorize " + os.environ.get("GSX_EXTRA_HIPCC_FLAGS", "")).encode())
+    return h.hexdigest()[:16]
+
+
 def ops_module_path():
     return os.path.join(HERE, "_gsx_ops" + sysconfig.get_config_var("EXT_SUFFIX"))
 

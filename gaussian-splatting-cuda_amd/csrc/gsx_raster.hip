@@ -77,7 +77,7 @@ GSX_DEV float pair_alpha(const Staged& s, f3 ray_o, f3 ray_d, f3& gro, f3& grd, 
 // ---- wave-level culling for the reference-order kernels (any camera model, any shutter) ----------------------------------------------
 // alpha >= 1/255 needs |grd_n x gro|^2 <= 2 ln(255 o): the distance from the Gaussian's centre to the ray, measured in the whitened
 // frame M = diag(1/s) R^T, which is at least (Euclidean distance) / s_max.  So a Gaussian whose bounding sphere of radius
-// s_max sqrt(2 ln(255 o)) misses the CONE that bounds the 64 rays of a wave contributes to none of its pixels.  The cone (apex = mean
+// s_max sqrt(2 ln(255 o)) misses the DOUBLE CONE that bounds the 64 ray lines of a wave contributes to none of its pixels.  The cone (apex = mean
 // ray origin, axis = mean direction, half angle = largest deviation, plus the spread of the origins for a rolling shutter) is built
 // once per wave; one lane tests one staged Gaussian (~15 VALU), the wave walks the survivors.  Conservative by construction.
 struct WaveCone { f3 apex, axis; float cos_g, sin_g, spread; bool any; };
@@ -123,8 +123,10 @@ GSX_DEV bool cone_hits_sphere(const WaveCone& c, f3 mu, float rad) {
     const f3 v = mu - c.apex;
     const float along = dot3(v, c.axis);
     const float perp = sqrtf(fmaxf(0.f, dot3(v, v) - along * along));
-    // distance from the point to the cone's surface along the surface normal (negative inside): perp cos g - along sin g
-    return perp * c.cos_g - along * c.sin_g <= (rad + c.spread) * 1.0001f + 1e-6f;
+    // distance from the point to the cone's surface along the surface normal (negative inside): perp cos g - |along| sin g.  The
+    // reference's alpha measures the distance to the infinite ray LINE (|grd_n x gro|, Fwd.cu:232-236), so a Gaussian on the backward
+    // extension of the rays contributes too (wide fisheye, spread origins): the test is against the DOUBLE cone, hence |along|.
+    return perp * c.cos_g - fabsf(along) * c.sin_g <= (rad + c.spread) * 1.0001f + 1e-6f;
 }
 
 // (mu, bounding radius) of a staged Gaussian

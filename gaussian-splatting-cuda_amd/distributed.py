@@ -211,6 +211,20 @@ class ShardedAdam:
             self._merge_owned_rows(p, lo, hi)
 
     @torch.no_grad()
+    def merge_moments(self):
+        """Bring every rank's Adam moments up to date under the current partition (each rank only stepped its own rows).  To be called
+        BEFORE the model is re-indexed or shrunk; afterwards the next step() starts a fresh partition."""
+        if self._bounds is None:
+            return
+        n_old, lo_old, hi_old = self._bounds
+        for st in self.opt.state.values():
+            if isinstance(st, dict):
+                for k in ("exp_avg", "exp_avg_sq"):
+                    if st[k].shape[0] >= n_old:
+                        self._merge_owned_rows(st[k][:n_old], lo_old, hi_old)
+        self._bounds = None
+
+    @torch.no_grad()
     def step(self, iteration, bucket=None):
         world, rank = dist.get_world_size(), dist.get_rank()
         self.bucket = bucket if bucket is not None else self.bucket
@@ -224,6 +238,15 @@ class ShardedAdam:
             # the partition moves: bring every rank's moments up to date under the OLD partition before rows change owner.
             # (rows appended or reset by the densification strategy since are zero on every rank; merging zeros keeps them zero)
             n_old, lo_old, hi_old = self._bounds
+            # only GROWTH by appended rows is supported here: after a shrink / re-index (MCMC.remove_gaussians, select_state) the old
+            # bounds no longer name the same Gaussians — checked BEFORE any collective touches the moments (call merge_moments() ahead
+            # of such a surgery instead)
+            for st in self.opt.state.values():
+                if isinstance(st, dict):
+                    for k in ("exp_avg", "exp_avg_sq"):
+                        if st[k].shape[0] < n_old:
+                            raise RuntimeError("ShardedAdam: the model shrank or was re-indexed (%d -> %d rows) between two steps; call "
+                                               "merge_moments() before the surgery so every rank holds complete moments" % (n_old, st[k].shape[0]))
             for st in self.opt.state.values():
                 if isinstance(st, dict):
                     for k in ("exp_avg", "exp_avg_sq"):

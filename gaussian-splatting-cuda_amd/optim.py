@@ -85,22 +85,25 @@ class FusedAdam:
     # ---- step ------------------------------------------------------------------------------------------------------------
     def begin_fused_sh_step(self, iteration):
         """The SH groups' share of step(iteration), handed to the render backward: the fused kernel gsx_sh_colors_bwd_adam applies it
-        where the SH gradient is produced (the 192 MB gradient is then never written or re-read).  Advances the sh0 / shN step counters
-        exactly as step() would and returns the kernel's arguments; the following step(iteration, skip_sh=True) updates the other groups.
+        where the SH gradient is produced (the 192 MB gradient is then never written or re-read).  Computes the sh0 / shN step counters
+        exactly as step() would (they are committed by the following step(skip_sh=True)) and returns the kernel's arguments; the following step(iteration, skip_sh=True) updates the other groups.
         Returns None when the split launch does not apply (K * 3 not a multiple of 4): call step() as usual then."""
         sh = self.model.sh
-        if not ((sh.shape[1] * 3) % 4 == 0 and sh.shape[1] > 1):
+        self._pending_sh = None
+        # (the kernel updates the tensor the render saved, `sh.contiguous()`: a non-contiguous model.sh would be stepped on a temporary copy)
+        if not ((sh.shape[1] * 3) % 4 == 0 and sh.shape[1] > 1 and sh.is_contiguous()):
             return None
         b1, b2 = self.betas
-        args = {}
+        args, pending = {}, {}
         for i, grp in enumerate(self.groups, start=1):
             name = grp["name"]
             if name not in ("sh0", "shN"):
                 continue
-            self.state["step:" + name] = t = self.step_count(name) + 1
+            pending[name] = t = self.step_count(name) + 1   # committed by step(skip_sh=True), i.e. after the fused kernel ran
             skip = i == 3 and (iteration <= 1000 or (self.skip_sh_steps and iteration % 2 != 0 and iteration <= 25000))
             args[name] = (not skip, grp["lr"] / (1.0 - math.pow(b1, t)), 1.0 / math.sqrt(1.0 - math.pow(b2, t)))
         assert args["sh0"][2] == args["shN"][2], "sh0 / shN step counters diverged"
+        self._pending_sh = pending
         st = self._moments("sh0")
         # positional tail of ops.sh_colors_bwd_adam: exp_avg, exp_avg_sq, step_sh0, step_shN, do_sh0, do_shN, beta1, beta2, eps, bc2_sqrt_rcp
         return (st["exp_avg"], st["exp_avg_sq"], args["sh0"][1], args["shN"][1], args["sh0"][0], args["shN"][0], b1, b2, self.eps, args["sh0"][2])
@@ -113,6 +116,13 @@ class FusedAdam:
         b1, b2 = self.betas
         sh = self.model.sh
         sh_grad = sh.grad
+        if skip_sh:   # the fused render backward stepped the SH tensor: only now do its step counters advance
+            pending = getattr(self, "_pending_sh", None)
+            if not pending:
+                raise RuntimeError("step(skip_sh=True) without a begin_fused_sh_step() that returned kernel arguments")
+            for name, t in pending.items():
+                self.state["step:" + name] = t
+        self._pending_sh = None
         r = (lambda t: t) if rows is None else (lambda t: t[rows[0]:rows[1]])
         split_ok = (sh.shape[1] * 3) % 4 == 0 and sh.shape[1] > 1
         do_sh, dense = {}, []

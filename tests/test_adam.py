@@ -157,11 +157,20 @@ def test_begin_fused_sh_step_bookkeeping():
     exp_avg, exp_avg_sq, step0, stepN, do0, doN, b1, b2, eps, bc2 = a
     assert exp_avg.shape == (5, 16, 3) and exp_avg_sq.shape == (5, 16, 3)
     assert do0 is True and doN is False                       # shN warm-up: untouched ...
-    assert opt.step_count("sh0") == 1 and opt.step_count("shN") == 1   # ... while its counter advances
+    assert opt.step_count("sh0") == 0 and opt.step_count("shN") == 0   # counters are committed only once the fused kernel has run:
+    opt.step(10, skip_sh=True)                                          # ... by the step() that follows the render backward
+    assert opt.step_count("sh0") == 1 and opt.step_count("shN") == 1   # (the shN counter advances during its warm-up, fused_adam.cpp:66-70)
     assert abs(step0 - 0.0025 / (1 - 0.9)) < 1e-12 and abs(stepN - 0.000125 / (1 - 0.9)) < 1e-12
     assert abs(bc2 - 1 / math.sqrt(1 - 0.999)) < 1e-9 and (b1, b2, eps) == (0.9, 0.999, 1e-15)
     a = opt.begin_fused_sh_step(1500)
+    opt.step(1500, skip_sh=True)
     assert a[4] is True and a[5] is True and opt.step_count("shN") == 2
     assert abs(a[2] - 0.0025 / (1 - 0.9 ** 2)) < 1e-12
     assert opt.step_count("means") == 0                       # the other groups are stepped by step(skip_sh=True)
     assert optim.FusedAdam.for_splat_data(model(9)).begin_fused_sh_step(1500) is None   # 27 floats per row: no 16 B vectors
+    import pytest
+    with pytest.raises(RuntimeError):
+        optim.FusedAdam.for_splat_data(model(16)).step(5, skip_sh=True)                 # nothing was handed to a render backward
+    m = model(16)
+    m.sh = torch.zeros(16, 5, 3).permute(1, 0, 2)                                       # non-contiguous SH tensor: no fused step
+    assert optim.FusedAdam.for_splat_data(m).begin_fused_sh_step(1500) is None

@@ -283,3 +283,72 @@ def test_point_cloud_ply_reader(tmp_path):
     (tmp_path / "nocol.ply").write_bytes(header2.encode() + np.zeros(2, dt2).tobytes())
     xyz2, rgb2 = io_ply.load_point_cloud_ply(str(tmp_path / "nocol.ply"))
     assert xyz2.shape == (2, 3) and np.all(rgb2 == 255)
+
+
+# ---- PLY interchange with the reference's own PLY library --------------------------------------------------------------------------
+# oracle/_ref/ply_ref_tool = the reference's vendored tinyply (include/external/tinyply.hpp + src/core/tinyply.cpp, compiled where they
+# lie by oracle/build_ref_ply.sh) behind a small driver: `write` issues exactly the calls of the reference's exporter
+# (src/core/splat_data.cpp:119-162), `read` parses a file with the same library.
+_PLY_TOOL = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "ply_ref_tool")
+_needs_tool = pytest.mark.skipif(not os.path.exists(_PLY_TOOL), reason="oracle/_ref/ply_ref_tool not built (needs /root/reference: oracle/build_ref_ply.sh)")
+
+
+def _reference_attribute_names(K):
+    """splat_data.cpp:401-419 (get_attribute_names), restated independently of gsx.io_ply."""
+    a = ["x", "y", "z", "nx", "ny", "nz"] + ["f_dc_%d" % i for i in range(3)] + ["f_rest_%d" % i for i in range(3 * (K - 1))] + ["opacity"]
+    return a + ["scale_%d" % i for i in range(3)] + ["rot_%d" % i for i in range(4)]
+
+
+@_needs_tool
+@pytest.mark.parametrize("K", [16, 4])
+def test_ply_written_by_the_reference_library_is_loaded(tmp_path, K):
+    """A splat PLY produced by the reference's exporter calls on the reference's PLY library, from blocks laid out as
+    SplatData::to_point_cloud does (splat_data.cpp:484-505: sh0 / shN as transpose(1,2).flatten(1), rotation normalised), loads into the
+    tensors it was made from."""
+    import subprocess
+    from gsx import io_ply
+    m = _model(N=53, K=K, seed=3)
+    sh = m.sh.numpy()
+    rot = torch.nn.functional.normalize(m.rotation_raw, dim=-1).numpy()
+    blocks = [m.means.numpy(), np.zeros((53, 3), np.float32), sh[:, :1].transpose(0, 2, 1).reshape(53, -1), sh[:, 1:].transpose(0, 2, 1).reshape(53, -1),
+              m.opacity_raw.numpy(), m.scaling_raw.numpy(), rot]
+    names = _reference_attribute_names(K)
+    buf, off = struct.pack("<ii", 53, len(blocks)), 0
+    for b in blocks:
+        b = np.ascontiguousarray(b, np.float32)
+        joined = "\n".join(names[off:off + b.shape[1]]).encode()
+        buf += struct.pack("<iii", b.shape[1], b.shape[1], len(joined)) + joined + b.tobytes()
+        off += b.shape[1]
+    assert off == len(names)
+    (tmp_path / "blocks.bin").write_bytes(buf)
+    r = subprocess.run([_PLY_TOOL, "write", str(tmp_path / "blocks.bin"), str(tmp_path / "ref.ply")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    back = io_ply.load_ply(str(tmp_path / "ref.ply"))
+    assert torch.equal(back.means, m.means) and torch.equal(back.sh, m.sh) and torch.equal(back.opacity_raw, m.opacity_raw)
+    assert torch.equal(back.scaling_raw, m.scaling_raw) and np.array_equal(back.rotation_raw.numpy(), rot)
+    assert back.active_sh_degree == int(np.sqrt(K)) - 1
+    # and byte for byte what our exporter writes for the same model (header included)
+    ours = io_ply.save_ply(m, str(tmp_path), iteration=1)
+    assert open(ours, "rb").read() == (tmp_path / "ref.ply").read_bytes()
+
+
+@_needs_tool
+def test_ply_written_by_us_is_parsed_by_the_reference_library(tmp_path):
+    import subprocess
+    from gsx import io_ply
+    m = _model(N=41, K=16, seed=8)
+    path = io_ply.save_ply(m, str(tmp_path), iteration=30000)
+    r = subprocess.run([_PLY_TOOL, "read", path, str(tmp_path / "cols.bin")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    raw = (tmp_path / "cols.bin").read_bytes()
+    rows, nprops, ln = struct.unpack_from("<iii", raw, 0)
+    names = raw[12:12 + ln].decode().split("\n")
+    cols = np.frombuffer(raw, "<f4", offset=12 + ln).reshape(nprops, rows)
+    assert rows == 41 and names == _reference_attribute_names(16)
+    col = {n: cols[i] for i, n in enumerate(names)}
+    assert np.array_equal(np.stack([col["x"], col["y"], col["z"]], 1), m.means.numpy())
+    assert np.array_equal(col["f_dc_1"], m.sh[:, 0, 1].numpy())
+    assert np.array_equal(col["f_rest_0"], m.sh[:, 1, 0].numpy()) and np.array_equal(col["f_rest_15"], m.sh[:, 1, 1].numpy())   # channel-major rest block
+    assert np.array_equal(col["f_rest_44"], m.sh[:, 15, 2].numpy())
+    assert np.array_equal(col["opacity"], m.opacity_raw[:, 0].numpy()) and np.array_equal(col["scale_2"], m.scaling_raw[:, 2].numpy())
+    np.testing.assert_allclose(np.stack([col["rot_%d" % i] for i in range(4)], 1), torch.nn.functional.normalize(m.rotation_raw, dim=-1).numpy(), atol=1e-7)

@@ -30,8 +30,11 @@ def main():
     traffic = lambda v: int((2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024) if v else 0  # noqa: E731
     pack, fwd, gather = find("pack_records"), find("raster_fwd_fast"), find("gsx_bwd_gather")
     bwd = find("raster_bwd_gq") or find("raster_bwd_gm") or find("raster_bwd_fast")
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-cuda_amd"))
+    import build as gbuild
     entry = {
         "source": source,
+        "blend_kernel_hash": gbuild.blend_kernel_hash(),   # bench.py reports these figures only while the blend sources still hash to this
         "rasterize_to_pixels_from_world_3dgs_fwd": {"hbm_bytes": traffic(pack) + traffic(fwd), "valu_insts": int(fwd["SQ_INSTS_VALU"]),
                                                     "kernels": "pack_records + raster_fwd_fast"},
         "rasterize_to_pixels_from_world_3dgs_bwd": {"hbm_bytes": traffic(bwd) + traffic(gather), "valu_insts": int(bwd["SQ_INSTS_VALU"]),

@@ -28,9 +28,12 @@ with open(out + "/kernel_stats.md", "w") as o:
                                                               float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
 print(open(out + "/kernel_stats.md").read()[:3000])
 PY
-if [ -z "$SKIP_PMC" ]; then   # SKIP_PMC=1: the blend kernels did not change since the last counter passes
+if [ -z "$SKIP_PMC" ]; then   # SKIP_PMC=1 only when the blend sources still hash to profiles/pmc.json's blend_kernel_hash
   bash tools/pmc_passes.sh "$out/pmc" > "$out/pmc.log" 2>&1
   tail -3 "$out/pmc.log"
+  # counter-derived figures of the blend ops, stamped with the hash of the blend sources they were measured on (bench.py drops them
+  # as "stale" once the sources change); written to profiles/pmc.json on this box -> copied to $out/pmc.json for the merge back
+  python tools/pmc_to_json.py "$out/pmc/summary.txt" s1m_1080p "profiles/${tag}_pmc_counters.md (rocprofv3 --pmc, separate passes, tools/pmc_passes.sh; bench step with the cfg2 camera)" > "$out/pmc_entry.json" && cp profiles/pmc.json "$out/pmc.json"
 fi
 python bench.py --scene 5m --steps 10 --warmup 3 --no-cpu-baseline > "$out/bench_s5m.json" 2> "$out/bench_s5m.err"
 echo "bench 5m rc=$?"
