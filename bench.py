@@ -52,6 +52,8 @@ def algorithmic_bytes(N, C, I, P, tiles, deg, K):  # noqa: E741  (SURVEY.md §8d
         "splat_activations_fwd": N * (40 + 44),
         "splat_activations_projection_ut": N * (12 + 40 + 44) + 32 * N * C,   # raw parameters in, activated copies + the projection's outputs out
         "splat_activations_bwd": N * (40 + 44 + 40),
+        # the fused front end (csrc/gsx_frontend.hip): raw parameters + active SH bases in; activated copies, projection, colours, 64 B record out
+        "frontend_fused": N * (12 + 12 + 16 + 4 + 12 * nb) + N * (32 + 32 + 12 + 64),
         "intersect_tile": 20 * N * C + 12 * N * C + (28 * N * C + 12 * I) + 144 * I,
         "intersect_offset": 8 * I + 4 * tiles,
         # binned variant = both reference ops in one pipeline: priced at the reference's algorithmic bytes for the two
@@ -74,7 +76,10 @@ class OpTimer:
         self.names = ["projection_ut_3dgs_fused", "spherical_harmonics_fwd", "spherical_harmonics_bwd", "intersect_tile",
                       "intersect_offset", "rasterize_to_pixels_from_world_3dgs_fwd", "rasterize_to_pixels_from_world_3dgs_bwd",
                       "sh_colors_fwd", "sh_colors_bwd", "sh_colors_bwd_adam", "splat_activations_fwd", "splat_activations_projection_ut", "splat_activations_bwd",
-                      "photometric_loss_fwd", "photometric_loss_bwd", "intersect_tile_binned", "adam_step", "adam_step_split", "adam_step_multi"]
+                      "photometric_loss_fwd", "photometric_loss_bwd", "intersect_tile_binned", "adam_step", "adam_step_split", "adam_step_multi",
+                      "frontend_fused", "rasterize_fwd_packed"]
+        # the blend forward on records the front end already packed is the same operator: one row in the table
+        self.alias = {"rasterize_fwd_packed": "rasterize_to_pixels_from_world_3dgs_fwd"}
         self.orig = {n: getattr(ops_mod, n) for n in self.names}
         self.events = {n: [] for n in self.names}
         self.enabled = False
@@ -84,15 +89,18 @@ class OpTimer:
 
     def _wrap(self, name):
         fn = self.orig[name]
+        key = self.alias.get(name, name)
 
         def wrapped(*a, **k):
-            if not self.enabled or (self.only is not None and name not in self.only):
+            if not self.enabled or (self.only is not None and key not in self.only):
                 return fn(*a, **k)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             r = fn(*a, **k)
+            if name == "frontend_fused" and r[8] is None:   # not supported for these arguments: nothing ran
+                return r
             e.record()
-            self.events[name].append((s, e))
+            self.events[key].append((s, e))
             return r
         return wrapped
 
@@ -442,6 +450,8 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
             "loss": "fused L1 + SSIM (lambda 0.2)" if fused_loss else "torch L1",
+            "front_end": ("one kernel (activations -> UT projection -> SH colours -> packed blend records); the blend forward's row excludes the record packing"
+                          if "frontend_fused" in all_ms else "separate launches; the blend forward's row includes its pack_records launch"),
         }
         # the blend kernels are VALU-issue bound: second roofline against the fp32 vector peak, from the committed counters
         valu = {}

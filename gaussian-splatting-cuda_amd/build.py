@@ -16,8 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIBGSX = os.path.join(HERE, "libgsx.so")
-HIP_SOURCES = ["gsx_capi.hip", "gsx_sh.hip", "gsx_projection.hip", "gsx_intersect.hip", "gsx_raster.hip", "gsx_raster_fast.hip", "gsx_mcmc.hip", "gsx_adam.hip", "gsx_ssim.hip"]
-HIP_HEADERS = ["gsx_device.hpp", "gsx_raster_common.hpp"]
+HIP_SOURCES = ["gsx_capi.hip", "gsx_sh.hip", "gsx_projection.hip", "gsx_intersect.hip", "gsx_raster.hip", "gsx_raster_fast.hip", "gsx_frontend.hip", "gsx_mcmc.hip", "gsx_adam.hip", "gsx_ssim.hip"]
+HIP_HEADERS = ["gsx_device.hpp", "gsx_raster_common.hpp", "gsx_record.hpp", "gsx_sh_basis.hpp", "gsx_ut_project.hpp"]
 
 
 def blend_kernel_hash():
@@ -25,7 +25,7 @@ def blend_kernel_hash():
     profiles/pmc.json carry the hash they were measured with, and bench.py reports them only while it still matches."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("gsx_raster_fast.hip", "gsx_raster_common.hpp", "gsx_device.hpp"):
+    for f in ("gsx_raster_fast.hip", "gsx_raster_common.hpp", "gsx_record.hpp", "gsx_device.hpp"):
         h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(("-O3 -fno-slp-vectorize " + os.environ.get("GSX_EXTRA_HIPCC_FLAGS", "")).encode())
     return h.hexdigest()[:16]

@@ -1,0 +1,167 @@
+// gsx_frontend.hip — the per-Gaussian front end of one `--gut` render in ONE streaming kernel (one camera):
+//
+//     SplatData activations (splat_data.cpp:267-286)  ->  projection_ut_3dgs_fused (ProjectionUT3DGSFused.cu:16-203)
+//       ->  SH colours (+0.5, clamp_min 0: rasterizer.cpp:248-262, SphericalHarmonicsCUDA.cu:373-399)
+//       ->  the packed 64 B camera-space record the blend kernels stage per tile intersection (gsx_record.hpp)
+//
+// The reference runs these as four groups of launches over the same Gaussians (activations, projection, SH + two elementwise ops, and the
+// per-batch set-up inside the blend kernel); gsx used to mirror that with four per-Gaussian kernels (activations + projection, SH colours,
+// pack_records, ~470 B of HBM traffic per Gaussian).  Here one lane owns one Gaussian from its raw parameters to its record:
+//     reads   means 12 + scaling_raw 12 + rotation_raw 16 + opacity_raw 4 + the active SH bases 12 (deg+1)^2     (236 B at degree 3)
+//     writes  scales 12 + quats 16 + opacities 4 (the activated copies the backward and the operators read) + radii 8 + means2d 8 +
+//             depths 4 + conics 12 + colours 12 + record 64                                                      (140 B)
+// = 376 B per visible Gaussian at degree 3; a culled Gaussian stops after the projection (84 B: its SH row is never fetched, its record
+// never written — no tile list can name it).  Every value is computed by the same device functions, in the same order of operations, as
+// the separate operators (ut_project, ShBasis::eval, store_packed_record): activated parameters, projection and colours are bit-identical;
+// the records agree to the last bit or two (the compiler contracts a few a*b+c of make_record differently in the two kernels) (tests/test_gpu_fused.py).
+// HBM-bound streaming; the 48 coefficient floats of a lane are fetched with twelve 16 B loads AFTER the projection (the wave's 64 rows
+// are one contiguous 12 KiB span, every fetched line is consumed by the wave's own loads through L1).
+#include "gsx_record.hpp"
+#include "gsx_sh_basis.hpp"
+#include "gsx_ut_project.hpp"
+
+namespace gsx {
+
+void set_error(const char* msg);
+int check_launch(const char* what);
+size_t raster_fwd_fast_workspace_bytes(uint32_t C, uint32_t N);
+
+constexpr int FE_BLOCK = 256;
+
+struct FrontendOut {
+    float* scales; float* quats; float* opacities;                   // activated copies [N,3] [N,4] [N]
+    int32_t* radii; float* means2d; float* depths; float* conics;   // projection [1,N,2] [1,N,2] [1,N] [1,N,3]
+    float* colors;                                                   // [1,N,3]
+    float4* packed;                                                  // [N] x 64 B records
+};
+
+template <int KIND, int DEG>
+__global__ __launch_bounds__(FE_BLOCK) void frontend_kernel(uint32_t N, uint32_t K, const float* __restrict__ means,
+                                                            const float* __restrict__ rotation_raw, const float* __restrict__ scaling_raw,
+                                                            const float* __restrict__ opacity_raw, const float* __restrict__ coeffs,
+                                                            gsx_cameras cams, uint32_t W, uint32_t H, float eps2d, float near_plane,
+                                                            float far_plane, float radius_clip, gsx_ut_params ut, FrontendOut out) {
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    constexpr int NB3 = NB * 3;
+    constexpr int NQ = (NB3 + 3) / 4;
+    const uint32_t gid = blockIdx.x * FE_BLOCK + threadIdx.x;
+    if (gid >= N) return;
+    const Camera<KIND> cam(cams, 0, W, H);
+    const ShutterPoses sp(cams.viewmats0, nullptr);
+
+    // ---- activations (projection_ut_kernel<KIND, true>, verbatim) ----
+    const f3 mean{means[(size_t)gid * 3], means[(size_t)gid * 3 + 1], means[(size_t)gid * 3 + 2]};
+    f3 scale{scaling_raw[(size_t)gid * 3], scaling_raw[(size_t)gid * 3 + 1], scaling_raw[(size_t)gid * 3 + 2]};
+    quat q{rotation_raw[(size_t)gid * 4], rotation_raw[(size_t)gid * 4 + 1], rotation_raw[(size_t)gid * 4 + 2], rotation_raw[(size_t)gid * 4 + 3]};
+    float opacity = opacity_raw[gid];
+    scale = {expf(scale.x), expf(scale.y), expf(scale.z)};
+    const float inv = 1.f / fmaxf(sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z), 1e-12f);
+    q = {q.w * inv, q.x * inv, q.y * inv, q.z * inv};
+    opacity = 1.f / (1.f + expf(-opacity));
+    out.scales[(size_t)gid * 3] = scale.x; out.scales[(size_t)gid * 3 + 1] = scale.y; out.scales[(size_t)gid * 3 + 2] = scale.z;
+    const float4 q_act = make_float4(q.w, q.x, q.y, q.z);
+    reinterpret_cast<float4*>(out.quats)[gid] = q_act;
+    out.opacities[gid] = opacity;
+    {   // glm::normalize(quat)
+        const float len = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+        if (len <= 0.f) q = {1.f, 0.f, 0.f, 0.f};
+        else { const float o = 1.f / len; q = {q.w * o, q.x * o, q.y * o, q.z * o}; }
+    }
+
+    // ---- projection ----
+    UtProjOut p;
+    const bool visible = ut_project<KIND>(cam, sp, mean, scale, q, true, opacity, W, H, eps2d, near_plane, far_plane, radius_clip, ut, p);
+    float* col = out.colors + (size_t)gid * 3;
+    if (!visible) {
+        out.radii[(size_t)gid * 2] = 0; out.radii[(size_t)gid * 2 + 1] = 0;   // as upstream, only radii is written for a culled Gaussian
+        col[0] = 0.f; col[1] = 0.f; col[2] = 0.f;                             // masked SH row (sh_colors_fwd writes zeros)
+        return;
+    }
+    reinterpret_cast<int2*>(out.radii)[gid] = make_int2((int32_t)p.radius_x, (int32_t)p.radius_y);
+    reinterpret_cast<float2*>(out.means2d)[gid] = make_float2(p.im.x, p.im.y);
+    out.depths[gid] = p.depth;
+    out.conics[(size_t)gid * 3] = p.c11 * p.ood;
+    out.conics[(size_t)gid * 3 + 1] = -p.c01 * p.ood;
+    out.conics[(size_t)gid * 3 + 2] = p.c00 * p.ood;
+
+    // ---- SH colours (sh_colors_fwd_direct_kernel, verbatim) ----
+    float row[NQ * 4];
+    const float4* src = reinterpret_cast<const float4*>(coeffs + (size_t)gid * K * 3u);
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        const float4 v = src[k];
+        row[k * 4] = v.x; row[k * 4 + 1] = v.y; row[k * 4 + 2] = v.z; row[k * 4 + 3] = v.w;
+    }
+    const f3 cp = cam_position(cams.viewmats0);
+    float x = mean.x - cp.x, y = mean.y - cp.y, z = mean.z - cp.z;
+    if (DEG >= 1) {
+        const float inorm = rsqrtf(x * x + y * y + z * z);
+        x *= inorm; y *= inorm; z *= inorm;
+    }
+    float Y[NB];
+    ShBasis<DEG>::template eval<false>(x, y, z, Y, nullptr, nullptr, nullptr);
+    float cr = 0.f, cg = 0.f, cb = 0.f;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        cr += Y[k] * row[k * 3];
+        cg += Y[k] * row[k * 3 + 1];
+        cb += Y[k] * row[k * 3 + 2];
+    }
+    RawG raw;
+    raw.rgb = {fmaxf(cr + 0.5f, 0.f), fmaxf(cg + 0.5f, 0.f), fmaxf(cb + 0.5f, 0.f)};
+    col[0] = raw.rgb.x; col[1] = raw.rgb.y; col[2] = raw.rgb.z;
+
+    // ---- packed record (pack_records_kernel, verbatim: from the ACTIVATED parameters, as the blend operators receive them) ----
+    raw.g = (int32_t)gid;
+    raw.mu = mean;
+    raw.q = q_act;
+    raw.sc = scale;
+    raw.opac = opacity;
+    const CamFrame cf = make_cam_frame(sp);
+    store_packed_record(raw, cf, out.packed + (size_t)gid * 4);
+}
+
+}  // namespace gsx
+
+using namespace gsx;
+
+extern "C" int gsx_frontend_fused_supported(uint32_t K, uint32_t degrees_to_use, const gsx_cameras* cams, const float* coeffs) {
+    if (!cams || cams->C != 1 || cams->camera_model != GSX_CAMERA_PINHOLE || cams->shutter != GSX_SHUTTER_GLOBAL || cams->viewmats1) return 0;
+    if (degrees_to_use > 4 || (degrees_to_use + 1) * (degrees_to_use + 1) > K) return 0;
+    const uint32_t nq4 = (((degrees_to_use + 1) * (degrees_to_use + 1) * 3 + 3) / 4) * 4;
+    return ((K * 3u) % 4u == 0u && nq4 <= K * 3u && (((uintptr_t)coeffs) & 15u) == 0) ? 1 : 0;   // rows of whole, aligned 16 B vectors
+}
+
+extern "C" int gsx_frontend_fused(uint32_t N, uint32_t K, uint32_t degrees_to_use, const float* means, const float* rotation_raw,
+                                  const float* scaling_raw, const float* opacity_raw, const float* coeffs, const gsx_cameras* cams,
+                                  uint32_t image_width, uint32_t image_height, float eps2d, float near_plane, float far_plane, float radius_clip,
+                                  const gsx_ut_params* ut, float* scales, float* quats, float* opacities, int32_t* radii, float* means2d,
+                                  float* depths, float* conics, float* colors, void* fwd_workspace, size_t workspace_bytes, void* stream) {
+    if (!cams || !ut) { set_error("frontend_fused: cams/ut is null"); return GSX_ERR_INVALID_ARGUMENT; }
+    if (!gsx_frontend_fused_supported(K, degrees_to_use, cams, coeffs)) {
+        set_error("frontend_fused: one global-shutter pinhole camera, SH rows of whole 16 B vectors (gsx_frontend_fused_supported)");
+        return GSX_ERR_UNSUPPORTED;
+    }
+    if (N == 0) return GSX_OK;
+    if (!means || !rotation_raw || !scaling_raw || !opacity_raw || !coeffs || !cams->viewmats0 || !cams->Ks || !scales || !quats || !opacities ||
+        !radii || !means2d || !depths || !conics || !colors || !fwd_workspace) {
+        set_error("frontend_fused: null pointer");
+        return GSX_ERR_INVALID_ARGUMENT;
+    }
+    if (workspace_bytes < raster_fwd_fast_workspace_bytes(1, N)) { set_error("frontend_fused: workspace too small (gsx_rasterize_fwd_workspace_bytes)"); return GSX_ERR_WORKSPACE_TOO_SMALL; }
+    FrontendOut out{scales, quats, opacities, radii, means2d, depths, conics, colors,
+                    (float4*)(((uintptr_t)fwd_workspace + 255) & ~(uintptr_t)255)};   // the blend forward's workspace layout
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((N + FE_BLOCK - 1) / FE_BLOCK), block(FE_BLOCK);
+    const bool distorted = cams->radial || cams->tangential || cams->thin_prism;
+#define GSX_FE(KIND, D)                                                                                                                     \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(frontend_kernel<KIND, D>), grid, block, 0, st, N, K, means, rotation_raw, scaling_raw, opacity_raw, coeffs, \
+                       *cams, image_width, image_height, eps2d, near_plane, far_plane, radius_clip, *ut, out)
+#define GSX_FE_DEG(KIND)                                                                                                    \
+    switch (degrees_to_use) { case 0: GSX_FE(KIND, 0); break; case 1: GSX_FE(KIND, 1); break; case 2: GSX_FE(KIND, 2); break; \
+                              case 3: GSX_FE(KIND, 3); break; default: GSX_FE(KIND, 4); break; }
+    if (distorted) { GSX_FE_DEG(CAM_OPENCV_PINHOLE) } else { GSX_FE_DEG(CAM_PERFECT_PINHOLE) }
+#undef GSX_FE_DEG
+#undef GSX_FE
+    return check_launch("frontend_fused");
+}

@@ -9,6 +9,7 @@
 // mean / covariance are summed in that order: with alpha = 0.1 the UT weights are -99 / +16.67, so
 // summation order is what decides +-1 px radii and hence tile membership.
 #include "gsx_device.hpp"
+#include "gsx_ut_project.hpp"
 
 namespace gsx {
 
@@ -55,91 +56,20 @@ __global__ __launch_bounds__(PROJ_BLOCK) void projection_ut_kernel(
         else { const float o = 1.f / len; q = {q.w * o, q.x * o, q.y * o, q.z * o}; }
     }
 
-    // camera-space depth at the centre-of-shutter pose (ProjectionUT3DGSFused.cu:74-82)
-    f3 tc; quat qc;
-    sp.at(0.5f, tc, qc);
-    const f3 mean_c = quat_rotate(qc, mean) + tc;
-    if (mean_c.z < near_plane || mean_c.z > far_plane) { radii[idx * 2] = 0; radii[idx * 2 + 1] = 0; return; }
-
-    // sigma points and weights
-    const float D = 3.f;
-    const float lambda = ut.alpha * ut.alpha * (D + ut.kappa) - D;
-    const m33 R = quat_to_mat_raw(q);
-    const float sq = sqrtf(D + lambda);
-    const float w_m0 = lambda / (D + lambda);
-    const float w_c0 = lambda / (D + lambda) + (1.f - ut.alpha * ut.alpha + ut.beta);
-    const float w_i = 1.f / (2.f * (D + lambda));
-    const float sc[3] = {scale.x, scale.y, scale.z};
-
-    const bool require_all = ut.require_all_sigma_points_valid != 0;
-    bool valid = require_all;
-    f2 ipts[7];
-    f2 im{0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        f3 pt = mean;
-        if (i > 0) {
-            const int ax = (i - 1) % 3;
-            const float f = sq * sc[ax];
-            const f3 delta{f * R.a[0][ax], f * R.a[1][ax], f * R.a[2][ax]};
-            pt = (i <= 3) ? (mean + delta) : (mean - delta);
-        }
-        f2 ip;
-        const bool pv = cam.world_to_image(pt, sp, ut.in_image_margin_factor, ip);
-        if (require_all) {
-            if (!pv) { radii[idx * 2] = 0; radii[idx * 2 + 1] = 0; return; }
-        } else {
-            valid |= pv;
-        }
-        ipts[i] = ip;
-        const float w = (i == 0) ? w_m0 : w_i;
-        im.x += w * ip.x;
-        im.y += w * ip.y;
+    UtProjOut o;
+    if (!ut_project<KIND>(cam, sp, mean, scale, q, opacities != nullptr, opacity_in, W, H, eps2d, near_plane, far_plane, radius_clip, ut, o)) {
+        radii[idx * 2] = 0; radii[idx * 2 + 1] = 0;   // as upstream, only radii is written for a culled Gaussian
+        return;
     }
-    if (!valid) { radii[idx * 2] = 0; radii[idx * 2 + 1] = 0; return; }
-
-    float c00 = 0.f, c01 = 0.f, c11 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const float dx = ipts[i].x - im.x, dy = ipts[i].y - im.y;
-        const float w = (i == 0) ? w_c0 : w_i;
-        c00 += w * (dx * dx);
-        c01 += w * (dx * dy);
-        c11 += w * (dy * dy);
-    }
-    // add_blur (Utils.cuh:171-179)
-    const float det_orig = c00 * c11 - c01 * c01;
-    c00 += eps2d; c11 += eps2d;
-    const float det = c00 * c11 - c01 * c01;
-    const float compensation = sqrtf(fmaxf(0.f, det_orig / det));
-    if (det <= 0.f) { radii[idx * 2] = 0; radii[idx * 2 + 1] = 0; return; }
-    const float ood = 1.f / det;
-
-    float extend = 3.33f;
-    if (opacities != nullptr) {
-        float opacity = opacity_in;
-        opacity *= compensation;
-        if (opacity < (1.f / 255.f)) { radii[idx * 2] = 0; radii[idx * 2 + 1] = 0; return; }
-        extend = fminf(extend, sqrtf(2.f * __logf(opacity / (1.f / 255.f))));
-    }
-    const float b = 0.5f * (c00 + c11);
-    const float tmp = sqrtf(fmaxf(0.01f, b * b - det));
-    const float r1 = extend * sqrtf(b + tmp);
-    const float radius_x = ceilf(fminf(extend * sqrtf(c00), r1));
-    const float radius_y = ceilf(fminf(extend * sqrtf(c11), r1));
-    if (radius_x <= radius_clip && radius_y <= radius_clip) { radii[idx * 2] = 0; radii[idx * 2 + 1] = 0; return; }
-    if (im.x + radius_x <= 0 || im.x - radius_x >= (float)W || im.y + radius_y <= 0 || im.y - radius_y >= (float)H) {
-        radii[idx * 2] = 0; radii[idx * 2 + 1] = 0; return;
-    }
-    radii[idx * 2] = (int32_t)radius_x;
-    radii[idx * 2 + 1] = (int32_t)radius_y;
-    means2d[idx * 2] = im.x;
-    means2d[idx * 2 + 1] = im.y;
-    depths[idx] = mean_c.z;
-    conics[idx * 3] = c11 * ood;
-    conics[idx * 3 + 1] = -c01 * ood;
-    conics[idx * 3 + 2] = c00 * ood;
-    if (compensations != nullptr) compensations[idx] = compensation;
+    radii[idx * 2] = (int32_t)o.radius_x;
+    radii[idx * 2 + 1] = (int32_t)o.radius_y;
+    means2d[idx * 2] = o.im.x;
+    means2d[idx * 2 + 1] = o.im.y;
+    depths[idx] = o.depth;
+    conics[idx * 3] = o.c11 * o.ood;
+    conics[idx * 3 + 1] = -o.c01 * o.ood;
+    conics[idx * 3 + 2] = o.c00 * o.ood;
+    if (compensations != nullptr) compensations[idx] = o.compensation;
 }
 
 }  // namespace gsx

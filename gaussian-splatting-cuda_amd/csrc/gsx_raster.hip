@@ -543,6 +543,17 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_fwd(
     uint32_t image_height, uint32_t tile_size, const gsx_cameras* cams, const gsx_ut_params* ut,
     const int32_t* tile_offsets, const int32_t* flatten_ids, float* renders, float* alphas, int32_t* last_ids,
     void* workspace, size_t workspace_bytes, void* stream) {
+    return gsx_rasterize_to_pixels_from_world_3dgs_fwd_packed(N, n_isects, means, quats, scales, colors, channels, opacities, backgrounds, masks,
+                                                              image_width, image_height, tile_size, cams, ut, tile_offsets, flatten_ids, renders,
+                                                              alphas, last_ids, workspace, workspace_bytes, 0, stream);
+}
+
+extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_fwd_packed(
+    uint32_t N, int64_t n_isects, const float* means, const float* quats, const float* scales, const float* colors,
+    uint32_t channels, const float* opacities, const float* backgrounds, const uint8_t* masks, uint32_t image_width,
+    uint32_t image_height, uint32_t tile_size, const gsx_cameras* cams, const gsx_ut_params* ut,
+    const int32_t* tile_offsets, const int32_t* flatten_ids, float* renders, float* alphas, int32_t* last_ids,
+    void* workspace, size_t workspace_bytes, int records_ready, void* stream) {
     (void)ut;
     RasterArgs a;
     int rc = fill_args(a, N, n_isects, means, quats, scales, colors, channels, opacities, backgrounds, masks, image_width,
@@ -558,7 +569,9 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_fwd(
     // fast path: global shutter; a fisheye additionally needs its (camera, tile) flag plane to fit
     if (hoist && !force_generic() && workspace != nullptr && workspace_bytes >= raster_fwd_fast_workspace_bytes(a.C, a.N) &&
         (kind != CAM_OPENCV_FISHEYE || (size_t)a.C * a.tw * a.th <= FAST_FLAG_BYTES)) {
-        only_tiles = launch_raster_fwd_fast(kind, a, renders, alphas, last_ids, workspace, workspace_bytes, st);
+        // records_ready: gsx_frontend_fused already wrote the packed records of exactly these inputs into this workspace (pinholes only)
+        only_tiles = launch_raster_fwd_fast(kind, a, renders, alphas, last_ids, workspace, workspace_bytes, st,
+                                            records_ready != 0 && kind != CAM_OPENCV_FISHEYE);
         if (only_tiles == nullptr) return check_launch("rasterize_to_pixels_from_world_3dgs_fwd(fast)");
         // fisheye: tiles whose list holds a Gaussian without a usable chart were left to the reference-order kernel below
     }

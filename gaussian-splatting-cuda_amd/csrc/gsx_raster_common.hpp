@@ -85,7 +85,7 @@ GSX_DEV uint32_t butterfly_value_of_lane(uint32_t lane) {
 // fast-path launchers (gsx_raster_fast.hip); kind is CAM_PERFECT_PINHOLE or CAM_OPENCV_PINHOLE, global shutter
 // (fisheye: returns the tile-flag plane the caller hands to the generic kernel for the flagged tiles; nullptr otherwise)
 const uint8_t* launch_raster_fwd_fast(int kind, RasterArgs a, float* renders, float* alphas, int32_t* last_ids, void* workspace,
-                                      size_t workspace_bytes, hipStream_t st);
+                                      size_t workspace_bytes, hipStream_t st, bool records_ready = false);
 size_t raster_fwd_fast_workspace_bytes(uint32_t C, uint32_t N);
 // returns false (nothing launched) when no sufficient workspace was supplied: the caller falls back to the generic kernels
 bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, const int32_t* last_ids,

@@ -30,6 +30,7 @@
 // 4. Dispatch.  1-D grid, XCD-aware: block b runs on XCD b % 8, so each XCD is given a contiguous band of
 //    tiles and neighbouring tiles (which share Gaussians) hit the same 4 MiB L2.
 #include "gsx_raster_common.hpp"
+#include "gsx_record.hpp"
 
 #include <cstdlib>
 #include <string>
@@ -56,100 +57,6 @@ __device__ unsigned long long g_stats[16];
 #define GSX_FCH 128
 #endif
 constexpr int FCH = GSX_FCH;  // Gaussians per forward chunk (double buffered)
-constexpr float LOG2_255 = 7.994353436858858f;
-constexpr float HALF_LOG2E = 0.7213475204444817f;  // 0.5 * log2(e)
-
-struct CamFrame {
-    float Rc[3][3];  // camera -> world rotation (== reference's R_inv, Cameras.cuh:262)
-    f3 c;            // camera centre in world space
-};
-
-GSX_DEV CamFrame make_cam_frame(const ShutterPoses& sp) {
-    CamFrame f;
-    const m33 Rinv = quat_to_mat_raw(quat_conj_over_norm2(sp.q0));
-    for (int r = 0; r < 3; ++r)
-        for (int k = 0; k < 3; ++k) f.Rc[r][k] = Rinv.a[r][k];
-    const f3 rt = mul(Rinv, sp.t0);
-    f.c = {-rt.x, -rt.y, -rt.z};
-    return f;
-}
-
-// raw per-Gaussian parameters (inputs of make_record: pack kernel and the backward's gather kernel)
-struct RawG {
-    f3 mu; float4 q; f3 sc; float opac; f3 rgb; int32_t g;
-};
-
-// Everything the pixel loop needs for one Gaussian (see header comment).  tb = tile bounds in (u,v).
-struct FastRec {
-    float u0, v0, hx, hy;        // footprint centre and conservative half extents in (u,v)
-    float l00, l01, l11, lo;     // triangular factor (pre-scaled by sqrt(0.5 log2 e / d0)), log2(opacity)
-    float d1, d2, d3, d4, d5;    // |A p|^2 / |A p_mu|^2 = 1 + d1 du + d2 dv + d3 du^2 + d4 du dv + d5 dv^2
-    // backward finishing only: columns of A, h = A p_mu, B0, B1, the cofactor columns, camera-space centre, 1/d0
-    f3 a0, a1, a2, h, B0, B1, c01, c12, c20, m;
-    float inv_d0;
-    float Mt[3][3];  // M(r,c) = (1/s_r) R(c,r)
-};
-
-template <bool BWD>
-GSX_DEV void make_record(const RawG& r, const CamFrame& cf, const float tb[4], FastRec& o) {
-    const m33 R = quat_to_rotmat(r.q.x, r.q.y, r.q.z, r.q.w);
-    const float is[3] = {1.f / r.sc.x, 1.f / r.sc.y, 1.f / r.sc.z};
-    float M[3][3], A[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) M[i][k] = is[i] * R.a[k][i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) A[i][j] = M[i][0] * cf.Rc[0][j] + M[i][1] * cf.Rc[1][j] + M[i][2] * cf.Rc[2][j];
-    const f3 dm = r.mu - cf.c;
-    const float mx = cf.Rc[0][0] * dm.x + cf.Rc[1][0] * dm.y + cf.Rc[2][0] * dm.z;
-    const float my = cf.Rc[0][1] * dm.x + cf.Rc[1][1] * dm.y + cf.Rc[2][1] * dm.z;
-    const float mz = cf.Rc[0][2] * dm.x + cf.Rc[1][2] * dm.y + cf.Rc[2][2] * dm.z;
-    const float imz = 1.f / mz;
-    o.u0 = mx * imz; o.v0 = my * imz;
-    const f3 a0{A[0][0], A[1][0], A[2][0]}, a1{A[0][1], A[1][1], A[2][1]}, a2{A[0][2], A[1][2], A[2][2]};
-    const f3 c01 = cross3(a0, a1), c12 = cross3(a1, a2), c20 = cross3(a2, a0);
-    const f3 B0 = (c20 - c01 * o.v0) * mz;
-    const f3 B1 = (c01 * o.u0 - c12) * mz;
-    const f3 h = a0 * o.u0 + a1 * o.v0 + a2;
-    const float d0 = dot3(h, h);
-    const float inv_d0 = 1.f / d0;
-    o.d1 = 2.f * dot3(h, a0) * inv_d0; o.d2 = 2.f * dot3(h, a1) * inv_d0;
-    o.d3 = dot3(a0, a0) * inv_d0; o.d4 = 2.f * dot3(a0, a1) * inv_d0; o.d5 = dot3(a1, a1) * inv_d0;
-    const float sL = sqrtf(HALF_LOG2E * inv_d0);
-    const float n0 = sqrtf(dot3(B0, B0));
-    const float l01r = dot3(B0, B1) / n0;
-    const f3 rr = B1 - B0 * (l01r / n0);
-    o.l00 = n0 * sL; o.l01 = l01r * sL; o.l11 = sqrtf(dot3(rr, rr)) * sL;
-    o.lo = __log2f(r.opac);
-    // conservative footprint: |L d|^2 <= tau2 * max_tile den'
-    const float tau2 = o.lo + LOG2_255;
-    float hx = -INFINITY, hy = -INFINITY;
-    if (tau2 > 0.f && fabsf(mz) > 1e-12f) {
-        float dmax = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float du = ((k & 1) ? tb[1] : tb[0]) - o.u0, dv = ((k & 2) ? tb[3] : tb[2]) - o.v0;
-            dmax = fmaxf(dmax, 1.f + du * (o.d1 + o.d3 * du + o.d4 * dv) + dv * (o.d2 + o.d5 * dv));
-        }
-        const float rad = sqrtf(tau2 * dmax) * 1.001f + 1e-7f;
-        hy = rad / o.l11;
-        hx = rad * sqrtf(o.l01 * o.l01 + o.l11 * o.l11) / (o.l00 * o.l11);
-        if (!(hx == hx) || !(hy == hy)) { hx = INFINITY; hy = INFINITY; }  // degenerate factor: never cull
-    }
-    o.hx = hx; o.hy = hy;
-    if (BWD) {
-        o.a0 = a0; o.a1 = a1; o.a2 = a2; o.h = h; o.B0 = B0; o.B1 = B1; o.c01 = c01; o.c12 = c12; o.c20 = c20;
-        o.m = {mx, my, mz}; o.inv_d0 = inv_d0;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) o.Mt[i][k] = M[i][k];
-    }
-}
-
 // ---- packed per-(camera, Gaussian) records ---------------------------------------------------------------
 // The tile kernels need, per (tile, Gaussian), data that lives in five separate arrays (means 12 B, quats 16 B,
 // scales 12 B, opacities 4 B, colours 12 B): five cache lines gathered for 60 useful bytes, and ~300 VALU to turn
@@ -175,21 +82,14 @@ __global__ __launch_bounds__(256) void pack_records_kernel(RasterArgs a, float4*
     raw.rgb = {a.colors[g * 3], a.colors[g * 3 + 1], a.colors[g * 3 + 2]};
     const ShutterPoses sp(a.cams.viewmats0 + c * 16, nullptr);
     const CamFrame cf = make_cam_frame(sp);
-    const float tb0[4] = {0.f, 0.f, 0.f, 0.f};
-    FastRec r;
-    make_record<false>(raw, cf, tb0, r);
-    if (!(r.hx > -INFINITY) && !(r.lo + LOG2_255 > 0.f)) r.lo = -INFINITY;  // never visible (opacity <= 1/255)
-    if (!(fabsf(r.l00) < INFINITY)) r.lo = -INFINITY;                       // camera-space z == 0: skipped
+    float4* o = packed + g * 4;
+    store_packed_record(raw, cf, o);
     if (bad) {
         const f3 dm = raw.mu - cf.c;
         const float mz = cf.Rc[0][2] * dm.x + cf.Rc[1][2] * dm.y + cf.Rc[2][2] * dm.z;
-        bad[g] = (mz > 0.f && fabsf(r.u0) <= 8.f && fabsf(r.v0) <= 8.f) ? 0 : 1;   // (NaN compares false: bad)
+        const float4 p0 = o[0];
+        bad[g] = (mz > 0.f && fabsf(p0.x) <= 8.f && fabsf(p0.y) <= 8.f) ? 0 : 1;   // (NaN compares false: bad)
     }
-    float4* o = packed + g * 4;
-    o[0] = make_float4(r.u0, r.v0, r.l00, r.l01);
-    o[1] = make_float4(r.l11, r.lo, r.d1, r.d2);
-    o[2] = make_float4(r.d3, r.d4, r.d5, raw.rgb.x);
-    o[3] = make_float4(raw.rgb.y, raw.rgb.z, 0.f, 0.f);
 }
 
 // fisheye: flags[camera, tile] = 1 when the tile's list holds a Gaussian without a usable chart.  One wave per tile.
@@ -487,11 +387,12 @@ static const float4* pack_into(int kind, RasterArgs& a, void* base, hipStream_t 
 }
 
 const uint8_t* launch_raster_fwd_fast(int kind, RasterArgs a, float* renders, float* alphas, int32_t* last_ids, void* workspace,
-                                      size_t workspace_bytes, hipStream_t st) {
+                                      size_t workspace_bytes, hipStream_t st, bool records_ready) {
     (void)workspace_bytes;
     const uint32_t n_tiles = a.tw * a.th;
     const dim3 grid(((n_tiles + 7u) / 8u) * 8u, a.C), block(RB);
-    pack_into(kind, a, workspace, st);
+    if (records_ready) a.packed = (const float4*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);   // written by the fused front end
+    else pack_into(kind, a, workspace, st);
     if (kind == CAM_PERFECT_PINHOLE)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_fwd_fast_kernel<CAM_PERFECT_PINHOLE>), grid, block, 0, st, a, renders, alphas, last_ids);
     else if (kind == CAM_OPENCV_PINHOLE)

@@ -88,6 +88,8 @@ gsx_ut_params make_ut(const UnscentedTransformParameters& u) {
 // workspace (packed per-Gaussian records) to the caller, the backward of the same inputs takes it back and skips re-packing.
 static thread_local at::Tensor* g_fwd_ws_out = nullptr;
 static thread_local const at::Tensor* g_fwd_ws_in = nullptr;
+// ... and the fused front end (gsx_ext::frontend_fused) hands the blend forward a workspace whose records are already packed
+static thread_local const at::Tensor* g_fwd_ws_ready = nullptr;
 
 // counters for bench.py (host synchronisations and capacity-hint outcomes of intersect_tile); never read by the ops themselves
 struct ShimStats { std::atomic<int64_t> host_syncs{0}, binned_calls{0}, hint_misses{0}, hint_cold{0}, ranked_calls{0}; };
@@ -291,13 +293,14 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> rasterize_to_pixels_from_world_3d
     at::Tensor alphas = at::empty({C, image_height, image_width, 1}, means.options());
     at::Tensor last_ids = at::empty({C, image_height, image_width}, means.options().dtype(at::kInt));
     const size_t fwsb = gsx_rasterize_fwd_workspace_bytes(C, N);
-    at::Tensor fws = at::empty({(int64_t)fwsb}, means.options().dtype(at::kByte));
-    check(gsx_rasterize_to_pixels_from_world_3dgs_fwd(
+    const bool ready = g_fwd_ws_ready && g_fwd_ws_ready->defined() && (size_t)g_fwd_ws_ready->numel() >= fwsb;   // packed by frontend_fused
+    at::Tensor fws = ready ? *g_fwd_ws_ready : at::empty({(int64_t)fwsb}, means.options().dtype(at::kByte));
+    check(gsx_rasterize_to_pixels_from_world_3dgs_fwd_packed(
               N, flatten_ids.size(0), means.data_ptr<float>(), quats.data_ptr<float>(), scales.data_ptr<float>(),
               colors.data_ptr<float>(), channels, opacities.data_ptr<float>(), fptr(backgrounds), bptr(masks), image_width,
               image_height, tile_size, &cams, &ut, tile_offsets.data_ptr<int32_t>(),
               flatten_ids.numel() ? flatten_ids.data_ptr<int32_t>() : nullptr, renders.data_ptr<float>(),
-              alphas.data_ptr<float>(), last_ids.data_ptr<int32_t>(), fws.data_ptr(), fwsb, cur_stream()),
+              alphas.data_ptr<float>(), last_ids.data_ptr<int32_t>(), fws.data_ptr(), (size_t)fws.numel(), ready ? 1 : 0, cur_stream()),
           "rasterize_to_pixels_from_world_3dgs_fwd");
     if (g_fwd_ws_out) *g_fwd_ws_out = fws;
     return std::make_tuple(renders, alphas, last_ids);
@@ -500,6 +503,42 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tenso
                                               radii.data_ptr<int32_t>(), means2d.data_ptr<float>(), depths.data_ptr<float>(),
                                               conics.data_ptr<float>(), cur_stream()), "splat_activations_projection_ut");
     return std::make_tuple(scales, quats, opac, radii, means2d, depths, conics);
+}
+
+// The whole per-Gaussian front end of one render in one launch (include/gsx.h: gsx_frontend_fused): returns scales, quats, opacities,
+// radii, means2d, depths, conics, colors and the blend-forward workspace with the packed records; an undefined workspace = not
+// supported for these arguments (the caller runs the separate operators).
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> frontend_fused(
+    const uint32_t degrees_to_use, const at::Tensor means, const at::Tensor sh, const at::Tensor scaling_raw, const at::Tensor rotation_raw,
+    const at::Tensor opacity_raw, const at::Tensor viewmats0, const at::Tensor Ks, const uint32_t image_width, const uint32_t image_height,
+    const float eps2d, const float near_plane, const float far_plane, const float radius_clip, const gsplat::CameraModelType camera_model,
+    const UnscentedTransformParameters ut_params, const at::optional<at::Tensor> radial_coeffs, const at::optional<at::Tensor> tangential_coeffs,
+    const at::optional<at::Tensor> thin_prism_coeffs) {
+    GSX_DEVICE_GUARD(means);
+    GSX_CHECK_INPUT(means); GSX_CHECK_INPUT(sh); GSX_CHECK_INPUT(scaling_raw); GSX_CHECK_INPUT(rotation_raw); GSX_CHECK_INPUT(opacity_raw);
+    TORCH_CHECK(means.scalar_type() == at::kFloat && sh.scalar_type() == at::kFloat, "float32 only");
+    TORCH_CHECK(sh.dim() == 3 && sh.size(0) == means.size(0) && sh.size(2) == 3, "sh must be [N,K,3]");
+    const uint32_t N = means.size(0), C = Ks.size(0), K = sh.size(1);
+    const gsx_cameras cams = make_cams(viewmats0, at::nullopt, Ks, camera_model, ShutterType::GLOBAL, radial_coeffs, tangential_coeffs, thin_prism_coeffs, C);
+    const gsx_ut_params ut = make_ut(ut_params);
+    at::Tensor none;
+    if (N == 0 || !gsx_frontend_fused_supported(K, degrees_to_use, &cams, sh.data_ptr<float>()))
+        return std::make_tuple(none, none, none, none, none, none, none, none, none);
+    at::Tensor scales = at::empty_like(scaling_raw), quats = at::empty_like(rotation_raw);
+    at::Tensor opac = at::empty({(int64_t)N}, means.options());
+    at::Tensor radii = at::empty({C, N, 2}, means.options().dtype(at::kInt));
+    at::Tensor means2d = at::empty({C, N, 2}, means.options());
+    at::Tensor depths = at::empty({C, N}, means.options());
+    at::Tensor conics = at::empty({C, N, 3}, means.options());
+    at::Tensor colors = at::empty({C, N, 3}, means.options());
+    const size_t fwsb = gsx_rasterize_fwd_workspace_bytes(C, N);
+    at::Tensor fws = at::empty({(int64_t)fwsb}, means.options().dtype(at::kByte));
+    check(gsx_frontend_fused(N, K, degrees_to_use, means.data_ptr<float>(), rotation_raw.data_ptr<float>(), scaling_raw.data_ptr<float>(),
+                             opacity_raw.data_ptr<float>(), sh.data_ptr<float>(), &cams, image_width, image_height, eps2d, near_plane, far_plane,
+                             radius_clip, &ut, scales.data_ptr<float>(), quats.data_ptr<float>(), opac.data_ptr<float>(), radii.data_ptr<int32_t>(),
+                             means2d.data_ptr<float>(), depths.data_ptr<float>(), conics.data_ptr<float>(), colors.data_ptr<float>(), fws.data_ptr(),
+                             fwsb, cur_stream()), "frontend_fused");
+    return std::make_tuple(scales, quats, opac, radii, means2d, depths, conics, colors, fws);
 }
 
 std::tuple<at::Tensor, at::Tensor, at::Tensor> splat_activations_fwd(const at::Tensor scaling_raw, const at::Tensor rotation_raw,
@@ -869,6 +908,20 @@ PYBIND11_MODULE(_gsx_ops, m) {
     m.def("projection_ut_3dgs_fused", &gsplat::projection_ut_3dgs_fused);
     m.def("rasterize_to_pixels_from_world_3dgs_fwd", &gsplat::rasterize_to_pixels_from_world_3dgs_fwd);
     m.def("rasterize_fwd_keep_ws", keep_fwd_ws(&gsplat::rasterize_to_pixels_from_world_3dgs_fwd));
+    m.def("rasterize_fwd_packed",   // the blend forward on a workspace whose records frontend_fused already packed (same inputs)
+          [](const at::Tensor means, const at::Tensor quats, const at::Tensor scales, const at::Tensor colors, const at::Tensor opacities,
+             const at::optional<at::Tensor> backgrounds, const at::optional<at::Tensor> masks, uint32_t image_width, uint32_t image_height,
+             uint32_t tile_size, const at::Tensor viewmats0, const at::optional<at::Tensor> viewmats1, const at::Tensor Ks,
+             const gsplat::CameraModelType camera_model, const UnscentedTransformParameters ut_params, ShutterType rs_type,
+             const at::optional<at::Tensor> radial_coeffs, const at::optional<at::Tensor> tangential_coeffs,
+             const at::optional<at::Tensor> thin_prism_coeffs, const at::Tensor tile_offsets, const at::Tensor flatten_ids, const at::Tensor fwd_ws) {
+              struct Reset { ~Reset() { g_fwd_ws_ready = nullptr; } } reset;
+              g_fwd_ws_ready = &fwd_ws;
+              return gsplat::rasterize_to_pixels_from_world_3dgs_fwd(means, quats, scales, colors, opacities, backgrounds, masks, image_width, image_height,
+                                                                     tile_size, viewmats0, viewmats1, Ks, camera_model, ut_params, rs_type, radial_coeffs,
+                                                                     tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids);
+          });
+    m.def("frontend_fused", &gsx_ext::frontend_fused);
     m.def("rasterize_to_pixels_from_world_3dgs_bwd",
           [](const at::Tensor means, const at::Tensor quats, const at::Tensor scales, const at::Tensor colors, const at::Tensor opacities,
              const at::optional<at::Tensor> backgrounds, const at::optional<at::Tensor> masks, uint32_t image_width, uint32_t image_height,

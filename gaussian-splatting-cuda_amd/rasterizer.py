@@ -11,6 +11,7 @@ Hot-path constants hard-coded upstream (rasterizer.cpp:176-181): eps2d 0.3, near
 radius_clip 0, tile 16, calc_compensations = antialiased, GLOBAL shutter, default UT parameters.
 """
 from dataclasses import dataclass, field
+import os
 from typing import Optional
 
 import torch
@@ -19,6 +20,9 @@ from . import ops
 
 TILE_SIZE = 16
 EPS2D, NEAR_PLANE, FAR_PLANE, RADIUS_CLIP = 0.3, 0.01, 10000.0, 0.0
+# rasterize_fused: one kernel for activations -> projection -> SH colours -> packed blend records (ops.frontend_fused); False = the
+# separate launches (A/B tools, tests)
+FUSED_FRONTEND = os.environ.get("GSX_FUSED_FRONTEND", "1") != "0"
 
 
 @dataclass
@@ -268,7 +272,17 @@ class GutRenderFunction(torch.autograd.Function):
         ut = ops.UnscentedTransformParameters()
         means_c, sh_c = means.contiguous(), sh.contiguous()
         sr, rr, orw = scaling_raw.contiguous(), rotation_raw.contiguous(), opacity_raw.reshape(-1).contiguous()
-        if scaling_modifier == 1.0:   # activations and projection in one launch (bit-identical to the two calls below)
+        fe = None
+        if scaling_modifier == 1.0 and FUSED_FRONTEND:
+            # the whole per-Gaussian front end in ONE kernel: activations -> projection -> SH colours -> packed blend records
+            # (same values as the separate launches below; an undefined workspace = camera / SH layout not supported)
+            fe = ops.frontend_fused(sh_degree, means_c, sh_c, sr, rr, orw, viewmat, K, width, height, EPS2D, NEAR_PLANE, FAR_PLANE, RADIUS_CLIP,
+                                    camera_model, ut, radial, tangential, None)
+            if fe[8] is None:
+                fe = None
+        if fe is not None:
+            scales, quats, opac, radii, means2d, depths, conics, colors, fe_ws = fe
+        elif scaling_modifier == 1.0:   # activations and projection in one launch (bit-identical to the two calls below)
             scales, quats, opac, radii, means2d, depths, conics = ops.splat_activations_projection_ut(
                 means_c, sr, rr, orw, viewmat, K, width, height, EPS2D, NEAR_PLANE, FAR_PLANE, RADIUS_CLIP, camera_model, ut, radial, tangential, None)
         else:
@@ -277,14 +291,21 @@ class GutRenderFunction(torch.autograd.Function):
             radii, means2d, depths, conics, _ = ops.projection_ut_3dgs_fused(
                 means_c, quats, scales, opac, viewmat, None, K, width, height, EPS2D, NEAR_PLANE, FAR_PLANE, RADIUS_CLIP, False,
                 camera_model, ut, ops.ShutterType.GLOBAL, radial, tangential, None)
-        colors = ops.sh_colors_fwd(sh_degree, means_c, viewmat, sh_c, radii)
+        if fe is None:
+            colors = ops.sh_colors_fwd(sh_degree, means_c, viewmat, sh_c, radii)
         tw, th = (width + TILE_SIZE - 1) // TILE_SIZE, (height + TILE_SIZE - 1) // TILE_SIZE
         # binned pipeline: flatten_ids + isect_offsets in one go (bit-identical to intersect_tile + intersect_offset, no isect_ids)
         _, _, flatten_ids, isect_offsets = ops.intersect_tile_binned(means2d, radii, depths, 1, TILE_SIZE, tw, th, False)
         opac2 = opac.unsqueeze(0)
-        renders, alphas, last_ids, fwd_ws = ops.rasterize_to_pixels_from_world_3dgs_fwd(
-            means_c, quats, scales, colors, opac2, bg, None, width, height, TILE_SIZE, viewmat, None, K, camera_model, ut,
-            ops.ShutterType.GLOBAL, radial, tangential, None, isect_offsets, flatten_ids, keep_ws=True)
+        if fe is not None:   # the records of exactly these inputs are already in fe_ws
+            renders, alphas, last_ids = ops.rasterize_fwd_packed(
+                means_c, quats, scales, colors, opac2, bg, None, width, height, TILE_SIZE, viewmat, None, K, camera_model, ut,
+                ops.ShutterType.GLOBAL, radial, tangential, None, isect_offsets, flatten_ids, fe_ws)
+            fwd_ws = fe_ws
+        else:
+            renders, alphas, last_ids, fwd_ws = ops.rasterize_to_pixels_from_world_3dgs_fwd(
+                means_c, quats, scales, colors, opac2, bg, None, width, height, TILE_SIZE, viewmat, None, K, camera_model, ut,
+                ops.ShutterType.GLOBAL, radial, tangential, None, isect_offsets, flatten_ids, keep_ws=True)
         ctx.fwd_ws = fwd_ws  # packed per-Gaussian records of exactly these inputs: the backward does not pack again
         ctx.save_for_backward(means_c, sh_c, sr, rr, orw, scales, quats, opac2, colors, radii, viewmat, K, isect_offsets,
                               flatten_ids, alphas, last_ids)

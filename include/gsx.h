@@ -27,8 +27,9 @@ extern "C" {
  *   1  round 1.
  *   2  gsx_intersect_bin_fill gained the positional `max_segment` argument; the pinned host word written by gsx_intersect_bin_count holds
  *      n_isects in its low 32 bits (0xFFFFFFFF on overflow) and the largest tile segment in its high 32 bits; gsx_sh_colors_bwd accepts
- *      NULL radii / colors; ranked fill entry points added. */
-#define GSX_ABI_VERSION 2
+ *      NULL radii / colors; ranked fill entry points added.
+ *   3  additions only: gsx_frontend_fused(_supported), gsx_rasterize_to_pixels_from_world_3dgs_fwd_packed. */
+#define GSX_ABI_VERSION 3
 
 typedef enum gsx_status {
     GSX_OK = 0,
@@ -154,6 +155,30 @@ int gsx_rasterize_to_pixels_from_world_3dgs_bwd(uint32_t N, int64_t n_isects, co
                                                 float* v_means, float* v_quats, float* v_scales, float* v_colors,
                                                 float* v_opacities, void* workspace, size_t workspace_bytes,
                                                 void* stream);
+/* Fused per-Gaussian front end of one render (one global-shutter pinhole camera): SplatData activations -> UT projection -> SH colours
+ * (+0.5, clamp_min 0) -> the packed 64 B records of the blend kernels, in ONE streaming kernel (csrc/gsx_frontend.hip: 376 B of HBM
+ * traffic per visible Gaussian at SH degree 3 instead of ~470 B over four launches).  Outputs bit-identical to gsx_splat_activations_projection_ut
+ * + gsx_sh_colors_fwd; records equal to rounding to the ones the blend forward packs for itself.  `fwd_workspace` (gsx_rasterize_fwd_workspace_bytes(1, N)) is then
+ * handed to gsx_rasterize_to_pixels_from_world_3dgs_fwd_packed(..., records_ready = 1) and later to ..._bwd_packed.  Outputs: scales
+ * [N,3], quats [N,4], opacities [N] (activated), radii int32 [1,N,2], means2d [1,N,2], depths [1,N], conics [1,N,3] (only radii for a
+ * culled Gaussian, as the projection), colors [1,N,3] (zero rows for culled Gaussians).  gsx_frontend_fused_supported: 1 when the
+ * camera block / SH layout qualify (C == 1, PINHOLE with or without distortion, GLOBAL shutter, (K*3) % 4 == 0, 16 B aligned coeffs). */
+int gsx_frontend_fused_supported(uint32_t K, uint32_t degrees_to_use, const gsx_cameras* cams, const float* coeffs);
+int gsx_frontend_fused(uint32_t N, uint32_t K, uint32_t degrees_to_use, const float* means, const float* rotation_raw,
+                       const float* scaling_raw, const float* opacity_raw, const float* coeffs, const gsx_cameras* cams,
+                       uint32_t image_width, uint32_t image_height, float eps2d, float near_plane, float far_plane, float radius_clip,
+                       const gsx_ut_params* ut, float* scales, float* quats, float* opacities, int32_t* radii, float* means2d,
+                       float* depths, float* conics, float* colors, void* fwd_workspace, size_t workspace_bytes, void* stream);
+/* The blend forward for a caller whose workspace already holds the packed records of exactly these inputs (records_ready = 1: written
+ * by gsx_frontend_fused; 0 = gsx_rasterize_to_pixels_from_world_3dgs_fwd). */
+int gsx_rasterize_to_pixels_from_world_3dgs_fwd_packed(uint32_t N, int64_t n_isects, const float* means,
+                                                       const float* quats, const float* scales, const float* colors,
+                                                       uint32_t channels, const float* opacities, const float* backgrounds,
+                                                       const uint8_t* masks, uint32_t image_width, uint32_t image_height,
+                                                       uint32_t tile_size, const gsx_cameras* cams, const gsx_ut_params* ut,
+                                                       const int32_t* tile_offsets, const int32_t* flatten_ids,
+                                                       float* renders, float* alphas, int32_t* last_ids, void* workspace,
+                                                       size_t workspace_bytes, int records_ready, void* stream);
 /* Same, for a caller that kept the forward's workspace alive: `packed_records` = gsx_rasterize_fwd_packed_records(the
  * workspace the forward of the SAME inputs ran with) lets the backward skip re-packing the per-(camera, Gaussian) records
  * (NULL = pack again).  The caller guarantees that neither the inputs nor that workspace changed in between. */

@@ -173,3 +173,54 @@ def test_activations_projection_in_one_launch_is_bit_identical(mods):
         assert int(vis.sum()) > 1000
         for a, b in ((m1, m2), (d1, d2), (c1, c2)):   # outputs of culled Gaussians are not written by either
             assert torch.equal(a[vis], b[vis])
+
+
+@pytest.mark.parametrize("deg,distorted", [(3, False), (0, False), (2, True)])
+def test_frontend_fused_is_bit_identical_to_the_separate_operators(mods, deg, distorted):
+    """ops.frontend_fused (activations -> UT projection -> SH colours -> packed blend records in ONE kernel, csrc/gsx_frontend.hip) against the
+    launches it replaces: activated parameters, projection and colours bit for bit; the packed records to the last bit or two (see
+    below), hence the blend forward / backward on them equal to rounding to the ones that pack for themselves."""
+    distributed, ops, rasterizer, scenes = mods
+    sc, cam = _setup(scenes, rasterizer, deg)
+    model = scenes.to_splat_data(sc, DEV)
+    ut = ops.UnscentedTransformParameters()
+    vm, K = cam.world_view_transform().contiguous(), cam.K_batched().contiguous()
+    radial = torch.tensor([[0.05, -0.02, 0.003, 0.0, 0.0, 0.0]], device=DEV) if distorted else None
+    tang = torch.tensor([[0.002, -0.001]], device=DEV) if distorted else None
+    sr, rr, orw = model.scaling_raw.contiguous(), model.rotation_raw.contiguous(), model.opacity_raw.reshape(-1).contiguous()
+    W, H = 96, 64      # a crop of the camera's image (principal point off centre): part of the scene is culled
+    cm = ops.CameraModelType.PINHOLE
+    fe = ops.frontend_fused(deg, model.means, model.sh, sr, rr, orw, vm, K, W, H, 0.3, 0.01, 1e4, 0.0, cm, ut, radial, tang, None)
+    assert fe[8] is not None
+    scales, quats, opac, radii, means2d, depths, conics, colors, ws = fe
+    ref = ops.splat_activations_projection_ut(model.means, sr, rr, orw, vm, K, W, H, 0.3, 0.01, 1e4, 0.0, cm, ut, radial, tang, None)
+    col_ref = ops.sh_colors_fwd(deg, model.means, vm, model.sh, ref[3])
+    vis = (ref[3] > 0).all(-1)
+    assert 0.2 < float(vis.float().mean()) < 1.0   # the camera culls some
+    for a, b, n in zip((scales, quats, opac, radii), ref[:4], ("scales", "quats", "opacities", "radii")):
+        assert torch.equal(a, b), n
+    for a, b, n in zip((means2d, depths, conics), ref[4:], ("means2d", "depths", "conics")):
+        assert torch.equal(a[vis], b[vis]), n       # (only radii is written for a culled Gaussian)
+    assert torch.equal(colors, col_ref)
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    _, _, fl, off = ops.intersect_tile_binned(means2d, radii, depths, 1, 16, tw, th, False)
+    bg = sc["background"][None].to(DEV)
+    args = (model.means, quats, scales, colors, opac[None].contiguous(), bg, None, W, H, 16, vm, None, K, cm, ut, ops.ShutterType.GLOBAL, radial, tang, None, off, fl)
+    a = ops.rasterize_fwd_packed(*args, ws)
+    b = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args, keep_ws=True)
+    # the packed records: the same device function compiled into two kernels — the compiler contracts a few of its a*b+c differently, so
+    # five of the sixteen fields may differ in the last bit; everything downstream agrees to rounding
+    def recs(w):
+        base = (w.data_ptr() + 255) // 256 * 256 - w.data_ptr()
+        return w[base:base + model.means.shape[0] * 64].view(torch.float32).reshape(-1, 16)
+    r_fe, r_pk = recs(ws)[vis[0]], recs(b[3])[vis[0]]
+    assert float(((r_fe - r_pk).abs() / r_pk.abs().amax(1, keepdim=True)).max()) < 5e-7   # relative to the record's largest entry
+    assert float((a[0] - b[0]).abs().max()) < 2e-6 and float((a[1] - b[1]).abs().max()) < 2e-6 and torch.equal(a[2], b[2])
+    g = torch.Generator().manual_seed(1)
+    v_rc, v_ra = torch.randn(1, H, W, 3, generator=g).to(DEV), torch.randn(1, H, W, 1, generator=g).to(DEV)
+    ga = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, a[1], a[2], v_rc, v_ra, fwd_ws=ws)
+    gb = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, a[1], a[2], v_rc, v_ra)
+    assert all(rel_l2(x.cpu().numpy(), y.cpu().numpy()) < 2e-6 for x, y in zip(ga, gb))
+    # a camera the front end does not take: undefined workspace, the caller falls back
+    fish = ops.frontend_fused(deg, model.means, model.sh, sr, rr, orw, vm, K, W, H, 0.3, 0.01, 1e4, 0.0, ops.CameraModelType.FISHEYE, ut, None, None, None)
+    assert fish[8] is None
