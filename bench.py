@@ -227,6 +227,7 @@ def main():
     ap.add_argument("--l1-loss", action="store_true", help="plain torch L1 loss instead of the reference's fused L1 + SSIM loss")
     ap.add_argument("--no-fwd-bwd", action="store_true", help="skip the extra fwd+bwd (no optimizer) timing loop")
     ap.add_argument("--fixed-camera", action="store_true", help="the cfg2 camera on every step (default: 8 poses around it, one per step)")
+    ap.add_argument("--spatial-sort", action="store_true", help="store the Gaussians in Morton order of their positions (same scene, spatially coherent memory order: gsx.layout)")
     ap.add_argument("--repeats", type=int, default=1, help="R > 1: time R x K steps and report the MEDIAN K-step time (sub-3 %% claims need it; "
                                                            "the contract's single K-step region is R = 1)")
     ap.add_argument("--launch-check", action="store_true", help="initialise the process group, report rank / world / backend and exit "
@@ -265,6 +266,11 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     scene = {"small": scenes.scene_small, "1m": scenes.scene_1m, "5m": scenes.scene_5m}[args.scene]()
+    if args.spatial_sort:   # the same Gaussians stored in Morton order of their positions (gsx.layout; what strategy.MCMC re-establishes after every growth step)
+        from gsx import layout
+        order = layout.morton_order(scene["means"])
+        for k in ("means", "quats", "scales", "opacities", "sh"):
+            scene[k] = scene[k][order].contiguous()
     N, W, H, deg = scene["means"].shape[0], scene["width"], scene["height"], scene["sh_degree"]
     model = scenes.to_splat_data(scene, dev)
     for p in model.params():
@@ -435,6 +441,7 @@ def main():
             "config": {"workload": workload, "n_gaussians": N, "width": W, "height": H, "sh_degree": deg,
                        "cameras": "cfg2 pose only" if args.fixed_camera else "%d poses (cfg2 + a 0.4 m orbit around it), a different one every step" % len(cams),
                        "n_isects_mean": round(I, 1), "n_isects_min": min(isects_timed), "n_isects_max": max(isects_timed),
+                       "gaussian_order": "morton (--spatial-sort)" if args.spatial_sort else "as generated (random)",
                        "cameras_per_step": world, "ranks": world, "backend": (dist.get_backend() if world > 1 else None),
                        "grad_exchange": ("none" if world == 1 else ("colour-gradient all-gather (3 floats / camera / Gaussian) + SH backward over all cameras on every rank; "
                                                                      "all-reduce of the other 11 floats under it" if xch is not None else "reduce-scatter + sharded Adam + all-gather" if sharded is not None else

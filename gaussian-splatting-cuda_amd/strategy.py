@@ -39,6 +39,8 @@ class MCMC:
                                                         params.opacity_lr, scene_scale)
         self.scheduler = optim.ExponentialLR(self.optimizer, 0.01 ** (1.0 / params.iterations), 0)
         self.on_resize = None   # callback(model) after add_new_gs replaced the parameter tensors (e.g. rebuild the gradient bucket)
+        self.before_reindex = None    # callback() before rows are permuted / removed (distributed.ShardedAdam.merge_moments: every rank needs complete moments first)
+        self.spatial_reorder = True   # after a growth step (the tensors are re-created anyway) store the Gaussians in Morton order: layout.py
         self._grew = False      # add_new_gs replaced the parameters this iteration: they carry no gradient (see step)
 
     # ---- helpers ---------------------------------------------------------------------------------------------------------
@@ -105,9 +107,26 @@ class MCMC:
             setattr(m, name, torch.cat([old.data, old.data.index_select(0, sampled)], 0).requires_grad_(True))
         self.optimizer.extend_state(n_new)
         self._grew = True
+        if self.spatial_reorder:
+            self.reorder_spatially(notify=False)
         if self.on_resize is not None:
             self.on_resize(m)
         return n_new
+
+    @torch.no_grad()
+    def reorder_spatially(self, notify=True):
+        """Stores the Gaussians (parameters and Adam moments alike) in Morton order of their positions (layout.py): the same model, a
+        memory order under which the intersection's slices and the blend's gathers are spatially coherent.  Returns the permutation."""
+        from . import layout
+        if self.before_reindex is not None:
+            self.before_reindex()
+        order = layout.morton_order(self.model.means.data)
+        for name in ("means", "sh", "scaling_raw", "rotation_raw", "opacity_raw"):
+            setattr(self.model, name, getattr(self.model, name).data.index_select(0, order).requires_grad_(True))
+        self.optimizer.select_state(order)
+        if notify and self.on_resize is not None:
+            self.on_resize(self.model)
+        return order
 
     # ---- mcmc.cpp:342-366 ------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -145,6 +164,8 @@ class MCMC:
         if int(mask.sum()) == 0:
             return
         keep = (~mask).nonzero().squeeze(-1)
+        if self.before_reindex is not None:
+            self.before_reindex()
         for name in ("means", "sh", "scaling_raw", "rotation_raw", "opacity_raw"):
             setattr(self.model, name, getattr(self.model, name).data.index_select(0, keep).requires_grad_(True))
         self.optimizer.select_state(keep)

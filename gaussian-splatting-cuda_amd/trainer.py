@@ -46,6 +46,8 @@ class Trainer:
         self.strategy.on_resize = self._rebuild_bucket
         self._rebuild_bucket(model)
         self.sharded = gdist.ShardedAdam(self.strategy.optimizer) if (sharded_adam and self.world > 1) else None
+        if self.sharded is not None:   # rows change owner when the strategy permutes / removes them: complete the moments on every rank first
+            self.strategy.before_reindex = self.sharded.merge_moments
         self.last_loss = None
 
     def _rebuild_bucket(self, model):

@@ -83,3 +83,41 @@ def test_gpu_mcmc_ops_vs_oracle():
     R = ops.quats_to_rotmats(t(g["quats"]))
     np.testing.assert_allclose(R.cpu().numpy(), g["rotmats"], rtol=1e-5, atol=1e-5)   # the reference's own quat_to_rotmat
     assert ops.relocation(t(opac[:0]), t(scales[:0]), t(ratios[:0]), t(b), 51)[0].numel() == 0
+
+
+def test_morton_order_and_spatial_reorder_keep_the_model_as_a_set():
+    """gsx.layout.morton_order is a permutation that clusters neighbours, and MCMC.reorder_spatially applies it to the parameters AND the
+    Adam moments (CPU tensors: no kernel runs)."""
+    import numpy as np
+    import torch
+    import gsx  # noqa: F401
+    from gsx import layout, parameters, rasterizer, strategy
+    g = torch.Generator().manual_seed(0)
+    n = 4096
+    means = torch.rand(n, 3, generator=g)
+    order = layout.morton_order(means)
+    assert torch.equal(torch.sort(order).values, torch.arange(n))
+    # neighbours in memory are neighbours in space: mean distance between consecutive Gaussians drops by a large factor
+    d_rand = (means[1:] - means[:-1]).norm(dim=1).mean()
+    ms = means[order]
+    d_sorted = (ms[1:] - ms[:-1]).norm(dim=1).mean()
+    assert float(d_sorted) < 0.25 * float(d_rand)
+    assert torch.equal(layout.morton_order(means), order)               # deterministic (stable sort): identical on every rank
+    bad = means.clone()
+    bad[7] = float("nan")
+    assert torch.equal(torch.sort(layout.morton_order(bad)).values, torch.arange(n))   # non-finite rows do not break it
+    model = rasterizer.SplatData(means=means.clone(), sh=torch.rand(n, 4, 3, generator=g), scaling_raw=torch.rand(n, 3, generator=g),
+                                 rotation_raw=torch.rand(n, 4, generator=g), opacity_raw=torch.rand(n, 1, generator=g), active_sh_degree=1)
+    st = strategy.MCMC(model, parameters.OptimizationParameters())
+    mom = st.optimizer._moments("means")
+    mom["exp_avg"].copy_(means * 3.0)           # moments that identify their row
+    before = {k: getattr(model, k).detach().clone() for k in ("means", "sh", "scaling_raw", "rotation_raw", "opacity_raw")}
+    calls = []
+    st.before_reindex = lambda: calls.append("merge")
+    st.on_resize = lambda m: calls.append("resize")
+    perm = st.reorder_spatially()
+    assert calls == ["merge", "resize"] and torch.equal(perm, order)
+    for k, v in before.items():
+        assert torch.equal(getattr(model, k).detach(), v[perm]) and getattr(model, k).requires_grad
+    assert torch.equal(st.optimizer._moments("means")["exp_avg"], model.means.detach() * 3.0)   # the moments moved with their rows
+    assert np.isclose(float(model.means.detach().sum()), float(before["means"].sum()), rtol=1e-6)
