@@ -227,7 +227,9 @@ def main():
     ap.add_argument("--l1-loss", action="store_true", help="plain torch L1 loss instead of the reference's fused L1 + SSIM loss")
     ap.add_argument("--no-fwd-bwd", action="store_true", help="skip the extra fwd+bwd (no optimizer) timing loop")
     ap.add_argument("--fixed-camera", action="store_true", help="the cfg2 camera on every step (default: 8 poses around it, one per step)")
-    ap.add_argument("--spatial-sort", action="store_true", help="store the Gaussians in Morton order of their positions (same scene, spatially coherent memory order: gsx.layout)")
+    ap.add_argument("--random-order", action="store_true", help="keep the Gaussians in the order the scene generator emits them (default: the same Gaussians "
+                                                                "stored in Morton order of their positions, gsx.layout — the order gsx's trainer maintains)")
+    ap.add_argument("--no-order-ablation", action="store_true", help="skip the extra leg that times the other memory order (N = 1 only)")
     ap.add_argument("--repeats", type=int, default=1, help="R > 1: time R x K steps and report the MEDIAN K-step time (sub-3 %% claims need it; "
                                                            "the contract's single K-step region is R = 1)")
     ap.add_argument("--launch-check", action="store_true", help="initialise the process group, report rank / world / backend and exit "
@@ -266,7 +268,11 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     scene = {"small": scenes.scene_small, "1m": scenes.scene_1m, "5m": scenes.scene_5m}[args.scene]()
-    if args.spatial_sort:   # the same Gaussians stored in Morton order of their positions (gsx.layout; what strategy.MCMC re-establishes after every growth step)
+    # Memory order of the Gaussians.  The scene generator emits them in random order; gsx stores a model in Morton order of the positions
+    # (gsx.layout: strategy.MCMC re-establishes it whenever densification re-indexes the tensors anyway) because the intersection's slices
+    # and the blend's record gathers are then spatially coherent.  Same Gaussians, same image; `order_ablation` times the other order.
+    scene_as_generated = dict(scene)
+    if not args.random_order:
         from gsx import layout
         order = layout.morton_order(scene["means"])
         for k in ("means", "quats", "scales", "opacities", "sh"):
@@ -441,7 +447,7 @@ def main():
             "config": {"workload": workload, "n_gaussians": N, "width": W, "height": H, "sh_degree": deg,
                        "cameras": "cfg2 pose only" if args.fixed_camera else "%d poses (cfg2 + a 0.4 m orbit around it), a different one every step" % len(cams),
                        "n_isects_mean": round(I, 1), "n_isects_min": min(isects_timed), "n_isects_max": max(isects_timed),
-                       "gaussian_order": "morton (--spatial-sort)" if args.spatial_sort else "as generated (random)",
+                       "gaussian_order": "as generated (random): --random-order" if args.random_order else "Morton order of the positions (gsx.layout; the same Gaussians as generated, permuted once before the timed region)",
                        "cameras_per_step": world, "ranks": world, "backend": (dist.get_backend() if world > 1 else None),
                        "grad_exchange": ("none" if world == 1 else ("colour-gradient all-gather (3 floats / camera / Gaussian) + SH backward over all cameras on every rank; "
                                                                      "all-reduce of the other 11 floats under it" if xch is not None else "reduce-scatter + sharded Adam + all-gather" if sharded is not None else
@@ -473,6 +479,39 @@ def main():
         if fwd_bwd_ms is not None:
             result["fwd_bwd"] = {"ms_per_frame": round(fwd_bwd_ms, 4), "frames_per_s": round(world * 1e3 / fwd_bwd_ms, 3),
                                  "what": "render + fused loss + backward (+ gradient all-reduce), no optimizer; same camera sequence"}
+        if world == 1 and not args.no_order_ablation and not args.unfused:
+            # the other memory order, same scene: a fresh model / optimizer, W warm-up + K timed training iterations (outside the contract's region)
+            other = dict(scene_as_generated)
+            if args.random_order:
+                from gsx import layout
+                o2 = layout.morton_order(other["means"])
+                for k in ("means", "quats", "scales", "opacities", "sh"):
+                    other[k] = other[k][o2].contiguous()
+            m2 = scenes.to_splat_data(other, dev)
+            for p_ in m2.params():
+                p_.requires_grad_(True)
+            b2 = gdist.GradBucket([getattr(m2, n) for n in names])
+            s2 = b2.sinks(tuple(names))
+            o2pt = optim.FusedAdam.for_splat_data(m2)
+
+            def step2(i):
+                cam = cams[i % len(cams)]
+                s2["_sh_adam"] = o2pt.begin_fused_sh_step(1001 + i) if sh_adam_ok else None
+                out2 = rasterizer.rasterize_fused(cam, m2, bg, grad_sinks=s2)
+                l2 = gloss.photometric_loss(out2.render_hwc, targets[i % len(targets)], 0.2) if fused_loss else (out2.image - targets[i % len(targets)]).abs().mean()
+                l2.backward()
+                o2pt.step(1001 + i, skip_sh=s2["_sh_adam"] is not None)
+            for i in range(args.warmup):
+                step2(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                step2(i)
+            torch.cuda.synchronize()
+            result["order_ablation"] = {"order": "Morton order of the positions" if args.random_order else "as generated (random)",
+                                        "ms_per_step": round((time.perf_counter() - t0) / args.steps * 1e3, 4),
+                                        "what": "the same training iteration on the same Gaussians stored in the other memory order (fresh model and optimizer)"}
+            del m2, b2, s2, o2pt
         if world == 1 and not args.no_cpu_baseline:
             threads = os.cpu_count() or 1
             dt, i_cpu = cpu_baseline(scene, threads)

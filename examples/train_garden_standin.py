@@ -6,7 +6,7 @@ start_refine 500, refine_every 100, max_cap 1M), strategy forced to MCMC (the on
 SURVEY §8f-3).  Ground-truth images are renders of a hidden 400 k-Gaussian scene; the trainee starts from 200 k of its points
 (positions jittered, as an SfM cloud would be) through init_model_from_pointcloud and grows to the 1 M cap.
 
-    python examples/train_garden_standin.py [iterations=4000] [--json out.json]
+    python examples/train_garden_standin.py [iterations=4000] [--json out.json] [--profile-ops]
 
 Prints one JSON line: iterations/s (whole loop, incl. densification), PSNR before / after over 24 held-in cameras, Gaussian count.
 """
@@ -114,6 +114,20 @@ def main():
            "psnr_before": round(before["psnr"], 2), "psnr_after": round(after["psnr"], 2),
            "ssim_before": round(before["ssim"], 4), "ssim_after": round(after["ssim"], 4),
            "active_sh_degree": model.active_sh_degree, "means_lr_end": tr.strategy.optimizer.groups[0]["lr"]}
+    if "--profile-ops" in sys.argv:   # per-operator HIP-event times of 48 more iterations at the final model size (bench.OpTimer)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        from gsx import ops
+        timer = bench.OpTimer(ops)
+        n_prof = 48 if (iters + 48) < params.iterations else 0
+        timer.enabled = True
+        t1 = time.perf_counter()
+        for it in range(iters + 1, iters + 1 + n_prof):
+            tr.train_step(it)
+        torch.cuda.synchronize()
+        timer.enabled = False
+        res["ops_ms"] = {k: round(v, 4) for k, v in sorted(timer.mean_ms().items(), key=lambda kv: -kv[1])}
+        res["ops_ms_iteration_wall"] = round((time.perf_counter() - t1) / max(1, n_prof) * 1e3, 4)
     line = json.dumps(res)
     print(line)
     if out_json:

@@ -32,6 +32,10 @@ def main():
         garden.N_GT = n
         model = garden.hidden_scene(dev)
         cam = garden.ring_cameras(dev)[4]
+    if os.environ.get("GSX_ISECT_SHUFFLE") == "1":   # the same model in random memory order (layout.py keeps the trainee in Morton order)
+        perm = torch.randperm(model.means.shape[0], device=dev)
+        for name in ("means", "sh", "scaling_raw", "rotation_raw", "opacity_raw"):
+            setattr(model, name, getattr(model, name).data.index_select(0, perm))
     ut = ops.UnscentedTransformParameters()
     with torch.no_grad():
         scales, quats, opac, radii, means2d, depths, conics = ops.splat_activations_projection_ut(
