@@ -7,7 +7,8 @@
 //
 // MI355X design.  An 11x11 separable Gaussian window over 5 (fwd) / 3 (bwd) per-pixel quantities; the work is LDS-bound,
 // not HBM-bound, so the kernels minimise LDS traffic instead of replaying the usual one-output-per-thread stencil:
-//   * a block owns a 64x16 pixel tile (one wave64 = one 64-pixel row segment -> 256 B coalesced row reads / writes);
+//   * a block of 512 threads owns a 64x32 pixel tile (one wave64 = one 64-pixel row segment -> 256 B coalesced row reads / writes; the
+//     10-pixel halo costs 1.52x the tile in fetches and 1.31x in horizontal-pass work — 1.88x / 1.63x with the 64x16 tile of round 2);
 //   * the horizontal pass gives every thread a strip of 4 outputs in one row (14+14 LDS reads for 4x5 outputs instead
 //     of 22 per output) with lanes running down the rows — odd LDS pitches (75 / 65 dwords) keep both the strip reads
 //     and the plane writes bank-conflict free;
@@ -29,11 +30,11 @@ int check_launch(const char* what);
 
 namespace ssim {
 
-constexpr int TX = 64, TY = 16, HALO = 5;
-constexpr int SX = TX + 2 * HALO, SY = TY + 2 * HALO;  // staged tile 74 x 26
+constexpr int TX = 64, TY = 32, HALO = 5;
+constexpr int SX = TX + 2 * HALO, SY = TY + 2 * HALO;  // staged tile 74 x 42
 constexpr int PA = 75;                                  // pitch of the staged input planes (odd: rows -> distinct banks)
 constexpr int PC = 65;                                  // pitch of the horizontally-convolved planes
-constexpr int NT = 256;
+constexpr int NT = 512;                                 // 8 waves: wave w owns rows 4w .. 4w+3 of the tile in the vertical pass
 
 // the reference's window: normalised Gaussian, sigma 1.5, 11 taps, as fp32 literals (ssim.cu:16-27)
 #define GSX_SSIM_TAPS                                                                                                          \
@@ -46,23 +47,23 @@ __device__ __forceinline__ void hconv5(const float (*sA)[PA], const float (*sB)[
     constexpr float w[11] = GSX_SSIM_TAPS;
     for (int it = threadIdx.x; it < SY * (TX / 4); it += NT) {
         const int r = it % SY, x0 = (it / SY) * 4;
-        float X[14], Y[14];
+        float X[14], Y[14], XX[14], YY[14], XY[14];   // the three products once per staged element (42 mul per 4 outputs) instead of per tap
 #pragma unroll
         for (int k = 0; k < 14; ++k) {
             X[k] = sA[r][x0 + k];
             Y[k] = sB[r][x0 + k];
+            XX[k] = X[k] * X[k]; YY[k] = Y[k] * Y[k]; XY[k] = X[k] * Y[k];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
 #pragma unroll
             for (int k = 0; k < 11; ++k) {
-                const float wx = w[k] * X[j + k], wy = w[k] * Y[j + k];
-                a0 += wx;
-                a1 = fmaf(wx, X[j + k], a1);
-                a2 += wy;
-                a3 = fmaf(wy, Y[j + k], a3);
-                a4 = fmaf(wx, Y[j + k], a4);
+                a0 = fmaf(w[k], X[j + k], a0);
+                a1 = fmaf(w[k], XX[j + k], a1);
+                a2 = fmaf(w[k], Y[j + k], a2);
+                a3 = fmaf(w[k], YY[j + k], a3);
+                a4 = fmaf(w[k], XY[j + k], a4);
             }
             sC[0][r][x0 + j] = a0;
             sC[1][r][x0 + j] = a1;
@@ -120,10 +121,12 @@ __device__ __forceinline__ void ssim_point(const float (&o)[5], float C1, float 
     const float s1 = o[1] - mu1_sq, s2 = o[3] - mu2_sq, s12 = o[4] - mu1 * mu2;
     const float A = mu1_sq + mu2_sq + C1, B = s1 + s2 + C2;
     const float Cn = 2.f * mu1 * mu2 + C1, Dn = 2.f * s12 + C2;
-    const float rAB = 1.f / (A * B);
+    // the reference's expressions (ssim.cu:255-268) with 1/A and 1/B formed once: two divisions instead of four
+    const float rA = 1.f / A, rB = 1.f / B, rAB = rA * rB;
     val = Cn * Dn * rAB;
-    d_mu1 = (mu2 * 2.f * Dn) * rAB - (mu2 * 2.f * Cn) * rAB - (mu1 * 2.f * Cn * Dn) / (A * A * B) + (mu1 * 2.f * Cn * Dn) / (A * B * B);
-    d_s1 = (-Cn * Dn) / (A * B * B);
+    const float t = (mu1 * 2.f) * val;          // mu1 2 Cn Dn / (A B)
+    d_mu1 = (mu2 * 2.f) * (Dn - Cn) * rAB - t * rA + t * rB;
+    d_s1 = -val * rB;
     d_s12 = (2.f * Cn) * rAB;
 }
 
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(NT) void ssim_bwd_kernel(int CH, int H, int W, cons
 
 // ---- fused photometric loss on the blend's own layout ----------------------------------------------------------------------
 // render [C,H,W,3] (unclamped blend output), gt [C,3,H,W].  Workspace: chained partial maps [3][C][3][H][W] + block partial sums.
-__global__ __launch_bounds__(NT) void loss_fwd_kernel(int H, int W, float chain, int crop, const float* __restrict__ render,
+__global__ __launch_bounds__(NT, 4) void loss_fwd_kernel(int H, int W, float chain, int crop, const float* __restrict__ render,
                                                       const float* __restrict__ gt, float* __restrict__ maps,
                                                       float2* __restrict__ block_sums) {
     __shared__ float sA[SY][PA], sB[SY][PA];
