@@ -12,5 +12,5 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU S
     timeout -k 5 100 rocprofv3 --kernel-trace --pmc $grp -d "$out/p$i" -o p$i --output-format csv -- python tools/run_fwd_bwd.py 2 all > "$out/p$i.log" 2>&1
     echo "pass $i ($grp): rc=$?"
 done
-python tools/pmc_summary.py "$out" raster_ sh_ bin_ tile_sort projection pack_ gather loss_ activations adam > "$out/summary.txt"
+python tools/pmc_summary.py "$out" raster_ sh_ bin_ tile_sort projection pack_ gather loss_ activations adam frontend > "$out/summary.txt"
 wc -l "$out/summary.txt"

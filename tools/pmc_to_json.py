@@ -36,7 +36,7 @@ def main():
         "source": source,
         "blend_kernel_hash": gbuild.blend_kernel_hash(),   # bench.py reports these figures only while the blend sources still hash to this
         "rasterize_to_pixels_from_world_3dgs_fwd": {"hbm_bytes": traffic(pack) + traffic(fwd), "valu_insts": int(fwd["SQ_INSTS_VALU"]),
-                                                    "kernels": "pack_records + raster_fwd_fast"},
+                                                    "kernels": ("pack_records + raster_fwd_fast" if pack else "raster_fwd_fast (records packed by the fused front end)")},
         "rasterize_to_pixels_from_world_3dgs_bwd": {"hbm_bytes": traffic(bwd) + traffic(gather), "valu_insts": int(bwd["SQ_INSTS_VALU"]),
                                                     "kernels": "raster_bwd_gq (or raster_bwd_fast) + gsx_bwd_gather; packed records reused from the forward"},
     }

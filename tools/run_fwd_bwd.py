@@ -14,6 +14,11 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 mode = sys.argv[2] if len(sys.argv) > 2 else "all"
 dev = "cuda:0"
 scene = {"1m": scenes.scene_1m, "5m": scenes.scene_5m}[os.environ.get("GSX_SCENE", "1m")]()
+if os.environ.get("GSX_RANDOM_ORDER") != "1":   # bench.py's default memory order (gsx.layout)
+    from gsx import layout
+    order = layout.morton_order(scene["means"])
+    for k in ("means", "quats", "scales", "opacities", "sh"):
+        scene[k] = scene[k][order].contiguous()
 model = scenes.to_splat_data(scene, dev)
 cam = rasterizer.Camera(viewmat=scene["viewmat"].to(dev), K=scene["K"].to(dev), width=scene["width"], height=scene["height"])
 bg = scene["background"].to(dev)
