@@ -9,11 +9,12 @@
 //     PINNED against the reference's own tests/torch_impl.cpp compiled unmodified
 //     (oracle/_ref, see oracle/build_ref.sh and tests/test_oracle_vs_ref.py) and against the
 //     golden vectors under tests/golden/ generated from it.
-//   * UT projection, intersect_offset, blend forward and blend backward are "PARITY UNPINNED":
-//     the reference has no CPU implementation, no golden vectors and no known-answer tests for
-//     them and its CUDA kernels cannot be compiled here (no nvcc, no glm).
-//     They are cross-validated instead (float64 re-evaluation, torch autograd of an independent
-//     differentiable forward, finite differences) in tests/.
+//   * UT projection (all camera models, rolling shutter, compensations), intersect_offset, blend forward and blend
+//     backward are PINNED (round 3) against golden tensors produced by the reference's OWN kernels: its gsplat/*.cu
+//     compiled unmodified for gfx950 where they lie (oracle/build_ref_hip.sh -> oracle/_ref/gsplat_ref_hip.so) and run
+//     on an MI355X by tests/golden/gen_ref_hip_golden.py; fixtures tests/golden/ref_hip/*.npz, checked in the CPU suite
+//     by tests/test_oracle_ref_hip_golden.py (and live on the GPU by tests/test_gpu_reference_hip.py).  The reference
+//     holds no vectors of its own for these stages.
 //
 // Every function cites the reference file:line it follows.  All functions are templated on the
 // scalar type: the `_f32` entry points follow the reference's fp32 operation order, the `_f64`
