@@ -67,12 +67,13 @@ __global__ __launch_bounds__(ISECT_BLOCK) void isect_fill_kernel(uint32_t total,
                                                                  const int64_t* __restrict__ cum, float tile_size,
                                                                  uint32_t tw, uint32_t th, uint32_t tile_n_bits,
                                                                  int64_t* __restrict__ isect_ids,
-                                                                 int32_t* __restrict__ flatten_ids) {
+                                                                 int32_t* __restrict__ flatten_ids,
+                                                                 const int64_t* __restrict__ camera_ids) {
     const uint32_t idx = blockIdx.x * ISECT_BLOCK + threadIdx.x;
     if (idx >= total) return;
     uint32_t x0, y0, x1, y1;
     if (!tile_rect(means2d, radii, idx, tile_size, tw, th, x0, y0, x1, y1)) return;
-    const int64_t cid = idx / N;
+    const int64_t cid = camera_ids ? camera_ids[idx] : (int64_t)(idx / N);   // packed [nnz] layout: IntersectTile.cu:85-93
     const int64_t cid_enc = cid << (32 + tile_n_bits);
     const int64_t depth_enc = (int64_t)__float_as_uint(depths[idx]);
     int64_t cur = (idx == 0) ? 0 : cum[idx - 1];
@@ -835,6 +836,17 @@ extern "C" int gsx_intersect_tile_fill(uint32_t C, uint32_t N, const float* mean
                                        uint32_t tile_width, uint32_t tile_height, int sort, int64_t n_isects,
                                        int64_t* isect_ids, int32_t* flatten_ids, void* workspace, size_t workspace_bytes,
                                        void* stream) {
+    return gsx_intersect_tile_fill_packed(C, N, 0, nullptr, means2d, radii, depths, cum_tiles_per_gauss, tile_size, tile_width, tile_height, sort,
+                                          n_isects, isect_ids, flatten_ids, workspace, workspace_bytes, stream);
+}
+
+// camera_ids != NULL: the packed layout of the reference (Intersect.cpp:31-38, IntersectTile.cu:85-88): the arrays hold nnz (camera, Gaussian)
+// pairs, camera_ids[nnz] (int64) names each pair's camera, flatten_ids index the nnz pairs; N is ignored.
+extern "C" int gsx_intersect_tile_fill_packed(uint32_t C, uint32_t N, uint32_t nnz, const int64_t* camera_ids, const float* means2d,
+                                              const int32_t* radii, const float* depths, const int64_t* cum_tiles_per_gauss,
+                                              uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, int sort, int64_t n_isects,
+                                              int64_t* isect_ids, int32_t* flatten_ids, void* workspace, size_t workspace_bytes,
+                                              void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (n_isects <= 0) return GSX_OK;
     if (n_isects > 0x7FFFFFFFll) { set_error("intersect_tile: n_isects must fit int32 (tile offsets are int32)"); return GSX_ERR_INVALID_ARGUMENT; }
@@ -842,8 +854,10 @@ extern "C" int gsx_intersect_tile_fill(uint32_t C, uint32_t N, const float* mean
         set_error("intersect_tile_fill: null pointer / zero tile size");
         return GSX_ERR_INVALID_ARGUMENT;
     }
-    const uint32_t total = C * N;
+    const uint32_t total = camera_ids ? nnz : C * N;
+    if (camera_ids) N = 1;
     const uint32_t tile_n_bits = bit_width_u32(tile_width * tile_height), cam_n_bits = bit_width_u32(C);
+    if (tile_n_bits + cam_n_bits > 32) { set_error("intersect_tile: tile_n_bits + cam_n_bits must be <= 32"); return GSX_ERR_INVALID_ARGUMENT; }
     int64_t* keys_out = isect_ids;
     int32_t* vals_out = flatten_ids;
     size_t temp = 0;
@@ -857,7 +871,7 @@ extern "C" int gsx_intersect_tile_fill(uint32_t C, uint32_t N, const float* mean
     }
     hipLaunchKernelGGL(isect_fill_kernel, dim3((total + ISECT_BLOCK - 1) / ISECT_BLOCK), dim3(ISECT_BLOCK), 0, st, total, N,
                        means2d, radii, depths, cum_tiles_per_gauss, (float)tile_size, tile_width, tile_height, tile_n_bits,
-                       keys_out, vals_out);
+                       keys_out, vals_out, camera_ids);
     if (sort) {
         void* tmp = ws + align_up((size_t)n_isects * 8, 256) + align_up((size_t)n_isects * 4, 256);
         if (rocprim::radix_sort_pairs(tmp, temp, (const uint64_t*)keys_out, (uint64_t*)isect_ids, (const int32_t*)vals_out,

@@ -170,16 +170,20 @@ static std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile_impl(const 
     GSX_CHECK_INPUT(means2d);
     GSX_CHECK_INPUT(radii);
     GSX_CHECK_INPUT(depths);
-    const bool packed = means2d.dim() == 2;
-    TORCH_CHECK(!packed, "packed mode is not supported (the reference's world-space path asserts packed == false, "
-                         "RasterizeToPixelsFromWorld3DGSFwd.cu:316-317)");
-    (void)camera_ids; (void)gaussian_ids;
+    const bool packed = means2d.dim() == 2;   // [nnz, 2]: the packed layout (Intersect.cpp:31-38); the world-space blend itself is non-packed only
+    if (packed) {
+        TORCH_CHECK(camera_ids.has_value() && gaussian_ids.has_value(), "When packed is set, camera_ids and gaussian_ids must be provided.");
+        GSX_CHECK_INPUT(camera_ids.value());
+        GSX_CHECK_INPUT(gaussian_ids.value());
+        TORCH_CHECK(camera_ids->scalar_type() == at::kLong && camera_ids->numel() == means2d.size(0), "camera_ids must be int64 [nnz]");
+    }
     TORCH_CHECK(means2d.scalar_type() == at::kFloat && depths.scalar_type() == at::kFloat, "float32 only");
     TORCH_CHECK(radii.scalar_type() == at::kInt, "radii must be int32");
     const uint32_t n_elements = means2d.numel() / 2;
-    const uint32_t N = C ? n_elements / C : 0;
+    const uint32_t N = packed ? n_elements : (C ? n_elements / C : 0);
+    const uint32_t C_count = packed ? 1u : C;   // the count pass does not look at the camera: nnz pairs are counted as one camera's
     static const bool force_device_sort = [] { const char* e = getenv("GSX_INTERSECT"); return e && std::string(e) == "sort"; }();
-    if (allow_binned && sort && !force_device_sort && n_elements && gsx_intersect_bin_supported(tile_width, tile_height)) {
+    if (!packed && allow_binned && sort && !force_device_sort && n_elements && gsx_intersect_bin_supported(tile_width, tile_height)) {
         // same three outputs through the binned pipeline (LDS histograms + per-tile LDS sort), ~2x faster than the device-wide sort
         auto r = gsx_ext::intersect_tile_binned(means2d, radii, depths, C, tile_size, tile_width, tile_height, true);
         return std::make_tuple(std::get<0>(r), std::get<1>(r), std::get<2>(r));
@@ -190,10 +194,10 @@ static std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile_impl(const 
     at::Tensor cum;
     if (n_elements) {
         cum = at::empty({(int64_t)n_elements}, depths.options().dtype(at::kLong));
-        const size_t wsb = gsx_intersect_count_workspace_bytes(C, N);
+        const size_t wsb = gsx_intersect_count_workspace_bytes(C_count, N);
         at::Tensor ws = at::empty({(int64_t)wsb}, depths.options().dtype(at::kByte));
         at::Tensor n_host = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
-        check(gsx_intersect_tile_count(C, N, means2d.data_ptr<float>(), radii.data_ptr<int32_t>(), tile_size, tile_width,
+        check(gsx_intersect_tile_count(C_count, N, means2d.data_ptr<float>(), radii.data_ptr<int32_t>(), tile_size, tile_width,
                                        tile_height, tiles_per_gauss.data_ptr<int32_t>(), cum.data_ptr<int64_t>(), nullptr,
                                        n_host.data_ptr<int64_t>(), ws.data_ptr(), wsb, st),
               "intersect_tile(count)");
@@ -206,9 +210,10 @@ static std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile_impl(const 
     if (n_isects) {
         const size_t wsb = gsx_intersect_fill_workspace_bytes(C, N, n_isects, sort ? 1 : 0);
         at::Tensor ws = at::empty({(int64_t)wsb}, depths.options().dtype(at::kByte));
-        check(gsx_intersect_tile_fill(C, N, means2d.data_ptr<float>(), radii.data_ptr<int32_t>(), depths.data_ptr<float>(),
-                                      cum.data_ptr<int64_t>(), tile_size, tile_width, tile_height, sort ? 1 : 0, n_isects,
-                                      isect_ids.data_ptr<int64_t>(), flatten_ids.data_ptr<int32_t>(), ws.data_ptr(), wsb, st),
+        check(gsx_intersect_tile_fill_packed(C, N, packed ? n_elements : 0u, packed ? camera_ids->data_ptr<int64_t>() : nullptr,
+                                             means2d.data_ptr<float>(), radii.data_ptr<int32_t>(), depths.data_ptr<float>(),
+                                             cum.data_ptr<int64_t>(), tile_size, tile_width, tile_height, sort ? 1 : 0, n_isects,
+                                             isect_ids.data_ptr<int64_t>(), flatten_ids.data_ptr<int32_t>(), ws.data_ptr(), wsb, st),
               "intersect_tile(fill)");
     }
     return std::make_tuple(tiles_per_gauss, isect_ids, flatten_ids);

@@ -28,7 +28,7 @@ extern "C" {
  *   2  gsx_intersect_bin_fill gained the positional `max_segment` argument; the pinned host word written by gsx_intersect_bin_count holds
  *      n_isects in its low 32 bits (0xFFFFFFFF on overflow) and the largest tile segment in its high 32 bits; gsx_sh_colors_bwd accepts
  *      NULL radii / colors; ranked fill entry points added.
- *   3  additions only: gsx_frontend_fused(_supported), gsx_rasterize_to_pixels_from_world_3dgs_fwd_packed. */
+ *   3  additions only: gsx_frontend_fused(_supported), gsx_rasterize_to_pixels_from_world_3dgs_fwd_packed, gsx_intersect_tile_fill_packed. */
 #define GSX_ABI_VERSION 3
 
 typedef enum gsx_status {
@@ -115,6 +115,13 @@ int gsx_intersect_tile_fill(uint32_t C, uint32_t N, const float* means2d, const 
                             const int64_t* cum_tiles_per_gauss, uint32_t tile_size, uint32_t tile_width,
                             uint32_t tile_height, int sort, int64_t n_isects, int64_t* isect_ids,
                             int32_t* flatten_ids, void* workspace, size_t workspace_bytes, void* stream);
+/* The packed layout of the reference (Intersect.cpp:31-38; IntersectTile.cu:85-88): means2d [nnz,2], radii [nnz,2], depths [nnz] hold nnz
+ * (camera, Gaussian) pairs, camera_ids int64 [nnz] names each pair's camera, the emitted flatten_ids index the nnz pairs.  Phase 1 is
+ * gsx_intersect_tile_count(1, nnz, ...) (the count does not look at the camera); `N` is ignored. */
+int gsx_intersect_tile_fill_packed(uint32_t C, uint32_t N, uint32_t nnz, const int64_t* camera_ids, const float* means2d,
+                                   const int32_t* radii, const float* depths, const int64_t* cum_tiles_per_gauss,
+                                   uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, int sort, int64_t n_isects,
+                                   int64_t* isect_ids, int32_t* flatten_ids, void* workspace, size_t workspace_bytes, void* stream);
 /* Intersect.cpp:124-137: offsets int32 [C,tile_height,tile_width]. */
 int gsx_intersect_offset(int64_t n_isects, const int64_t* isect_ids, uint32_t C, uint32_t tile_width,
                          uint32_t tile_height, int32_t* offsets, void* stream);

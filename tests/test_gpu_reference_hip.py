@@ -308,3 +308,41 @@ def test_blend_on_lists_with_gaussians_behind_and_beside_the_camera(ref, mods, p
     errs = {n: rel_l2(np32(a), np32(b)) for n, a, b in zip(GRADS, hb, rb)}
     parity_record("lists with Gaussians behind the camera (%s kernels) blend backward: HIP vs reference kernel (rel-L2)" % path, **errs)
     assert all(e < 1e-3 for e in errs.values()), errs
+
+
+def test_intersect_tile_packed_layout(ref, mods):
+    """The packed [nnz] layout of intersect_tile (Intersect.cpp:31-38, IntersectTile.cu:85-88; no reference call site uses it, the operator has it):
+    HIP vs the reference kernel bit for bit, and both against the oracle's non-packed result mapped through the (camera, Gaussian) -> nnz index."""
+    ops, scenes = mods
+    sc = ref_hip_cases.small_scene(scenes, N=3000, size=96, seed=31, f=70.0)
+    vm2 = torch.stack([sc["viewmat"], scenes.look_at_viewmat((0.4, 0.1, -0.3), (0.0, 0.0, 2.5))])
+    K2 = torch.stack([sc["K"], sc["K"]])
+    a = dict(means=dev(sc["means"]), quats=dev(sc["quats"]), scales=dev(sc["scales"]), opacities=dev(sc["opacities"]))
+    W, H, tw, th = 64, 48, 4, 3      # a crop of the cameras' images: part of the scene is culled, the nnz list is a strict subset
+    radii, means2d, depths, _, _ = ref.projection_ut_3dgs_fused(a["means"], a["quats"], a["scales"], a["opacities"], dev(vm2), None, dev(K2), W, H, 0.3, 0.01, 1e4,
+                                                                0.0, False, 0, None, 4, None, None, None)
+    C, N = 2, 3000
+    vis = (radii > 0).all(-1)                                   # [C, N]
+    cam_ids, gauss_ids = vis.nonzero(as_tuple=True)             # nnz pairs in (camera, Gaussian) order
+    nnz = int(cam_ids.numel())
+    assert 100 < nnz < C * N
+    p_m2d, p_rad, p_dep = means2d[vis].contiguous(), radii[vis].contiguous(), depths[vis].contiguous()
+    assert p_m2d.shape == (nnz, 2)
+    r_tpg, r_ids, r_fl = ref.intersect_tile(p_m2d, p_rad, p_dep, cam_ids, gauss_ids, C, 16, tw, th, True)
+    h_tpg, h_ids, h_fl = ops.intersect_tile(p_m2d, p_rad, p_dep, cam_ids, gauss_ids, C, 16, tw, th, True)
+    assert h_tpg.shape == (nnz,) and torch.equal(h_tpg, r_tpg) and torch.equal(h_ids, r_ids) and torch.equal(h_fl, r_fl)
+    u_tpg, u_ids, u_fl = ops.intersect_tile(p_m2d, p_rad, p_dep, cam_ids, gauss_ids, C, 16, tw, th, False)      # unsorted emission order
+    ru = ref.intersect_tile(p_m2d, p_rad, p_dep, cam_ids, gauss_ids, C, 16, tw, th, False)
+    assert torch.equal(u_ids, ru[1]) and torch.equal(u_fl, ru[2])
+    # oracle: the non-packed result of the same projection, flatten ids mapped through (camera, Gaussian) -> position in the nnz list
+    o_tpg, o_ids, o_fl = oracle.intersect_tile(np32(means2d), radii.cpu().numpy(), np32(depths), C, 16, tw, th, True)
+    lut = torch.full((C * N,), -1, dtype=torch.int64)
+    lut[(cam_ids * N + gauss_ids).cpu()] = torch.arange(nnz)
+    assert np.array_equal(o_ids, h_ids.cpu().numpy()) and np.array_equal(lut[torch.from_numpy(o_fl).long()].numpy(), h_fl.cpu().numpy())
+    assert np.array_equal(o_tpg.reshape(-1)[(cam_ids * N + gauss_ids).cpu().numpy()], h_tpg.cpu().numpy())
+    off = ops.intersect_offset(h_ids, C, tw, th)
+    assert torch.equal(off, ref.intersect_offset(r_ids, C, tw, th))
+    # missing id tensors: the reference's message
+    with pytest.raises(RuntimeError, match="camera_ids and gaussian_ids must be provided"):
+        ops.intersect_tile(p_m2d, p_rad, p_dep, None, None, C, 16, tw, th, True)
+    parity_record("intersect_tile packed layout: HIP vs reference kernel vs oracle", nnz=nnz, n_isects=int(h_fl.numel()), exact=1)
