@@ -416,6 +416,18 @@ def main():
             gbs = ab[n] / (ms * 1e-3) / 1e9
             kernels[n] = {"ms": round(ms, 4), "algorithmic_bytes": int(ab[n]), "GBps": round(gbs, 1),
                           "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
+        if "intersect_tile_binned" in kernels:
+            # The row above prices the binned pipeline at the bytes of the two reference ops it replaces (six device-wide radix passes it never
+            # performs): flattering.  What it actually moves: count (means2d + radii in, tiles_per_gauss + per-block histograms out), prefix
+            # (histograms read and rewritten), scatter (means2d + radii + depths in, one 8 B key per intersection out), per-tile sorts (keys in,
+            # flatten_ids out).
+            nb_hist = 256 * tiles * 4
+            moved = N * 16 + N * 4 + nb_hist + 2 * nb_hist + N * 20 + 8 * I + 8 * I + 4 * I
+            row = kernels["intersect_tile_binned"]
+            row["algorithmic_bytes_is"] = "the two reference ops' bytes (60 N C + 164 I + 4 tiles): the pipeline does not perform their radix passes"
+            row["bytes_moved_estimate"] = int(moved)
+            row["GBps_moved"] = round(moved / (row["ms"] * 1e-3) / 1e9, 1)
+            row["frac_hbm_moved"] = round(moved / (row["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         n_adam_steps = max(1, min(args.steps, 8))
         if adam_ms > 0:
             ms = adam_ms / n_adam_steps

@@ -26,6 +26,7 @@ namespace gsx {
 
 void set_error(const char* msg);
 int check_launch(const char* what);
+const char* test_switch(const char* name);
 
 constexpr int ISECT_BLOCK = 256;
 
@@ -899,7 +900,7 @@ extern "C" int gsx_intersect_offset(int64_t n_isects, const int64_t* isect_ids, 
 // Slices per camera: 256 (one 1024-thread block per CU); GSX_BIN_NB overrides it for experiments (a multiple of 32 up to 1024; read once).
 static uint32_t bin_nb() {
     static const uint32_t nb = [] {
-        const char* e = getenv("GSX_BIN_NB");
+        const char* e = test_switch("GSX_BIN_NB");
         const long v = e ? atol(e) : 256;
         return (v >= 32 && v <= (long)BIN_NB_MAX && v % 32 == 0) ? (uint32_t)v : 256u;
     }();

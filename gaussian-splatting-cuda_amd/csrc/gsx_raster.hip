@@ -524,7 +524,7 @@ static int fill_args(RasterArgs& a, uint32_t N, int64_t n_isects, const float* m
 
 // GSX_RASTER_PATH=generic forces the reference-order kernels (used by the tests to cover both paths)
 static bool force_generic() {
-    const char* e = getenv("GSX_RASTER_PATH");
+    const char* e = test_switch("GSX_RASTER_PATH");
     return e != nullptr && strcmp(e, "generic") == 0;
 }
 

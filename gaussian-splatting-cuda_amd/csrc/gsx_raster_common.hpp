@@ -7,6 +7,7 @@ namespace gsx {
 
 void set_error(const char* msg);
 int check_launch(const char* what);
+const char* test_switch(const char* name);   // gsx_capi.hip: getenv gated by GSX_TEST_SWITCHES=1
 
 constexpr int TILE = 16;
 constexpr int RB = 256;  // threads per workgroup == Gaussians per chunk

@@ -1131,7 +1131,7 @@ bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, 
     const dim3 ggrid((a.N + 255u) / 256u), gblock(256);
     // Two backward kernels, same records and gather: Gaussian-major (the default; S-1M 0.49 vs 0.86 ms, S-5M @4K 1.9 vs 2.5 ms, garden
     // stand-in 248 vs 226 it/s) and pixel-major (GSX_BWD=pm forces it: tests, tools).
-    const bool force_pm = [] { const char* e = getenv("GSX_BWD"); return e && std::string(e) == "pm"; }();   // read per launch: the tests switch it
+    const bool force_pm = [] { const char* e = test_switch("GSX_BWD"); return e && std::string(e) == "pm"; }();   // read per launch: the tests switch it
     const bool gaussian_major = !force_pm;
 #define GSX_BLEND_BWD(KERNEL, KIND)                                                                                                        \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<KIND>), grid, block, 0, st, a, render_alphas, last_ids, v_render_colors, v_render_alphas, ws_rec, ws_head)

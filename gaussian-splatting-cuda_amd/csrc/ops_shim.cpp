@@ -182,7 +182,7 @@ static std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile_impl(const 
     const uint32_t n_elements = means2d.numel() / 2;
     const uint32_t N = packed ? n_elements : (C ? n_elements / C : 0);
     const uint32_t C_count = packed ? 1u : C;   // the count pass does not look at the camera: nnz pairs are counted as one camera's
-    static const bool force_device_sort = [] { const char* e = getenv("GSX_INTERSECT"); return e && std::string(e) == "sort"; }();
+    static const bool force_device_sort = [] { const char* e = gsx_test_switch("GSX_INTERSECT"); return e && std::string(e) == "sort"; }();
     if (!packed && allow_binned && sort && !force_device_sort && n_elements && gsx_intersect_bin_supported(tile_width, tile_height)) {
         // same three outputs through the binned pipeline (LDS histograms + per-tile LDS sort), ~2x faster than the device-wide sort
         auto r = gsx_ext::intersect_tile_binned(means2d, radii, depths, C, tile_size, tile_width, tile_height, true);
@@ -652,7 +652,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
     constexpr int64_t kRankedMeanKeys = 2500;
     const int64_t nseg_all = (int64_t)C * tile_width * tile_height;
     bool ranked = hint_seg > 4096 && hint >= kRankedMeanKeys * nseg_all;
-    if (const char* e = std::getenv("GSX_INTERSECT_FILL")) ranked = std::strcmp(e, "ranked") == 0 ? true : (std::strcmp(e, "keys") == 0 ? false : ranked);
+    if (const char* e = gsx_test_switch("GSX_INTERSECT_FILL")) ranked = std::strcmp(e, "ranked") == 0 ? true : (std::strcmp(e, "keys") == 0 ? false : ranked);
     ranked = ranked && n_elements && gsx_intersect_ranked_supported(C, N);
     at::Tensor ranks, order;
     if (ranked) {

@@ -76,6 +76,10 @@ typedef struct gsx_cameras {
 
 const char* gsx_last_error(void);
 int gsx_abi_version(void);
+/* Test / A-B switches (environment variables GSX_RASTER_PATH, GSX_BWD, GSX_INTERSECT, GSX_INTERSECT_FILL, GSX_BIN_NB) are honoured only when
+ * GSX_TEST_SWITCHES=1 is set in the environment (read once per process): an embedding host inherits no hidden switch.  Returns the value
+ * of `name` under that gate, else NULL. */
+const char* gsx_test_switch(const char* name);
 
 /* ---- spherical harmonics: gsplat/Ops.h:12-25, SphericalHarmonics.cpp:15-75 ------------------ */
 /* dirs [n,3], coeffs [n,K,3], masks [n] bool(uint8) or NULL -> colors [n,3].

@@ -4,6 +4,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("GSX_TEST_SWITCHES", "1")   # the tests flip libgsx's A/B switches (GSX_RASTER_PATH, GSX_BWD, ...): include/gsx.h gsx_test_switch
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -113,3 +113,18 @@ def test_shim_exports_the_reference_operator_symbols():
                    "_ZN7fast_gs9optimizer9adam_stepEPfS1_S1_PKfiffffff", "_Z9fusedssimffRN2at6TensorES1_b",
                    "_Z18fusedssim_backwardffRN2at6TensorES1_S1_S1_S1_S1_"]:
         assert needle in syms, needle
+
+
+def test_ab_switches_are_gated():
+    """libgsx.so looks at its A/B environment switches only when GSX_TEST_SWITCHES=1 (an embedding host inherits none of them):
+    include/gsx.h gsx_test_switch.  The gate is read once per process, hence the subprocesses."""
+    import subprocess
+    import sys
+    code = ("import ctypes,sys; lib=ctypes.CDLL(sys.argv[1]); lib.gsx_test_switch.restype=ctypes.c_char_p; "
+            "print(lib.gsx_test_switch(b'GSX_BWD'))")
+    lib_path = os.path.join(ROOT, "gaussian-splatting-cuda_amd", "libgsx.so")
+    env = {k: v for k, v in os.environ.items() if k != "GSX_TEST_SWITCHES"}
+    env["GSX_BWD"] = "pm"
+    off = subprocess.run([sys.executable, "-c", code, lib_path], env=env, stdout=subprocess.PIPE, text=True, check=True).stdout.strip()
+    on = subprocess.run([sys.executable, "-c", code, lib_path], env=dict(env, GSX_TEST_SWITCHES="1"), stdout=subprocess.PIPE, text=True, check=True).stdout.strip()
+    assert off == "None" and on == "b'pm'"

@@ -2,6 +2,7 @@
 selected by environment switches (GSX_BWD=pm = pixel-major backward, GSX_RASTER_PATH=generic, GSX_AB_CAMERA=fisheye|rolling), one process per variant;
 GSX_AB_SAVE=path keeps the gradients for tools/blend_ab_compare.py.   python tools/blend_ab.py [1m|5m|dense] [n]"""
 import os
+os.environ.setdefault("GSX_TEST_SWITCHES", "1")   # this tool flips libgsx's A/B switches (include/gsx.h: gsx_test_switch)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

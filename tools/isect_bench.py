@@ -4,6 +4,7 @@ With train=K the model is the stand-in's trainee after K training iterations ins
 Run on the GPU box:  python tools/isect_bench.py [N=1000000] [scale_mul=1.0] [reps=30] [train=0]"""
 import importlib.util
 import os
+os.environ.setdefault("GSX_TEST_SWITCHES", "1")   # this tool flips libgsx's A/B switches (include/gsx.h: gsx_test_switch)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,4 +1,5 @@
 #!/usr/bin/env bash
+export GSX_TEST_SWITCHES=1   # the A/B switches below are honoured only under this gate (include/gsx.h: gsx_test_switch)
 # kernel-trace stats of the blend ops in isolation: bash tools/ktrace_blend.sh <outdir> <1m|5m>   (GSX_BWD selects the backward variant)
 out=${1:-gpurun_out/kt}; scene=${2:-1m}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

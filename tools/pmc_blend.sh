@@ -1,4 +1,5 @@
 #!/usr/bin/env bash
+export GSX_TEST_SWITCHES=1   # the A/B switches below are honoured only under this gate (include/gsx.h: gsx_test_switch)
 # PMC counters of the two blend ops in isolation (tools/blend_ab.py), one small counter group per rocprofv3 pass, each under `timeout`.
 # Usage (GPU box): [GSX_BWD=pm] bash tools/pmc_blend.sh gpurun_out/pmc_blend [1m|5m]
 out=${1:-gpurun_out/pmc_blend}
