@@ -168,6 +168,36 @@ GSX_DEV bool footprint_hits(float4 c, float l00, float l01, float l11, float b0,
     return !(fminf(n1, n2) > c.z);
 }
 
+// The same test for the four blocks of a 2 x 2 arrangement whose rectangles are products of two u-ranges (xr[0], xr[1]) and two v-ranges
+// (yr[0], yr[1]) — the four 4x4 blocks of a wave's quadrant under a perfect pinhole (block sb = 2 sy + sx).  The 1-D pieces (clamped
+// offsets, their products with the factor) are formed once per range: ~60 instead of 4 x 23 VALU.  Bit sb of the result = block sb is reached.
+GSX_DEV uint32_t footprint_hits_2x2(float4 c, float l00, float l01, float l11, const float (&xr)[2][2], const float (&yr)[2][2]) {
+    float xa[2], xb[2], xc[2], lxa[2], lxb[2], lxc[2], kxc[2], ya[2], yb[2], m[2], e1s[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        xa[k] = xr[k][0] - c.x; xb[k] = xr[k][1] - c.x;
+        xc[k] = __builtin_amdgcn_fmed3f(0.f, xa[k], xb[k]);
+        lxa[k] = l00 * xa[k]; lxb[k] = l00 * xb[k]; lxc[k] = l00 * xc[k]; kxc[k] = c.w * xc[k];
+        ya[k] = yr[k][0] - c.y; yb[k] = yr[k][1] - c.y;
+        const float yc = __builtin_amdgcn_fmed3f(0.f, ya[k], yb[k]);
+        m[k] = l01 * yc;
+        const float e1 = l11 * yc;
+        e1s[k] = e1 * e1;
+    }
+    uint32_t hits = 0u;
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb) {
+        const int sx = sb & 1, sy = sb >> 1;
+        const float t = __builtin_amdgcn_fmed3f(-m[sy], lxa[sx], lxb[sx]) + m[sy];
+        const float n1 = fmaf(t, t, e1s[sy]);
+        const float ys = __builtin_amdgcn_fmed3f(kxc[sx], ya[sy], yb[sy]);
+        const float t2 = fmaf(l01, ys, lxc[sx]), e2 = l11 * ys;
+        const float n2 = fmaf(t2, t2, e2 * e2);
+        hits |= (!(fminf(n1, n2) > c.z)) ? (1u << sb) : 0u;
+    }
+    return hits;
+}
+
 // one staged Gaussian: the 64 B record (AoS, read at a wave-uniform index with one base address) + the cull plane entry
 struct StagedRec { float4 r0, r1, r2, r3, cull; };   // cull = (u0, v0, rad2, k2): footprint()
 
@@ -854,9 +884,16 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
             const float4 cc = make_float4(s_rec[0][c & (GS - 1)], s_rec[1][c & (GS - 1)], s_rec[14][c & (GS - 1)], s_rec[15][c & (GS - 1)]);
             const float c00 = s_rec[2][c & (GS - 1)], c01 = s_rec[3][c & (GS - 1)], c11 = s_rec[4][c & (GS - 1)];
             const int32_t idx = chunk_end - c;
+            uint32_t hits4 = 0u;
+            if (KIND == CAM_PERFECT_PINHOLE) {   // the blocks' (u, v) rectangles are products of two u-ranges and two v-ranges: shared 1-D pieces
+                const float xr[2][2] = {{sbb[0][0], sbb[0][1]}, {sbb[1][0], sbb[1][1]}}, yr[2][2] = {{sbb[0][2], sbb[0][3]}, {sbb[2][2], sbb[2][3]}};
+                hits4 = footprint_hits_2x2(cc, c00, c01, c11, xr, yr);
+            }
 #pragma unroll
             for (int sb = 0; sb < 4; ++sb) {
-                const bool hit = in && idx <= sb_last[sb] && footprint_hits(cc, c00, c01, c11, sbb[sb][0], sbb[sb][1], sbb[sb][2], sbb[sb][3]);
+                const bool fp = KIND == CAM_PERFECT_PINHOLE ? ((hits4 >> sb) & 1u) != 0u
+                                                             : footprint_hits(cc, c00, c01, c11, sbb[sb][0], sbb[sb][1], sbb[sb][2], sbb[sb][3]);
+                const bool hit = in && idx <= sb_last[sb] && fp;
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
                 if (hit) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
