@@ -500,7 +500,8 @@ static int fill_args(RasterArgs& a, uint32_t N, int64_t n_isects, const float* m
         set_error("rasterize_to_pixels_from_world_3dgs: Unsupported number of channels (only 3)");
         return GSX_ERR_INVALID_ARGUMENT;
     }
-    if (tile_size != TILE) { set_error("rasterize_to_pixels_from_world_3dgs: tile_size must be 16"); return GSX_ERR_UNSUPPORTED; }
+    // tile_size = the tile size the LISTS were built for: 16 (the reference's) or 32 (extension: one list per 2 x 2 pixel tiles, fast path only)
+    if (tile_size != TILE && tile_size != 2 * TILE) { set_error("rasterize_to_pixels_from_world_3dgs: tile_size must be 16 (or 32: coarse lists, fast path)"); return GSX_ERR_UNSUPPORTED; }
     if (!means || !quats || !scales || !colors || !opacities || !tile_offsets || !cams->viewmats0 || !cams->Ks ||
         (n_isects > 0 && !flatten_ids)) {
         set_error("rasterize_to_pixels_from_world_3dgs: null pointer");
@@ -515,6 +516,8 @@ static int fill_args(RasterArgs& a, uint32_t N, int64_t n_isects, const float* m
     a.means = means; a.quats = quats; a.scales = scales; a.colors = colors; a.opacities = opacities;
     a.backgrounds = backgrounds; a.masks = masks;
     a.W = W; a.H = H; a.tw = (W + TILE - 1) / TILE; a.th = (H + TILE - 1) / TILE;
+    a.lshift = tile_size == TILE ? 0u : 1u;
+    a.ltw = (W + tile_size - 1) / tile_size; a.lth = (H + tile_size - 1) / tile_size;
     a.cams = *cams;
     a.tile_offsets = tile_offsets; a.flatten_ids = flatten_ids;
     a.packed = nullptr;
@@ -568,13 +571,14 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_fwd_packed(
     const uint8_t* only_tiles = nullptr;
     // fast path: global shutter; a fisheye additionally needs its (camera, tile) flag plane to fit
     if (hoist && !force_generic() && workspace != nullptr && workspace_bytes >= raster_fwd_fast_workspace_bytes(a.C, a.N) &&
-        (kind != CAM_OPENCV_FISHEYE || (size_t)a.C * a.tw * a.th <= FAST_FLAG_BYTES)) {
+        (kind != CAM_OPENCV_FISHEYE || ((size_t)a.C * a.tw * a.th <= FAST_FLAG_BYTES && a.lshift == 0))) {
         // records_ready: gsx_frontend_fused already wrote the packed records of exactly these inputs into this workspace (pinholes only)
         only_tiles = launch_raster_fwd_fast(kind, a, renders, alphas, last_ids, workspace, workspace_bytes, st,
                                             records_ready != 0 && kind != CAM_OPENCV_FISHEYE);
         if (only_tiles == nullptr) return check_launch("rasterize_to_pixels_from_world_3dgs_fwd(fast)");
         // fisheye: tiles whose list holds a Gaussian without a usable chart were left to the reference-order kernel below
     }
+    if (a.lshift) { set_error("rasterize fwd: lists per 32 x 32 pixels need the fast path (global-shutter pinhole, workspace, no GSX_RASTER_PATH=generic)"); return GSX_ERR_UNSUPPORTED; }
 #define GSX_FWD(KIND)                                                                                                  \
     do {                                                                                                               \
         if (hoist) hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_fwd_kernel<KIND, true>), grid, block, 0, st, a, renders, alphas, last_ids, only_tiles); \
@@ -642,12 +646,13 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd_packed(
     const int kind = cam_kind(*cams);
     const uint8_t* only_tiles = nullptr;
     bool fast_done = false;
-    if (hoist && !force_generic() && (kind != CAM_OPENCV_FISHEYE || (size_t)a.C * a.tw * a.th <= FAST_FLAG_BYTES)) {
+    if (hoist && !force_generic() && (kind != CAM_OPENCV_FISHEYE || ((size_t)a.C * a.tw * a.th <= FAST_FLAG_BYTES && a.lshift == 0))) {
         fast_done = launch_raster_bwd_fast(kind, a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors,
                                            v_opacities, workspace, workspace_bytes, (const float4*)packed_records, st, &only_tiles);
         if (fast_done && only_tiles == nullptr) return check_launch("rasterize_to_pixels_from_world_3dgs_bwd(fast)");
         // fisheye: the gather kernel has written every output element; the reference-order kernel adds the flagged tiles on top
     }
+    if (a.lshift) { set_error("rasterize bwd: lists per 32 x 32 pixels need the fast path (global-shutter pinhole, a workspace of gsx_rasterize_bwd_workspace_bytes(C, N, 4 * n_isects))"); return GSX_ERR_UNSUPPORTED; }
     // Reference-order kernels.  With a workspace and no fast-path results to add to, the per-(tile, Gaussian) gradients travel as
     // chained 64 B records + one gather pass instead of 14 device-scope float atomics each (rolling shutter, forced generic path).
     float4* grad_rec = nullptr;

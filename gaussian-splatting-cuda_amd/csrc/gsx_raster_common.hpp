@@ -19,6 +19,10 @@ struct RasterArgs {
     const float* means; const float* quats; const float* scales; const float* colors; const float* opacities;
     const float* backgrounds; const uint8_t* masks;
     uint32_t W, H, tw, th;
+    // The lists (tile_offsets / flatten_ids) may have been built for tiles of 16 << lshift pixels (lshift = 1: one list per 2 x 2 pixel
+    // tiles, an extension of the fused path for frames whose Gaussians cover many tiles — the pixel tiles of the kernels stay 16 x 16, a
+    // tile walks the list of its 32 x 32 parent and the footprint tests drop what does not reach it).  ltw x lth = the list grid.
+    uint32_t lshift, ltw, lth;
     gsx_cameras cams;
     const int32_t* tile_offsets; const int32_t* flatten_ids;
     const float4* packed;  // optional [C*N] x 64 B camera-space records (gsx_raster_fast.hip: pack_records_kernel), else nullptr
@@ -29,6 +33,18 @@ struct RasterArgs {
 
 constexpr size_t FAST_FLAG_BYTES = 262144;  // capacity of the tile-flag plane (C * tiles); larger grids take the generic kernels
 
+
+// range [start, end) of pixel tile (tile_x, tile_y) of camera cid in the sorted intersection list, and the slot of that tile's per-list-entry
+// records (the backward's moment records): with lists per 32 x 32 pixels the four pixel tiles that share a list entry get four slots
+GSX_DEV void tile_list_range(const RasterArgs& a, uint32_t cid, uint32_t tile_x, uint32_t tile_y, int32_t& start, int32_t& end) {
+    const uint32_t lt = (tile_y >> a.lshift) * a.ltw + (tile_x >> a.lshift), n_lt = a.ltw * a.lth;
+    const int32_t* toff = a.tile_offsets + (size_t)cid * n_lt;
+    start = toff[lt];
+    end = (cid == a.C - 1 && lt == n_lt - 1) ? (int32_t)a.n_isects : toff[lt + 1];
+}
+GSX_DEV int32_t tile_record_slot(const RasterArgs& a, int32_t isect, uint32_t tile_x, uint32_t tile_y) {
+    return a.lshift ? (isect << 2) | (int32_t)(((tile_y & 1u) << 1) | (tile_x & 1u)) : isect;
+}
 
 // pixel owned by this thread: wave w owns the 8x8 quadrant (w&1, w>>1) of the tile, lane l the pixel (l&7, l>>3)
 GSX_DEV void thread_pixel(uint32_t tid, uint32_t tile_x, uint32_t tile_y, uint32_t& i, uint32_t& j) {

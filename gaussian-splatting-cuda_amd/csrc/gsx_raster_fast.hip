@@ -304,9 +304,8 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
     const float ww = w * w;
     const bool no_cull = KIND == CAM_OPENCV_FISHEYE && !(tb[0] > -INFINITY);
 
-    const int32_t* toff = a.tile_offsets + (size_t)cid * a.th * a.tw;
-    const int32_t range_start = toff[tile_id];
-    const int32_t range_end = (cid == a.C - 1 && tile_id == a.tw * a.th - 1) ? (int32_t)a.n_isects : toff[tile_id + 1];
+    int32_t range_start, range_end;
+    tile_list_range(a, cid, tile_x, tile_y, range_start, range_end);
     const int32_t n_chunks = (range_end - range_start + FCH - 1) / FCH;
 
     // Compositing state.  The alpha clamp min(0.999, .) is folded into the exponential: the loop works with alpha' = alpha / 0.999
@@ -503,9 +502,8 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
     const float ww = w * w;
     const bool no_cull = KIND == CAM_OPENCV_FISHEYE && !(tb[0] > -INFINITY);
 
-    const int32_t* toff = a.tile_offsets + (size_t)cid * a.th * a.tw;
-    const int32_t range_start = toff[tile_id];
-    const int32_t range_end = (cid == a.C - 1 && tile_id == a.tw * a.th - 1) ? (int32_t)a.n_isects : toff[tile_id + 1];
+    int32_t range_start, range_end;
+    tile_list_range(a, cid, tile_x, tile_y, range_start, range_end);
 
     const float T_final = 1.f - render_alphas[pix];
     float T = T_final;
@@ -609,7 +607,7 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
 
         // one thread per touched Gaussian of the chunk: 64 B moment record at its sorted index, chained per Gaussian
         if ((int32_t)tid < chunk_size && ((s_touched[tid >> 6] >> (tid & 63u)) & 1ull)) {
-            const int32_t isect = chunk_end - (int32_t)tid;
+            const int32_t isect = tile_record_slot(a, chunk_end - (int32_t)tid, tile_x, tile_y);
             const int32_t prev = atomicExch(&ws_head[s_gid[tid]], isect);
             float4* rec = ws_rec + (size_t)isect * 4;
             rec[0] = make_float4(s_acc[0][tid], s_acc[1][tid], s_acc[2][tid], s_acc[3][tid]);
@@ -811,9 +809,8 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
     uv_bounds(active, uc, vc, wave, lane, s_bounds, wb, tb, wide);   // contains a barrier
     const bool no_cull = KIND == CAM_OPENCV_FISHEYE && !(tb[0] > -INFINITY);
 
-    const int32_t* toff = a.tile_offsets + (size_t)cid * a.th * a.tw;
-    const int32_t range_start = toff[tile_id];
-    const int32_t range_end = (cid == a.C - 1 && tile_id == a.tw * a.th - 1) ? (int32_t)a.n_isects : toff[tile_id + 1];
+    int32_t range_start, range_end;
+    tile_list_range(a, cid, tile_x, tile_y, range_start, range_end);
 
     {   // per-pixel carries -> LDS
         const float T_final = 1.f - render_alphas[pix];
@@ -1014,7 +1011,7 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
 
         // one thread per touched Gaussian of the super-chunk: 64 B moment record at its sorted index, chained per Gaussian
         if ((int32_t)tid < chunk_size && s_acc[15][tid] > 0.f) {
-            const int32_t isect = chunk_end - (int32_t)tid;
+            const int32_t isect = tile_record_slot(a, chunk_end - (int32_t)tid, tile_x, tile_y);
             const int32_t prev = atomicExch(&ws_head[s_gid[tid]], isect);
             float4* rec = ws_rec + (size_t)isect * 4;
             rec[0] = make_float4(s_acc[0][tid], s_acc[1][tid], s_acc[2][tid], s_acc[3][tid]);
@@ -1152,11 +1149,11 @@ bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, 
                             float* v_scales, float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes,
                             const float4* packed_from_fwd, hipStream_t st, const uint8_t** tile_flags_out) {
     *tile_flags_out = nullptr;
-    if (workspace == nullptr || workspace_bytes < raster_bwd_fast_workspace_bytes(a.C, a.N, a.n_isects)) return false;
+    if (workspace == nullptr || workspace_bytes < raster_bwd_fast_workspace_bytes(a.C, a.N, a.n_isects << (2 * a.lshift))) return false;
     const uint32_t n_tiles = a.tw * a.th;
     const dim3 grid(((n_tiles + 7u) / 8u) * 8u, a.C), block(RB);
     float4* ws_rec = (float4*)workspace;
-    int32_t* ws_head = (int32_t*)((char*)workspace + align256((size_t)a.n_isects * 64));
+    int32_t* ws_head = (int32_t*)((char*)workspace + align256(((size_t)a.n_isects << (2 * a.lshift)) * 64));   // lists per 32 x 32 pixels: four record slots per entry
     if (packed_from_fwd) {  // the forward of the same inputs left its packed records (and tile flags) with the caller: only the list heads are reset
         a.packed = packed_from_fwd;
         if (kind == CAM_OPENCV_FISHEYE) a.tile_flags = ws_flags(packed_from_fwd, a.C, a.N);

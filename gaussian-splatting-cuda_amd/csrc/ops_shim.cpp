@@ -357,7 +357,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
         if (isects_cap > cap || isects_cap < cap / 4) cap = isects_cap + isects_cap / 8;   // grows with 12 % head room; a much lighter scene starts over
         isects_cap = cap;
     }
-    const size_t wsb = gsx_rasterize_bwd_workspace_bytes(C, N, isects_cap);
+    const size_t wsb = gsx_rasterize_bwd_workspace_bytes(C, N, tile_size == 32 ? 4 * isects_cap : isects_cap);   // lists per 32 x 32 pixels: four record slots per entry
     at::Tensor ws = at::empty({(int64_t)wsb}, means.options().dtype(at::kByte));  // caching allocator, like CUB temp storage upstream
     const void* packed = (g_fwd_ws_in && g_fwd_ws_in->defined())
                              ? gsx_rasterize_fwd_packed_records(g_fwd_ws_in->data_ptr(), (size_t)g_fwd_ws_in->numel(), C, N) : nullptr;

@@ -24,6 +24,28 @@ EPS2D, NEAR_PLANE, FAR_PLANE, RADIUS_CLIP = 0.3, 0.01, 10000.0, 0.0
 # separate launches (A/B tools, tests)
 FUSED_FRONTEND = os.environ.get("GSX_FUSED_FRONTEND", "1") != "0"
 
+# rasterize_fused: size of the tiles the intersection LISTS are built for.  16 = the reference's; 32 = one list per 2 x 2 pixel tiles
+# (include/gsx.h, the blend entry points' `tile_size`): same image, the intersection handles ~3x fewer keys when the Gaussians cover
+# many tiles (trained dense scenes), at the price of longer candidate lists per pixel tile when they are small (S-1M).  Chosen per
+# problem shape from the previous frame's list density, with hysteresis; GSX_LIST_TILE=16|32 forces one (tests, A/B tools).
+_LIST_TILE_STATE = {}
+LIST_TILE_UP, LIST_TILE_DOWN = 3000.0, 5000.0   # keys per 16-px tile above which 32-px lists pay / keys per 32-px tile below which they stop paying
+
+
+def _list_tile_for(key):
+    forced = os.environ.get("GSX_LIST_TILE")
+    if forced in ("16", "32"):
+        return int(forced)
+    return _LIST_TILE_STATE.get(key, 16)
+
+
+def _list_tile_update(key, list_tile, n_isects, n_list_tiles):
+    density = n_isects / max(1, n_list_tiles)
+    if list_tile == 16 and density >= LIST_TILE_UP:
+        _LIST_TILE_STATE[key] = 32
+    elif list_tile == 32 and density < LIST_TILE_DOWN:
+        _LIST_TILE_STATE[key] = 16
+
 
 @dataclass
 class Camera:
@@ -293,23 +315,28 @@ class GutRenderFunction(torch.autograd.Function):
                 camera_model, ut, ops.ShutterType.GLOBAL, radial, tangential, None)
         if fe is None:
             colors = ops.sh_colors_fwd(sh_degree, means_c, viewmat, sh_c, radii)
-        tw, th = (width + TILE_SIZE - 1) // TILE_SIZE, (height + TILE_SIZE - 1) // TILE_SIZE
+        # tile size of the intersection lists: 32-px lists only on the fast blend path (global-shutter pinhole) — see _LIST_TILE_STATE
+        lt_key = (means_c.shape[0], width, height, means_c.device.index)
+        list_tile = _list_tile_for(lt_key) if camera_model == ops.CameraModelType.PINHOLE else TILE_SIZE
+        tw, th = (width + list_tile - 1) // list_tile, (height + list_tile - 1) // list_tile
         # binned pipeline: flatten_ids + isect_offsets in one go (bit-identical to intersect_tile + intersect_offset, no isect_ids)
-        _, _, flatten_ids, isect_offsets = ops.intersect_tile_binned(means2d, radii, depths, 1, TILE_SIZE, tw, th, False)
+        _, _, flatten_ids, isect_offsets = ops.intersect_tile_binned(means2d, radii, depths, 1, list_tile, tw, th, False)
+        _list_tile_update(lt_key, list_tile, int(flatten_ids.shape[0]), tw * th)
         opac2 = opac.unsqueeze(0)
         if fe is not None:   # the records of exactly these inputs are already in fe_ws
             renders, alphas, last_ids = ops.rasterize_fwd_packed(
-                means_c, quats, scales, colors, opac2, bg, None, width, height, TILE_SIZE, viewmat, None, K, camera_model, ut,
+                means_c, quats, scales, colors, opac2, bg, None, width, height, list_tile, viewmat, None, K, camera_model, ut,
                 ops.ShutterType.GLOBAL, radial, tangential, None, isect_offsets, flatten_ids, fe_ws)
             fwd_ws = fe_ws
         else:
             renders, alphas, last_ids, fwd_ws = ops.rasterize_to_pixels_from_world_3dgs_fwd(
-                means_c, quats, scales, colors, opac2, bg, None, width, height, TILE_SIZE, viewmat, None, K, camera_model, ut,
+                means_c, quats, scales, colors, opac2, bg, None, width, height, list_tile, viewmat, None, K, camera_model, ut,
                 ops.ShutterType.GLOBAL, radial, tangential, None, isect_offsets, flatten_ids, keep_ws=True)
         ctx.fwd_ws = fwd_ws  # packed per-Gaussian records of exactly these inputs: the backward does not pack again
         ctx.save_for_backward(means_c, sh_c, sr, rr, orw, scales, quats, opac2, colors, radii, viewmat, K, isect_offsets,
                               flatten_ids, alphas, last_ids)
         ctx.extra = (bg, width, height, sh_degree, scaling_modifier, camera_model, radial, tangential, grad_sinks, ut)
+        ctx.list_tile = list_tile
         ctx.mark_non_differentiable(radii, means2d, depths, flatten_ids, isect_offsets)
         ctx.set_materialize_grads(False)  # no zero tensors for the outputs nobody differentiates (six fill launches per step)
         return renders, alphas, radii, means2d, depths, flatten_ids, isect_offsets
@@ -324,7 +351,7 @@ class GutRenderFunction(torch.autograd.Function):
         if v_renders is None:
             v_renders = torch.zeros(alphas.shape[:-1] + (3,), dtype=alphas.dtype, device=alphas.device)
         v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_to_pixels_from_world_3dgs_bwd(
-            means, quats, scales, colors, opac2, bg, None, width, height, TILE_SIZE, viewmat, None, K, camera_model, ut,
+            means, quats, scales, colors, opac2, bg, None, width, height, ctx.list_tile, viewmat, None, K, camera_model, ut,
             ops.ShutterType.GLOBAL, radial, tangential, None, isect_offsets, flatten_ids, alphas, last_ids,
             v_renders.contiguous(), None if v_alphas is None else v_alphas.contiguous(), fwd_ws=ctx.fwd_ws)
         if scaling_modifier != 1.0:

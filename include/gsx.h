@@ -142,6 +142,11 @@ int gsx_rasterize_to_pixels_from_world_3dgs_fwd(uint32_t N, int64_t n_isects, co
                                                 const int32_t* tile_offsets, const int32_t* flatten_ids,
                                                 float* renders, float* alphas, int32_t* last_ids, void* workspace,
                                                 size_t workspace_bytes, void* stream);
+/* Extension: `tile_size` = 32 means the LISTS (tile_offsets [C, ceil(H/32), ceil(W/32)], flatten_ids) were built for 32 x 32 pixel tiles
+ * (intersect_tile / gsx_intersect_bin_* with tile_size 32): the kernels still work on 16 x 16 pixel tiles, each walking the list of its
+ * 32 x 32 parent — the footprint tests drop what does not reach it, the image is the same.  For frames whose Gaussians cover many tiles
+ * (a trained dense scene: 59 tiles per Gaussian) the intersection then handles 3x fewer keys.  Fast path only (global-shutter pinhole,
+ * workspace given); `last_ids` index the coarse list; the backward needs gsx_rasterize_bwd_workspace_bytes(C, N, 4 * n_isects). */
 /* `workspace` (optional; gsx_rasterize_fwd_workspace_bytes): room for one packed 64 B camera-space record per
  * (camera, Gaussian), so that staging a tile gathers ONE cache line per Gaussian instead of five (means, quats,
  * scales, opacities, colours live in five arrays).  NULL / too small = the reference-order (generic) kernels. */

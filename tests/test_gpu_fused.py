@@ -224,3 +224,44 @@ def test_frontend_fused_is_bit_identical_to_the_separate_operators(mods, deg, di
     # a camera the front end does not take: undefined workspace, the caller falls back
     fish = ops.frontend_fused(deg, model.means, model.sh, sr, rr, orw, vm, K, W, H, 0.3, 0.01, 1e4, 0.0, ops.CameraModelType.FISHEYE, ut, None, None, None)
     assert fish[8] is None
+
+
+@pytest.mark.parametrize("size", [(160, 112), (150, 100)])
+def test_lists_per_32px_tiles_give_the_same_render(mods, size, monkeypatch):
+    """rasterize_fused with the intersection lists built per 32 x 32 pixels (one list per 2 x 2 pixel tiles: include/gsx.h, the blend entry
+    points' tile_size = 32) against the reference's 16-pixel lists: the same Gaussians reach every pixel in the same order, so the image is
+    bit-identical; the gradients agree to rounding (the backward's records are summed in another order).  Also an image size that is not a
+    multiple of 32."""
+    distributed, ops, rasterizer, scenes = mods
+    sc, cam = _setup(scenes, rasterizer, 3)
+    W, H = size
+    cam = rasterizer.Camera(viewmat=cam.viewmat, K=cam.K, width=W, height=H)
+    bg = sc["background"].to(DEV) + 0.1
+    w = torch.linspace(0.5, 1.5, W, device=DEV)
+
+    def run(list_tile):
+        monkeypatch.setenv("GSX_LIST_TILE", str(list_tile))
+        model = scenes.to_splat_data(sc, DEV)
+        for p in model.params():
+            p.requires_grad_(True)
+        out = rasterizer.rasterize_fused(cam, model, bg)
+        ((out.image * w).sum() + 0.3 * out.alpha.sum()).backward()
+        return model, out
+
+    m16, o16 = run(16)
+    m32, o32 = run(32)
+    assert o32.n_isects < o16.n_isects                      # fewer keys ...
+    assert torch.equal(o16.image, o32.image) and torch.equal(o16.alpha, o32.alpha)   # ... the same image, bit for bit
+    for a, b, n in zip(m16.params(), m32.params(), ["means", "sh", "scaling_raw", "rotation_raw", "opacity_raw"]):
+        assert rel_l2(b.grad.cpu().numpy(), a.grad.cpu().numpy()) < 2e-6, n
+    # the hysteresis rule: dense lists switch a problem shape to 32-pixel lists, sparse ones back
+    monkeypatch.delenv("GSX_LIST_TILE")
+    key = ("shape",)
+    rasterizer._LIST_TILE_STATE.pop(key, None)
+    assert rasterizer._list_tile_for(key) == 16
+    rasterizer._list_tile_update(key, 16, 4000 * 100, 100)
+    assert rasterizer._list_tile_for(key) == 32
+    rasterizer._list_tile_update(key, 32, 9000 * 25, 25)
+    assert rasterizer._list_tile_for(key) == 32
+    rasterizer._list_tile_update(key, 32, 1000 * 25, 25)
+    assert rasterizer._list_tile_for(key) == 16
