@@ -588,20 +588,6 @@ __global__ __launch_bounds__(1024) void giant_merge_kernel(const int4* __restric
 // writing its ranks into a C*N-bit bitmap in LDS (128 KB at 1 M) and reading the set bits back in order: no comparison, no merge
 // passes, any segment size (tile_sort_bitmap_kernel, ~5 us + 3 ps per key per CU).  Lighter tiles take the merge sorts above with
 // 4-byte keys.  flatten_ids = order[rank]; the result is the same total order, bit for bit.
-__global__ __launch_bounds__(ISECT_BLOCK) void rank_keys_kernel(uint32_t total, const int32_t* __restrict__ radii, const float* __restrict__ depths,
-                                                                uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    const uint32_t i = blockIdx.x * ISECT_BLOCK + threadIdx.x;
-    if (i >= total) return;
-    const int2 r = reinterpret_cast<const int2*>(radii)[i];
-    keys[i] = (r.x > 0 && r.y > 0) ? __float_as_uint(depths[i]) : 0xFFFFFFFFu;   // (culled Gaussians: behind every visible one)
-    vals[i] = i;
-}
-
-__global__ __launch_bounds__(ISECT_BLOCK) void rank_invert_kernel(uint32_t total, const uint32_t* __restrict__ order, uint32_t* __restrict__ ranks) {
-    const uint32_t r = blockIdx.x * ISECT_BLOCK + threadIdx.x;
-    if (r < total) ranks[order[r]] = r;
-}
-
 // inclusive prefix sum over the 64 lanes with DPP row operations (no LDS traffic: six adds)
 GSX_DEV uint32_t wave_incl_scan_u32(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
@@ -612,6 +598,165 @@ GSX_DEV uint32_t wave_incl_scan_u32(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2, 3
     return v;
 }
+
+GSX_DEV uint32_t rank_key_of(const int32_t* __restrict__ radii, const float* __restrict__ depths, uint32_t i) {
+    const int2 r = reinterpret_cast<const int2*>(radii)[i];
+    return (r.x > 0 && r.y > 0) ? __float_as_uint(depths[i]) : 0xFFFFFFFFu;   // (culled Gaussians: behind every visible one)
+}
+
+__global__ __launch_bounds__(ISECT_BLOCK) void rank_keys_kernel(uint32_t total, const int32_t* __restrict__ radii, const float* __restrict__ depths,
+                                                                uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint32_t i = blockIdx.x * ISECT_BLOCK + threadIdx.x;
+    if (i >= total) return;
+    keys[i] = rank_key_of(radii, depths, i);
+    vals[i] = i;
+}
+
+__global__ __launch_bounds__(ISECT_BLOCK) void rank_invert_kernel(uint32_t total, const uint32_t* __restrict__ order, uint32_t* __restrict__ ranks) {
+    const uint32_t r = blockIdx.x * ISECT_BLOCK + threadIdx.x;
+    if (r < total) ranks[order[r]] = r;
+}
+
+// ---- depth ranks without a library sort: a stable LSD radix sort of the C*N (depth bits, flatten index) pairs in four 8-bit digit
+// passes, three launches per pass, sized for the ~1 M pairs of a frame (the whole problem lives in L2 / Infinity Cache: launch count and
+// latency are the cost, not bytes).  A block owns RS_TILE consecutive pairs, a wave 64-pair rounds of them in index order.
+//   rs_hist:    LDS histogram of the block's digits -> hist[digit][block]   (pass 0 builds the keys from radii / depths on the fly)
+//   rs_scan:    one wave per digit: exclusive scan of its row over the blocks (DPP wave scan), row total -> total[digit]
+//   rs_scatter: every block scans total[] itself, ranks its pairs stably inside each wave with ballots ("match any" over the digit's
+//               bits: the lanes below me with my digit), sums the waves' counts, and stores each pair at
+//               digit base + blocks before + waves before + rank in the wave.  The last pass writes order[] and ranks[] directly.
+// Measured at 1 M pairs (tools/rank_sort_bench.py): 100 us (hist 7 + scan 5 + scatter 13 per pass) against 155 us for rocPRIM's pair
+// sort + key / inversion passes; 11-bit digits (three passes): 139 us — 2048 output streams per block cost more than the pass they save;
+// 4096-pair tiles: 109 us; counting the next pass's block histogram with global atomics inside the scatter: 2.2 ms.
+#ifndef GSX_RS_BITS
+#define GSX_RS_BITS 8
+#endif
+#ifndef GSX_RS_ROUNDS
+#define GSX_RS_ROUNDS 8
+#endif
+constexpr uint32_t RS_BLOCK = 256, RS_WAVES = RS_BLOCK / 64, RS_ROUNDS = GSX_RS_ROUNDS, RS_TILE = RS_BLOCK * RS_ROUNDS;
+constexpr uint32_t RS_BITS = GSX_RS_BITS, RS_BINS = 1u << RS_BITS, RS_PASSES = (32u + RS_BITS - 1u) / RS_BITS;
+// a digit's row of the block histogram table: an odd number of 256 B units, so that one block's column (stride = row) spreads over the
+// memory channels instead of camping on a few
+__host__ __device__ inline uint32_t rs_row(uint32_t nblk) { return (((nblk + 63u) / 64u) | 1u) * 64u; }
+
+template <bool FIRST>
+GSX_DEV uint32_t rs_load_key(const uint32_t* __restrict__ keys, const int32_t* __restrict__ radii, const float* __restrict__ depths, uint32_t i) {
+    return FIRST ? rank_key_of(radii, depths, i) : keys[i];
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(uint32_t total, uint32_t nblk, uint32_t shift, const uint32_t* __restrict__ keys,
+                                                           const int32_t* __restrict__ radii, const float* __restrict__ depths,
+                                                           uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_hist[RS_BINS];
+    for (uint32_t d = threadIdx.x; d < RS_BINS; d += RS_BLOCK) s_hist[d] = 0u;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * RS_TILE + threadIdx.x;
+#pragma unroll
+    for (uint32_t r = 0; r < RS_ROUNDS; ++r) {
+        const uint32_t i = base + r * RS_BLOCK;
+        if (i < total) atomicAdd(&s_hist[(rs_load_key<FIRST>(keys, radii, depths, i) >> shift) & (RS_BINS - 1u)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < RS_BINS; d += RS_BLOCK) hist[(size_t)d * rs_row(nblk) + blockIdx.x] = s_hist[d];
+}
+
+// row `digit` of hist (nblk <= 64 * RS_SCAN_PER_LANE entries) -> exclusive prefix in place, row total -> total[digit]
+constexpr uint32_t RS_SCAN_PER_LANE = 8;
+__global__ __launch_bounds__(RS_BLOCK) void rs_scan_kernel(uint32_t nblk, uint32_t* __restrict__ hist, uint32_t* __restrict__ total) {
+    const uint32_t lane = threadIdx.x & 63u, digit = blockIdx.x * RS_WAVES + (threadIdx.x >> 6);
+    uint32_t* row = hist + (size_t)digit * rs_row(nblk);
+    uint32_t v[RS_SCAN_PER_LANE], sum = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < RS_SCAN_PER_LANE; ++k) {
+        const uint32_t b = lane * RS_SCAN_PER_LANE + k;
+        v[k] = b < nblk ? row[b] : 0u;
+        sum += v[k];
+    }
+    const uint32_t incl = wave_incl_scan_u32(sum);
+    uint32_t run = incl - sum;
+#pragma unroll
+    for (uint32_t k = 0; k < RS_SCAN_PER_LANE; ++k) {
+        const uint32_t b = lane * RS_SCAN_PER_LANE + k;
+        if (b < nblk) row[b] = run;
+        run += v[k];
+    }
+    if (lane == 63u) total[digit] = incl;
+}
+
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(uint32_t total, uint32_t nblk, uint32_t shift, const uint32_t* __restrict__ keys_in,
+                                                              const uint32_t* __restrict__ vals_in, const int32_t* __restrict__ radii,
+                                                              const float* __restrict__ depths, const uint32_t* __restrict__ hist,
+                                                              const uint32_t* __restrict__ digit_total, uint32_t* __restrict__ keys_out,
+                                                              uint32_t* __restrict__ vals_out, uint32_t* __restrict__ ranks) {
+    __shared__ uint32_t s_cnt[RS_WAVES][RS_BINS];   // per wave: digit counts, then the counts of the waves before it
+    __shared__ uint32_t s_base[RS_BINS];            // first slot of this block's pairs of a digit
+    __shared__ uint32_t s_wsum[RS_WAVES];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t d = threadIdx.x; d < RS_WAVES * RS_BINS; d += RS_BLOCK) (&s_cnt[0][0])[d] = 0u;
+    // a wave's pairs are consecutive: rounds of 64 in index order (stability = block, wave, round, lane order)
+    const uint32_t first = blockIdx.x * RS_TILE + wave * (64u * RS_ROUNDS) + lane;
+    uint32_t key[RS_ROUNDS], val[RS_ROUNDS], lrank[RS_ROUNDS];
+#pragma unroll
+    for (uint32_t r = 0; r < RS_ROUNDS; ++r) {
+        const uint32_t i = first + r * 64u;
+        key[r] = i < total ? rs_load_key<FIRST>(keys_in, radii, depths, i) : 0u;
+        val[r] = FIRST ? i : (i < total ? vals_in[i] : 0u);
+    }
+    __syncthreads();
+    const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (uint32_t r = 0; r < RS_ROUNDS; ++r) {
+        const bool valid = first + r * 64u < total;
+        const uint32_t d = (key[r] >> shift) & (RS_BINS - 1u);
+        uint64_t peers = __builtin_amdgcn_ballot_w64(valid);   // the valid lanes of the round with my digit
+#pragma unroll
+        for (uint32_t bit = 0; bit < RS_BITS; ++bit) {
+            const bool one = (d >> bit) & 1u;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(one);
+            peers &= one ? m : ~m;
+        }
+        if (valid) {
+            lrank[r] = s_cnt[wave][d] + (uint32_t)__builtin_popcountll(peers & below);
+            if ((peers >> lane) == 1ull) s_cnt[wave][d] += (uint32_t)__builtin_popcountll(peers);   // the highest peer books the round
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the row is private to the wave: LDS operations of a wave stay in order
+    }
+    __syncthreads();
+    {   // thread t: digits 8t .. 8t+7 — digit bases (scan of the digit totals), blocks before, waves before
+        constexpr uint32_t PER = RS_BINS / RS_BLOCK;
+        const uint32_t d0 = threadIdx.x * PER;
+        uint32_t tot[PER], sum = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) { tot[k] = digit_total[d0 + k]; sum += tot[k]; }
+        const uint32_t incl = wave_incl_scan_u32(sum);
+        if (lane == 63u) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (uint32_t w = 0; w < wave; ++w) run += s_wsum[w];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t d = d0 + k;
+            s_base[d] = run + hist[(size_t)d * rs_row(nblk) + blockIdx.x];
+            run += tot[k];
+            uint32_t before = 0u;
+#pragma unroll
+            for (uint32_t w = 0; w < RS_WAVES; ++w) { const uint32_t c = s_cnt[w][d]; s_cnt[w][d] = before; before += c; }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < RS_ROUNDS; ++r) {
+        if (first + r * 64u >= total) continue;
+        const uint32_t d = (key[r] >> shift) & (RS_BINS - 1u);
+        const uint32_t dst = s_base[d] + s_cnt[wave][d] + lrank[r];
+        if (LAST) { vals_out[dst] = val[r]; ranks[val[r]] = dst; }
+        else { keys_out[dst] = key[r]; vals_out[dst] = val[r]; }
+    }
+}
+
 
 // Persistent grid, one 1024-thread block per CU; dynamic LDS: n_words (a multiple of 4096) 32-bit words of bitmap, then 16 staging
 // rows of BITMAP_STAGE ranks (one per wave).  The sorted ranks overwrite the segment's keys in place (every key has been read by
@@ -1051,9 +1196,14 @@ static size_t rank_sort_temp_bytes(uint32_t total) {
     return align_up(bytes, 256);
 }
 
+static uint32_t rs_blocks(uint32_t total) { return (total + RS_TILE - 1u) / RS_TILE; }
+static size_t rs_hist_bytes(uint32_t total) { return align_up((size_t)RS_BINS * rs_row(rs_blocks(total)) * 4, 256); }
+static size_t rs_table_bytes(uint32_t total) { return rs_hist_bytes(total) + align_up((size_t)RS_BINS * 4, 256); }
+
 extern "C" size_t gsx_intersect_depth_ranks_workspace_bytes(uint32_t C, uint32_t N) {
     const uint32_t total = C * N;
-    return 3 * align_up((size_t)total * 4, 256) + rank_sort_temp_bytes(total) + 256;
+    const size_t lib = rank_sort_temp_bytes(total), own = align_up((size_t)total * 4, 256) + rs_table_bytes(total);
+    return 3 * align_up((size_t)total * 4, 256) + (lib > own ? lib : own) + 256;
 }
 
 extern "C" int gsx_intersect_depth_ranks(uint32_t C, uint32_t N, const int32_t* radii, const float* depths, uint32_t* ranks, uint32_t* order,
@@ -1067,20 +1217,50 @@ extern "C" int gsx_intersect_depth_ranks(uint32_t C, uint32_t N, const int32_t* 
     }
     const uint32_t total = C * N;
     const size_t stride = align_up((size_t)total * 4, 256);
-    uint32_t* keys_in = (uint32_t*)workspace;
-    uint32_t* keys_out = (uint32_t*)((char*)workspace + stride);
-    uint32_t* vals_in = (uint32_t*)((char*)workspace + 2 * stride);
-    void* temp = (char*)workspace + 3 * stride;
-    size_t temp_bytes = rank_sort_temp_bytes(total);
-    const uint32_t grid = (total + ISECT_BLOCK - 1) / ISECT_BLOCK;
-    hipLaunchKernelGGL(rank_keys_kernel, dim3(grid), dim3(ISECT_BLOCK), 0, st, total, radii, depths, keys_in, vals_in);
-    // stable LSD radix sort over the 32 depth bits: equal depths keep ascending flatten index, as the 64-bit keys' low bits do
-    if (rocprim::radix_sort_pairs<RankSortConfig>(temp, temp_bytes, (const uint32_t*)keys_in, keys_out, (const uint32_t*)vals_in, order, (size_t)total, 0u, 32u, st,
-                                  false) != hipSuccess) {
-        set_error("intersect_depth_ranks: radix sort failed");
-        return GSX_ERR_LAUNCH_FAILED;
+    uint32_t* keys_a = (uint32_t*)workspace;
+    uint32_t* keys_b = (uint32_t*)((char*)workspace + stride);
+    uint32_t* vals_a = (uint32_t*)((char*)workspace + 2 * stride);
+    void* rest = (char*)workspace + 3 * stride;
+    const char* sw = test_switch("GSX_RANK_SORT");
+    if (sw && !strcmp(sw, "rocprim")) {
+        // second implementation (tests, A/B): the library's stable pair sort + an inversion pass
+        size_t temp_bytes = rank_sort_temp_bytes(total);
+        const uint32_t grid = (total + ISECT_BLOCK - 1) / ISECT_BLOCK;
+        hipLaunchKernelGGL(rank_keys_kernel, dim3(grid), dim3(ISECT_BLOCK), 0, st, total, radii, depths, keys_a, vals_a);
+        if (rocprim::radix_sort_pairs<RankSortConfig>(rest, temp_bytes, (const uint32_t*)keys_a, keys_b, (const uint32_t*)vals_a, order, (size_t)total, 0u, 32u,
+                                                      st, false) != hipSuccess) {
+            set_error("intersect_depth_ranks: radix sort failed");
+            return GSX_ERR_LAUNCH_FAILED;
+        }
+        hipLaunchKernelGGL(rank_invert_kernel, dim3(grid), dim3(ISECT_BLOCK), 0, st, total, (const uint32_t*)order, ranks);
+        return check_launch("intersect_depth_ranks");
     }
-    hipLaunchKernelGGL(rank_invert_kernel, dim3(grid), dim3(ISECT_BLOCK), 0, st, total, (const uint32_t*)order, ranks);
+    // stable LSD radix sort over the 32 depth bits: equal depths keep ascending flatten index, as the 64-bit keys' low bits do
+    uint32_t* vals_b = (uint32_t*)rest;
+    uint32_t* hist = (uint32_t*)((char*)rest + stride);
+    uint32_t* digit_total = (uint32_t*)((char*)hist + rs_hist_bytes(total));
+    const uint32_t nblk = rs_blocks(total);
+    const dim3 gb(nblk), gs(RS_BINS / RS_WAVES), blk(RS_BLOCK);
+    const uint32_t *kin = nullptr, *vin = nullptr;
+    uint32_t *kout = keys_a, *vout = vals_a;
+    for (uint32_t pass = 0; pass < RS_PASSES; ++pass) {
+        const uint32_t shift = pass * RS_BITS;
+        const bool first = pass == 0, last = pass + 1 == RS_PASSES;
+        if (first) hipLaunchKernelGGL(rs_hist_kernel<true>, gb, blk, 0, st, total, nblk, shift, kin, radii, depths, hist);
+        else hipLaunchKernelGGL(rs_hist_kernel<false>, gb, blk, 0, st, total, nblk, shift, kin, radii, depths, hist);
+        hipLaunchKernelGGL(rs_scan_kernel, gs, blk, 0, st, nblk, hist, digit_total);
+#define GSX_RS_SCATTER(F, L, KO, VO, RK) hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_scatter_kernel<F, L>), gb, blk, 0, st, total, nblk, shift, kin, vin, radii, depths, \
+                                                             (const uint32_t*)hist, (const uint32_t*)digit_total, KO, VO, RK)
+        if (last) GSX_RS_SCATTER(false, true, (uint32_t*)nullptr, order, ranks);
+        else if (first) GSX_RS_SCATTER(true, false, kout, vout, (uint32_t*)nullptr);
+        else GSX_RS_SCATTER(false, false, kout, vout, (uint32_t*)nullptr);
+#undef GSX_RS_SCATTER
+        kin = kout; vin = vout;
+        kout = kout == keys_a ? keys_b : keys_a;
+        vout = vout == vals_a ? vals_b : vals_a;
+    }
+    static_assert(RS_PASSES >= 2 && RS_PASSES * RS_BITS >= 32 && RS_BINS % RS_BLOCK == 0 && RS_BINS % RS_WAVES == 0, "digit split");
+    static_assert((uint64_t)64 * RS_SCAN_PER_LANE * RS_TILE >= (uint64_t)RANK_MAX_WORDS * 32u, "rs_scan_kernel: one wave scans a digit's row");
     return check_launch("intersect_depth_ranks");
 }
 

@@ -179,3 +179,46 @@ def test_whole_render_chain_through_the_raw_c_abi_on_a_side_stream():
                                                          _ptr(bg), None, u32(W), u32(H), u32(16), ctypes.byref(cams), ctypes.byref(ut), _ptr(tile_off),
                                                          _ptr(fl), _ptr(ren), _ptr(alp), _ptr(last), _ptr(rws), sz(rws.numel()), st)
     assert rc < 0 and len(lib.gsx_last_error()) > 0
+
+
+def _depth_ranks(lib, radii, depths, C, N):
+    dev = "cuda:0"
+    R, D = torch.from_numpy(radii).to(dev), torch.from_numpy(depths).to(dev)
+    ranks = torch.full((C * N,), -1, dtype=torch.int32, device=dev)
+    order = torch.full((C * N,), -1, dtype=torch.int32, device=dev)
+    lib.gsx_intersect_depth_ranks_workspace_bytes.restype = ctypes.c_size_t
+    wb = lib.gsx_intersect_depth_ranks_workspace_bytes(ctypes.c_uint32(C), ctypes.c_uint32(N))
+    ws = torch.empty(wb, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    rc = lib.gsx_intersect_depth_ranks(ctypes.c_uint32(C), ctypes.c_uint32(N), _ptr(R), _ptr(D), _ptr(ranks), _ptr(order), _ptr(ws), ctypes.c_size_t(wb), None)
+    assert rc == 0, lib.gsx_last_error()
+    torch.cuda.synchronize()
+    return ranks.cpu().numpy(), order.cpu().numpy()
+
+
+@pytest.mark.parametrize("C,N,kind", [(1, 1, "random"), (1, 63, "ties"), (1, 2049, "random"), (2, 5000, "ties"), (1, 70001, "quantised"),
+                                      (1, 1 << 20, "random"), (3, 349525, "ties")])
+def test_depth_ranks_are_the_stable_order_of_the_depth_bits(C, N, kind, monkeypatch):
+    """gsx_intersect_depth_ranks (hand-written three-pass LSD radix sort): order = stable argsort of (depth bits | culled -> 0xFFFFFFFF),
+    ranks = its inverse; the library sort behind GSX_RANK_SORT=rocprim returns the same arrays."""
+    lib = _lib()
+    rng = np.random.default_rng(N + C)
+    total = C * N
+    if kind == "random":
+        depths = rng.uniform(0.01, 1e3, total).astype(np.float32)
+    elif kind == "ties":
+        depths = rng.integers(1, 40, total).astype(np.float32) * 0.25          # long runs of equal keys: stability decides
+    else:
+        depths = (np.exp(rng.uniform(-4, 6, total)) * 64).round().astype(np.float32) / 64
+    radii = rng.integers(0, 3, (total, 2)).astype(np.int32)                    # 5/9 of the Gaussians culled
+    keys = np.where((radii > 0).all(-1), depths.view(np.uint32), np.uint32(0xFFFFFFFF))
+    want_order = np.argsort(keys, kind="stable").astype(np.int32)
+    want_ranks = np.empty(total, np.int32)
+    want_ranks[want_order] = np.arange(total, dtype=np.int32)
+    ranks, order = _depth_ranks(lib, radii, depths, C, N)
+    np.testing.assert_array_equal(order, want_order)
+    np.testing.assert_array_equal(ranks, want_ranks)
+    monkeypatch.setenv("GSX_RANK_SORT", "rocprim")
+    ranks2, order2 = _depth_ranks(lib, radii, depths, C, N)
+    np.testing.assert_array_equal(order2, want_order)
+    np.testing.assert_array_equal(ranks2, want_ranks)
