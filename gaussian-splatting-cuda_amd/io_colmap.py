@@ -23,11 +23,14 @@ CAMERA_MODELS = {0: ("SIMPLE_PINHOLE", 3), 1: ("PINHOLE", 4), 2: ("SIMPLE_RADIAL
 
 
 def qvec2rotmat(q):
-    """colmap.cpp:25-51 (w, x, y, z)."""
-    w, x, y, z = (float(v) for v in q)
-    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
-                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
-                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], np.float32)
+    """colmap.cpp:30-51 (w, x, y, z): the quaternion is normalised (torch F::normalize, eps 1e-12) and R composed in fp32, operation by
+    operation as there — R is bit-identical to the reference reader's (tests/test_io.py checks it against that reader)."""
+    qn = torch.nn.functional.normalize(torch.as_tensor(np.asarray(q, dtype=np.float32)), dim=0).numpy()
+    w, x, y, z = (np.float32(v) for v in qn)
+    one, two = np.float32(1.0), np.float32(2.0)
+    return np.array([[one - two * (y * y + z * z), two * (x * y - z * w), two * (x * z + y * w)],
+                     [two * (x * y + z * w), one - two * (x * x + z * z), two * (y * z - x * w)],
+                     [two * (x * z - y * w), two * (y * z + x * w), one - two * (x * x + y * y)]], np.float32)
 
 
 def read_cameras_binary(path, scale_factor=1.0):
@@ -208,6 +211,28 @@ def _pad4(a):
     return out
 
 
+def _correct_dimensions(cameras):
+    """colmap.cpp:852-877: when the FIRST image file exists and its size differs from the COLMAP database's (relative difference above
+    1e-5 on either axis), every camera takes that file's size and has fx, cx scaled by actual_w / expected_w and fy, cy by
+    actual_h / expected_h of the first camera (fp32 arithmetic as there); distortion coefficients are dimensionless and stay."""
+    if not cameras or not os.path.exists(cameras[0].image_path):
+        return
+    from PIL import Image
+    try:
+        with Image.open(cameras[0].image_path) as im:
+            actual_w, actual_h = im.size
+    except Exception as e:  # noqa: BLE001
+        raise RuntimeError(f"Load failed: {cameras[0].image_path} : {e}") from e
+    c0 = cameras[0].camera
+    sx, sy = np.float32(actual_w) / np.float32(c0.width), np.float32(actual_h) / np.float32(c0.height)
+    if abs(sx - np.float32(1.0)) <= 1e-5 and abs(sy - np.float32(1.0)) <= 1e-5:
+        return
+    scale = torch.tensor([[sx, 1.0, sx], [1.0, sy, sy], [1.0, 1.0, 1.0]], dtype=torch.float32)
+    for c in cameras:
+        c.camera.width, c.camera.height = int(actual_w), int(actual_h)
+        c.camera.K = c.camera.K * scale.to(c.camera.K.device)
+
+
 def load_colmap(base_path, images_folder="images", device="cpu"):
     sparse = os.path.join(base_path, "sparse", "0")
     if not os.path.isdir(sparse):
@@ -244,6 +269,7 @@ def load_colmap(base_path, images_folder="images", device="cpu"):
                      camera_model=kind, radial=None if radial is None else torch.from_numpy(radial).to(device),
                      tangential=None if tangential is None else torch.from_numpy(tangential).to(device))
         scene.cameras.append(ColmapCamera(cam, img["name"], os.path.join(base_path, images_folder, img["name"]), uid, c["model"]))
+    _correct_dimensions(scene.cameras)
     scene.camera_locations = np.stack(locs) if locs else np.zeros((0, 3), np.float32)
     scene.scene_center = scene.camera_locations.mean(0) if locs else np.zeros(3, np.float32)
     p3d, p3d_txt = os.path.join(sparse, "points3D.bin"), os.path.join(sparse, "points3D.txt")

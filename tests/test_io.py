@@ -352,3 +352,57 @@ def test_ply_written_by_us_is_parsed_by_the_reference_library(tmp_path):
     assert np.array_equal(col["f_rest_44"], m.sh[:, 15, 2].numpy())
     assert np.array_equal(col["opacity"], m.opacity_raw[:, 0].numpy()) and np.array_equal(col["scale_2"], m.scaling_raw[:, 2].numpy())
     np.testing.assert_allclose(np.stack([col["rot_%d" % i] for i in range(4)], 1), torch.nn.functional.normalize(m.rotation_raw, dim=-1).numpy(), atol=1e-7)
+
+
+def _colmap_reference_outputs(name, kw, root):
+    """What the reference's own reader parsed from case `name`: the committed golden (tests/golden/colmap_ref/, generated by
+    gen_colmap_ref_golden.py) and, where oracle/_ref/colmap_ref_tool is built, a live run on the model just written under `root`."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import colmap_cases
+    outs = [colmap_cases.parse_tool_output(open(os.path.join(os.path.dirname(__file__), "golden", "colmap_ref", name + ".txt")).read())]
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "colmap_ref_tool")
+    if os.path.exists(tool):
+        r = subprocess.run([tool, str(root), kw.get("images_folder", "images"), "text" if kw.get("text") else "bin"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(colmap_cases.parse_tool_output(r.stdout))
+    return outs
+
+
+@pytest.mark.parametrize("name", ["bin", "text", "bin_images_2", "text_images_4", "bin_resized_files", "bin_reordered"])
+def test_colmap_loader_agrees_with_the_reference_reader(tmp_path, name):
+    """io_colmap.load_colmap against the reference's reader (src/loader/formats/colmap.cpp, compiled unmodified: oracle/build_ref_colmap.sh)
+    on models this file's own struct.pack writer produces from COLMAP's published layout: every accepted camera model, binary and text,
+    down-scaled image folders, the first-image dimension correction, image order.  Intrinsics, sizes, names, model mapping, distortion
+    vectors, R, T and the point cloud must be EQUAL (fp32, bit for bit); the scene centre (a mean of -R^T t over the cameras) to 5e-7."""
+    import sys
+    import gsx  # noqa: F401
+    from gsx import io_colmap, ops
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import colmap_cases
+    kw = colmap_cases.CASES[name]
+    colmap_cases.write_model(tmp_path, **kw)
+    sc = io_colmap.load_colmap(str(tmp_path), images_folder=kw.get("images_folder", "images"))
+    model_ids = {n: i for i, n in enumerate(["SIMPLE_PINHOLE", "PINHOLE", "SIMPLE_RADIAL", "RADIAL", "OPENCV", "OPENCV_FISHEYE", "FULL_OPENCV", "FOV",
+                                             "SIMPLE_RADIAL_FISHEYE", "RADIAL_FISHEYE", "THIN_PRISM_FISHEYE"])}
+    for ref in _colmap_reference_outputs(name, kw, tmp_path):
+        assert "error" not in ref and len(ref["cameras"]) == len(sc.cameras) == len(colmap_cases.CAMERAS)
+        for ours, rc in zip(sc.cameras, ref["cameras"]):
+            cam = ours.camera
+            assert ours.image_name == rc["name"] and ours.uid == rc["uid"] and model_ids[ours.model] == rc["model"]
+            assert (cam.width, cam.height) == (rc["width"], rc["height"])
+            assert int(cam.camera_model) == rc["model_type"]                       # gsplat::CameraModelType (PINHOLE 0, FISHEYE 2)
+            K = cam.K.numpy()
+            assert (K[0, 0], K[1, 1], K[0, 2], K[1, 2]) == (rc["fx"], rc["fy"], rc["cx"], rc["cy"]), (ours.image_name, K, rc)
+            vm = cam.viewmat.numpy()
+            assert np.array_equal(vm[:3, :3], rc["R"])
+            assert np.array_equal(vm[:3, 3], rc["T"])
+            for mine, theirs in ((cam.radial, rc["radial"]), (cam.tangential, rc["tangential"])):
+                if theirs.size == 0:
+                    assert mine is None
+                else:   # ours is padded with zeros to >= 4 entries, as the reference pads at render time (rasterizer.cpp:183-195)
+                    m = mine.numpy()
+                    assert np.array_equal(m[:theirs.size], theirs) and not m[theirs.size:].any()
+        np.testing.assert_allclose(sc.scene_center, ref["center"], rtol=0, atol=5e-7)
+        assert np.array_equal(sc.points, ref["points"]) and np.array_equal(sc.colors.astype(np.float32), ref["colors"])
