@@ -75,3 +75,22 @@ def render_chain(ref, means, quats, scales, opacities, sh, sh_degree, viewmat, K
                                                         last_ids, v_render_colors, v_render_alphas)
         out.update(v_means=g[0], v_quats=g[1], v_scales=g[2], v_colors=g[3], v_opacities=g[4])
     return out
+
+
+def train_path():
+    return os.path.join(HERE, "_ref", "gsplat_ref_train.so")
+
+
+def load_train():
+    """oracle/_ref/gsplat_ref_train.so (oracle/build_ref_train.sh): the reference's fused SSIM kernels behind their autograd wrapper
+    (fused_ssim / fusedssim / fusedssim_backward) and its fused Adam step (adam_step); None when not built."""
+    if "train" in _cache:
+        return _cache["train"]
+    mod = None
+    if os.path.exists(train_path()):
+        import torch  # noqa: F401
+        spec = importlib.util.spec_from_file_location("gsplat_ref_train", train_path())
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    _cache["train"] = mod
+    return mod
