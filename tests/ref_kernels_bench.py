@@ -1,7 +1,7 @@
 """The reference's OWN kernels (its .cu files compiled unmodified for gfx950: oracle/_ref/gsplat_ref_hip{,_fast}.so, gsplat_ref_train.so)
 timed beside this library's operators on the same MI355X, same tensors, same operator interface (gsplat/Ops.h) — S-1M @1080p.
-Checker libraries only: nothing here is the product path.  Prints a markdown table.
-Usage (GPU box): python tools/ref_kernels_bench.py [morton|generator] > gpurun_out/ref_kernels.md"""
+Checker libraries only: nothing here is the product path (it lives under tests/ because only tests may load oracle/).  Prints a markdown table.
+Usage (GPU box): python tests/ref_kernels_bench.py [morton|generator] > gpurun_out/ref_kernels.md"""
 import os
 import sys
 
