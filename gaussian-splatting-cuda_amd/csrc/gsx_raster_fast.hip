@@ -395,6 +395,204 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
     }
 }
 
+// ---- forward, four lists per wave ("quad" variant) -------------------------------------------------------------------------------
+// Same arithmetic per (pixel, Gaussian) pair and the same order per pixel as raster_fwd_fast_kernel (bit-identical output), but the wave
+// no longer walks ONE list of the Gaussians that reach its 8x8 quadrant: its four DPP rows own the four 4x4 pixel blocks of the quadrant
+// and every row walks the list of the Gaussians that reach ITS block — four different Gaussians per wave instruction.  At S-1M a
+// Gaussian that reaches a quadrant reaches 2.4 of its 4 blocks on average, so the longest of the four lists is ~0.67 of the quadrant's
+// list: a third fewer wave steps for the same pairs.  Per chunk every wave tests its 64 candidates per batch against the four blocks
+// (footprint_hits_2x2 under a perfect pinhole), compacts the survivors into four byte lists in LDS (ballot + mbcnt), pads the shorter
+// lists with the index of a NULL record (alpha = 0: never taken) and steps through them with one uniform counter: no per-lane queue
+// state, one extra ds_read_u8 and a shift per step instead of the scalar bit walk.
+static_assert(FCH == 128, "raster_fwd_quad_kernel: four byte lists of FCH entries = one ds_write_b64 per lane");
+template <int KIND>
+__global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_quad_kernel(RasterArgs a, float* __restrict__ render_colors,
+                                                                            float* __restrict__ render_alphas, int32_t* __restrict__ last_ids) {
+    __shared__ float4 s_rec[2][FCH + 1][4];   // AoS records, double buffered; [FCH] = the null record
+    __shared__ float4 s_cull[2][FCH];
+    __shared__ float s_bounds[4][4];
+    __shared__ int s_wdone[2][4];
+    // [wave][block][FCH]: indices into the chunk's records, consumed by the wave that wrote them (4 x FCH = 512 B per wave: one ds_write_b64 per
+    // lane pre-fills them); + the byte the last list's look-ahead reads past its end
+    __shared__ __attribute__((aligned(8))) uint8_t s_list_flat[4 * 4 * FCH + 8];
+    uint8_t (*s_list)[4][FCH] = reinterpret_cast<uint8_t (*)[4][FCH]>(s_list_flat);
+    const uint32_t cid = blockIdx.y;
+    uint32_t tile_id;
+    if (!swizzled_tile(blockIdx.x, a.tw * a.th, tile_id)) return;
+    const uint32_t tile_y = tile_id / a.tw, tile_x = tile_id - tile_y * a.tw;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, qd = lane >> 4;
+    // lane -> pixel: DPP row qd = 4x4 block (qd & 1, qd >> 1) of the wave's quadrant, 16 lanes = its pixels row-major
+    const uint32_t j = tile_x * TILE + (wave & 1u) * 8u + (qd & 1u) * 4u + (lane & 3u);
+    const uint32_t i = tile_y * TILE + (wave >> 1) * 8u + (qd >> 1) * 4u + ((lane >> 2) & 3u);
+    const bool inside = i < a.H && j < a.W;
+    const size_t pix = (size_t)cid * a.H * a.W + (size_t)i * a.W + j;
+    const float* bg = a.backgrounds ? a.backgrounds + cid * 3 : nullptr;
+    if (a.masks != nullptr && !a.masks[(size_t)cid * a.th * a.tw + tile_id]) {  // Fwd.cu:143-150
+        if (inside)
+            for (int k = 0; k < 3; ++k) render_colors[pix * 3 + k] = bg ? bg[k] : 0.f;
+        return;
+    }
+    if (KIND == CAM_OPENCV_FISHEYE && a.tile_flags != nullptr && a.tile_flags[(size_t)cid * a.th * a.tw + tile_id]) return;  // generic kernel's tile
+    const Camera<KIND> cam(a.cams, cid, a.W, a.H);
+    float u, v, w;
+    const bool ray_ok = pixel_ray(cam, i, j, u, v, w);
+    bool done = !inside || !ray_ok;
+    // (u, v) bounds of the valid pixels: per block (DPP row), per wave, per tile
+    float qb[4];
+    bool wide = false;
+    {
+        float bu = u, bv = v;
+        if (KIND == CAM_OPENCV_FISHEYE) {
+            wide = !done && w < 0.05f;
+            const float iw = 1.f / fmaxf(w, 0.05f);
+            bu = u * iw; bv = v * iw;
+        }
+        qb[0] = wide ? -INFINITY : (!done ? bu : INFINITY); qb[1] = wide ? INFINITY : (!done ? bu : -INFINITY);
+        qb[2] = wide ? -INFINITY : (!done ? bv : INFINITY); qb[3] = wide ? INFINITY : (!done ? bv : -INFINITY);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            qb[0] = fminf(qb[0], __shfl_xor(qb[0], o)); qb[1] = fmaxf(qb[1], __shfl_xor(qb[1], o));
+            qb[2] = fminf(qb[2], __shfl_xor(qb[2], o)); qb[3] = fmaxf(qb[3], __shfl_xor(qb[3], o));
+        }
+    }
+    float bq[4][4];   // the four blocks' bounds, wave-uniform
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bq[q][k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qb[k]), 16 * q));
+    float tb[4];
+    {
+        const float umin = fminf(fminf(bq[0][0], bq[1][0]), fminf(bq[2][0], bq[3][0])), umax = fmaxf(fmaxf(bq[0][1], bq[1][1]), fmaxf(bq[2][1], bq[3][1]));
+        const float vmin = fminf(fminf(bq[0][2], bq[1][2]), fminf(bq[2][2], bq[3][2])), vmax = fmaxf(fmaxf(bq[0][3], bq[1][3]), fmaxf(bq[2][3], bq[3][3]));
+        if (lane == 0) { s_bounds[wave][0] = umin; s_bounds[wave][1] = umax; s_bounds[wave][2] = vmin; s_bounds[wave][3] = vmax; }
+        if (tid < 8) {   // the null records: lo' = -inf, unit denominator
+            float4* nr = s_rec[tid >> 2][FCH];
+            nr[tid & 3] = (tid & 3) == 1 ? make_float4(0.f, -INFINITY, 0.f, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        tb[0] = fminf(fminf(s_bounds[0][0], s_bounds[1][0]), fminf(s_bounds[2][0], s_bounds[3][0]));
+        tb[1] = fmaxf(fmaxf(s_bounds[0][1], s_bounds[1][1]), fmaxf(s_bounds[2][1], s_bounds[3][1]));
+        tb[2] = fminf(fminf(s_bounds[0][2], s_bounds[1][2]), fminf(s_bounds[2][2], s_bounds[3][2]));
+        tb[3] = fmaxf(fmaxf(s_bounds[0][3], s_bounds[1][3]), fmaxf(s_bounds[2][3], s_bounds[3][3]));
+    }
+    // perfect pinhole: the blocks' rectangles are products of two u-ranges and two v-ranges (columns / rows of the quadrant)
+    float xr[2][2], yr[2][2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        xr[k][0] = fminf(bq[k][0], bq[k + 2][0]); xr[k][1] = fmaxf(bq[k][1], bq[k + 2][1]);
+        yr[k][0] = fminf(bq[2 * k][2], bq[2 * k + 1][2]); yr[k][1] = fmaxf(bq[2 * k][3], bq[2 * k + 1][3]);
+    }
+    const float ww = w * w;
+    const bool no_cull = KIND == CAM_OPENCV_FISHEYE && !(tb[0] > -INFINITY);
+
+    int32_t range_start, range_end;
+    tile_list_range(a, cid, tile_x, tile_y, range_start, range_end);
+    const int32_t n_chunks = (range_end - range_start + FCH - 1) / FCH;
+
+    constexpr float K999 = 0.999f, LOG2_K999 = -0.0014434168696687174f, THR = (1.f / 255.f) / 0.999f;   // see raster_fwd_fast_kernel
+    float T = 1.f;
+    uint32_t cur_idx = 0;
+    float out_r = 0.f, out_g = 0.f, out_b = 0.f;
+    float thr = done ? INFINITY : THR;
+    bool wave_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
+    uint8_t* my_list = s_list[wave][qd];
+    int32_t g_pre = 0;
+    bool have = (int32_t)tid < FCH && range_start + (int32_t)tid < range_end;
+    if (have) g_pre = a.flatten_ids[range_start + (int32_t)tid];
+    for (int32_t b = 0; b < n_chunks; ++b) {
+        const int buf = b & 1;
+        const int32_t chunk_start = range_start + FCH * b;
+        if (have) {
+            StagedRec sr;
+            stage_one(a, tb, g_pre, sr);
+            if (no_cull) sr.cull.z = INFINITY;
+            sr.r1.y -= LOG2_K999; sr.r2.w *= K999; sr.r3.x *= K999; sr.r3.y *= K999;
+            s_rec[buf][tid][0] = sr.r0; s_rec[buf][tid][1] = sr.r1; s_rec[buf][tid][2] = sr.r2; s_rec[buf][tid][3] = sr.r3;
+            s_cull[buf][tid] = sr.cull;
+        }
+        if (lane == 0) s_wdone[buf][wave] = wave_done ? 1 : 0;
+        __syncthreads();
+        if (s_wdone[buf][0] & s_wdone[buf][1] & s_wdone[buf][2] & s_wdone[buf][3]) break;  // Fwd.cu:188-190
+        have = (b + 1 < n_chunks) && (int32_t)tid < FCH && (chunk_start + FCH + (int32_t)tid < range_end);
+        if (have) g_pre = a.flatten_ids[chunk_start + FCH + (int32_t)tid];  // in flight during the pixel loop
+        if (wave_done) continue;
+        const int32_t chunk_size = min(FCH, range_end - chunk_start);
+        // the four lists of this wave for the chunk: every candidate (one per lane, 64 per batch) against the four blocks, survivors
+        // compacted per block in list order; the lists were pre-filled with the null record's index, so the shorter ones idle to the end
+        reinterpret_cast<unsigned long long*>(&s_list[wave][0][0])[lane] = 0x0101010101010101ull * (unsigned long long)FCH;
+        uint32_t cnt[4] = {0u, 0u, 0u, 0u};
+        for (int32_t sub = 0; sub < chunk_size; sub += 64) {
+            uint32_t hits = 0u;
+            if (sub + (int32_t)lane < chunk_size) {
+                const float4 c = s_cull[buf][sub + lane];
+                const float4 q0 = s_rec[buf][sub + lane][0], q1 = s_rec[buf][sub + lane][1];   // (.., .., l00, l01), (l11, ..)
+                if (KIND == CAM_PERFECT_PINHOLE) {
+                    hits = footprint_hits_2x2(c, q0.z, q0.w, q1.x, xr, yr);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) hits |= footprint_hits(c, q0.z, q0.w, q1.x, bq[q][0], bq[q][1], bq[q][2], bq[q][3]) ? (1u << q) : 0u;
+                }
+            }
+            GSX_STAT_ADD(1, min(64, chunk_size - sub));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool h = (hits >> q) & 1u;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(h);
+                const uint32_t pos = cnt[q] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (h) s_list[wave][q][pos] = (uint8_t)(sub + (int32_t)lane);
+                cnt[q] += (uint32_t)__popcll(m);
+            }
+        }
+        const uint32_t steps = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the lists are private to the wave
+        GSX_STAT_ADD(0, steps);
+        uint32_t cur = 0xFFFFFFFFu;   // record index (inside the chunk) of the last Gaussian this pixel took
+        uint32_t t_next = my_list[0];
+        for (uint32_t k = 0; k < steps; ++k) {
+            // one compositing step: every lane evaluates the Gaussian of ITS block's list for its pixel (same instruction sequence as
+            // raster_fwd_fast_kernel's)
+            const uint32_t t = t_next;
+            t_next = my_list[k + 1];                     // (one past the end at the last step: inside the LDS arrays, never used)
+            const float4* rp = s_rec[buf][t];
+            const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+            const float du = KIND == CAM_OPENCV_FISHEYE ? fmaf(-w, r0.x, u) : u - r0.x;   // fisheye: unnormalised ray (u, v, w), see fast_alpha_ray
+            const float dv = KIND == CAM_OPENCV_FISHEYE ? fmaf(-w, r0.y, v) : v - r0.y;
+            const float t0 = fmaf(r0.w, dv, r0.z * du);
+            const float t1 = r1.x * dv;
+            const float num2 = fmaf(t0, t0, t1 * t1);
+            const float den = KIND == CAM_OPENCV_FISHEYE
+                                  ? fmaf(du, fmaf(r2.x, du, fmaf(r2.y, dv, r1.z * w)), fmaf(dv, fmaf(r2.z, dv, r1.w * w), ww))
+                                  : fmaf(du, fmaf(r2.x, du, fmaf(r2.y, dv, r1.z)), fmaf(dv, fmaf(r2.z, dv, r1.w), 1.f));
+            const float ap = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(fmaf(-num2, __builtin_amdgcn_rcpf(den), r1.y)), 0.f, 1.f);
+            bool take = ap >= thr;                       // alpha >= 1/255 and the pixel is not finished (Fwd.cu:240)
+            float wgt = take ? ap * T : 0.f;             // alpha T / 0.999
+            T = fmaf(-K999, wgt, T);                     // T (1 - alpha), in place
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(T <= 1e-4f) != 0ull, 0)) {
+                const bool stop = T <= 1e-4f;            // this pixel does NOT take the Gaussian (Fwd.cu:245-248): see raster_fwd_fast_kernel
+                take = take && !stop;
+                T = stop ? fmaf(K999, wgt, T) : T;
+                wgt = stop ? 0.f : wgt;
+                thr = stop ? INFINITY : thr;
+            }
+            out_r = fmaf(r2.w, wgt, out_r); out_g = fmaf(r3.x, wgt, out_g); out_b = fmaf(r3.y, wgt, out_b);
+            cur = take ? t : cur;
+#ifdef GSX_STATS
+            { const unsigned long long cc = __builtin_amdgcn_ballot_w64(take); GSX_STAT_ADD(2, cc != 0ull); GSX_STAT_ADD(3, __popcll(cc)); }
+#endif
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next chunk's pre-fill stays behind this chunk's reads
+        cur_idx = cur != 0xFFFFFFFFu ? (uint32_t)chunk_start + cur : cur_idx;
+        if (__builtin_amdgcn_ballot_w64(thr < INFINITY) == 0ull) wave_done = true;   // all 64 pixels finished
+    }
+    if (inside) {
+        render_alphas[pix] = 1.f - T;
+        render_colors[pix * 3] = bg ? out_r + T * bg[0] : out_r;
+        render_colors[pix * 3 + 1] = bg ? out_g + T * bg[1] : out_g;
+        render_colors[pix * 3 + 2] = bg ? out_b + T * bg[2] : out_b;
+        last_ids[pix] = (int32_t)cur_idx;
+    }
+}
+
 // forward workspace, from its 256 B aligned base: packed records [C*N] x 64 B | fisheye: "no chart" bytes [C*N] | tile flags
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 size_t raster_fwd_fast_workspace_bytes(uint32_t C, uint32_t N) { return 256 + (size_t)C * N * 64 + align256((size_t)C * N) + FAST_FLAG_BYTES; }
@@ -422,12 +620,22 @@ const uint8_t* launch_raster_fwd_fast(int kind, RasterArgs a, float* renders, fl
     const dim3 grid(((n_tiles + 7u) / 8u) * 8u, a.C), block(RB);
     if (records_ready) a.packed = (const float4*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);   // written by the fused front end
     else pack_into(kind, a, workspace, st);
-    if (kind == CAM_PERFECT_PINHOLE)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_fwd_fast_kernel<CAM_PERFECT_PINHOLE>), grid, block, 0, st, a, renders, alphas, last_ids);
-    else if (kind == CAM_OPENCV_PINHOLE)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_fwd_fast_kernel<CAM_OPENCV_PINHOLE>), grid, block, 0, st, a, renders, alphas, last_ids);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(raster_fwd_fast_kernel<CAM_OPENCV_FISHEYE>), grid, block, 0, st, a, renders, alphas, last_ids);
+    // Which forward kernel: four lists per wave pay where a Gaussian that reaches a quadrant misses part of its four blocks — small
+    // footprints.  Measured (tools/fwd_quad_ab.py, same box): S-1M (3.4 tiles per Gaussian) 0.272 -> 0.232 ms, its fisheye twin 0.320 ->
+    // 0.265; S-5M @4K (5.3 tiles) -5 .. +7 %, a saturated scene (5.9) +3 %, large footprints with 32-pixel lists +18 % (every block sees
+    // nearly every survivor and the four block tests per candidate are pure cost).  Rule: 16-pixel lists and at most 4.5 intersections
+    // per (camera, Gaussian) on average; GSX_FWD=quad|wave forces one (tests, A/B tools; read per launch).
+    bool quad = a.lshift == 0u && 2 * a.n_isects <= 9 * (int64_t)a.C * (int64_t)a.N;
+    if (const char* e = test_switch("GSX_FWD")) quad = std::string(e) == "quad" ? true : (std::string(e) == "wave" ? false : quad);
+#define GSX_BLEND_FWD(KERNEL)                                                                                                            \
+    do {                                                                                                                                 \
+        if (kind == CAM_PERFECT_PINHOLE) hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<CAM_PERFECT_PINHOLE>), grid, block, 0, st, a, renders, alphas, last_ids); \
+        else if (kind == CAM_OPENCV_PINHOLE) hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<CAM_OPENCV_PINHOLE>), grid, block, 0, st, a, renders, alphas, last_ids); \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<CAM_OPENCV_FISHEYE>), grid, block, 0, st, a, renders, alphas, last_ids);               \
+    } while (0)
+    if (quad) GSX_BLEND_FWD(raster_fwd_quad_kernel);
+    else GSX_BLEND_FWD(raster_fwd_fast_kernel);
+#undef GSX_BLEND_FWD
     return a.tile_flags;
 }
 

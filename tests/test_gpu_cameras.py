@@ -16,6 +16,13 @@ def t(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 
 
+@pytest.fixture(autouse=True, params=["wave", "quad"])
+def forward_kernel(request, monkeypatch):
+    """Every camera case runs with each forward kernel of the fast path forced (one list per 8x8 quadrant / four lists per wave)."""
+    monkeypatch.setenv("GSX_FWD", request.param)
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def mods():
     import gsx  # noqa: F401

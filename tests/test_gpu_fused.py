@@ -265,3 +265,28 @@ def test_lists_per_32px_tiles_give_the_same_render(mods, size, monkeypatch):
     assert rasterizer._list_tile_for(key) == 32
     rasterizer._list_tile_update(key, 32, 1000 * 25, 25)
     assert rasterizer._list_tile_for(key) == 16
+
+
+@pytest.mark.parametrize("size,list_tile", [((160, 112), 16), ((150, 100), 16), ((150, 100), 32)])
+def test_forward_kernels_are_bit_identical(mods, size, list_tile, monkeypatch):
+    """The two forward kernels of the fast path (GSX_FWD=wave: one list per 8x8 quadrant; quad: four lists per wave, one per DPP row / 4x4
+    block) evaluate the same pairs in the same order with the same instructions: image, alpha and last ids are EQUAL — ragged image sizes,
+    16- and 32-pixel lists; and the launcher's own choice (no switch) is one of the two."""
+    distributed, ops, rasterizer, scenes = mods
+    sc, cam = _setup(scenes, rasterizer, 3)
+    W, H = size
+    cam = rasterizer.Camera(viewmat=cam.viewmat, K=cam.K, width=W, height=H)
+    bg = sc["background"].to(DEV) + 0.1
+    monkeypatch.setenv("GSX_LIST_TILE", str(list_tile))
+    outs = {}
+    for mode in ("wave", "quad", None):
+        if mode is None:
+            monkeypatch.delenv("GSX_FWD")
+        else:
+            monkeypatch.setenv("GSX_FWD", mode)
+        model = scenes.to_splat_data(sc, DEV)
+        with torch.no_grad():
+            o = rasterizer.rasterize_fused(cam, model, bg)
+        outs[mode] = (o.image.clone(), o.alpha.clone())
+    for k in ("quad", None):
+        assert torch.equal(outs["wave"][0], outs[k][0]) and torch.equal(outs["wave"][1], outs[k][1]), k

@@ -155,16 +155,19 @@ def _fwd(ops, sc, b, bg=True):
         ops.ShutterType.GLOBAL, None, None, None, b["off"], b["fl"])
 
 
-@pytest.fixture(params=["fast", "generic"])
+@pytest.fixture(params=["fast", "fast-quad", "generic"])
 def raster_path(request):
-    """Both kernel families: the MI355X fast path and the reference-order generic path."""
-    old = os.environ.get("GSX_RASTER_PATH")
-    os.environ["GSX_RASTER_PATH"] = request.param
-    yield request.param
-    if old is None:
-        os.environ.pop("GSX_RASTER_PATH", None)
-    else:
-        os.environ["GSX_RASTER_PATH"] = old
+    """Both kernel families: the MI355X fast path — with each of its two forward kernels forced (one list per 8x8 quadrant / four lists per
+    wave; the launcher picks by footprint size) — and the reference-order generic path."""
+    old = {k: os.environ.get(k) for k in ("GSX_RASTER_PATH", "GSX_FWD")}
+    os.environ["GSX_RASTER_PATH"] = "generic" if request.param == "generic" else "fast"
+    os.environ["GSX_FWD"] = "quad" if request.param == "fast-quad" else "wave"
+    yield "fast" if request.param.startswith("fast") else "generic"
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 @pytest.mark.parametrize("N,size,seed", [(3000, 128, 3), (10000, 256, 42), (500, 100, 9)])
