@@ -28,7 +28,9 @@ def main():
     k = parse(summary)
     find = lambda sub: next((v for n, v in k.items() if sub in n), None)  # noqa: E731
     traffic = lambda v: int((2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024) if v else 0  # noqa: E731
-    pack, fwd, gather = find("pack_records"), find("raster_fwd_fast"), find("gsx_bwd_gather")
+    pack, gather = find("pack_records"), find("gsx_bwd_gather")
+    fwd_name = "raster_fwd_quad" if find("raster_fwd_quad") else "raster_fwd_fast"   # whichever forward kernel the launcher took for this workload
+    fwd = find(fwd_name)
     bwd = find("raster_bwd_gq") or find("raster_bwd_gm") or find("raster_bwd_fast")
     sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-cuda_amd"))
     import build as gbuild
@@ -36,7 +38,7 @@ def main():
         "source": source,
         "blend_kernel_hash": gbuild.blend_kernel_hash(),   # bench.py reports these figures only while the blend sources still hash to this
         "rasterize_to_pixels_from_world_3dgs_fwd": {"hbm_bytes": traffic(pack) + traffic(fwd), "valu_insts": int(fwd["SQ_INSTS_VALU"]),
-                                                    "kernels": ("pack_records + raster_fwd_fast" if pack else "raster_fwd_fast (records packed by the fused front end)")},
+                                                    "kernels": ("pack_records + " + fwd_name if pack else fwd_name + " (records packed by the fused front end)")},
         "rasterize_to_pixels_from_world_3dgs_bwd": {"hbm_bytes": traffic(bwd) + traffic(gather), "valu_insts": int(bwd["SQ_INSTS_VALU"]),
                                                     "kernels": "raster_bwd_gq (or raster_bwd_fast) + gsx_bwd_gather; packed records reused from the forward"},
     }
