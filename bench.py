@@ -328,7 +328,7 @@ def main():
         # the reference's photometric loss (trainer.cpp:103-127): 0.8 L1 + 0.2 (1 - SSIM), fused on the blend's own layout
         target = targets[i % len(targets)]
         loss = gloss.photometric_loss(out.render_hwc, target, 0.2) if fused_loss else (out.image - target).abs().mean()
-        loss.backward()
+        gloss.backward(loss)
         if sharded is not None and with_adam:
             sharded.step(1001 + i)  # reduce-scatter -> Adam on this rank's rows -> all-gather of the updated parameters
         else:

@@ -80,7 +80,7 @@ class Trainer:
         out = rasterizer.rasterize_fused(self.cameras[i], self.model, self.bg, grad_sinks=self.sinks)
         gt = self.images[i]
         loss = gloss.photometric_loss(out.render_hwc, gt, self.params.lambda_dssim)
-        loss.backward()
+        gloss.backward(loss)
         if self.sharded is not None:
             # the regularisers are the same on every rank, so adding them before the mean over the ranks gives the same sum; the
             # exchange itself (reduce-scatter ... all-gather) brackets the optimizer step and is skipped with it when the model grew
