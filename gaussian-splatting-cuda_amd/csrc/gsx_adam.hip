@@ -31,21 +31,25 @@ __global__ __launch_bounds__(256) void adam_step_kernel(uint64_t rows, uint32_t 
     }
 }
 
+// Streaming accesses: the optimizer touches every byte once per step — nontemporal loads / stores keep the 1.6 GB of a 1 M-Gaussian step
+// from displacing the lines the next render re-reads (measured: 59 floats x 1 M, six launches: 0.299 -> 0.276 ms = 6.0 TB/s).
+// (nt_load4 / nt_store4: gsx_device.hpp)
+
 // contiguous fast path: 16 B per lane per array
 __global__ __launch_bounds__(256) void adam_step_vec4_kernel(uint64_t n4, float4* __restrict__ param, float4* __restrict__ exp_avg,
                                                              float4* __restrict__ exp_avg_sq, const float4* __restrict__ grad, float lr,
                                                              float beta1, float beta2, float eps, float bc1_rcp, float bc2_sqrt_rcp) {
     const float step_size = lr * bc1_rcp;
     for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * 256u) {
-        const float4 g = grad[i];
-        float4 m = exp_avg[i], v = exp_avg_sq[i], p = param[i];
+        const float4 g = nt_load4(&grad[i]);
+        float4 m = nt_load4(&exp_avg[i]), v = nt_load4(&exp_avg_sq[i]), p = nt_load4(&param[i]);
 #define GSX_ADAM1(F)                                                        \
         m.F = beta1 * m.F + (1.0f - beta1) * g.F;                           \
         v.F = beta2 * v.F + (1.0f - beta2) * g.F * g.F;                     \
         p.F -= step_size * m.F / (sqrtf(v.F) * bc2_sqrt_rcp + eps);
         GSX_ADAM1(x) GSX_ADAM1(y) GSX_ADAM1(z) GSX_ADAM1(w)
 #undef GSX_ADAM1
-        param[i] = p; exp_avg[i] = m; exp_avg_sq[i] = v;
+        nt_store4(p, &param[i]); nt_store4(m, &exp_avg[i]); nt_store4(v, &exp_avg_sq[i]);
     }
 }
 
@@ -58,8 +62,8 @@ __global__ __launch_bounds__(256) void adam_step_split_kernel(uint64_t n4, uint3
     for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * 256u) {
         const uint32_t c = (uint32_t)((i * 4u) % cols);
         if (c + 3 < split ? !do_a : (c >= split ? !do_b : false)) continue;  // whole vector in a disabled block
-        const float4 g = grad[i];
-        float4 m = exp_avg[i], v = exp_avg_sq[i], p = param[i];
+        const float4 g = nt_load4(&grad[i]);
+        float4 m = nt_load4(&exp_avg[i]), v = nt_load4(&exp_avg_sq[i]), p = nt_load4(&param[i]);
 #define GSX_ADAM1(F, J)                                                                          \
         {                                                                                        \
             const bool a = c + J < split;                                                        \
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256) void adam_step_split_kernel(uint64_t n4, uint3
         }
         GSX_ADAM1(x, 0) GSX_ADAM1(y, 1) GSX_ADAM1(z, 2) GSX_ADAM1(w, 3)
 #undef GSX_ADAM1
-        param[i] = p; exp_avg[i] = m; exp_avg_sq[i] = v;
+        nt_store4(p, &param[i]); nt_store4(m, &exp_avg[i]); nt_store4(v, &exp_avg_sq[i]);
     }
 }
 
@@ -100,10 +104,10 @@ __global__ __launch_bounds__(256) void adam_step_multi_kernel(AdamMulti a, float
     p -= step_size * m / (sqrtf(v) * bc2 + eps);
     if (vec) {
         for (uint64_t i = (uint64_t)b * 256u + threadIdx.x; i < n4; i += (uint64_t)nb * 256u) {
-            const float4 g = reinterpret_cast<const float4*>(G)[i];
-            float4 m = reinterpret_cast<float4*>(M)[i], v = reinterpret_cast<float4*>(V)[i], p = reinterpret_cast<float4*>(P)[i];
+            const float4 g = nt_load4(reinterpret_cast<const float4*>(G) + i);
+            float4 m = nt_load4(reinterpret_cast<float4*>(M) + i), v = nt_load4(reinterpret_cast<float4*>(V) + i), p = nt_load4(reinterpret_cast<float4*>(P) + i);
             GSX_ADAM1(p.x, m.x, v.x, g.x) GSX_ADAM1(p.y, m.y, v.y, g.y) GSX_ADAM1(p.z, m.z, v.z, g.z) GSX_ADAM1(p.w, m.w, v.w, g.w)
-            reinterpret_cast<float4*>(P)[i] = p; reinterpret_cast<float4*>(M)[i] = m; reinterpret_cast<float4*>(V)[i] = v;
+            nt_store4(p, reinterpret_cast<float4*>(P) + i); nt_store4(m, reinterpret_cast<float4*>(M) + i); nt_store4(v, reinterpret_cast<float4*>(V) + i);
         }
     }
     for (uint64_t i = (vec ? n4 * 4 : 0) + (uint64_t)b * 256u + threadIdx.x; i < n; i += (uint64_t)nb * 256u) {   // tail (or everything, unaligned)

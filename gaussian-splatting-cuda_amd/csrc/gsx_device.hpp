@@ -16,6 +16,14 @@
 
 namespace gsx {
 
+// 16 B nontemporal (streaming) global accesses: for data a kernel touches exactly once (optimizer state, one-shot records)
+typedef float gsx_nt4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float4* p) {
+    const gsx_nt4 t = __builtin_nontemporal_load(reinterpret_cast<const gsx_nt4*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void nt_store4(float4 v, float4* p) { __builtin_nontemporal_store(gsx_nt4{v.x, v.y, v.z, v.w}, reinterpret_cast<gsx_nt4*>(p)); }
+
 #define GSX_DEV __device__ __forceinline__
 
 struct f2 { float x, y; };

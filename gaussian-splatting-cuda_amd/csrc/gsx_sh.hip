@@ -433,7 +433,7 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_colors_bwd_kernel(uint32_t C, uin
                         const float* sp = tile + er * LS + rr;
                         g[b] = make_float4(sp[0], sp[1], sp[2], sp[3]);
                         col[b] = rr;
-                        p[b] = pp[j]; m[b] = pm[j]; v[b] = pv[j];
+                        p[b] = pp[j]; m[b] = nt_load4(pm + j); v[b] = nt_load4(pv + j);   // moments: touched once per step, streamed
                     }
 #pragma unroll
                     for (int b = 0; b < BA; ++b) {
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_colors_bwd_kernel(uint32_t C, uin
                         GSX_SH_ADAM1(x, 0) GSX_SH_ADAM1(y, 1) GSX_SH_ADAM1(z, 2) GSX_SH_ADAM1(w, 3)
 #undef GSX_SH_ADAM1
                         const uint32_t j = j0 + 64u * b;
-                        pp[j] = p[b]; pm[j] = m[b]; pv[j] = v[b];
+                        pp[j] = p[b]; nt_store4(m[b], pm + j); nt_store4(v[b], pv + j);   // (the parameters stay cached: the next render reads them)
                     }
                 }
             } else
