@@ -173,7 +173,11 @@ def test_whole_render_chain_through_the_raw_c_abi_on_a_side_stream():
     stream.synchronize()
     ref = ops.rasterize_to_pixels_from_world_3dgs_bwd(*common, alp_s, last_s, v_rc, v_ra)
     for a, b in zip(outs, ref):
-        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=1e-6)
+        # the same kernels launched twice: a Gaussian's moment records are chained in the order its tiles' workgroups retire, so its
+        # sums round differently from launch to launch (tools/bwd_repeat_check.py: 1e-6 rel-L2) — entries that cancel to ~1e-6 of the
+        # tensor's scale can differ by 1e-3 of themselves: compare against the tensor's scale, not element by element
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max() and np.linalg.norm(a - b) <= 1e-5 * np.linalg.norm(b)
     # unsupported request: 4 colour channels (rejected upstream too, Rasterization.cpp:65)
     rc = lib.gsx_rasterize_to_pixels_from_world_3dgs_fwd(u32(N), i64(n_isects), _ptr(means), _ptr(quats), _ptr(scales), _ptr(colors), u32(4), _ptr(opac2),
                                                          _ptr(bg), None, u32(W), u32(H), u32(16), ctypes.byref(cams), ctypes.byref(ut), _ptr(tile_off),

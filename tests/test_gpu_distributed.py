@@ -45,6 +45,9 @@ def _worker(rank, world, port, out_dir, sharded, exchange="colors"):
     tag = "rows" if exchange == "rows" else str(int(sharded))
     for it in range(1, 46):
         tr.train_step(it)
+        if it == 9:   # before the first refinement step: only Adam has amplified the rounding so far
+            torch.cuda.synchronize()
+            np.save(os.path.join(out_dir, "early_%s_%d.npy" % (tag, rank)), torch.cat([p.detach().reshape(-1) for p in model.params()]).cpu().numpy())
     torch.cuda.synchronize()
     flat = torch.cat([p.detach().reshape(-1) for p in model.params()]).cpu().numpy()
     np.save(os.path.join(out_dir, "params_%s_%d.npy" % (tag, rank)), flat)
@@ -66,8 +69,10 @@ def test_two_rank_training_keeps_replicas_bit_identical(tmp_path, sharded):
 
 def test_two_rank_color_exchange_matches_row_all_reduce(tmp_path):
     """distributed.ColorGradExchange on real kernels (pre-masked gsx_sh_colors_bwd over both cameras on both ranks): replicas stay
-    bit-identical through relocation + growth, and the trained parameters agree with the all-reduce variant's to rounding (the two
-    exchanges sum the same terms in a different order; 45 Adam steps amplify the last bits, hence 1e-3 on the parameter norm)."""
+    bit-identical through relocation + growth, and the trained parameters agree with the all-reduce variant's to rounding: 1e-4 of the
+    parameter norm after the nine steps before the first refinement (the two exchanges sum the same terms in a different order, the
+    backward's record lists are chained in launch order, Adam amplifies the last bits), and loosely after 45 steps — relocation draws
+    from a multinomial over the opacities, so a last-bit difference can move a Gaussian and the runs part discretely (seen: 4e-3)."""
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), False, "colors"), nprocs=world, join=True)
     a, b = np.load(tmp_path / "params_0_0.npy"), np.load(tmp_path / "params_0_1.npy")
@@ -76,4 +81,6 @@ def test_two_rank_color_exchange_matches_row_all_reduce(tmp_path):
     r, r1 = np.load(tmp_path / "params_rows_0.npy"), np.load(tmp_path / "params_rows_1.npy")
     assert np.array_equal(r, r1)
     assert r.shape == a.shape
-    assert np.linalg.norm(a - r) / np.linalg.norm(r) < 1e-3
+    ea, er = np.load(tmp_path / "early_0_0.npy"), np.load(tmp_path / "early_rows_0.npy")
+    assert np.linalg.norm(ea - er) / np.linalg.norm(er) < 1e-4
+    assert np.linalg.norm(a - r) / np.linalg.norm(r) < 5e-2
