@@ -1,7 +1,8 @@
-"""CPU models of the two multi-block sorts of the binned intersection (gsx_intersect.hip), statement for statement, so that their index
+"""CPU models of the multi-block sorts of the binned intersection (gsx_intersect.hip), statement for statement, so that their index
 arithmetic is checked where no GPU is needed: (1) giant segments — 16 384-key sorted chunks, then merge passes that are parallel over
 16 384-key output windows whose merge-path splits a wave finds by a 64-way search (giant_list / giant_chunk_sort / giant_merge,
-merge_split_wave); (2) the ranked variant's bitmap sort (tile_sort_bitmap_kernel: per-wave word ranges, popcount prefix, emission).
+merge_split_wave); (2) the ranked variant's bitmap sort (tile_sort_bitmap_kernel: per-wave word ranges, popcount prefix, emission); (3) its depth ranks: the
+four-pass LSD radix sort (block histograms, per-digit scan over the blocks, ballot-ranked stable scatter).
 The GPU kernels themselves are compared bit for bit with the device-wide sort in tests/test_gpu_ops.py."""
 import numpy as np
 import pytest
@@ -116,3 +117,64 @@ def test_bitmap_sort_emits_ranks_in_order(total, n):
         assert direct > 0                                            # a tile holding most of the frame's Gaussians: the direct-store branch
     else:
         assert staged > 0 and direct == 0
+
+
+# ---- depth ranks: the four-pass LSD radix sort (rs_hist / rs_scan / rs_scatter, gsx_intersect.hip) --------------------------------
+RS_BLOCK, RS_ROUNDS, RS_BITS = 256, 8, 8
+RS_TILE, RS_BINS = RS_BLOCK * RS_ROUNDS, 1 << RS_BITS
+
+
+def radix_pass(keys, vals, shift):
+    """One digit pass, statement for statement: block histograms hist[digit][block]; per digit an exclusive scan over the blocks + the
+    digit total; per block the scan of the totals, then per wave (64-pair rounds in index order) the rank of a pair among the lanes
+    below it with the same digit ("match any" by ballots) + the wave's running count + the counts of the waves before it."""
+    total = len(keys)
+    nblk = (total + RS_TILE - 1) // RS_TILE
+    digit = (keys >> np.uint32(shift)) & np.uint32(RS_BINS - 1)
+    hist = np.zeros((RS_BINS, nblk), np.int64)
+    for b in range(nblk):
+        np.add.at(hist[:, b], digit[b * RS_TILE:(b + 1) * RS_TILE], 1)
+    prefix = np.cumsum(hist, axis=1) - hist                      # rs_scan_kernel: exclusive over the blocks, in place
+    digit_total = hist.sum(axis=1)
+    base = np.cumsum(digit_total) - digit_total                  # every scatter block scans the totals itself
+    out_k, out_v = np.empty_like(keys), np.empty_like(vals)
+    waves = RS_BLOCK // 64
+    for b in range(nblk):
+        cnt = np.zeros((waves, RS_BINS), np.int64)
+        lrank = {}
+        for w in range(waves):
+            first = b * RS_TILE + w * 64 * RS_ROUNDS
+            for r in range(RS_ROUNDS):
+                lanes = [i for i in range(first + r * 64, first + r * 64 + 64) if i < total]
+                seen = {}
+                for i in lanes:                                   # rank among the valid lanes below with the same digit
+                    d = int(digit[i])
+                    lrank[i] = cnt[w, d] + seen.get(d, 0)
+                    seen[d] = seen.get(d, 0) + 1
+                for d, c in seen.items():                         # the highest peer books the round
+                    cnt[w, d] += c
+        before = np.cumsum(cnt, axis=0) - cnt                     # the counts of the waves before, per digit
+        for w in range(waves):
+            first = b * RS_TILE + w * 64 * RS_ROUNDS
+            for i in range(first, min(first + 64 * RS_ROUNDS, total)):
+                d = int(digit[i])
+                dst = base[d] + prefix[d, b] + before[w, d] + lrank[i]
+                out_k[dst], out_v[dst] = keys[i], vals[i]
+    return out_k, out_v
+
+
+@pytest.mark.parametrize("total,kind", [(1, "random"), (63, "ties"), (2049, "random"), (5000, "ties"), (9000, "high-bits")])
+def test_lsd_radix_passes_give_the_stable_order(total, kind):
+    rng = np.random.default_rng(total)
+    if kind == "random":
+        keys = rng.integers(0, 1 << 32, total, dtype=np.uint64).astype(np.uint32)
+    elif kind == "ties":
+        keys = (rng.integers(1, 40, total).astype(np.float32) * 0.25).view(np.uint32)
+    else:
+        keys = (rng.integers(0, 4, total, dtype=np.uint64).astype(np.uint32) << np.uint32(30)) | np.uint32(0x00FFFFFF)
+    keys[rng.random(total) < 0.3] = 0xFFFFFFFF                    # culled Gaussians rank last
+    k, v = keys.copy(), np.arange(total, dtype=np.uint32)
+    for p in range(4):
+        k, v = radix_pass(k, v, RS_BITS * p)
+    want = np.argsort(keys, kind="stable")
+    assert np.array_equal(v, want.astype(np.uint32)) and np.array_equal(k, keys[want])
