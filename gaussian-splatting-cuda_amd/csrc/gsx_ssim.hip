@@ -74,6 +74,38 @@ __device__ __forceinline__ void hconv5(const float (*sA)[PA], const float (*sB)[
     }
 }
 
+// horizontal pass of the fused training loss: FOUR quantities (X, Y, X^2 + Y^2, XY).  SSIM and its three partials depend on the two
+// windowed variances only through their SUM (ssim.cu:255-268: B = sigma1^2 + sigma2^2 + C2 is the only place they enter), and the window
+// is linear, so one convolution of X^2 + Y^2 replaces the two of X^2 and Y^2: a fifth fewer taps in both passes and a fifth less LDS.
+__device__ __forceinline__ void hconv4(const float (*sA)[PA], const float (*sB)[PA], float (*sC)[SY][PC]) {
+    constexpr float w[11] = GSX_SSIM_TAPS;
+    for (int it = threadIdx.x; it < SY * (TX / 4); it += NT) {
+        const int r = it % SY, x0 = (it / SY) * 4;
+        float X[14], Y[14], SQ[14], XY[14];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) {
+            X[k] = sA[r][x0 + k];
+            Y[k] = sB[r][x0 + k];
+            SQ[k] = fmaf(X[k], X[k], Y[k] * Y[k]); XY[k] = X[k] * Y[k];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                a0 = fmaf(w[k], X[j + k], a0);
+                a1 = fmaf(w[k], Y[j + k], a1);
+                a2 = fmaf(w[k], SQ[j + k], a2);
+                a3 = fmaf(w[k], XY[j + k], a3);
+            }
+            sC[0][r][x0 + j] = a0;
+            sC[1][r][x0 + j] = a1;
+            sC[2][r][x0 + j] = a2;
+            sC[3][r][x0 + j] = a3;
+        }
+    }
+}
+
 // horizontal pass, 3 already-formed quantities
 __device__ __forceinline__ void hconv3(const float (*sD)[SY][PA], float (*sC)[SY][PC]) {
     constexpr float w[11] = GSX_SSIM_TAPS;
@@ -125,6 +157,21 @@ __device__ __forceinline__ void ssim_point(const float (&o)[5], float C1, float 
     const float rA = 1.f / A, rB = 1.f / B, rAB = rA * rB;
     val = Cn * Dn * rAB;
     const float t = (mu1 * 2.f) * val;          // mu1 2 Cn Dn / (A B)
+    d_mu1 = (mu2 * 2.f) * (Dn - Cn) * rAB - t * rA + t * rB;
+    d_s1 = -val * rB;
+    d_s12 = (2.f * Cn) * rAB;
+}
+
+// the same from the four moments of hconv4: o = (mu1, mu2, E[x^2 + y^2], E[xy])
+__device__ __forceinline__ void ssim_point4(const float (&o)[4], float C1, float C2, float& val, float& d_mu1, float& d_s1, float& d_s12) {
+    const float mu1 = o[0], mu2 = o[1];
+    const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2;
+    const float s_sum = (o[2] - mu1_sq) - mu2_sq, s12 = o[3] - mu1 * mu2;   // sigma1^2 + sigma2^2, sigma12
+    const float A = mu1_sq + mu2_sq + C1, B = s_sum + C2;
+    const float Cn = 2.f * mu1 * mu2 + C1, Dn = 2.f * s12 + C2;
+    const float rA = 1.f / A, rB = 1.f / B, rAB = rA * rB;
+    val = Cn * Dn * rAB;
+    const float t = (mu1 * 2.f) * val;
     d_mu1 = (mu2 * 2.f) * (Dn - Cn) * rAB - t * rA + t * rB;
     d_s1 = -val * rB;
     d_s12 = (2.f * Cn) * rAB;
@@ -221,7 +268,7 @@ __global__ __launch_bounds__(NT, 4) void loss_fwd_kernel(int H, int W, float cha
                                                       const float* __restrict__ gt, float* __restrict__ maps,
                                                       float2* __restrict__ block_sums) {
     __shared__ float sA[SY][PA], sB[SY][PA];
-    __shared__ float sC[5][SY][PC];
+    __shared__ float sC[4][SY][PC];
     __shared__ float2 s_red[NT / 64];
     const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY;
     const int x = threadIdx.x & 63, y0 = (threadIdx.x >> 6) * 4;
@@ -244,16 +291,16 @@ __global__ __launch_bounds__(NT, 4) void loss_fwd_kernel(int H, int W, float cha
         float adiff[4];  // |X - Y| of this thread's pixels, read before the planes are restaged for the next channel
 #pragma unroll
         for (int j = 0; j < 4; ++j) adiff[j] = fabsf(sA[y0 + j + HALO][x + HALO] - sB[y0 + j + HALO][x + HALO]);
-        hconv5(sA, sB, sC);
+        hconv4(sA, sB, sC);
         __syncthreads();
-        float o[4][5];
-        vconv<5>(sC, x, y0, o);
+        float o[4][4];
+        vconv<4>(sC, x, y0, o);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int gx = tx0 + x, gy = ty0 + y0 + j;
             if (gx < W && gy < H) {
                 float val, d0, d1, d2;
-                ssim_point(o[j], C1, C2, val, d0, d1, d2);
+                ssim_point4(o[j], C1, C2, val, d0, d1, d2);
                 const bool valid = gx >= crop && gx < W - crop && gy >= crop && gy < H - crop;
                 const float ch = valid ? chain : 0.f;
                 const size_t idx = plane + (size_t)gy * W + gx;
