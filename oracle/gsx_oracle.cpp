@@ -15,6 +15,9 @@
 //     on an MI355X by tests/golden/gen_ref_hip_golden.py; fixtures tests/golden/ref_hip/*.npz, checked in the CPU suite
 //     by tests/test_oracle_ref_hip_golden.py (and live on the GPU by tests/test_gpu_reference_hip.py).  The reference
 //     holds no vectors of its own for these stages.
+//   * the training-side restatements (fused Adam, L1 + fused SSIM loss, relocation / add_noise) are compared on the GPU with the
+//     reference's own kernels as well (oracle/_ref/gsplat_ref_train.so, gsplat_ref_hip.so: tests/test_gpu_reference_train.py checks the
+//     HIP kernels against them; tests/test_adam.py, test_loss.py, test_mcmc_ops.py check the HIP kernels against this oracle).
 //
 // Every function cites the reference file:line it follows.  All functions are templated on the
 // scalar type: the `_f32` entry points follow the reference's fp32 operation order, the `_f64`
