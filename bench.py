@@ -77,9 +77,11 @@ class OpTimer:
                       "intersect_offset", "rasterize_to_pixels_from_world_3dgs_fwd", "rasterize_to_pixels_from_world_3dgs_bwd",
                       "sh_colors_fwd", "sh_colors_bwd", "sh_colors_bwd_adam", "splat_activations_fwd", "splat_activations_projection_ut", "splat_activations_bwd",
                       "photometric_loss_fwd", "photometric_loss_bwd", "intersect_tile_binned", "adam_step", "adam_step_split", "adam_step_multi",
-                      "frontend_fused", "rasterize_fwd_packed"]
-        # the blend forward on records the front end already packed is the same operator: one row in the table
-        self.alias = {"rasterize_fwd_packed": "rasterize_to_pixels_from_world_3dgs_fwd"}
+                      "frontend_fused", "rasterize_fwd_packed", "intersect_tile_binned_guarded"]
+        # the blend forward on records the front end already packed is the same operator: one row in the table; so is the binned
+        # intersection under the guarded protocol (the same kernels; the exact protocol's row additionally contains the host's wait for n_isects)
+        self.alias = {"rasterize_fwd_packed": "rasterize_to_pixels_from_world_3dgs_fwd", "intersect_tile_binned_guarded": "intersect_tile_binned"}
+        self.host_delay_us = 0.0   # --host-delay-us: busy-wait after every intersection call (a slow / busy host between the count and the blend launch)
         self.orig = {n: getattr(ops_mod, n) for n in self.names}
         self.events = {n: [] for n in self.names}
         self.enabled = False
@@ -92,6 +94,12 @@ class OpTimer:
         key = self.alias.get(name, name)
 
         def wrapped(*a, **k):
+            if self.host_delay_us > 0.0 and key == "intersect_tile_binned":
+                r = fn(*a, **k)
+                t_end = time.perf_counter() + self.host_delay_us * 1e-6
+                while time.perf_counter() < t_end:
+                    pass
+                return r
             if not self.enabled or (self.only is not None and key not in self.only):
                 return fn(*a, **k)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -232,6 +240,10 @@ def main():
     ap.add_argument("--no-order-ablation", action="store_true", help="skip the extra leg that times the other memory order (N = 1 only)")
     ap.add_argument("--repeats", type=int, default=1, help="R > 1: time R x K steps and report the MEDIAN K-step time (sub-3 %% claims need it; "
                                                            "the contract's single K-step region is R = 1)")
+    ap.add_argument("--exact-lists", action="store_true", help="the reference's protocol: the host reads n_isects inside intersect_tile every iteration (one "
+                                                               "stream-draining sync per step; default: guarded lists, include/gsx.h — no host read on the render path)")
+    ap.add_argument("--host-delay-us", type=float, default=0.0, help="A/B tool: busy-wait this long on the host after every intersection call (what a slower or "
+                                                                     "busier host adds between reading n_isects and launching the blend; disables the per-op table)")
     ap.add_argument("--launch-check", action="store_true", help="initialise the process group, report rank / world / backend and exit "
                                                                 "(tests the N > 1 launch logic without touching a GPU)")
     args = ap.parse_args()
@@ -298,8 +310,12 @@ def main():
     # fused SH backward + Adam: with the dense exchanges (all-reduce variants / sharded Adam) the SH gradient has to exist as a tensor
     sh_adam_ok = not args.unfused_adam and not args.unfused and sharded is None and (world == 1 or color_xch)
     timer = OpTimer(ops)
+    timer.host_delay_us = args.host_delay_us
     sinks = bucket.sinks(tuple(names))
-    counter = {"i": 0, "isects": []}
+    counter = {"i": 0, "isects": [], "repeated": 0}
+    guarded = not (args.exact_lists or args.unfused)
+    if guarded and world > 1:   # a frame that overflowed on any rank is repeated on every rank (host-side agreement over gloo)
+        sinks["_lists_agree"] = gdist.ListsAgreement()
     xch = None
     if color_xch:
         xch = gdist.ColorGradExchange(bucket, names)
@@ -315,20 +331,29 @@ def main():
         cam = cams[(i * world + rank) % len(cams)]  # every step, every rank: another camera
         # the SH tensor's Adam step rides on the SH backward (no 192 MB gradient round trip); the other groups are stepped below
         fused_sh = with_adam and sh_adam_ok
-        sinks["_sh_adam"] = opt.begin_fused_sh_step(1001 + i) if fused_sh else None
-        fused_sh = sinks["_sh_adam"] is not None
         if xch is not None:   # the step's whole camera batch, in rank order (every rank knows the schedule)
             xch.begin_step(torch.stack([cams[(i * world + r) % len(cams)].viewmat for r in range(world)]))
-        # fused glue: gradients are written straight into the flat bucket (no zero fill, no AccumulateGrad adds)
-        if args.unfused:
-            bucket.zero_()
-            out = rasterizer.rasterize(cam, model, bg)
-        else:
-            out = rasterizer.rasterize_fused(cam, model, bg, grad_sinks=sinks)
-        # the reference's photometric loss (trainer.cpp:103-127): 0.8 L1 + 0.2 (1 - SSIM), fused on the blend's own layout
         target = targets[i % len(targets)]
-        loss = gloss.photometric_loss(out.render_hwc, target, 0.2) if fused_loss else (out.image - target).abs().mean()
-        gloss.backward(loss)
+        for attempt in range(4):
+            sinks["_sh_adam"] = opt.begin_fused_sh_step(1001 + i) if fused_sh else None
+            fused_sh = sinks["_sh_adam"] is not None
+            # fused glue: gradients are written straight into the flat bucket (no zero fill, no AccumulateGrad adds)
+            if args.unfused:
+                bucket.zero_()
+                out = rasterizer.rasterize(cam, model, bg)
+            else:
+                # guarded lists (default): no host read of n_isects; an iteration whose lists outgrew their capacity stops in backward()
+                # before the SH tensor's Adam step / the gradient exchange and is repeated (counted: config.iterations_repeated)
+                out = rasterizer.rasterize_fused(cam, model, bg, grad_sinks=sinks, guarded=guarded)
+            # the reference's photometric loss (trainer.cpp:103-127): 0.8 L1 + 0.2 (1 - SSIM), fused on the blend's own layout
+            loss = gloss.photometric_loss(out.render_hwc, target, 0.2) if fused_loss else (out.image - target).abs().mean()
+            try:
+                gloss.backward(loss)
+                break
+            except rasterizer.IsectCapacityMiss:
+                counter["repeated"] += 1
+                if attempt == 3:
+                    raise
         if sharded is not None and with_adam:
             sharded.step(1001 + i)  # reduce-scatter -> Adam on this rank's rows -> all-gather of the updated parameters
         else:
@@ -379,7 +404,9 @@ def main():
         step(True)
     torch.cuda.synchronize()
     ops.shim_stats(True)
+    ops.shim_guarded_stats(True)
     counter["isects"] = []
+    counter["repeated"] = 0
     # Only the two blend ops (the roofline kernels) are bracketed with HIP events inside the timed region — each event record opens
     # a ~5 us bubble on the stream, 24 ops x 2 events would cost ~0.1 ms per step.  The per-op table of the other ops is measured
     # in a separate pass after the timed region.
@@ -389,6 +416,8 @@ def main():
     elapsed = sorted(elapsed_all)[len(elapsed_all) // 2]   # R = 1: the contract's single region; R > 1: the median region
     timer.enabled = False
     host_syncs, binned_calls, hint_misses, hint_cold = ops.shim_stats(True)
+    guarded_calls, guarded_waits, guarded_misses = ops.shim_guarded_stats(True)
+    repeated_timed = counter["repeated"]
     isects_timed = list(counter["isects"])
     blend_ms = timer.mean_ms()
     timer.reset()
@@ -454,6 +483,9 @@ def main():
             "unit": "iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            # sum of the per-operator HIP-event times of one iteration (the blend ops inside the timed region, the others in the per-op pass):
+            # ms_per_step above this = time the GPU spent between kernels (launch gaps, host-boundness)
+            "gpu_ms_per_step": round(sum(v["ms"] for v in kernels.values()), 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "n_gaussians": N, "width": W, "height": H, "sh_degree": deg,
@@ -468,6 +500,11 @@ def main():
                        "grad_exchange_bytes": int(getattr(bucket, "last_reduced_bytes", 0)) if world > 1 else 0,
                        "grad_bucket_bytes": bucket.nbytes(),
                        "host_syncs_per_step": round(host_syncs / (args.steps * len(elapsed_all)), 2),
+                       "intersect_protocol": ("guarded lists (include/gsx.h): the host never reads n_isects on the render path; it confirms the count inside "
+                                              "backward() with the forward, the loss and the blend backward queued behind it" if guarded else
+                                              "exact: the host reads n_isects inside intersect_tile (one stream-draining sync per iteration, as upstream Intersect.cpp:76)"),
+                       "guarded_confirms_that_waited_per_step": round(guarded_waits / (args.steps * len(elapsed_all)), 2),
+                       "iterations_repeated": int(repeated_timed), "host_delay_us": args.host_delay_us,
                        "intersect_hint_misses": int(hint_misses), "intersect_cold_calls": int(hint_cold)},
             "repeats": {"R": len(elapsed_all), "ms_per_step_each": [round(e / args.steps * 1e3, 4) for e in elapsed_all], "reported": "median"},
             "gaussians_x_pixels_per_s": round(world * N * P / (elapsed / args.steps), 1),
@@ -509,9 +546,15 @@ def main():
             def step2(i):
                 cam = cams[i % len(cams)]
                 s2["_sh_adam"] = o2pt.begin_fused_sh_step(1001 + i) if sh_adam_ok else None
-                out2 = rasterizer.rasterize_fused(cam, m2, bg, grad_sinks=s2)
-                l2 = gloss.photometric_loss(out2.render_hwc, targets[i % len(targets)], 0.2) if fused_loss else (out2.image - targets[i % len(targets)]).abs().mean()
-                l2.backward()
+                for attempt in range(4):
+                    out2 = rasterizer.rasterize_fused(cam, m2, bg, grad_sinks=s2, guarded=guarded)
+                    l2 = gloss.photometric_loss(out2.render_hwc, targets[i % len(targets)], 0.2) if fused_loss else (out2.image - targets[i % len(targets)]).abs().mean()
+                    try:
+                        l2.backward()
+                        break
+                    except rasterizer.IsectCapacityMiss:
+                        if attempt == 3:
+                            raise
                 o2pt.step(1001 + i, skip_sh=s2["_sh_adam"] is not None)
             for i in range(args.warmup):
                 step2(i)

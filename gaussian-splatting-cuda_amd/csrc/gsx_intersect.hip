@@ -860,7 +860,8 @@ __global__ __launch_bounds__(ISECT_BLOCK) void ranked_finalize_kernel(int64_t ca
 // exclusive scan of n counters by one 1024-thread block (n = C*tiles + 1: a few thousand entries; the generic device scan
 // costs three launches for them).  out[i] = sum(in[0..i)), in[n-1] is ignored and out[n-1] = grand total.
 __global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t n, const uint32_t* __restrict__ in, int32_t* __restrict__ out,
-                                                        uint32_t* __restrict__ max_count) {
+                                                        uint32_t* __restrict__ max_count, int64_t capacity, int64_t seg_bound,
+                                                        int32_t* __restrict__ lists_status) {
     // exclusive scan of n - 1 counts, out[n - 1] = total.  Runs in 64 bits: a frame with more than 2^31 - 1 intersections does not
     // wrap silently — every offset saturates at INT32_MAX and the total is written as -1, which both consumers reject (the fill's
     // n_isects guard in the C ABI, the shim's TORCH_CHECK): such a scene needs the device-wide sort's int64 scan.
@@ -903,6 +904,13 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t n, const uint32
         atomicMax(&s_max, my_max);
         __syncthreads();
         if (threadIdx.x == 0) *max_count = s_max;
+    }
+    // Guarded protocol (gsx_intersect_bin_count_guarded): the consumers of the lists learn ON THE DEVICE whether the fill that was launched
+    // with `capacity` slots and merge passes for segments up to `seg_bound` keys produced complete lists: *lists_status = the total, or -1.
+    if (lists_status != nullptr && threadIdx.x == 0) {   // (s_carry and s_max are final: written before the barriers above)
+        const unsigned long long total = s_carry;
+        const bool ok = total <= (unsigned long long)capacity && (seg_bound <= 0 || (int64_t)s_max <= seg_bound);
+        *lists_status = ok ? (int32_t)total : -1;
     }
 }
 
@@ -1065,6 +1073,14 @@ extern "C" size_t gsx_intersect_bin_count_workspace_bytes(uint32_t C, uint32_t t
 extern "C" int gsx_intersect_bin_count(uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, uint32_t tile_size,
                                        uint32_t tile_width, uint32_t tile_height, int32_t* tiles_per_gauss, int32_t* tile_offsets,
                                        int64_t* n_isects_host_pinned, void* workspace, size_t workspace_bytes, void* stream) {
+    return gsx_intersect_bin_count_guarded(C, N, means2d, radii, tile_size, tile_width, tile_height, tiles_per_gauss, tile_offsets,
+                                           n_isects_host_pinned, workspace, workspace_bytes, 0, 0, nullptr, stream);
+}
+
+extern "C" int gsx_intersect_bin_count_guarded(uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, uint32_t tile_size,
+                                               uint32_t tile_width, uint32_t tile_height, int32_t* tiles_per_gauss, int32_t* tile_offsets,
+                                               int64_t* n_isects_host_pinned, void* workspace, size_t workspace_bytes, int64_t capacity,
+                                               int64_t max_segment, int32_t* lists_status, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const uint64_t total64 = (uint64_t)C * N;
     if (total64 > 0x7FFFFFFFull) { set_error("intersect_bin_count: C*N must fit int32 (flatten ids are int32)"); return GSX_ERR_INVALID_ARGUMENT; }
@@ -1078,6 +1094,7 @@ extern "C" int gsx_intersect_bin_count(uint32_t C, uint32_t N, const float* mean
     }
     if (nseg == 0 || N == 0) {
         (void)hipMemsetAsync(tile_offsets, 0, (size_t)(nseg + 1) * 4, st);
+        if (lists_status) (void)hipMemsetAsync(lists_status, 0, 4, st);   // complete (empty) lists
         if (n_isects_host_pinned) *n_isects_host_pinned = 0;
         return check_launch("intersect_bin_count(empty)");
     }
@@ -1092,7 +1109,8 @@ extern "C" int gsx_intersect_bin_count(uint32_t C, uint32_t N, const float* mean
     // offsets[t] = intersections before (camera, tile) t; offsets[nseg] = n_isects
     // (the largest segment lands in the slack word behind the counts; it travels to the host in the upper half of the pinned word)
     uint32_t* max_count = (uint32_t*)((char*)workspace + bin_hist_bytes(C, n_tiles) + align_up((size_t)(nseg + 1) * 4, 256));
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, nseg + 1, (const uint32_t*)counts, tile_offsets, max_count);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, nseg + 1, (const uint32_t*)counts, tile_offsets, max_count, capacity, max_segment,
+                       lists_status);
     if (n_isects_host_pinned) {
         *n_isects_host_pinned = 0;  // low 32 bits: n_isects (-1 = more than 2^31 - 1), high 32 bits: keys of the largest (camera, tile) segment
         (void)hipMemcpyAsync(n_isects_host_pinned, tile_offsets + nseg, 4, hipMemcpyDeviceToHost, st);

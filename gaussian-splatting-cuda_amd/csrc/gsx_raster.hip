@@ -179,7 +179,9 @@ __global__ __launch_bounds__(RB) void raster_fwd_kernel(RasterArgs a, float* __r
 
     const int32_t* toff = a.tile_offsets + (size_t)cid * a.th * a.tw;
     const int32_t range_start = toff[tile_id];
-    const int32_t range_end = (cid == a.C - 1 && tile_id == a.tw * a.th - 1) ? (int32_t)a.n_isects : toff[tile_id + 1];
+    bool lists_ok;
+    const int32_t lists_end = lists_total(a, lists_ok);
+    const int32_t range_end = !lists_ok ? range_start : ((cid == a.C - 1 && tile_id == a.tw * a.th - 1) ? lists_end : toff[tile_id + 1]);
     const int32_t n_chunks = (range_end - range_start + RB - 1) / RB;
 
     float T = 1.f;
@@ -277,7 +279,9 @@ __global__ __launch_bounds__(RB) void raster_bwd_kernel(RasterArgs a, const floa
 
     const int32_t* toff = a.tile_offsets + (size_t)cid * a.th * a.tw;
     const int32_t range_start = toff[tile_id];
-    const int32_t range_end = (cid == a.C - 1 && tile_id == a.tw * a.th - 1) ? (int32_t)a.n_isects : toff[tile_id + 1];
+    bool lists_ok;
+    const int32_t lists_end = lists_total(a, lists_ok);
+    const int32_t range_end = !lists_ok ? range_start : ((cid == a.C - 1 && tile_id == a.tw * a.th - 1) ? lists_end : toff[tile_id + 1]);
 
     const float T_final = 1.f - render_alphas[pix];
     float T = T_final;
@@ -522,6 +526,8 @@ static int fill_args(RasterArgs& a, uint32_t N, int64_t n_isects, const float* m
     a.tile_offsets = tile_offsets; a.flatten_ids = flatten_ids;
     a.packed = nullptr;
     a.tile_flags = nullptr;
+    a.lists_status = nullptr;
+    a.n_isects_expected = n_isects;
     return GSX_OK;
 }
 
@@ -557,11 +563,24 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_fwd_packed(
     uint32_t image_height, uint32_t tile_size, const gsx_cameras* cams, const gsx_ut_params* ut,
     const int32_t* tile_offsets, const int32_t* flatten_ids, float* renders, float* alphas, int32_t* last_ids,
     void* workspace, size_t workspace_bytes, int records_ready, void* stream) {
+    return gsx_rasterize_to_pixels_from_world_3dgs_fwd_guarded(N, n_isects, means, quats, scales, colors, channels, opacities, backgrounds, masks,
+                                                               image_width, image_height, tile_size, cams, ut, tile_offsets, flatten_ids, renders,
+                                                               alphas, last_ids, workspace, workspace_bytes, records_ready, nullptr, n_isects, stream);
+}
+
+extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_fwd_guarded(
+    uint32_t N, int64_t n_isects, const float* means, const float* quats, const float* scales, const float* colors,
+    uint32_t channels, const float* opacities, const float* backgrounds, const uint8_t* masks, uint32_t image_width,
+    uint32_t image_height, uint32_t tile_size, const gsx_cameras* cams, const gsx_ut_params* ut,
+    const int32_t* tile_offsets, const int32_t* flatten_ids, float* renders, float* alphas, int32_t* last_ids,
+    void* workspace, size_t workspace_bytes, int records_ready, const int32_t* lists_status, int64_t n_isects_expected, void* stream) {
     (void)ut;
     RasterArgs a;
     int rc = fill_args(a, N, n_isects, means, quats, scales, colors, channels, opacities, backgrounds, masks, image_width,
                        image_height, tile_size, cams, tile_offsets, flatten_ids, "fwd");
     if (rc != GSX_OK) return rc;
+    a.lists_status = lists_status;
+    if (lists_status != nullptr && n_isects_expected > 0) a.n_isects_expected = n_isects_expected;
     if (!renders || !alphas || !last_ids) { set_error("rasterize fwd: null output"); return GSX_ERR_INVALID_ARGUMENT; }
     if (a.C == 0 || image_width == 0 || image_height == 0) return GSX_OK;
     const dim3 grid(a.tw, a.th, a.C), block(RB);
@@ -618,11 +637,26 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd_packed(
     const int32_t* tile_offsets, const int32_t* flatten_ids, const float* render_alphas, const int32_t* last_ids,
     const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats, float* v_scales,
     float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes, const void* packed_records, void* stream) {
+    return gsx_rasterize_to_pixels_from_world_3dgs_bwd_guarded(N, n_isects, means, quats, scales, colors, channels, opacities, backgrounds, masks,
+                                                               image_width, image_height, tile_size, cams, ut, tile_offsets, flatten_ids,
+                                                               render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales,
+                                                               v_colors, v_opacities, workspace, workspace_bytes, packed_records, nullptr, stream);
+}
+
+extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd_guarded(
+    uint32_t N, int64_t n_isects, const float* means, const float* quats, const float* scales, const float* colors,
+    uint32_t channels, const float* opacities, const float* backgrounds, const uint8_t* masks, uint32_t image_width,
+    uint32_t image_height, uint32_t tile_size, const gsx_cameras* cams, const gsx_ut_params* ut,
+    const int32_t* tile_offsets, const int32_t* flatten_ids, const float* render_alphas, const int32_t* last_ids,
+    const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats, float* v_scales,
+    float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes, const void* packed_records,
+    const int32_t* lists_status, void* stream) {
     (void)ut;
     RasterArgs a;
     int rc = fill_args(a, N, n_isects, means, quats, scales, colors, channels, opacities, backgrounds, masks, image_width,
                        image_height, tile_size, cams, tile_offsets, flatten_ids, "bwd");
     if (rc != GSX_OK) return rc;
+    a.lists_status = lists_status;
     if (!render_alphas || !last_ids || !v_render_colors || !v_means || !v_quats || !v_scales || !v_colors || !v_opacities) {
         set_error("rasterize bwd: null pointer");
         return GSX_ERR_INVALID_ARGUMENT;

@@ -29,7 +29,22 @@ struct RasterArgs {
     // fisheye fast path only: per-(camera, tile) flag "some Gaussian of this tile's list has no usable (u0, v0) chart (it sits at or
     // beyond ~83 degrees off the optical axis)": the fast kernels skip flagged tiles, the generic kernels then run ONLY those
     const uint8_t* tile_flags;
+    // Guarded lists (gsx_intersect_bin_count_guarded): `n_isects` is then only the CAPACITY of flatten_ids and *lists_status holds the
+    // frame's true total — or -1 when the total (or the largest segment) outgrew what the optimistic fill was launched with.  The last
+    // list ends at the total; an overflowed frame has EMPTY lists (background image, zero gradients: nothing unwritten is ever read)
+    // and the host, which reads the same verdict later, renders it again.  nullptr = `n_isects` is exact (the reference's protocol).
+    const int32_t* lists_status;
+    int64_t n_isects_expected;   // list-density estimate for launch decisions (kernel variants); = n_isects when exact
 };
+
+// end of the LAST list of the frame (every other list ends where the next one starts); `ok` = false: overflowed frame, all lists empty
+GSX_DEV int32_t lists_total(const RasterArgs& a, bool& ok) {
+    ok = true;
+    if (a.lists_status == nullptr) return (int32_t)a.n_isects;
+    const int32_t tot = *a.lists_status;   // wave-uniform address: one scalar load
+    ok = tot >= 0;
+    return tot;
+}
 
 constexpr size_t FAST_FLAG_BYTES = 262144;  // capacity of the tile-flag plane (C * tiles); larger grids take the generic kernels
 
@@ -39,8 +54,11 @@ constexpr size_t FAST_FLAG_BYTES = 262144;  // capacity of the tile-flag plane (
 GSX_DEV void tile_list_range(const RasterArgs& a, uint32_t cid, uint32_t tile_x, uint32_t tile_y, int32_t& start, int32_t& end) {
     const uint32_t lt = (tile_y >> a.lshift) * a.ltw + (tile_x >> a.lshift), n_lt = a.ltw * a.lth;
     const int32_t* toff = a.tile_offsets + (size_t)cid * n_lt;
+    bool ok;
+    const int32_t total = lists_total(a, ok);
     start = toff[lt];
-    end = (cid == a.C - 1 && lt == n_lt - 1) ? (int32_t)a.n_isects : toff[lt + 1];
+    end = (cid == a.C - 1 && lt == n_lt - 1) ? total : toff[lt + 1];
+    if (!ok) end = start;
 }
 GSX_DEV int32_t tile_record_slot(const RasterArgs& a, int32_t isect, uint32_t tile_x, uint32_t tile_y) {
     return a.lshift ? (isect << 2) | (int32_t)(((tile_y & 1u) << 1) | (tile_x & 1u)) : isect;

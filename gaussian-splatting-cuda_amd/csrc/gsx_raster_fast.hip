@@ -97,7 +97,9 @@ __global__ __launch_bounds__(256) void tile_flag_kernel(RasterArgs a, const uint
     const uint32_t n_tiles = a.tw * a.th, t = blockIdx.x * 4u + (threadIdx.x >> 6), cid = blockIdx.y, lane = threadIdx.x & 63u;
     if (t >= n_tiles) return;
     const int32_t* toff = a.tile_offsets + (size_t)cid * n_tiles;
-    const int32_t lo = toff[t], hi = (cid == a.C - 1 && t == n_tiles - 1) ? (int32_t)a.n_isects : toff[t + 1];
+    bool lists_ok;
+    const int32_t total = lists_total(a, lists_ok);
+    const int32_t lo = toff[t], hi = !lists_ok ? lo : ((cid == a.C - 1 && t == n_tiles - 1) ? total : toff[t + 1]);
     bool any = false;
     for (int32_t i = lo + (int32_t)lane; i < hi; i += 64) any = any || bad[a.flatten_ids[i]] != 0;
     const unsigned long long m = __builtin_amdgcn_ballot_w64(any);
@@ -625,7 +627,7 @@ const uint8_t* launch_raster_fwd_fast(int kind, RasterArgs a, float* renders, fl
     // 0.265; S-5M @4K (5.3 tiles) -5 .. +7 %, a saturated scene (5.9) +3 %, large footprints with 32-pixel lists +18 % (every block sees
     // nearly every survivor and the four block tests per candidate are pure cost).  Rule: 16-pixel lists and at most 4.5 intersections
     // per (camera, Gaussian) on average; GSX_FWD=quad|wave forces one (tests, A/B tools; read per launch).
-    bool quad = a.lshift == 0u && 2 * a.n_isects <= 9 * (int64_t)a.C * (int64_t)a.N;
+    bool quad = a.lshift == 0u && 2 * a.n_isects_expected <= 9 * (int64_t)a.C * (int64_t)a.N;
     if (const char* e = test_switch("GSX_FWD")) quad = std::string(e) == "quad" ? true : (std::string(e) == "wave" ? false : quad);
 #define GSX_BLEND_FWD(KERNEL)                                                                                                            \
     do {                                                                                                                                 \

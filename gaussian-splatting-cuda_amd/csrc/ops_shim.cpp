@@ -92,8 +92,87 @@ static thread_local const at::Tensor* g_fwd_ws_in = nullptr;
 static thread_local const at::Tensor* g_fwd_ws_ready = nullptr;
 
 // counters for bench.py (host synchronisations and capacity-hint outcomes of intersect_tile); never read by the ops themselves
-struct ShimStats { std::atomic<int64_t> host_syncs{0}, binned_calls{0}, hint_misses{0}, hint_cold{0}, ranked_calls{0}; };
+struct ShimStats { std::atomic<int64_t> host_syncs{0}, binned_calls{0}, hint_misses{0}, hint_cold{0}, ranked_calls{0}, guarded_calls{0}, guarded_waits{0}, guarded_misses{0}; };
 static ShimStats g_stats;
+
+
+// ---- capacity hints of the binned intersection -------------------------------------------------------------------------------
+// The ONLY state the shim keeps between calls: a process-wide map {(device, C, N, tile grid) -> recent maxima of n_isects and of the
+// largest tile segment}, mutex protected, decaying slowly so that one outlier view does not pin memory for ever.  It never changes a
+// result: it sizes the optimistic fill (exact protocol: outputs narrowed / fill repeated on a miss; guarded protocol: the frame is
+// rendered again on a miss).  A model that grows (densification changes N every few hundred iterations) would start cold after every
+// resize: the entry with N = 0 holds the last call of the same (device, C, tile grid) at any N and stands in, scaled by the ratio of
+// the Gaussian counts.
+using HintKey = std::tuple<int, uint32_t, uint32_t, uint32_t, uint32_t>;
+static std::mutex g_hint_mutex;
+static std::map<HintKey, std::pair<int64_t, int64_t>> g_hints;   // (n_isects, largest segment)
+static std::map<HintKey, std::pair<int64_t, int64_t>> g_last;    // the last confirmed frame of the shape, undecayed (launch decisions)
+static std::map<HintKey, uint32_t> g_hint_last_n;
+
+static HintKey hint_key_any(const HintKey& k) { return std::make_tuple(std::get<0>(k), std::get<1>(k), 0u, std::get<3>(k), std::get<4>(k)); }
+
+static void hint_lookup(const HintKey& key, int64_t& hint, int64_t& hint_seg, int64_t* last_total = nullptr) {
+    std::lock_guard<std::mutex> lock(g_hint_mutex);
+    const HintKey any = hint_key_any(key);
+    auto it = g_hints.find(key);
+    hint = hint_seg = 0;
+    if (it != g_hints.end()) {
+        hint = it->second.first; hint_seg = it->second.second;
+    } else if ((it = g_hints.find(any)) != g_hints.end() && g_hint_last_n[any] > 0) {
+        const double grow = std::min(2.0, std::max(1.0, (double)std::get<2>(key) / (double)g_hint_last_n[any]));
+        hint = (int64_t)((double)it->second.first * grow); hint_seg = (int64_t)((double)it->second.second * grow);
+    }
+    if (last_total) {
+        auto lt = g_last.find(key);
+        *last_total = lt != g_last.end() ? lt->second.first : hint;
+    }
+}
+
+static void hint_update(const HintKey& key, int64_t n_isects, int64_t max_seg) {
+    std::lock_guard<std::mutex> lock(g_hint_mutex);
+    if (g_hints.size() > 4096) { g_hints.clear(); g_last.clear(); }   // (a long run that resizes thousands of times: start over rather than grow without bound)
+    auto& h = g_hints[key];
+    h.first = std::max<int64_t>(n_isects, h.first - h.first / 128);  // running maximum with a slow decay
+    h.second = std::max<int64_t>(max_seg, h.second - h.second / 128);
+    const HintKey any = hint_key_any(key);
+    g_hints[any] = std::make_pair(n_isects, max_seg);
+    g_last[key] = std::make_pair(n_isects, max_seg);
+    g_hint_last_n[any] = std::get<2>(key);
+}
+
+
+// Handle of one guarded intersection (include/gsx.h "guarded lists"): the lists were filled optimistically into `capacity` slots and the
+// blend kernels read the verdict from `status` on the device; the host reads the same verdict here, whenever it likes, and must do so
+// (confirm) before it applies anything irreversible to a frame rendered from these lists.  confirm() waits for the 8-byte word the count
+// copied to pinned memory — by then hundreds of microseconds of queued kernels sit behind that copy, so the wait does not drain the stream —
+// and feeds the capacity hints.
+struct IsectLists {
+    at::Tensor n_host;    // pinned: n_isects | largest segment << 32
+    at::Tensor status;    // device int32 [1]: n_isects, or -1 = lists incomplete (frame renders empty); undefined = exact lists (cold call)
+    std::shared_ptr<at::cuda::CUDAEvent> ready;
+    HintKey key;
+    int64_t capacity = 0, seg_bound = 0, expected = 0;
+    bool ranked = false, confirmed = false, complete = true;
+    int64_t n_isects = 0, max_seg = 0;
+
+    bool is_ready() const { return confirmed || ready->query(); }
+    std::tuple<int64_t, int64_t, bool> confirm() {
+        if (!confirmed) {
+            if (!ready->query()) g_stats.guarded_waits++;   // the host got here before the GPU passed the count
+            ready->synchronize();
+            const uint64_t word = (uint64_t)n_host.data_ptr<int64_t>()[0];
+            n_isects = (int64_t)(word & 0xFFFFFFFFull); max_seg = (int64_t)(word >> 32);
+            TORCH_CHECK(n_isects <= 0x7FFFFFFFll, "intersect_tile: more than 2^31 - 1 intersections (tile offsets are int32, as upstream's isect_offsets)");
+            hint_update(key, n_isects, max_seg);
+            complete = n_isects <= capacity && (ranked || max_seg <= seg_bound);
+            if (!complete) { g_stats.hint_misses++; g_stats.guarded_misses++; }
+            confirmed = true;
+        }
+        return std::make_tuple(n_isects, max_seg, complete);
+    }
+};
+// side channel of the fused render path: the blend ops called next take their lists guarded by this handle (set by the Python bindings)
+static thread_local const IsectLists* g_lists = nullptr;
 
 namespace gsx_ext {
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned(const at::Tensor means2d, const at::Tensor radii,
@@ -300,12 +379,15 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> rasterize_to_pixels_from_world_3d
     const size_t fwsb = gsx_rasterize_fwd_workspace_bytes(C, N);
     const bool ready = g_fwd_ws_ready && g_fwd_ws_ready->defined() && (size_t)g_fwd_ws_ready->numel() >= fwsb;   // packed by frontend_fused
     at::Tensor fws = ready ? *g_fwd_ws_ready : at::empty({(int64_t)fwsb}, means.options().dtype(at::kByte));
-    check(gsx_rasterize_to_pixels_from_world_3dgs_fwd_packed(
+    // guarded lists (fused render path): flatten_ids has its capacity length, the kernels read the frame's verdict from the handle's device word
+    const bool guarded = g_lists != nullptr && g_lists->status.defined();
+    check(gsx_rasterize_to_pixels_from_world_3dgs_fwd_guarded(
               N, flatten_ids.size(0), means.data_ptr<float>(), quats.data_ptr<float>(), scales.data_ptr<float>(),
               colors.data_ptr<float>(), channels, opacities.data_ptr<float>(), fptr(backgrounds), bptr(masks), image_width,
               image_height, tile_size, &cams, &ut, tile_offsets.data_ptr<int32_t>(),
               flatten_ids.numel() ? flatten_ids.data_ptr<int32_t>() : nullptr, renders.data_ptr<float>(),
-              alphas.data_ptr<float>(), last_ids.data_ptr<int32_t>(), fws.data_ptr(), (size_t)fws.numel(), ready ? 1 : 0, cur_stream()),
+              alphas.data_ptr<float>(), last_ids.data_ptr<int32_t>(), fws.data_ptr(), (size_t)fws.numel(), ready ? 1 : 0,
+              guarded ? g_lists->status.data_ptr<int32_t>() : nullptr, guarded ? g_lists->expected : 0, cur_stream()),
           "rasterize_to_pixels_from_world_3dgs_fwd");
     if (g_fwd_ws_out) *g_fwd_ws_out = fws;
     return std::make_tuple(renders, alphas, last_ids);
@@ -361,7 +443,8 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
     at::Tensor ws = at::empty({(int64_t)wsb}, means.options().dtype(at::kByte));  // caching allocator, like CUB temp storage upstream
     const void* packed = (g_fwd_ws_in && g_fwd_ws_in->defined())
                              ? gsx_rasterize_fwd_packed_records(g_fwd_ws_in->data_ptr(), (size_t)g_fwd_ws_in->numel(), C, N) : nullptr;
-    check(gsx_rasterize_to_pixels_from_world_3dgs_bwd_packed(
+    const bool guarded = g_lists != nullptr && g_lists->status.defined();
+    check(gsx_rasterize_to_pixels_from_world_3dgs_bwd_guarded(
               N, flatten_ids.size(0), means.data_ptr<float>(), quats.data_ptr<float>(), scales.data_ptr<float>(),
               colors.data_ptr<float>(), channels, opacities.data_ptr<float>(), fptr(backgrounds), bptr(masks), image_width,
               image_height, tile_size, &cams, &ut, tile_offsets.data_ptr<int32_t>(),
@@ -369,7 +452,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
               last_ids.data_ptr<int32_t>(), v_render_colors.data_ptr<float>(),
               v_render_alphas.defined() ? v_render_alphas.data_ptr<float>() : nullptr,
               v_means.data_ptr<float>(), v_quats.data_ptr<float>(), v_scales.data_ptr<float>(), v_colors.data_ptr<float>(),
-              v_opacities.data_ptr<float>(), ws.data_ptr(), wsb, packed, cur_stream()),
+              v_opacities.data_ptr<float>(), ws.data_ptr(), wsb, packed, guarded ? g_lists->status.data_ptr<int32_t>() : nullptr, cur_stream()),
           "rasterize_to_pixels_from_world_3dgs_bwd");
     return std::make_tuple(v_means, v_quats, v_scales, v_colors, v_opacities);
 }
@@ -595,10 +678,18 @@ void adam_step_split(at::Tensor param, at::Tensor exp_avg, at::Tensor exp_avg_sq
 
 // intersect_tile(sort = true) + intersect_offset through the binned pipeline: (tiles_per_gauss, isect_ids | empty, flatten_ids,
 // isect_offsets [C, tile_height, tile_width]); same values as the two reference ops.
-std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned(const at::Tensor means2d, const at::Tensor radii,
-                                                                                 const at::Tensor depths, const uint32_t C,
-                                                                                 const uint32_t tile_size, const uint32_t tile_width,
-                                                                                 const uint32_t tile_height, const bool want_isect_ids) {
+// `lists` == nullptr: the exact protocol — the op's outputs have exactly n_isects rows, so the host has to read that number (the one
+// sync of the op, as upstream: Intersect.cpp:76).  To keep the GPU busy meanwhile, the fill is launched optimistically into buffers
+// sized from the capacity hint; the host then waits only for the 8-byte copy, not for the fill, and repeats the fill if the guess was
+// too small.
+// `lists` != nullptr: the guarded protocol (include/gsx.h) — nothing blocks: flatten_ids keeps its capacity length, the verdict lands in
+// lists->status on the device and in lists->n_host on the host, lists->confirm() reads it later.  Without a hint (first call of a
+// problem shape) the exact protocol runs and the handle comes back confirmed.
+static std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned_core(const at::Tensor& means2d, const at::Tensor& radii,
+                                                                                             const at::Tensor& depths, const uint32_t C,
+                                                                                             const uint32_t tile_size, const uint32_t tile_width,
+                                                                                             const uint32_t tile_height, const bool want_isect_ids,
+                                                                                             IsectLists* lists) {
     GSX_DEVICE_GUARD(means2d);
     GSX_CHECK_INPUT(means2d); GSX_CHECK_INPUT(radii); GSX_CHECK_INPUT(depths);
     TORCH_CHECK(means2d.dim() == 3, "intersect_tile_binned: means2d must be [C,N,2]");
@@ -606,46 +697,14 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
     if (!gsx_intersect_bin_supported(tile_width, tile_height)) {  // tile grid too large for LDS counters: the device-wide sort
         auto r = gsplat::intersect_tile(means2d, radii, depths, at::nullopt, at::nullopt, C, tile_size, tile_width, tile_height, true);
         at::Tensor off = gsplat::intersect_offset(std::get<1>(r), C, tile_width, tile_height);
+        if (lists) { lists->confirmed = true; lists->n_isects = std::get<2>(r).size(0); lists->expected = lists->capacity = lists->n_isects; }
         return std::make_tuple(std::get<0>(r), want_isect_ids ? std::get<1>(r) : at::empty({0}, std::get<1>(r).options()), std::get<2>(r), off);
     }
     const uint32_t n_elements = means2d.numel() / 2, N = C ? n_elements / C : 0;
     void* st = cur_stream();
-    at::Tensor tiles_per_gauss = at::empty_like(depths, depths.options().dtype(at::kInt));
-    at::Tensor offsets = at::empty({(int64_t)C * tile_height * tile_width + 1}, depths.options().dtype(at::kInt));
-    const size_t cwb = gsx_intersect_bin_count_workspace_bytes(C, tile_width, tile_height);
-    at::Tensor cws = at::empty({(int64_t)cwb}, depths.options().dtype(at::kByte));
-    at::Tensor n_host = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
-    check(gsx_intersect_bin_count(C, N, n_elements ? means2d.data_ptr<float>() : nullptr, n_elements ? radii.data_ptr<int32_t>() : nullptr, tile_size,
-                                  tile_width, tile_height, n_elements ? tiles_per_gauss.data_ptr<int32_t>() : nullptr, offsets.data_ptr<int32_t>(),
-                                  n_host.data_ptr<int64_t>(), cws.data_ptr(), cwb, st), "intersect_tile_binned(count)");
-    // The op's outputs have exactly n_isects rows, so the host has to read that number (the one sync of the op, as upstream:
-    // Intersect.cpp:76).  To keep the GPU busy meanwhile, the fill is launched optimistically into buffers sized from a capacity
-    // hint; the host then waits only for the 4-byte copy, not for the fill.  If the guess was too small the fill is repeated with
-    // the exact size.  The hint is the ONLY state the shim keeps between calls: a process-wide map {(device, C, N, tile grid) ->
-    // recent maxima of n_isects and of the largest tile segment}, mutex protected, decaying 2 % per call so that one outlier view does not pin memory for ever.
-    // It never changes a result (the outputs are narrowed to the exact length); it only decides whether the fill runs once or twice.
-    at::cuda::CUDAEvent total_ready;
-    total_ready.record(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
-    static std::mutex hint_mutex;
-    static std::map<std::tuple<int, uint32_t, uint32_t, uint32_t, uint32_t>, std::pair<int64_t, int64_t>> hints;   // (n_isects, largest segment)
-    const auto key = std::make_tuple((int)means2d.get_device(), C, N, tile_width, tile_height);
-    // The hint also carries the largest (camera, tile) segment of the last call: it fixes how many merge passes the optimistic fill
-    // launches for segments above 16384 keys (none for most scenes).  A frame whose largest segment outgrows the bound is refilled.
-    // A model that grows (densification changes N every few hundred iterations) would start cold after every resize: the entry with
-    // N = 0 holds the last call of the same (device, C, tile grid) at any N and stands in, scaled by the ratio of the Gaussian counts.
-    const auto key_any = std::make_tuple((int)means2d.get_device(), C, 0u, tile_width, tile_height);
-    static std::map<std::tuple<int, uint32_t, uint32_t, uint32_t, uint32_t>, uint32_t> last_n;
-    int64_t hint = 0, hint_seg = 0;
-    {
-        std::lock_guard<std::mutex> lock(hint_mutex);
-        auto it = hints.find(key);
-        if (it != hints.end()) {
-            hint = it->second.first; hint_seg = it->second.second;
-        } else if ((it = hints.find(key_any)) != hints.end() && last_n[key_any] > 0) {
-            const double grow = std::min(2.0, std::max(1.0, (double)N / (double)last_n[key_any]));
-            hint = (int64_t)((double)it->second.first * grow); hint_seg = (int64_t)((double)it->second.second * grow);
-        }
-    }
+    const HintKey key = std::make_tuple((int)means2d.get_device(), C, N, tile_width, tile_height);
+    int64_t hint = 0, hint_seg = 0, last_total = 0;
+    hint_lookup(key, hint, hint_seg, &last_total);
     // Frames with heavy tiles (last call: a tile above 4096 keys and at least kRankedMeanKeys keys per tile on average) take the ranked
     // fill: one frame-wide depth ranking (~50 us), then 4-byte keys and bitmap sorts for the heavy tiles.  Same outputs bit for bit,
     // so the choice — like the capacity hint — only affects speed.  GSX_INTERSECT_FILL=ranked|keys forces one or the other.
@@ -654,6 +713,26 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
     bool ranked = hint_seg > 4096 && hint >= kRankedMeanKeys * nseg_all;
     if (const char* e = gsx_test_switch("GSX_INTERSECT_FILL")) ranked = std::strcmp(e, "ranked") == 0 ? true : (std::strcmp(e, "keys") == 0 ? false : ranked);
     ranked = ranked && n_elements && gsx_intersect_ranked_supported(C, N);
+    int64_t capacity = 0, seg_bound = 0;
+    if (hint > 0 && n_elements) {
+        capacity = std::min<int64_t>(hint + hint / 8 + 4096, 0x7FFFFFFFll);
+        seg_bound = std::max<int64_t>(hint_seg + hint_seg / 4, 16384);   // (16384: no giant-segment launches at all)
+    }
+    const bool guarded = lists != nullptr && capacity > 0;
+
+    at::Tensor tiles_per_gauss = at::empty_like(depths, depths.options().dtype(at::kInt));
+    at::Tensor offsets = at::empty({(int64_t)C * tile_height * tile_width + 1}, depths.options().dtype(at::kInt));
+    const size_t cwb = gsx_intersect_bin_count_workspace_bytes(C, tile_width, tile_height);
+    at::Tensor cws = at::empty({(int64_t)cwb}, depths.options().dtype(at::kByte));
+    at::Tensor n_host = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+    at::Tensor status;
+    if (guarded) status = at::empty({1}, depths.options().dtype(at::kInt));
+    check(gsx_intersect_bin_count_guarded(C, N, n_elements ? means2d.data_ptr<float>() : nullptr, n_elements ? radii.data_ptr<int32_t>() : nullptr, tile_size,
+                                          tile_width, tile_height, n_elements ? tiles_per_gauss.data_ptr<int32_t>() : nullptr, offsets.data_ptr<int32_t>(),
+                                          n_host.data_ptr<int64_t>(), cws.data_ptr(), cwb, capacity, ranked ? 0 : seg_bound,
+                                          guarded ? status.data_ptr<int32_t>() : nullptr, st), "intersect_tile_binned(count)");
+    auto total_ready = std::make_shared<at::cuda::CUDAEvent>();
+    total_ready->record(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
     at::Tensor ranks, order;
     if (ranked) {
         ranks = at::empty({(int64_t)n_elements}, depths.options().dtype(at::kInt));
@@ -665,46 +744,41 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
         g_stats.ranked_calls++;
     }
     at::Tensor flatten_ids, isect_ids;
-    auto fill = [&](int64_t capacity, int64_t seg_bound) {
-        flatten_ids = at::empty({capacity}, depths.options().dtype(at::kInt));
-        isect_ids = at::empty({want_isect_ids ? capacity : 0}, depths.options().dtype(at::kLong));
+    auto fill = [&](int64_t cap, int64_t bound) {
+        flatten_ids = at::empty({cap}, depths.options().dtype(at::kInt));
+        isect_ids = at::empty({want_isect_ids ? cap : 0}, depths.options().dtype(at::kLong));
         if (ranked) {
-            const size_t fwb = gsx_intersect_bin_fill_ranked_workspace_bytes(capacity);
+            const size_t fwb = gsx_intersect_bin_fill_ranked_workspace_bytes(cap);
             at::Tensor fws = at::empty({(int64_t)fwb}, depths.options().dtype(at::kByte));
             check(gsx_intersect_bin_fill_ranked(C, N, means2d.data_ptr<float>(), radii.data_ptr<int32_t>(), depths.data_ptr<float>(), tile_size,
-                                                tile_width, tile_height, offsets.data_ptr<int32_t>(), capacity, cws.data_ptr(),
+                                                tile_width, tile_height, offsets.data_ptr<int32_t>(), cap, cws.data_ptr(),
                                                 (const uint32_t*)ranks.data_ptr<int32_t>(), (const uint32_t*)order.data_ptr<int32_t>(),
                                                 flatten_ids.data_ptr<int32_t>(), want_isect_ids ? isect_ids.data_ptr<int64_t>() : nullptr,
                                                 fws.data_ptr(), fwb, st), "intersect_tile_binned(ranked fill)");
             return;
         }
-        const size_t fwb = gsx_intersect_bin_fill_workspace_bytes(C, tile_width, tile_height, capacity);
+        const size_t fwb = gsx_intersect_bin_fill_workspace_bytes(C, tile_width, tile_height, cap);
         at::Tensor fws = at::empty({(int64_t)fwb}, depths.options().dtype(at::kByte));
         check(gsx_intersect_bin_fill(C, N, means2d.data_ptr<float>(), radii.data_ptr<int32_t>(), depths.data_ptr<float>(), tile_size, tile_width,
-                                     tile_height, offsets.data_ptr<int32_t>(), capacity, seg_bound, cws.data_ptr(), flatten_ids.data_ptr<int32_t>(),
+                                     tile_height, offsets.data_ptr<int32_t>(), cap, bound, cws.data_ptr(), flatten_ids.data_ptr<int32_t>(),
                                      want_isect_ids ? isect_ids.data_ptr<int64_t>() : nullptr, fws.data_ptr(), fwb, st), "intersect_tile_binned(fill)");
     };
-    int64_t capacity = 0, seg_bound = 0;
-    if (hint > 0 && n_elements) {
-        capacity = std::min<int64_t>(hint + hint / 8 + 4096, 0x7FFFFFFFll);
-        seg_bound = std::max<int64_t>(hint_seg + hint_seg / 4, 16384);   // (16384: no giant-segment launches at all)
-        fill(capacity, seg_bound);
+    if (capacity > 0) fill(capacity, seg_bound);
+    at::Tensor isect_offsets = offsets.narrow(0, 0, (int64_t)C * tile_height * tile_width).view({(int64_t)C, (int64_t)tile_height, (int64_t)tile_width});
+    g_stats.binned_calls++;
+    if (guarded) {   // nobody waits: the consumers read the verdict on the device, the host confirms later
+        lists->n_host = n_host; lists->status = status; lists->ready = total_ready; lists->key = key;
+        lists->capacity = capacity; lists->seg_bound = seg_bound; lists->ranked = ranked;
+        lists->expected = last_total > 0 ? std::min(last_total, capacity) : capacity;
+        g_stats.guarded_calls++;
+        return std::make_tuple(tiles_per_gauss, isect_ids, flatten_ids, isect_offsets);
     }
-    total_ready.synchronize();
+    total_ready->synchronize();
     g_stats.host_syncs++;
     const uint64_t word = (uint64_t)n_host.data_ptr<int64_t>()[0];
     const int64_t n_isects = (int64_t)(word & 0xFFFFFFFFull), max_seg = (int64_t)(word >> 32);
     TORCH_CHECK(n_isects <= 0x7FFFFFFFll, "intersect_tile: more than 2^31 - 1 intersections (tile offsets are int32, as upstream's isect_offsets)");
-    {
-        std::lock_guard<std::mutex> lock(hint_mutex);
-        auto& h = hints[key];
-        h.first = std::max<int64_t>(n_isects, h.first - h.first / 50);  // running maximum with a slow decay
-        h.second = std::max<int64_t>(max_seg, h.second - h.second / 50);
-        hints[key_any] = std::make_pair(n_isects, max_seg);
-        last_n[key_any] = N;
-        if (hints.size() > 4096) hints.clear();   // (a long run that resizes thousands of times: start over rather than grow without bound)
-    }
-    g_stats.binned_calls++;
+    hint_update(key, n_isects, max_seg);
     const bool seg_ok = ranked || max_seg <= seg_bound;   // (the ranked fill has no merge passes to run short of)
     if (capacity > 0 && (n_isects > capacity || !seg_ok)) g_stats.hint_misses++;
     if (capacity == 0 && n_isects > 0) g_stats.hint_cold++;
@@ -717,8 +791,28 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
         flatten_ids = at::empty({0}, depths.options().dtype(at::kInt));
         isect_ids = at::empty({0}, depths.options().dtype(at::kLong));
     }
-    at::Tensor isect_offsets = offsets.narrow(0, 0, (int64_t)C * tile_height * tile_width).view({(int64_t)C, (int64_t)tile_height, (int64_t)tile_width});
+    if (lists) {   // cold call of the guarded entry: exact lists, already confirmed
+        lists->confirmed = true; lists->complete = true; lists->n_isects = n_isects; lists->max_seg = max_seg;
+        lists->capacity = lists->expected = n_isects; lists->key = key;
+    }
     return std::make_tuple(tiles_per_gauss, isect_ids, flatten_ids, isect_offsets);
+}
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned(const at::Tensor means2d, const at::Tensor radii,
+                                                                                 const at::Tensor depths, const uint32_t C,
+                                                                                 const uint32_t tile_size, const uint32_t tile_width,
+                                                                                 const uint32_t tile_height, const bool want_isect_ids) {
+    return intersect_tile_binned_core(means2d, radii, depths, C, tile_size, tile_width, tile_height, want_isect_ids, nullptr);
+}
+
+// the guarded protocol: (tiles_per_gauss, flatten_ids [capacity], isect_offsets, handle)
+std::tuple<at::Tensor, at::Tensor, at::Tensor, std::shared_ptr<IsectLists>> intersect_tile_binned_guarded(const at::Tensor means2d, const at::Tensor radii,
+                                                                                                          const at::Tensor depths, const uint32_t C,
+                                                                                                          const uint32_t tile_size, const uint32_t tile_width,
+                                                                                                          const uint32_t tile_height) {
+    auto lists = std::make_shared<IsectLists>();
+    auto r = intersect_tile_binned_core(means2d, radii, depths, C, tile_size, tile_width, tile_height, false, lists.get());
+    return std::make_tuple(std::get<0>(r), std::get<2>(r), std::get<3>(r), lists);
 }
 
 // fusedssim / fusedssim_backward (include/kernels/ssim.cuh:11-29): same tuple returns
@@ -906,6 +1000,13 @@ PYBIND11_MODULE(_gsx_ops, m) {
         .value("ROLLING_BOTTOM_TO_TOP", ShutterType::ROLLING_BOTTOM_TO_TOP)
         .value("ROLLING_RIGHT_TO_LEFT", ShutterType::ROLLING_RIGHT_TO_LEFT)
         .value("GLOBAL", ShutterType::GLOBAL);
+    py::class_<IsectLists, std::shared_ptr<IsectLists>>(m, "IsectLists")
+        .def_property_readonly("status", [](const IsectLists& l) { return l.status.defined() ? at::optional<at::Tensor>(l.status) : at::nullopt; })
+        .def_readonly("capacity", &IsectLists::capacity)
+        .def_readonly("expected", &IsectLists::expected)
+        .def_readonly("confirmed", &IsectLists::confirmed)
+        .def("ready", &IsectLists::is_ready)     // non-blocking: has the GPU passed the count?
+        .def("confirm", &IsectLists::confirm);   // (n_isects, largest segment, complete); waits for the count if it has to
     m.def("spherical_harmonics_fwd", &gsplat::spherical_harmonics_fwd);
     m.def("spherical_harmonics_bwd", &gsplat::spherical_harmonics_bwd);
     m.def("intersect_tile", &gsplat::intersect_tile);
@@ -919,13 +1020,18 @@ PYBIND11_MODULE(_gsx_ops, m) {
              uint32_t tile_size, const at::Tensor viewmats0, const at::optional<at::Tensor> viewmats1, const at::Tensor Ks,
              const gsplat::CameraModelType camera_model, const UnscentedTransformParameters ut_params, ShutterType rs_type,
              const at::optional<at::Tensor> radial_coeffs, const at::optional<at::Tensor> tangential_coeffs,
-             const at::optional<at::Tensor> thin_prism_coeffs, const at::Tensor tile_offsets, const at::Tensor flatten_ids, const at::Tensor fwd_ws) {
-              struct Reset { ~Reset() { g_fwd_ws_ready = nullptr; } } reset;
+             const at::optional<at::Tensor> thin_prism_coeffs, const at::Tensor tile_offsets, const at::Tensor flatten_ids, const at::Tensor fwd_ws,
+             std::shared_ptr<IsectLists> lists) {          // handle of intersect_tile_binned_guarded (None: exact lists)
+              struct Reset { ~Reset() { g_fwd_ws_ready = nullptr; g_lists = nullptr; } } reset;
               g_fwd_ws_ready = &fwd_ws;
+              g_lists = lists.get();
               return gsplat::rasterize_to_pixels_from_world_3dgs_fwd(means, quats, scales, colors, opacities, backgrounds, masks, image_width, image_height,
                                                                      tile_size, viewmats0, viewmats1, Ks, camera_model, ut_params, rs_type, radial_coeffs,
                                                                      tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids);
-          });
+          }, py::arg("means"), py::arg("quats"), py::arg("scales"), py::arg("colors"), py::arg("opacities"), py::arg("backgrounds"), py::arg("masks"),
+          py::arg("image_width"), py::arg("image_height"), py::arg("tile_size"), py::arg("viewmats0"), py::arg("viewmats1"), py::arg("Ks"),
+          py::arg("camera_model"), py::arg("ut_params"), py::arg("rs_type"), py::arg("radial_coeffs"), py::arg("tangential_coeffs"),
+          py::arg("thin_prism_coeffs"), py::arg("tile_offsets"), py::arg("flatten_ids"), py::arg("fwd_ws"), py::arg("lists") = std::shared_ptr<IsectLists>());
     m.def("frontend_fused", &gsx_ext::frontend_fused);
     m.def("rasterize_to_pixels_from_world_3dgs_bwd",
           [](const at::Tensor means, const at::Tensor quats, const at::Tensor scales, const at::Tensor colors, const at::Tensor opacities,
@@ -936,14 +1042,20 @@ PYBIND11_MODULE(_gsx_ops, m) {
              const at::optional<at::Tensor> thin_prism_coeffs, const at::Tensor tile_offsets, const at::Tensor flatten_ids,
              const at::Tensor render_alphas, const at::Tensor last_ids, const at::Tensor v_render_colors,
              const at::optional<at::Tensor> v_render_alphas,  // None = no gradient through the alpha output
-             const at::optional<at::Tensor> fwd_ws) {           // workspace kept from rasterize_fwd_keep_ws of the same inputs
-              struct Reset { ~Reset() { g_fwd_ws_in = nullptr; } } reset;
+             const at::optional<at::Tensor> fwd_ws,             // workspace kept from rasterize_fwd_keep_ws of the same inputs
+             std::shared_ptr<IsectLists> lists) {               // handle of intersect_tile_binned_guarded the forward ran with (None: exact lists)
+              struct Reset { ~Reset() { g_fwd_ws_in = nullptr; g_lists = nullptr; } } reset;
               g_fwd_ws_in = fwd_ws.has_value() ? &fwd_ws.value() : nullptr;
+              g_lists = lists.get();
               return gsplat::rasterize_to_pixels_from_world_3dgs_bwd(
                   means, quats, scales, colors, opacities, backgrounds, masks, image_width, image_height, tile_size, viewmats0, viewmats1, Ks,
                   camera_model, ut_params, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids,
                   render_alphas, last_ids, v_render_colors, v_render_alphas.has_value() ? v_render_alphas.value() : at::Tensor());
-          });
+          }, py::arg("means"), py::arg("quats"), py::arg("scales"), py::arg("colors"), py::arg("opacities"), py::arg("backgrounds"), py::arg("masks"),
+          py::arg("image_width"), py::arg("image_height"), py::arg("tile_size"), py::arg("viewmats0"), py::arg("viewmats1"), py::arg("Ks"),
+          py::arg("camera_model"), py::arg("ut_params"), py::arg("rs_type"), py::arg("radial_coeffs"), py::arg("tangential_coeffs"),
+          py::arg("thin_prism_coeffs"), py::arg("tile_offsets"), py::arg("flatten_ids"), py::arg("render_alphas"), py::arg("last_ids"),
+          py::arg("v_render_colors"), py::arg("v_render_alphas"), py::arg("fwd_ws") = at::optional<at::Tensor>(), py::arg("lists") = std::shared_ptr<IsectLists>());
     m.def("quats_to_rotmats", &gsplat::quats_to_rotmats);
     m.def("relocation", &gsplat::relocation);
     m.def("add_noise", &gsplat::add_noise);
@@ -965,6 +1077,12 @@ PYBIND11_MODULE(_gsx_ops, m) {
     m.def("splat_activations_projection_ut", &gsx_ext::splat_activations_projection_ut);
     m.def("splat_activations_bwd", &gsx_ext::splat_activations_bwd);
     m.def("intersect_tile_binned", &gsx_ext::intersect_tile_binned);
+    m.def("intersect_tile_binned_guarded", &gsx_ext::intersect_tile_binned_guarded);
+    m.def("shim_guarded_stats", [](bool reset) {  // (guarded intersect calls, confirms that had to wait for the GPU, frames whose lists were incomplete)
+        auto r = std::make_tuple((int64_t)g_stats.guarded_calls, (int64_t)g_stats.guarded_waits, (int64_t)g_stats.guarded_misses);
+        if (reset) { g_stats.guarded_calls = 0; g_stats.guarded_waits = 0; g_stats.guarded_misses = 0; }
+        return r;
+    });
     m.def("intersect_tile_device_sort", [](const at::Tensor means2d, const at::Tensor radii, const at::Tensor depths, uint32_t C, uint32_t tile_size,
                                            uint32_t tile_width, uint32_t tile_height, bool sort) {
         return gsplat::intersect_tile_device_sort(means2d, radii, depths, C, tile_size, tile_width, tile_height, sort);

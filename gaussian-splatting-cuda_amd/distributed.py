@@ -352,6 +352,31 @@ class ColorGradExchange:
         self._pending = []
 
 
+class ListsAgreement:
+    """Guarded intersection lists (rasterizer.rasterize_fused(guarded=True)) under N ranks: a frame whose lists overflowed on ANY rank
+    is rendered again on EVERY rank, so the collectives of the step stay matched and the replicas identical.  The verdicts meet on
+    the HOST — a MIN all-reduce of one int over a gloo group (loopback TCP, tens of microseconds) — while every GPU still has the
+    forward, the loss and the blend backward queued: no device-side collective, no stream synchronisation.
+    Wiring: `sinks["_lists_agree"] = ListsAgreement()` (constructed collectively on every rank)."""
+
+    def __init__(self):
+        self.group = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self.group = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+        self._flag = torch.zeros(1, dtype=torch.int32)
+        self.disagreements = 0   # iterations repeated because some OTHER rank overflowed
+
+    def __call__(self, ok):
+        if self.group is None:
+            return bool(ok)
+        self._flag[0] = 1 if ok else 0
+        dist.all_reduce(self._flag, op=dist.ReduceOp.MIN, group=self.group)
+        agreed = bool(int(self._flag[0]))
+        if ok and not agreed:
+            self.disagreements += 1
+        return agreed
+
+
 def shard_cameras(cameras, rank, world):
     """Camera i of the step's batch goes to rank i % world (one camera per GPU when len == world)."""
     return [c for i, c in enumerate(cameras) if i % world == rank]

@@ -35,8 +35,9 @@ def rasterize_to_pixels_from_world_3dgs_fwd(*args, keep_ws=False):
     return _C.rasterize_fwd_keep_ws(*args) if keep_ws else _C.rasterize_to_pixels_from_world_3dgs_fwd(*args)
 
 
-def rasterize_to_pixels_from_world_3dgs_bwd(*args, fwd_ws=None):
-    return _C.rasterize_to_pixels_from_world_3dgs_bwd(*args, fwd_ws)
+def rasterize_to_pixels_from_world_3dgs_bwd(*args, fwd_ws=None, lists=None):
+    """`lists`: the IsectLists handle of intersect_tile_binned_guarded the forward ran with (guarded protocol, include/gsx.h)."""
+    return _C.rasterize_to_pixels_from_world_3dgs_bwd(*args, fwd_ws, lists)
 
 
 quats_to_rotmats = _C.quats_to_rotmats
@@ -57,6 +58,8 @@ adam_step = _C.adam_step
 adam_step_multi = _C.adam_step_multi
 adam_step_wrapper = _C.adam_step_wrapper
 intersect_tile_binned = _C.intersect_tile_binned
+intersect_tile_binned_guarded = _C.intersect_tile_binned_guarded   # no host read of n_isects: (tiles_per_gauss, flatten_ids [capacity], offsets, IsectLists)
+shim_guarded_stats = _C.shim_guarded_stats
 intersect_tile_device_sort = _C.intersect_tile_device_sort
 adam_step_split = _C.adam_step_split
 fusedssim = _C.fusedssim

@@ -32,6 +32,13 @@ _LIST_TILE_STATE = {}
 LIST_TILE_UP, LIST_TILE_DOWN = 3000.0, 5000.0   # keys per 16-px tile above which 32-px lists pay / keys per 32-px tile below which they stop paying
 
 
+class IsectCapacityMiss(RuntimeError):
+    """Guarded lists (rasterize_fused(guarded=True)): this frame's intersections outgrew the capacity the optimistic fill was launched
+    with, so the kernels rendered it with EMPTY lists.  Raised from the render's backward BEFORE anything irreversible ran (the SH
+    tensor's fused Adam step, a gradient exchange); the capacity hint has been raised: run the iteration again (trainer.Trainer and
+    bench.py do)."""
+
+
 def _list_tile_for(key):
     forced = os.environ.get("GSX_LIST_TILE")
     if forced in ("16", "32"):
@@ -104,8 +111,24 @@ class RenderOutput:
     visibility: torch.Tensor = None
     width: int = 0
     height: int = 0
-    n_isects: int = 0
+    _n_isects: int = 0
+    lists: object = None   # ops.IsectLists handle of a guarded render (rasterize_fused(guarded=True)), else None
     aux: dict = field(default_factory=dict)
+
+    @property
+    def n_isects(self):
+        """Number of tile intersections of the frame; on a guarded render this reads the count the GPU copied to the host (waits for
+        it if the GPU has not passed the intersection yet)."""
+        return self._n_isects if self.lists is None else int(self.lists.confirm()[0])
+
+    @n_isects.setter
+    def n_isects(self, value):
+        self._n_isects = int(value)
+
+    def confirm(self):
+        """Guarded render: True when the frame's lists were complete (the image is the frame's image); False = the capacity was
+        exceeded and the kernels rendered EMPTY lists: render again (the hint has been raised).  Always True on an exact render."""
+        return True if self.lists is None else bool(self.lists.confirm()[2])
 
     @property
     def image(self):
@@ -288,9 +311,11 @@ def rasterize(camera: Camera, model: SplatData, bg_color: Optional[torch.Tensor]
 # all-reduce bucket): no zero fill and no AccumulateGrad add pass over the 192 MB SH gradient.
 # ---------------------------------------------------------------------------------------------------------
 class GutRenderFunction(torch.autograd.Function):
+    last_lists = None
+
     @staticmethod
     def forward(ctx, means, sh, scaling_raw, rotation_raw, opacity_raw, viewmat, K, bg, width, height, sh_degree, scaling_modifier,
-                camera_model, radial, tangential, grad_sinks):
+                camera_model, radial, tangential, grad_sinks, guarded=False):
         ut = ops.UnscentedTransformParameters()
         means_c, sh_c = means.contiguous(), sh.contiguous()
         sr, rr, orw = scaling_raw.contiguous(), rotation_raw.contiguous(), opacity_raw.reshape(-1).contiguous()
@@ -320,13 +345,21 @@ class GutRenderFunction(torch.autograd.Function):
         list_tile = _list_tile_for(lt_key) if camera_model == ops.CameraModelType.PINHOLE else TILE_SIZE
         tw, th = (width + list_tile - 1) // list_tile, (height + list_tile - 1) // list_tile
         # binned pipeline: flatten_ids + isect_offsets in one go (bit-identical to intersect_tile + intersect_offset, no isect_ids)
-        _, _, flatten_ids, isect_offsets = ops.intersect_tile_binned(means2d, radii, depths, 1, list_tile, tw, th, False)
-        _list_tile_update(lt_key, list_tile, int(flatten_ids.shape[0]), tw * th)
+        lists = None
+        if guarded and fe is not None:
+            # guarded protocol (include/gsx.h): no host read of n_isects — flatten_ids keeps its capacity length, the blend kernels read
+            # the frame's verdict on the device, backward() confirms it on the host before anything irreversible
+            _, flatten_ids, isect_offsets, lists = ops.intersect_tile_binned_guarded(means2d, radii, depths, 1, list_tile, tw, th)
+            if lists.confirmed:   # first call of a problem shape: the exact protocol ran
+                _list_tile_update(lt_key, list_tile, int(lists.confirm()[0]), tw * th)
+        else:
+            _, _, flatten_ids, isect_offsets = ops.intersect_tile_binned(means2d, radii, depths, 1, list_tile, tw, th, False)
+            _list_tile_update(lt_key, list_tile, int(flatten_ids.shape[0]), tw * th)
         opac2 = opac.unsqueeze(0)
         if fe is not None:   # the records of exactly these inputs are already in fe_ws
             renders, alphas, last_ids = ops.rasterize_fwd_packed(
                 means_c, quats, scales, colors, opac2, bg, None, width, height, list_tile, viewmat, None, K, camera_model, ut,
-                ops.ShutterType.GLOBAL, radial, tangential, None, isect_offsets, flatten_ids, fe_ws)
+                ops.ShutterType.GLOBAL, radial, tangential, None, isect_offsets, flatten_ids, fe_ws, lists)
             fwd_ws = fe_ws
         else:
             renders, alphas, last_ids, fwd_ws = ops.rasterize_to_pixels_from_world_3dgs_fwd(
@@ -337,6 +370,9 @@ class GutRenderFunction(torch.autograd.Function):
                               flatten_ids, alphas, last_ids)
         ctx.extra = (bg, width, height, sh_degree, scaling_modifier, camera_model, radial, tangential, grad_sinks, ut)
         ctx.list_tile = list_tile
+        ctx.lists = lists
+        ctx.lt_update = (lt_key, list_tile, tw * th)
+        GutRenderFunction.last_lists = lists   # picked up by rasterize_fused right after apply() (a handle is not a tensor output)
         ctx.mark_non_differentiable(radii, means2d, depths, flatten_ids, isect_offsets)
         ctx.set_materialize_grads(False)  # no zero tensors for the outputs nobody differentiates (six fill launches per step)
         return renders, alphas, radii, means2d, depths, flatten_ids, isect_offsets
@@ -344,7 +380,7 @@ class GutRenderFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_renders, v_alphas, *unused):
         if v_renders is None and v_alphas is None:
-            return (None,) * 16
+            return (None,) * 17
         (means, sh, sr, rr, orw, scales, quats, opac2, colors, radii, viewmat, K, isect_offsets, flatten_ids, alphas,
          last_ids) = ctx.saved_tensors
         bg, width, height, sh_degree, scaling_modifier, camera_model, radial, tangential, sinks, ut = ctx.extra
@@ -353,7 +389,7 @@ class GutRenderFunction(torch.autograd.Function):
         v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_to_pixels_from_world_3dgs_bwd(
             means, quats, scales, colors, opac2, bg, None, width, height, ctx.list_tile, viewmat, None, K, camera_model, ut,
             ops.ShutterType.GLOBAL, radial, tangential, None, isect_offsets, flatten_ids, alphas, last_ids,
-            v_renders.contiguous(), None if v_alphas is None else v_alphas.contiguous(), fwd_ws=ctx.fwd_ws)
+            v_renders.contiguous(), None if v_alphas is None else v_alphas.contiguous(), fwd_ws=ctx.fwd_ws, lists=ctx.lists)
         if scaling_modifier != 1.0:
             v_scales = v_scales * scaling_modifier
         s = sinks or {}
@@ -361,6 +397,20 @@ class GutRenderFunction(torch.autograd.Function):
         # start exchanging them ("_early_ready" callback) while the SH backward — 81 % of the gradient bytes — is still running
         g_s, g_r, g_o = ops.splat_activations_bwd(sr, rr, orw, v_scales, v_quats, v_opac.reshape(-1), s.get("scaling_raw"),
                                                  s.get("rotation_raw"), s.get("opacity_raw"))
+        if ctx.lists is not None and not getattr(ctx, "lists_checked", False):
+            # Guarded lists: the one place the host looks at the frame's intersection count — with the forward, the loss and the blend
+            # backward (~0.9 ms at S-1M) queued behind the 8-byte copy it waits for, so the stream never drains.  Everything so far only
+            # overwrote gradient buffers; what follows (the SH tensor's Adam step inside the SH backward, a gradient exchange) is not
+            # repeatable, so an overflowed frame stops here.  Under N ranks the verdict is agreed first ("_lists_agree": every rank
+            # repeats the iteration when any rank overflowed — the collectives below stay matched).
+            n_is, _, ok = ctx.lists.confirm()
+            ctx.lists_checked = True
+            _list_tile_update(ctx.lt_update[0], ctx.lt_update[1], int(n_is), ctx.lt_update[2])
+            if s.get("_lists_agree") is not None:
+                ok = s["_lists_agree"](ok)
+            if not ok:
+                raise IsectCapacityMiss("rasterize_fused(guarded=True): intersection lists incomplete (%d intersections, capacity %d): "
+                                        "run the iteration again" % (n_is, ctx.lists.capacity))
         if s.get("_early_ready") is not None:
             s["_early_ready"]()
         if s.get("_color_exchange") is not None:
@@ -379,16 +429,20 @@ class GutRenderFunction(torch.autograd.Function):
         if bg is not None and ctx.needs_input_grad[7]:
             v_bg = (v_renders * (1.0 - alphas)).float().sum(dim=(-3, -2))
         if sinks:  # gradients already sit in the caller's buffers
-            return (None,) * 7 + (v_bg,) + (None,) * 8
-        return (v_means, v_sh, g_s, g_r, g_o.reshape(-1, 1), None, None, v_bg) + (None,) * 8
+            return (None,) * 7 + (v_bg,) + (None,) * 9
+        return (v_means, v_sh, g_s, g_r, g_o.reshape(-1, 1), None, None, v_bg) + (None,) * 9
 
 
 def rasterize_fused(camera: Camera, model: SplatData, bg_color: Optional[torch.Tensor], scaling_modifier: float = 1.0,
                     sh_degree: Optional[int] = None, grad_sinks: Optional[dict] = None,
-                    with_visibility: bool = False) -> RenderOutput:
+                    with_visibility: bool = False, guarded: bool = False) -> RenderOutput:
     """Same result as rasterize() (RGB mode) through the fused glue kernels.  `grad_sinks` maps
     {"means","sh","scaling_raw","rotation_raw","opacity_raw"} to preallocated gradient buffers that backward
-    overwrites (autograd then sees no gradient for the parameters: use the sinks as `.grad`)."""
+    overwrites (autograd then sees no gradient for the parameters: use the sinks as `.grad`).
+    guarded=True: the render never reads n_isects on the host (include/gsx.h "guarded lists"): the intersection lists are filled into
+    a capacity taken from the previous frames of the same shape and the kernels check on the device that it sufficed.  The caller
+    must be ready to repeat the frame: backward() raises IsectCapacityMiss before anything irreversible when it did not (a
+    forward-only caller asks `out.confirm()`).  Same image and gradients as guarded=False whenever the lists were complete."""
     W, H = int(camera.width), int(camera.height)
     viewmat, K = camera.world_view_transform().contiguous(), camera.K_batched().contiguous()
     sh_degree = model.active_sh_degree if sh_degree is None else sh_degree
@@ -397,8 +451,9 @@ def rasterize_fused(camera: Camera, model: SplatData, bg_color: Optional[torch.T
     radial, tangential = _distortion_args(camera, cam_model, model.means.device)
     renders, alphas, radii, means2d, depths, flatten_ids, isect_offsets = GutRenderFunction.apply(
         model.means, model.sh, model.scaling_raw, model.rotation_raw, model.opacity_raw, viewmat, K, bg, W, H, sh_degree,
-        scaling_modifier, cam_model, radial, tangential, grad_sinks)
+        scaling_modifier, cam_model, radial, tangential, grad_sinks, guarded)
     out = RenderOutput()
+    out.lists, GutRenderFunction.last_lists = GutRenderFunction.last_lists, None
     out.render_hwc = renders  # [1,H,W,3] unclamped: what loss.photometric_loss consumes; out.image is derived on first access
     out.alpha = alphas.squeeze(0).permute(2, 0, 1)
     out.means2d, out.depths = means2d, depths.squeeze(0)
@@ -406,6 +461,7 @@ def rasterize_fused(camera: Camera, model: SplatData, bg_color: Optional[torch.T
         out.radii = radii.squeeze(0).max(-1).values
         out.visibility = out.radii > 0
     out.width, out.height = W, H
-    out.n_isects = int(flatten_ids.shape[0])
+    if out.lists is None:
+        out.n_isects = int(flatten_ids.shape[0])
     out.aux = dict(isect_offsets=isect_offsets, flatten_ids=flatten_ids, radii_full=radii)
     return out

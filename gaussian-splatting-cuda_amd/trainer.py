@@ -21,7 +21,7 @@ from .strategy import MCMC, OptimizationParameters
 
 class Trainer:
     def __init__(self, model, cameras, images, params: OptimizationParameters = None, background=None, scene_scale=1.0, seed=0,
-                 sharded_adam=False, exchange="colors", fused_sh_adam=True):
+                 sharded_adam=False, exchange="colors", fused_sh_adam=True, guarded_lists=True):
         """cameras: list of rasterizer.Camera; images: list of [3,H,W] ground-truth tensors on the device.
         sharded_adam (world > 1): reduce-scatter -> Adam on this rank's 1/world of the Gaussians -> all-gather of the parameters
         (distributed.ShardedAdam) instead of all-reduce + replicated Adam.
@@ -29,7 +29,9 @@ class Trainer:
         host sync); "rows" = all-reduce of the gradient rows some camera of the step saw (one host sync for the row count).
         fused_sh_adam: on iterations without densification the SH tensor's Adam step is applied inside the SH backward
         (gsx_sh_colors_bwd_adam: the SH gradient is never written); needs the complete SH gradient on this rank, i.e. one GPU or the
-        colour exchange.  Refine iterations keep the separate step: relocation / growth run between backward and optimizer there."""
+        colour exchange.  Refine iterations keep the separate step: relocation / growth run between backward and optimizer there.
+        guarded_lists: render with rasterize_fused(guarded=True) — no host read of n_isects per iteration (include/gsx.h "guarded lists");
+        an iteration whose intersection lists outgrew their capacity is repeated before its optimizer step (`capacity_misses` counts them)."""
         self.model, self.cameras, self.images = model, cameras, images
         self.params = params or OptimizationParameters()
         self.bg = background
@@ -46,6 +48,10 @@ class Trainer:
         self.strategy.on_resize = self._rebuild_bucket
         self._rebuild_bucket(model)
         self.sharded = gdist.ShardedAdam(self.strategy.optimizer) if (sharded_adam and self.world > 1) else None
+        self.guarded, self.capacity_misses = guarded_lists, 0
+        self._lists_agree = gdist.ListsAgreement() if (guarded_lists and self.world > 1) else None
+        if self._lists_agree is not None:
+            self.sinks["_lists_agree"] = self._lists_agree
         if self.sharded is not None:   # rows change owner when the strategy permutes / removes them: complete the moments on every rank first
             self.strategy.before_reindex = self.sharded.merge_moments
         self.last_loss = None
@@ -57,9 +63,11 @@ class Trainer:
             self.sinks = self.bucket.sinks(tuple(names))
             self.xch = gdist.ColorGradExchange(self.bucket, names)
             self.sinks["_color_exchange"] = self.xch
-            return
-        self.bucket = gdist.GradBucket(model.params())
-        self.sinks = self.bucket.sinks()
+        else:
+            self.bucket = gdist.GradBucket(model.params())
+            self.sinks = self.bucket.sinks()
+        if getattr(self, "_lists_agree", None) is not None:
+            self.sinks["_lists_agree"] = self._lists_agree
 
     @torch.no_grad()
     def _add_regularisers(self):
@@ -75,12 +83,21 @@ class Trainer:
         if self.exchange == "colors":   # the step's camera batch in rank order
             self.xch.begin_step(torch.stack([self.cameras[(it * self.world + r) % len(self.cameras)].viewmat for r in range(self.world)]))
         fuse = self.fused_sh_adam and it < self.params.iterations and not self.strategy.is_refining(it)
-        self.sinks["_sh_adam"] = self.strategy.optimizer.begin_fused_sh_step(it) if fuse else None
-        fuse = self.sinks["_sh_adam"] is not None
-        out = rasterizer.rasterize_fused(self.cameras[i], self.model, self.bg, grad_sinks=self.sinks)
         gt = self.images[i]
-        loss = gloss.photometric_loss(out.render_hwc, gt, self.params.lambda_dssim)
-        gloss.backward(loss)
+        for attempt in range(4):
+            self.sinks["_sh_adam"] = self.strategy.optimizer.begin_fused_sh_step(it) if fuse else None
+            fuse = self.sinks["_sh_adam"] is not None
+            # guarded lists: the render never waits for n_isects; a frame whose lists outgrew their capacity stops in backward() before
+            # the SH tensor's Adam step / the gradient exchange and is rendered again (the capacity hint has been raised by then)
+            out = rasterizer.rasterize_fused(self.cameras[i], self.model, self.bg, grad_sinks=self.sinks, guarded=self.guarded)
+            loss = gloss.photometric_loss(out.render_hwc, gt, self.params.lambda_dssim)
+            try:
+                gloss.backward(loss)
+                break
+            except rasterizer.IsectCapacityMiss:
+                self.capacity_misses += 1
+                if attempt == 3:
+                    raise
         if self.sharded is not None:
             # the regularisers are the same on every rank, so adding them before the mean over the ranks gives the same sum; the
             # exchange itself (reduce-scatter ... all-gather) brackets the optimizer step and is skipped with it when the model grew

@@ -28,8 +28,10 @@ extern "C" {
  *   2  gsx_intersect_bin_fill gained the positional `max_segment` argument; the pinned host word written by gsx_intersect_bin_count holds
  *      n_isects in its low 32 bits (0xFFFFFFFF on overflow) and the largest tile segment in its high 32 bits; gsx_sh_colors_bwd accepts
  *      NULL radii / colors; ranked fill entry points added.
- *   3  additions only: gsx_frontend_fused(_supported), gsx_rasterize_to_pixels_from_world_3dgs_fwd_packed, gsx_intersect_tile_fill_packed. */
-#define GSX_ABI_VERSION 3
+ *   3  additions only: gsx_frontend_fused(_supported), gsx_rasterize_to_pixels_from_world_3dgs_fwd_packed, gsx_intersect_tile_fill_packed.
+ *   4  additions only: the guarded list protocol (no host read of n_isects on the render path): gsx_intersect_bin_count_guarded,
+ *      gsx_rasterize_to_pixels_from_world_3dgs_{fwd,bwd}_guarded. */
+#define GSX_ABI_VERSION 4
 
 typedef enum gsx_status {
     GSX_OK = 0,
@@ -245,6 +247,42 @@ int gsx_intersect_bin_fill(uint32_t C, uint32_t N, const float* means2d, const i
                            uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, const int32_t* tile_offsets,
                            int64_t n_isects, int64_t max_segment, const void* count_workspace, int32_t* flatten_ids, int64_t* isect_ids,
                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* Guarded lists: the render path WITHOUT a host read of n_isects.  A caller that has an upper-bound guess (`capacity` slots in flatten_ids,
+ * merge passes for segments up to `max_segment` keys; 0 = no segment bound, as for the ranked fill) passes both to the count; bin_scan then
+ * writes the verdict on the device: *lists_status (int32) = n_isects when the fill launched with these bounds produces complete lists, -1
+ * when it does not.  The blend entry points below take that word: the last list ends at the total instead of at the host's `n_isects` (which is
+ * then only the capacity of flatten_ids), and a frame whose verdict is -1 is rendered with EMPTY lists (background, zero gradients: no
+ * unwritten slot of flatten_ids is ever read).  The host reads the same verdict whenever it likes — the pinned word of bin_count still
+ * arrives — and renders an overflowed frame again with enough room BEFORE it applies anything irreversible (an optimizer step).
+ * Same results as the exact protocol whenever the verdict is >= 0; nothing blocks between the count and the blend. */
+int gsx_intersect_bin_count_guarded(uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, uint32_t tile_size,
+                                    uint32_t tile_width, uint32_t tile_height, int32_t* tiles_per_gauss, int32_t* tile_offsets,
+                                    int64_t* n_isects_host_pinned, void* workspace, size_t workspace_bytes, int64_t capacity,
+                                    int64_t max_segment, int32_t* lists_status, void* stream);
+/* gsx_rasterize_to_pixels_from_world_3dgs_{fwd,bwd}_packed on guarded lists: `n_isects` = capacity of flatten_ids (the backward's workspace
+ * is sized by it), `lists_status` = the device word above (NULL = `n_isects` is exact: identical to the _packed entry points),
+ * `n_isects_expected` = the caller's estimate of the total for launch decisions (which forward kernel; 0 = use the capacity). */
+int gsx_rasterize_to_pixels_from_world_3dgs_fwd_guarded(uint32_t N, int64_t n_isects, const float* means,
+                                                        const float* quats, const float* scales, const float* colors,
+                                                        uint32_t channels, const float* opacities, const float* backgrounds,
+                                                        const uint8_t* masks, uint32_t image_width, uint32_t image_height,
+                                                        uint32_t tile_size, const gsx_cameras* cams, const gsx_ut_params* ut,
+                                                        const int32_t* tile_offsets, const int32_t* flatten_ids,
+                                                        float* renders, float* alphas, int32_t* last_ids, void* workspace,
+                                                        size_t workspace_bytes, int records_ready, const int32_t* lists_status,
+                                                        int64_t n_isects_expected, void* stream);
+int gsx_rasterize_to_pixels_from_world_3dgs_bwd_guarded(uint32_t N, int64_t n_isects, const float* means,
+                                                        const float* quats, const float* scales, const float* colors,
+                                                        uint32_t channels, const float* opacities, const float* backgrounds,
+                                                        const uint8_t* masks, uint32_t image_width, uint32_t image_height,
+                                                        uint32_t tile_size, const gsx_cameras* cams, const gsx_ut_params* ut,
+                                                        const int32_t* tile_offsets, const int32_t* flatten_ids,
+                                                        const float* render_alphas, const int32_t* last_ids,
+                                                        const float* v_render_colors, const float* v_render_alphas,
+                                                        float* v_means, float* v_quats, float* v_scales, float* v_colors,
+                                                        float* v_opacities, void* workspace, size_t workspace_bytes,
+                                                        const void* packed_records, const int32_t* lists_status, void* stream);
 
 /* Ranked variant of the fill for frames with heavy tiles (same outputs, bit for bit; same reference interface).  The Gaussians of
  * the frame are ranked once by (depth bits, flatten index) — gsx_intersect_depth_ranks: ranks[c*N + n] = position in that order,
