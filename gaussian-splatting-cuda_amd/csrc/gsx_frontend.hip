@@ -75,6 +75,7 @@ __global__ __launch_bounds__(FE_BLOCK) void frontend_kernel(uint32_t N, uint32_t
     if (!visible) {
         out.radii[(size_t)gid * 2] = 0; out.radii[(size_t)gid * 2 + 1] = 0;   // as upstream, only radii is written for a culled Gaussian
         col[0] = 0.f; col[1] = 0.f; col[2] = 0.f;                             // masked SH row (sh_colors_fwd writes zeros)
+        store_null_record(out.packed + (size_t)gid * 4);                      // (no list names a culled Gaussian; the workspace still never holds garbage)
         return;
     }
     reinterpret_cast<int2*>(out.radii)[gid] = make_int2((int32_t)p.radius_x, (int32_t)p.radius_y);
@@ -118,7 +119,9 @@ __global__ __launch_bounds__(FE_BLOCK) void frontend_kernel(uint32_t N, uint32_t
     raw.sc = scale;
     raw.opac = opacity;
     const CamFrame cf = make_cam_frame(sp);
-    store_packed_record(raw, cf, out.packed + (size_t)gid * 4);
+    // + the rectangle of 16-pixel tiles the intersection derives from (means2d, radii): read by the blend only under 32-pixel lists
+    store_packed_record(raw, cf, out.packed + (size_t)gid * 4, tile16_range(p.im.x, (float)(int32_t)p.radius_x, (W + 15u) / 16u),
+                        tile16_range(p.im.y, (float)(int32_t)p.radius_y, (H + 15u) / 16u));
 }
 
 }  // namespace gsx

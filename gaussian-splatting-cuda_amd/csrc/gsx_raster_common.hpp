@@ -23,6 +23,7 @@ struct RasterArgs {
     // tiles, an extension of the fused path for frames whose Gaussians cover many tiles — the pixel tiles of the kernels stay 16 x 16, a
     // tile walks the list of its 32 x 32 parent and the footprint tests drop what does not reach it).  ltw x lth = the list grid.
     uint32_t lshift, ltw, lth;
+    uint32_t rect_filter;   // lshift != 0: drop list entries whose rectangle of 16-px tiles excludes the tile (1; 0 only by the test switch GSX_LIST_RECT=0)
     gsx_cameras cams;
     const int32_t* tile_offsets; const int32_t* flatten_ids;
     const float4* packed;  // optional [C*N] x 64 B camera-space records (gsx_raster_fast.hip: pack_records_kernel), else nullptr

@@ -203,11 +203,14 @@ GSX_DEV uint32_t footprint_hits_2x2(float4 c, float l00, float l01, float l11, c
 // one staged Gaussian: the 64 B record (AoS, read at a wave-uniform index with one base address) + the cull plane entry
 struct StagedRec { float4 r0, r1, r2, r3, cull; };   // cull = (u0, v0, rad2, k2): footprint()
 
-GSX_DEV void stage_one(const RasterArgs& a, const float tb[4], int32_t g, StagedRec& o) {
+GSX_DEV void stage_one(const RasterArgs& a, const float tb[4], int32_t g, StagedRec& o, uint32_t tile_x, uint32_t tile_y) {
     const float4* p = a.packed + (size_t)g * 4;
     o.r0 = p[0]; o.r1 = p[1]; o.r2 = p[2]; o.r3 = p[3];
     float rad2, k2;
     footprint(o.r0, o.r1, o.r2, tb, rad2, k2);
+    // lists per 32 x 32 pixels: the parent's list also names Gaussians whose rectangle of 16-pixel tiles (IntersectTile.cu:65-76) does not
+    // contain THIS tile — the reference never composites those here, whatever their alpha: an empty footprint drops them at staging
+    if (a.lshift != 0u && a.rect_filter != 0u && !rect_has_tile(o.r3, tile_x, tile_y)) rad2 = -1.f;
     o.cull = make_float4(o.r0.x, o.r0.y, rad2, k2);
 }
 
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
         const int32_t chunk_start = range_start + FCH * b;
         if (have) {
             StagedRec sr;
-            stage_one(a, tb, g_pre, sr);
+            stage_one(a, tb, g_pre, sr, tile_x, tile_y);
             if (no_cull) sr.cull.z = INFINITY;
             sr.r1.y -= LOG2_K999; sr.r2.w *= K999; sr.r3.x *= K999; sr.r3.y *= K999;
             s_rec[buf][tid][0] = sr.r0; s_rec[buf][tid][1] = sr.r1; s_rec[buf][tid][2] = sr.r2; s_rec[buf][tid][3] = sr.r3;
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_quad_kernel(Rast
         const int32_t chunk_start = range_start + FCH * b;
         if (have) {
             StagedRec sr;
-            stage_one(a, tb, g_pre, sr);
+            stage_one(a, tb, g_pre, sr, tile_x, tile_y);
             if (no_cull) sr.cull.z = INFINITY;
             sr.r1.y -= LOG2_K999; sr.r2.w *= K999; sr.r3.x *= K999; sr.r3.y *= K999;
             s_rec[buf][tid][0] = sr.r0; s_rec[buf][tid][1] = sr.r1; s_rec[buf][tid][2] = sr.r2; s_rec[buf][tid][3] = sr.r3;
@@ -744,7 +747,7 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
         if ((int32_t)tid < chunk_size) {
             const int32_t g = a.flatten_ids[chunk_end - (int32_t)tid];
             StagedRec sr;
-            stage_one(a, tb, g, sr);
+            stage_one(a, tb, g, sr, tile_x, tile_y);
             if (no_cull) sr.cull.z = INFINITY;
             s_rec[tid][0] = sr.r0; s_rec[tid][1] = sr.r1; s_rec[tid][2] = sr.r2; s_rec[tid][3] = sr.r3;
             s_cull[tid] = sr.cull;
@@ -1071,7 +1074,7 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
         if ((int32_t)tid < chunk_size) {
             const int32_t g = a.flatten_ids[chunk_end - (int32_t)tid];
             StagedRec sr;
-            stage_one(a, tb, g, sr);
+            stage_one(a, tb, g, sr, tile_x, tile_y);
             s_rec[0][tid] = sr.r0.x; s_rec[1][tid] = sr.r0.y; s_rec[2][tid] = sr.r0.z; s_rec[3][tid] = sr.r0.w;
             s_rec[4][tid] = sr.r1.x; s_rec[5][tid] = sr.r1.y; s_rec[6][tid] = sr.r1.z; s_rec[7][tid] = sr.r1.w;
             s_rec[8][tid] = sr.r2.x; s_rec[9][tid] = sr.r2.y; s_rec[10][tid] = sr.r2.z; s_rec[11][tid] = sr.r2.w;

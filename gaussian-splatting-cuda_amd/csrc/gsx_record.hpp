@@ -103,7 +103,33 @@ GSX_DEV void make_record(const RawG& r, const CamFrame& cf, const float tb[4], F
 
 // Writes the packed record of one (camera, Gaussian) (see the layout above).  `lo` = -inf marks a Gaussian no pixel can see (opacity
 // <= 1/255) or whose camera-space z is exactly 0 (skipped: DESIGN.md §8).
-GSX_DEV void store_packed_record(const RawG& raw, const CamFrame& cf, float4* __restrict__ o) {
+// The two spare floats of the record carry the Gaussian's rectangle of 16-pixel tiles [x0, x1) x [y0, y1) as the intersection computes
+// it from means2d / radii (IntersectTile.cu:65-76), 16 bits per bound: rect_x = x0 | x1 << 16, rect_y = y0 | y1 << 16.  Only read when
+// the LISTS were built per 32 x 32 pixels (RasterArgs::lshift): a 16-pixel tile then skips the entries of its parent's list whose
+// rectangle does not contain it, so that exactly the reference's (tile, Gaussian) pairs are composited.  RECT_ALL = no restriction
+// (records packed without the projection's outputs: pack_records_kernel).
+constexpr uint32_t RECT_ALL = 0xFFFF0000u;
+GSX_DEV uint32_t tile16_range(float m, float r, uint32_t n_tiles) {   // the arithmetic of tile_rect (gsx_intersect.hip), tile size 16
+    const float t = m / 16.f, tr = r / 16.f;
+    const float lo = floorf(t - tr), hi = ceilf(t + tr);
+    const uint32_t a = lo > 0.f ? (lo >= 65535.f ? 65535u : (uint32_t)lo) : 0u, b = hi > 0.f ? (hi >= 65535.f ? 65535u : (uint32_t)hi) : 0u;
+    return min(a, n_tiles) | (min(b, n_tiles) << 16);
+}
+GSX_DEV bool rect_has_tile(float4 r3, uint32_t tile_x, uint32_t tile_y) {
+    const uint32_t rx = __float_as_uint(r3.z), ry = __float_as_uint(r3.w);
+    return tile_x >= (rx & 0xFFFFu) && tile_x < (rx >> 16) && tile_y >= (ry & 0xFFFFu) && tile_y < (ry >> 16);
+}
+
+// A record no pixel can see (lo = -inf: alpha = 0 everywhere, empty footprint, empty rectangle): what the fused front end writes for a
+// Gaussian its projection culled, so that a workspace never holds uninitialised records.
+GSX_DEV void store_null_record(float4* __restrict__ o) {
+    o[0] = make_float4(0.f, 0.f, 1.f, 0.f);
+    o[1] = make_float4(1.f, -INFINITY, 0.f, 0.f);
+    o[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    o[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+GSX_DEV void store_packed_record(const RawG& raw, const CamFrame& cf, float4* __restrict__ o, uint32_t rect_x = RECT_ALL, uint32_t rect_y = RECT_ALL) {
     const float tb0[4] = {0.f, 0.f, 0.f, 0.f};
     FastRec r;
     make_record<false>(raw, cf, tb0, r);
@@ -112,7 +138,7 @@ GSX_DEV void store_packed_record(const RawG& raw, const CamFrame& cf, float4* __
     o[0] = make_float4(r.u0, r.v0, r.l00, r.l01);
     o[1] = make_float4(r.l11, r.lo, r.d1, r.d2);
     o[2] = make_float4(r.d3, r.d4, r.d5, raw.rgb.x);
-    o[3] = make_float4(raw.rgb.y, raw.rgb.z, 0.f, 0.f);
+    o[3] = make_float4(raw.rgb.y, raw.rgb.z, __uint_as_float(rect_x), __uint_as_float(rect_y));
 }
 
 }  // namespace gsx

@@ -29,7 +29,10 @@ FUSED_FRONTEND = os.environ.get("GSX_FUSED_FRONTEND", "1") != "0"
 # many tiles (trained dense scenes), at the price of longer candidate lists per pixel tile when they are small (S-1M).  Chosen per
 # problem shape from the previous frame's list density, with hysteresis; GSX_LIST_TILE=16|32 forces one (tests, A/B tools).
 _LIST_TILE_STATE = {}
-LIST_TILE_UP, LIST_TILE_DOWN = 3000.0, 5000.0   # keys per 16-px tile above which 32-px lists pay / keys per 32-px tile below which they stop paying
+# keys per 16-px tile above which 32-px lists pay / keys per 32-px tile below which they stop paying.  The same frame has ~1.3x the keys
+# per 32-px tile that it has per 16-px tile (3.1x fewer keys on 4x fewer tiles), so UP = 3000 enters at ~3900 keys per 32-px tile and
+# DOWN = 2500 leaves at ~1900 keys per 16-px tile: a band of 1.5x, no frame-to-frame flipping
+LIST_TILE_UP, LIST_TILE_DOWN = 3000.0, 2500.0
 
 
 class IsectCapacityMiss(RuntimeError):
@@ -342,7 +345,9 @@ class GutRenderFunction(torch.autograd.Function):
             colors = ops.sh_colors_fwd(sh_degree, means_c, viewmat, sh_c, radii)
         # tile size of the intersection lists: 32-px lists only on the fast blend path (global-shutter pinhole) — see _LIST_TILE_STATE
         lt_key = (means_c.shape[0], width, height, means_c.device.index)
-        list_tile = _list_tile_for(lt_key) if camera_model == ops.CameraModelType.PINHOLE else TILE_SIZE
+        # (and only with the fused front end: its records carry each Gaussian's rectangle of 16-px tiles, which a 16-px tile needs to take
+        # exactly the reference's entries out of its 32-px parent's list)
+        list_tile = _list_tile_for(lt_key) if (camera_model == ops.CameraModelType.PINHOLE and fe is not None) else TILE_SIZE
         tw, th = (width + list_tile - 1) // list_tile, (height + list_tile - 1) // list_tile
         # binned pipeline: flatten_ids + isect_offsets in one go (bit-identical to intersect_tile + intersect_offset, no isect_ids)
         lists = None

@@ -236,6 +236,111 @@ def test_s5m_4k_full_frame(ref, mods):
     _stagewise(ref, ops, scenes.scene_5m(), {}, "S-5M @4K", with_oracle=False, fwd_strict=False)
 
 
+def _blend_generic_vs_reference(ref, ops, sc, tag):
+    """The reference-operation-order kernels (gsx_raster.hip, forced with GSX_RASTER_PATH=generic: cross-product form, no Delta-form) on the
+    reference chain's own colours and lists, against the reference's blend kernels: is the fast path's handful of pixels beyond 1e-4 the
+    price of its algebra, or of ANY second fp32 evaluation of the same frame?  Recorded next to the fast path's numbers."""
+    import os
+    a = _scene_args(sc, {})
+    v_rc, v_ra = _grads(sc)
+    W, H = a["width"], a["height"]
+    R = ref_hip.render_chain(ref, a["means"], a["quats"], a["scales"], a["opacities"], a["sh"], a["sh_degree"], a["viewmat"], a["K"], W, H, a["background"],
+                             v_render_colors=v_rc, v_render_alphas=v_ra)
+    cm, shut = _hip_enums(ops, a)
+    ut = ops.UnscentedTransformParameters()
+    op = a["opacities"][None].contiguous()
+    common = (a["means"], a["quats"], a["scales"], R["colors"], op, a["background"], None, W, H, 16, a["viewmat"], None, a["K"], cm, ut, shut,
+              None, None, None, R["tile_offsets"], R["flatten_ids"])
+    cmax = float(R["colors"].max())
+    r_ren, r_alp, r_last = np32(R["renders"]), np32(R["alphas"]), R["last_ids"].cpu().numpy()
+    out = {}
+    for path in ("generic", "fast"):
+        old = os.environ.get("GSX_RASTER_PATH")
+        if path == "generic":
+            os.environ["GSX_RASTER_PATH"] = "generic"
+        try:
+            G = ops.rasterize_to_pixels_from_world_3dgs_fwd(*common)
+            B = ops.rasterize_to_pixels_from_world_3dgs_bwd(*common, R["alphas"], R["last_ids"], v_rc, v_ra)
+            torch.cuda.synchronize()
+        finally:
+            if old is None:
+                os.environ.pop("GSX_RASTER_PATH", None)
+            else:
+                os.environ["GSX_RASTER_PATH"] = old
+        who = "HIP reference-order kernels (GSX_RASTER_PATH=generic)" if path == "generic" else "HIP fast kernels (same run)"
+        fw = _fwd_stats(tag, who, r_ren, r_alp, r_last, np32(G[0]), np32(G[1]), G[2].cpu().numpy(), cmax)
+        bw = parity_record("%s blend backward: %s vs reference kernel (rel-L2)" % (tag, who), **{n: rel_l2(np32(g), np32(R[n])) for n, g in zip(GRADS, B)})
+        assert fw["rgb_max_err"] <= fw["one_gaussian_bound"] and fw["rgb_pixels_over_1e4"] <= 4e-4 * fw["pixels"], fw
+        for g in GRADS:
+            assert bw[g] < 1e-3, (path, g, bw)
+        out[path] = (fw, bw)
+    return out
+
+
+def test_s1m_generic_order_kernels_vs_reference(ref, mods):
+    """VERDICT r03 weak #1(a): the full BASELINE frame through the reference-ORDER kernels too."""
+    ops, scenes = mods
+    _blend_generic_vs_reference(ref, ops, scenes.scene_1m(), "S-1M @1080p")
+
+
+def test_s5m_4k_generic_order_kernels_vs_reference(ref, mods):
+    ops, scenes = mods
+    _blend_generic_vs_reference(ref, ops, scenes.scene_5m(), "S-5M @4K")
+
+
+def test_s1m_bench_path_gradients_vs_reference_chain(ref, mods):
+    """VERDICT r03 weak #1(b): the gradients of the path bench.py times — rasterize_fused: fused front end -> guarded binned intersection ->
+    packed-record blend -> Gaussian-major backward + gather -> activation Jacobians -> fused SH backward, written into the flat gradient
+    bucket — against the reference chain's backward at S-1M: its blend backward (RasterizeToPixelsFromWorld3DGSBwd.cu:229-372) and SH backward
+    kernels, with the activation Jacobians of the reference's torch glue (exp / normalize / sigmoid, splat_data.cpp:267-286) in torch.
+    rel-L2 per parameter tensor < 1e-3 (north_star)."""
+    ops, scenes = mods
+    import gsx  # noqa: F401
+    from gsx import distributed, rasterizer
+    sc = scenes.scene_1m()
+    model = scenes.to_splat_data(sc, DEV)
+    W, H, deg = sc["width"], sc["height"], sc["sh_degree"]
+    v_rc, v_ra = _grads(sc)
+    # ---- the reference chain on the activations its glue computes from the same raw parameters
+    raw_s = model.scaling_raw.detach().clone().requires_grad_(True)
+    raw_q = model.rotation_raw.detach().clone().requires_grad_(True)
+    raw_o = model.opacity_raw.detach().clone().requires_grad_(True)
+    scales, quats, opac = torch.exp(raw_s), torch.nn.functional.normalize(raw_q, dim=-1), torch.sigmoid(raw_o).squeeze(-1)
+    vm, K, bg = dev(sc["viewmat"][None]), dev(sc["K"][None]), dev(sc["background"][None])
+    means, sh = model.means.detach(), model.sh.detach()
+    R = ref_hip.render_chain(ref, means, quats.detach().contiguous(), scales.detach().contiguous(), opac.detach().contiguous(), sh, deg, vm, K, W, H, bg,
+                             v_render_colors=v_rc, v_render_alphas=v_ra)
+    v_col = (R["v_colors"] * (R["colors"] > 0)).contiguous()          # clamp_min(c + 0.5, 0)
+    Kb = sh.shape[1]
+    v_coeffs, v_dirs = ref.spherical_harmonics_bwd(Kb, deg, R["dirs"].contiguous(), sh[None].contiguous(), R["masks"], v_col, True)
+    ref_g = {"means": (R["v_means"] + v_dirs[0]), "sh": v_coeffs[0]}
+    torch.autograd.backward([scales, quats, opac], [R["v_scales"], R["v_quats"], R["v_opacities"][0]])
+    ref_g.update(scaling_raw=raw_s.grad, rotation_raw=raw_q.grad, opacity_raw=raw_o.grad)
+    # ---- the bench path
+    for p in model.params():
+        p.requires_grad_(True)
+    names = ["means", "sh", "scaling_raw", "rotation_raw", "opacity_raw"]
+    bucket = distributed.GradBucket([getattr(model, n) for n in names])
+    bucket.flat.fill_(float("nan"))
+    cam = rasterizer.Camera(viewmat=sc["viewmat"].to(DEV), K=sc["K"].to(DEV), width=W, height=H)
+    rec = {}
+    for guarded in (False, True):   # the second render takes the guarded protocol (the first one warmed the capacity hint of this shape)
+        out = rasterizer.rasterize_fused(cam, model, sc["background"].to(DEV), grad_sinks=bucket.sinks(tuple(names)), guarded=guarded)
+        ((out.render_hwc * v_rc).sum() + (out.alpha * v_ra[0, :, :, 0][None]).sum()).backward()
+        torch.cuda.synchronize()
+        if guarded:
+            assert out.lists is not None and out.lists.status is not None and out.confirm()
+        for n in names:
+            rec[("guarded_" if guarded else "exact_") + n] = rel_l2(np32(getattr(model, n).grad), np32(ref_g[n].reshape(getattr(model, n).shape)))
+    err = (out.render_hwc.detach() - R["renders"]).abs().amax(-1)
+    rec = parity_record("S-1M @1080p END TO END gradients: rasterize_fused with gradient sinks (the bench path; exact and guarded lists) vs the reference "
+                        "chain's backward (rel-L2 per parameter tensor)", rgb_pixels_over_1e4=int((err > 1e-4).sum()), n_isects=int(out.n_isects),
+                        n_isects_ref=int(R["flatten_ids"].numel()), **rec)
+    for k, v in rec.items():
+        if k.startswith(("exact_", "guarded_")):
+            assert v < 1e-3, (k, v)
+
+
 def test_reference_fast_math_flavour_band(mods):
     """The reference's release build compiles its kernels with --use_fast_math (gsplat/CMakeLists.txt:75).  Two legitimate builds of the
     SAME reference kernels (IEEE vs fast-math) on S-1M: how far they are from each other is the band inside which 'matches the
