@@ -14,8 +14,8 @@
 // never written — no tile list can name it).  Every value is computed by the same device functions, in the same order of operations, as
 // the separate operators (ut_project, ShBasis::eval, store_packed_record): activated parameters, projection and colours are bit-identical;
 // the records agree to the last bit or two (the compiler contracts a few a*b+c of make_record differently in the two kernels) (tests/test_gpu_fused.py).
-// HBM-bound streaming; the 48 coefficient floats of a lane are fetched with twelve 16 B loads AFTER the projection (the wave's 64 rows
-// are one contiguous 12 KiB span, every fetched line is consumed by the wave's own loads through L1).
+// HBM-bound streaming; the coefficient rows are fetched AFTER the projection (rows of culled Gaussians never), through LDS where the
+// layout allows it (see frontend_kernel).
 #include "gsx_record.hpp"
 #include "gsx_sh_basis.hpp"
 #include "gsx_ut_project.hpp"
@@ -24,6 +24,7 @@ namespace gsx {
 
 void set_error(const char* msg);
 int check_launch(const char* what);
+const char* test_switch(const char* name);
 size_t raster_fwd_fast_workspace_bytes(uint32_t C, uint32_t N);
 
 constexpr int FE_BLOCK = 256;
@@ -35,7 +36,15 @@ struct FrontendOut {
     float4* packed;                                                  // [N] x 64 B records
 };
 
-template <int KIND, int DEG>
+// STAGE != 0: the wave's 64 coefficient rows — one contiguous 64 * K * 12 B span — are streamed into LDS with fully coalesced 16 B / lane
+// loads and every lane then reads ITS row from LDS (pitch 52 floats: a quarter wave's ds_read_b128 cover the 64 banks exactly once),
+// instead of twelve 192 B-strided 16 B loads per lane that pull every line through L1 twelve times.  STAGE == 2 passes the rows through
+// a 32-row tile in two halves (6.6 KB of LDS per wave instead of 13.3: 4 instead of 3 waves per SIMD).  Measured in the training step
+// (S-1M, bench per-op events, same box): direct loads 0.0915 ms, whole tile 0.084, two halves 0.079 (= 4.8 TB/s; four quarters 0.079).
+// Taken when the active bases are the whole row and rows are multiples of 16 B (K = (deg + 1)^2, K * 3 % 4 == 0: degree 3 with K = 16 —
+// two halves —, degree 1 with K = 4 — whole tile); otherwise the lane loads the active part of its row itself.  Rows of culled Gaussians
+// are not fetched either way.  GSX_FE_STAGE=0|1|2 (test switch) forces a variant.
+template <int KIND, int DEG, int STAGE>
 __global__ __launch_bounds__(FE_BLOCK) void frontend_kernel(uint32_t N, uint32_t K, const float* __restrict__ means,
                                                             const float* __restrict__ rotation_raw, const float* __restrict__ scaling_raw,
                                                             const float* __restrict__ opacity_raw, const float* __restrict__ coeffs,
@@ -44,33 +53,88 @@ __global__ __launch_bounds__(FE_BLOCK) void frontend_kernel(uint32_t N, uint32_t
     constexpr int NB = (DEG + 1) * (DEG + 1);
     constexpr int NB3 = NB * 3;
     constexpr int NQ = (NB3 + 3) / 4;
+    constexpr int LQ = NQ + 1;   // LDS row pitch in float4 (STAGE)
+    constexpr int TROWS = STAGE == 2 ? 32 : 64;   // rows of the wave's tile (STAGE == 2: the wave's rows pass through it in two halves)
+    __shared__ float4 s_rows[STAGE ? (FE_BLOCK / 64) * TROWS * LQ : 1];
     const uint32_t gid = blockIdx.x * FE_BLOCK + threadIdx.x;
-    if (gid >= N) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const bool in_range = gid < N;
+    if (!STAGE && !in_range) return;
     const Camera<KIND> cam(cams, 0, W, H);
     const ShutterPoses sp(cams.viewmats0, nullptr);
 
-    // ---- activations (projection_ut_kernel<KIND, true>, verbatim) ----
-    const f3 mean{means[(size_t)gid * 3], means[(size_t)gid * 3 + 1], means[(size_t)gid * 3 + 2]};
-    f3 scale{scaling_raw[(size_t)gid * 3], scaling_raw[(size_t)gid * 3 + 1], scaling_raw[(size_t)gid * 3 + 2]};
-    quat q{rotation_raw[(size_t)gid * 4], rotation_raw[(size_t)gid * 4 + 1], rotation_raw[(size_t)gid * 4 + 2], rotation_raw[(size_t)gid * 4 + 3]};
-    float opacity = opacity_raw[gid];
-    scale = {expf(scale.x), expf(scale.y), expf(scale.z)};
-    const float inv = 1.f / fmaxf(sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z), 1e-12f);
-    q = {q.w * inv, q.x * inv, q.y * inv, q.z * inv};
-    opacity = 1.f / (1.f + expf(-opacity));
-    out.scales[(size_t)gid * 3] = scale.x; out.scales[(size_t)gid * 3 + 1] = scale.y; out.scales[(size_t)gid * 3 + 2] = scale.z;
-    const float4 q_act = make_float4(q.w, q.x, q.y, q.z);
-    reinterpret_cast<float4*>(out.quats)[gid] = q_act;
-    out.opacities[gid] = opacity;
-    {   // glm::normalize(quat)
-        const float len = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-        if (len <= 0.f) q = {1.f, 0.f, 0.f, 0.f};
-        else { const float o = 1.f / len; q = {q.w * o, q.x * o, q.y * o, q.z * o}; }
-    }
-
-    // ---- projection ----
+    f3 mean{0.f, 0.f, 0.f}, scale{1.f, 1.f, 1.f};
+    float4 q_act = make_float4(1.f, 0.f, 0.f, 0.f);
+    float opacity = 0.f;
     UtProjOut p;
-    const bool visible = ut_project<KIND>(cam, sp, mean, scale, q, true, opacity, W, H, eps2d, near_plane, far_plane, radius_clip, ut, p);
+    bool visible = false;
+    if (in_range) {
+        // ---- activations (projection_ut_kernel<KIND, true>, verbatim) ----
+        mean = {means[(size_t)gid * 3], means[(size_t)gid * 3 + 1], means[(size_t)gid * 3 + 2]};
+        scale = {scaling_raw[(size_t)gid * 3], scaling_raw[(size_t)gid * 3 + 1], scaling_raw[(size_t)gid * 3 + 2]};
+        quat q{rotation_raw[(size_t)gid * 4], rotation_raw[(size_t)gid * 4 + 1], rotation_raw[(size_t)gid * 4 + 2], rotation_raw[(size_t)gid * 4 + 3]};
+        opacity = opacity_raw[gid];
+        scale = {expf(scale.x), expf(scale.y), expf(scale.z)};
+        const float inv = 1.f / fmaxf(sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z), 1e-12f);
+        q = {q.w * inv, q.x * inv, q.y * inv, q.z * inv};
+        opacity = 1.f / (1.f + expf(-opacity));
+        out.scales[(size_t)gid * 3] = scale.x; out.scales[(size_t)gid * 3 + 1] = scale.y; out.scales[(size_t)gid * 3 + 2] = scale.z;
+        q_act = make_float4(q.w, q.x, q.y, q.z);
+        reinterpret_cast<float4*>(out.quats)[gid] = q_act;
+        out.opacities[gid] = opacity;
+        {   // glm::normalize(quat)
+            const float len = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+            if (len <= 0.f) q = {1.f, 0.f, 0.f, 0.f};
+            else { const float o = 1.f / len; q = {q.w * o, q.x * o, q.y * o, q.z * o}; }
+        }
+        // ---- projection ----
+        visible = ut_project<KIND>(cam, sp, mean, scale, q, true, opacity, W, H, eps2d, near_plane, far_plane, radius_clip, ut, p);
+    }
+    float row[NQ * 4];
+    if (STAGE) {
+        // ---- the wave's coefficient rows -> LDS -> this lane's registers (only the rows of visible Gaussians are fetched) ----
+        const unsigned long long live = __builtin_amdgcn_ballot_w64(visible);
+        if (live != 0ull) {
+            const uint32_t e0 = blockIdx.x * FE_BLOCK + wave * 64u;
+            const uint32_t rows = min(64u, N - e0);
+            const float4* src = reinterpret_cast<const float4*>(coeffs + (size_t)e0 * K * 3u);
+            float4* tile = s_rows + wave * (uint32_t)(TROWS * LQ);
+            constexpr int NH = 64 / TROWS, NL = NQ / NH;   // passes, loads per lane and pass
+            static_assert(NQ % NH == 0, "rows split into equal passes");
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                float4 v[NL];
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {   // NL loads of 16 B per lane issued back to back
+                    const uint32_t j = lane + 64u * (uint32_t)i;            // float4 index inside this pass's TROWS rows
+                    const uint32_t e = j / (uint32_t)NQ + (uint32_t)(h * TROWS);
+                    const bool ok = e < rows && ((live >> (e & 63u)) & 1ull) != 0ull;
+                    v[i] = ok ? src[(size_t)h * TROWS * NQ + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {   // (rows of culled Gaussians are written as zeros: nobody reads them)
+                    const uint32_t j = lane + 64u * (uint32_t)i;
+                    const uint32_t el = j / (uint32_t)NQ;
+                    tile[el * (uint32_t)LQ + (j - el * (uint32_t)NQ)] = v[i];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the tile is private to this wave: no block barrier
+                __builtin_amdgcn_wave_barrier();
+                if ((int)(lane / TROWS) == h) {
+                    const float4* rq = tile + (lane % TROWS) * LQ;
+#pragma unroll
+                    for (int k = 0; k < NQ; ++k) {
+                        const float4 r4 = rq[k];
+                        row[k * 4] = r4.x; row[k * 4 + 1] = r4.y; row[k * 4 + 2] = r4.z; row[k * 4 + 3] = r4.w;
+                    }
+                }
+                if (h + 1 < NH) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+    }
+    if (!in_range) return;
     float* col = out.colors + (size_t)gid * 3;
     if (!visible) {
         out.radii[(size_t)gid * 2] = 0; out.radii[(size_t)gid * 2 + 1] = 0;   // as upstream, only radii is written for a culled Gaussian
@@ -86,12 +150,13 @@ __global__ __launch_bounds__(FE_BLOCK) void frontend_kernel(uint32_t N, uint32_t
     out.conics[(size_t)gid * 3 + 2] = p.c00 * p.ood;
 
     // ---- SH colours (sh_colors_fwd_direct_kernel, verbatim) ----
-    float row[NQ * 4];
-    const float4* src = reinterpret_cast<const float4*>(coeffs + (size_t)gid * K * 3u);
+    if (!STAGE) {
+        const float4* src = reinterpret_cast<const float4*>(coeffs + (size_t)gid * K * 3u);
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) {
-        const float4 v = src[k];
-        row[k * 4] = v.x; row[k * 4 + 1] = v.y; row[k * 4 + 2] = v.z; row[k * 4 + 3] = v.w;
+        for (int k = 0; k < NQ; ++k) {
+            const float4 v = src[k];
+            row[k * 4] = v.x; row[k * 4 + 1] = v.y; row[k * 4 + 2] = v.z; row[k * 4 + 3] = v.w;
+        }
     }
     const f3 cp = cam_position(cams.viewmats0);
     float x = mean.x - cp.x, y = mean.y - cp.y, z = mean.z - cp.z;
@@ -157,14 +222,22 @@ extern "C" int gsx_frontend_fused(uint32_t N, uint32_t K, uint32_t degrees_to_us
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((N + FE_BLOCK - 1) / FE_BLOCK), block(FE_BLOCK);
     const bool distorted = cams->radial || cams->tangential || cams->thin_prism;
-#define GSX_FE(KIND, D)                                                                                                                     \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(frontend_kernel<KIND, D>), grid, block, 0, st, N, K, means, rotation_raw, scaling_raw, opacity_raw, coeffs, \
+    // rows staged through LDS when the active bases are the whole, 16 B-multiple row (see frontend_kernel); GSX_FE_STAGE=0 (test switch): never
+    const uint32_t nb = (degrees_to_use + 1) * (degrees_to_use + 1);
+    const char* sw = test_switch("GSX_FE_STAGE");
+    const int stage = (nb == K && (K * 3u) % 4u == 0u) ? ((sw && sw[0] >= '0' && sw[0] <= '2') ? sw[0] - '0' : 2) : 0;
+#define GSX_FE(KIND, D, S)                                                                                                                  \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(frontend_kernel<KIND, D, S>), grid, block, 0, st, N, K, means, rotation_raw, scaling_raw, opacity_raw, coeffs, \
                        *cams, image_width, image_height, eps2d, near_plane, far_plane, radius_clip, *ut, out)
-#define GSX_FE_DEG(KIND)                                                                                                    \
-    switch (degrees_to_use) { case 0: GSX_FE(KIND, 0); break; case 1: GSX_FE(KIND, 1); break; case 2: GSX_FE(KIND, 2); break; \
-                              case 3: GSX_FE(KIND, 3); break; default: GSX_FE(KIND, 4); break; }
+#define GSX_FE_ST(KIND, D) do { if (stage == 2) GSX_FE(KIND, D, 2); else if (stage == 1) GSX_FE(KIND, D, 1); else GSX_FE(KIND, D, 0); } while (0)
+#define GSX_FE_DEG(KIND)                                                                                       \
+    switch (degrees_to_use) { case 0: GSX_FE(KIND, 0, 0); break;                                                    \
+                              case 1: if (stage) GSX_FE(KIND, 1, 1); else GSX_FE(KIND, 1, 0); break;           \
+                              case 2: GSX_FE(KIND, 2, 0); break; case 3: GSX_FE_ST(KIND, 3); break;            \
+                              default: GSX_FE(KIND, 4, 0); break; }
     if (distorted) { GSX_FE_DEG(CAM_OPENCV_PINHOLE) } else { GSX_FE_DEG(CAM_PERFECT_PINHOLE) }
 #undef GSX_FE_DEG
+#undef GSX_FE_ST
 #undef GSX_FE
     return check_launch("frontend_fused");
 }

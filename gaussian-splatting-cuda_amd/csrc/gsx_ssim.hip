@@ -34,6 +34,8 @@ constexpr int TX = 64, TY = 32, HALO = 5;
 constexpr int SX = TX + 2 * HALO, SY = TY + 2 * HALO;  // staged tile 74 x 42
 constexpr int PA = 75;                                  // pitch of the staged input planes (odd: rows -> distinct banks)
 constexpr int PC = 65;                                  // pitch of the horizontally-convolved planes
+// (round 4: pitches = 3 mod 16 (83 / 67) remove the remaining 2-way conflict between the two row groups of a wave in the horizontal
+// pass — measured flat, 0.0543 / 0.0443 ms either way: the kernels are bound by their phase structure, not by LDS conflicts)
 constexpr int NT = 512;                                 // 8 waves: wave w owns rows 4w .. 4w+3 of the tile in the vertical pass
 
 // the reference's window: normalised Gaussian, sigma 1.5, 11 taps, as fp32 literals (ssim.cu:16-27)
@@ -262,6 +264,16 @@ __global__ __launch_bounds__(NT) void ssim_bwd_kernel(int CH, int H, int W, cons
     }
 }
 
+__host__ __device__ __forceinline__ uint32_t loss_blocks_per_image(int H, int W) { return (uint32_t)((W + TX - 1) / TX) * (uint32_t)((H + TY - 1) / TY); }
+__device__ __forceinline__ bool loss_tile(int W, int H, int& tx0, int& ty0, int& tile_id) {
+    const uint32_t ntx = (uint32_t)(W + TX - 1) / TX, n = ntx * ((uint32_t)(H + TY - 1) / TY), per = (n + 7u) / 8u, b = blockIdx.x;
+    const uint32_t t = (b & 7u) * per + (b >> 3);
+    if ((b >> 3) >= per || t >= n) return false;
+    tile_id = (int)t;
+    ty0 = (int)(t / ntx) * TY; tx0 = (int)(t % ntx) * TX;
+    return true;
+}
+
 // ---- fused photometric loss on the blend's own layout ----------------------------------------------------------------------
 // render [C,H,W,3] (unclamped blend output), gt [C,3,H,W].  Workspace: chained partial maps [3][C][3][H][W] + block partial sums.
 __global__ __launch_bounds__(NT, 4) void loss_fwd_kernel(int H, int W, float chain, int crop, const float* __restrict__ render,
@@ -270,7 +282,8 @@ __global__ __launch_bounds__(NT, 4) void loss_fwd_kernel(int H, int W, float cha
     __shared__ float sA[SY][PA], sB[SY][PA];
     __shared__ float sC[4][SY][PC];
     __shared__ float2 s_red[NT / 64];
-    const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY;
+    int tx0, ty0, tile_id;
+    if (!loss_tile(W, H, tx0, ty0, tile_id)) return;
     const int x = threadIdx.x & 63, y0 = (threadIdx.x >> 6) * 4;
     const size_t npix = (size_t)H * W;
     const size_t q_stride = (size_t)gridDim.z * 3 * npix;
@@ -304,6 +317,8 @@ __global__ __launch_bounds__(NT, 4) void loss_fwd_kernel(int H, int W, float cha
                 const bool valid = gx >= crop && gx < W - crop && gy >= crop && gy < H - crop;
                 const float ch = valid ? chain : 0.f;
                 const size_t idx = plane + (size_t)gy * W + gx;
+                // (ordinary stores: the backward runs right behind and finds the maps in the Infinity Cache; stored nontemporally the forward
+                // gains 3 us — the maps no longer evict the render / target lines the next channel pass re-reads — and the backward loses 11)
                 maps[idx] = d0 * ch;
                 maps[q_stride + idx] = d1 * ch;
                 maps[2 * q_stride + idx] = d2 * ch;
@@ -326,7 +341,7 @@ __global__ __launch_bounds__(NT, 4) void loss_fwd_kernel(int H, int W, float cha
             t.x += s_red[k].x;
             t.y += s_red[k].y;
         }
-        block_sums[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t;
+        block_sums[(size_t)blockIdx.z * loss_blocks_per_image(H, W) + (size_t)tile_id] = t;
     }
 }
 
@@ -362,7 +377,8 @@ __global__ __launch_bounds__(NT) void loss_bwd_kernel(int H, int W, float l1_coe
                                                       const float* __restrict__ maps, float* __restrict__ v_render) {
     __shared__ float sD[3][SY][PA];
     __shared__ float sC[3][SY][PC];
-    const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY;
+    int tx0, ty0, tile_id;
+    if (!loss_tile(W, H, tx0, ty0, tile_id)) return;
     const int x = threadIdx.x & 63, y0 = (threadIdx.x >> 6) * 4;
     const size_t npix = (size_t)H * W;
     const size_t q_stride = (size_t)gridDim.z * 3 * npix;
@@ -375,7 +391,7 @@ __global__ __launch_bounds__(NT) void loss_bwd_kernel(int H, int W, float l1_coe
             const int gy = ty0 + ly - HALO, gx = tx0 + lx - HALO;
             const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
             const size_t idx = plane + (size_t)gy * W + gx;
-            sD[0][ly][lx] = in ? maps[idx] : 0.f;
+            sD[0][ly][lx] = in ? maps[idx] : 0.f;   // (plain loads: neighbouring tiles share the halo lines through L2; nontemporal loads: 0.044 -> 0.055 ms)
             sD[1][ly][lx] = in ? maps[q_stride + idx] : 0.f;
             sD[2][ly][lx] = in ? maps[2 * q_stride + idx] : 0.f;
         }
@@ -413,6 +429,13 @@ __global__ __launch_bounds__(NT) void loss_bwd_kernel(int H, int W, float l1_coe
 }
 
 inline dim3 tile_grid(uint32_t B, uint32_t H, uint32_t W) { return dim3((W + TX - 1) / TX, (H + TY - 1) / TY, B); }
+// fused loss kernels: 1-D XCD-aware grid (block b runs on XCD b % 8): every XCD takes a contiguous row-major run of tiles, so that the halo
+// lines neighbouring tiles share are fetched into ONE L2 instead of two (a 74-float row of a 64-pixel tile touches four 128 B lines, two of
+// them shared with its neighbours: with tiles dealt round-robin to the XCDs the loss kernels fetched 2.0x / 2.1x their algorithmic bytes).
+// Same-box A/B at 1080p (tools/loss_ab.py, each kernel on its own): forward 0.0607 -> 0.0558 ms, backward 0.0512 -> 0.0444; inside the
+// training step (bench.py per-op events) 0.064 + 0.054 -> 0.061 + 0.047.  (Round 2 measured an XCD-aware order as slower; that was with
+// the 64 x 16 tiles.)
+inline dim3 loss_grid(uint32_t B, uint32_t H, uint32_t W) { const uint32_t n = ((W + TX - 1) / TX) * ((H + TY - 1) / TY); return dim3(((n + 7u) / 8u) * 8u, 1, B); }
 
 }  // namespace ssim
 }  // namespace gsx
@@ -454,7 +477,7 @@ extern "C" int gsx_fused_ssim_bwd(uint32_t B, uint32_t CH, uint32_t H, uint32_t 
 }
 
 static size_t loss_maps_bytes(uint32_t C, uint32_t H, uint32_t W) { return (size_t)9 * C * H * W * sizeof(float); }
-static uint32_t loss_blocks(uint32_t C, uint32_t H, uint32_t W) { return C * ((H + TY - 1) / TY) * ((W + TX - 1) / TX); }
+static uint32_t loss_blocks(uint32_t C, uint32_t H, uint32_t W) { return C * loss_blocks_per_image((int)H, (int)W); }
 
 extern "C" size_t gsx_photometric_loss_workspace_bytes(uint32_t C, uint32_t H, uint32_t W) {
     return loss_maps_bytes(C, H, W) + (size_t)loss_blocks(C, H, W) * sizeof(float2);
@@ -476,7 +499,7 @@ extern "C" int gsx_photometric_loss_fwd(uint32_t C, uint32_t H, uint32_t W, floa
     // Upstream's backward scatters dL/dmap into a zero image only when it cropped (fused_ssim.cuh:85-96): for images of
     // 10 px or less the SSIM term contributes no gradient.  Kept.
     const float chain = crop ? (float)(-(double)lambda_dssim / n_valid) : 0.f;
-    hipLaunchKernelGGL(loss_fwd_kernel, tile_grid(C, H, W), dim3(NT), 0, st, (int)H, (int)W, chain, crop, render, gt, maps, sums);
+    hipLaunchKernelGGL(loss_fwd_kernel, loss_grid(C, H, W), dim3(NT), 0, st, (int)H, (int)W, chain, crop, render, gt, maps, sums);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(NT), 0, st, loss_blocks(C, H, W), (const float2*)sums, 1.0 / n_all, 1.0 / n_valid,
                        lambda_dssim, loss3);
     return check_launch("gsx_photometric_loss_fwd");
@@ -490,7 +513,7 @@ extern "C" int gsx_photometric_loss_bwd(uint32_t C, uint32_t H, uint32_t W, floa
     if (workspace_bytes < gsx_photometric_loss_workspace_bytes(C, H, W)) { set_error("gsx_photometric_loss_bwd: workspace too small"); return GSX_ERR_WORKSPACE_TOO_SMALL; }
     if (C > 65535u) { set_error("gsx_photometric_loss_bwd: more than 65535 images"); return GSX_ERR_UNSUPPORTED; }
     const double n_all = (double)C * 3.0 * (double)H * (double)W;
-    hipLaunchKernelGGL(loss_bwd_kernel, tile_grid(C, H, W), dim3(NT), 0, (hipStream_t)stream, (int)H, (int)W,
+    hipLaunchKernelGGL(loss_bwd_kernel, loss_grid(C, H, W), dim3(NT), 0, (hipStream_t)stream, (int)H, (int)W,
                        (float)((1.0 - (double)lambda_dssim) / n_all), grad_loss, grad_scale, render, gt, (const float*)workspace, v_render);
     return check_launch("gsx_photometric_loss_bwd");
 }
