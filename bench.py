@@ -240,6 +240,11 @@ def main():
     ap.add_argument("--no-order-ablation", action="store_true", help="skip the extra leg that times the other memory order (N = 1 only)")
     ap.add_argument("--repeats", type=int, default=1, help="R > 1: time R x K steps and report the MEDIAN K-step time (sub-3 %% claims need it; "
                                                            "the contract's single K-step region is R = 1)")
+    ap.add_argument("--mcmc", dest="mcmc", action="store_true", default=None, help="run the MCMC strategy's per-iteration operators inside the step (noise "
+                                                                                   "injection, its lr schedule); default: on for --scene 5m (configs[4] names the MCMC strategy)")
+    ap.add_argument("--no-mcmc", dest="mcmc", action="store_false")
+    ap.add_argument("--no-exchange-variants", action="store_true", help="N > 1: skip the extra leg that times the other gradient exchange (dense all-reduce "
+                                                                         "behind the colour exchange, or the reverse)")
     ap.add_argument("--exact-lists", action="store_true", help="the reference's protocol: the host reads n_isects inside intersect_tile every iteration (one "
                                                                "stream-draining sync per step; default: guarded lists, include/gsx.h — no host read on the render path)")
     ap.add_argument("--host-delay-us", type=float, default=0.0, help="A/B tool: busy-wait this long on the host after every intersection call (what a slower or "
@@ -293,44 +298,68 @@ def main():
     model = scenes.to_splat_data(scene, dev)
     for p in model.params():
         p.requires_grad_(True)
-    color_xch = world > 1 and not (args.dense_allreduce or args.sparse_allreduce or args.sharded_adam or args.unfused or args.no_overlap)
-    names = ["means", "sh", "scaling_raw", "rotation_raw", "opacity_raw"]
-    if color_xch:   # SH gradient first: everything that is all-reduced (means, scaling, rotation, opacity) is ONE contiguous span behind it
-        names = ["sh", "means", "scaling_raw", "rotation_raw", "opacity_raw"]
-    bucket = gdist.GradBucket([getattr(model, n) for n in names])
+    main_mode = ("single" if world == 1 else "sharded" if args.sharded_adam else "sparse" if args.sparse_allreduce else
+                 "dense" if (args.dense_allreduce or args.unfused or args.no_overlap) else "colour")
     poses = [scene["viewmat"].clone()] if args.fixed_camera else camera_poses(scene)
     cams = [rasterizer.Camera(viewmat=vm.to(dev), K=scene["K"].to(dev), width=W, height=H) for vm in poses]
     bg = scene["background"].to(dev)
     g = torch.Generator().manual_seed(1234)
     targets = [torch.rand(3, H, W, generator=g).to(dev) for _ in range(min(len(cams), 2))]  # (which noise image is irrelevant to the timing)
     fused_loss = not (args.l1_loss or args.unfused)
-    opt = optim.FusedAdam.for_splat_data(model)  # reference learning rates (include/core/parameters.hpp:19-23)
-    sharded = gdist.ShardedAdam(opt, bucket) if (args.sharded_adam and world > 1) else None
-
-    # fused SH backward + Adam: with the dense exchanges (all-reduce variants / sharded Adam) the SH gradient has to exist as a tensor
-    sh_adam_ok = not args.unfused_adam and not args.unfused and sharded is None and (world == 1 or color_xch)
+    # configs[4] is worded "5M Gaussians @ 4K, MCMC strategy": --scene 5m runs the MCMC strategy's per-iteration work too (noise injection
+    # every iteration, mcmc.cpp:342-366; its optimizer and lr schedule; relocation / growth fall on every 100th iteration — none inside a
+    # 20-step region: timed separately as `mcmc_refine_ms`)
+    strategy = None
+    if args.mcmc if args.mcmc is not None else args.scene == "5m":
+        from gsx.parameters import OptimizationParameters
+        from gsx.strategy import MCMC
+        prm = OptimizationParameters()
+        prm.max_cap = N            # the model is at its cap: relocation only, no growth
+        sgen = torch.Generator(device=dev)
+        sgen.manual_seed(7)
+        strategy = MCMC(model, prm, 1.0, sgen)
+        opt = strategy.optimizer
+    else:
+        opt = optim.FusedAdam.for_splat_data(model)  # reference learning rates (include/core/parameters.hpp:19-23)
     timer = OpTimer(ops)
     timer.host_delay_us = args.host_delay_us
-    sinks = bucket.sinks(tuple(names))
     counter = {"i": 0, "isects": [], "repeated": 0}
     guarded = not (args.exact_lists or args.unfused)
-    if guarded and world > 1:   # a frame that overflowed on any rank is repeated on every rank (host-side agreement over gloo)
-        sinks["_lists_agree"] = gdist.ListsAgreement()
-    xch = None
-    if color_xch:
-        xch = gdist.ColorGradExchange(bucket, names)
-        sinks["_color_exchange"] = xch
-    overlap = world > 1 and xch is None and sharded is None and not args.sparse_allreduce and not args.unfused and not args.no_overlap
-    early = {"h": None}
-    if overlap:   # parameter order of the bucket: means, sh, scaling_raw, rotation_raw, opacity_raw -> the tail starts at parameter 2
-        sinks["_early_ready"] = lambda: early.__setitem__("h", bucket.all_reduce_mean_tail_async(2))
+    lists_agree = gdist.ListsAgreement() if (guarded and world > 1) else None   # a frame that overflowed on any rank is repeated on every rank
+
+    def make_leg(mode):
+        """One gradient-exchange configuration over the SAME model and optimizer: the flat gradient bucket (re-points every p.grad), the
+        sinks the render backward writes into, and the exchange objects."""
+        L = {"mode": mode, "xch": None, "sharded": None, "early": {"h": None}}
+        # colour exchange: SH gradient first, so that everything that is all-reduced (means, scaling, rotation, opacity) is ONE span behind it
+        L["names"] = ["sh", "means", "scaling_raw", "rotation_raw", "opacity_raw"] if mode == "colour" else ["means", "sh", "scaling_raw", "rotation_raw", "opacity_raw"]
+        L["bucket"] = gdist.GradBucket([getattr(model, n) for n in L["names"]])
+        L["sinks"] = L["bucket"].sinks(tuple(L["names"]))
+        if lists_agree is not None:
+            L["sinks"]["_lists_agree"] = lists_agree
+        if mode == "sharded":
+            L["sharded"] = gdist.ShardedAdam(opt, L["bucket"])
+        if mode == "colour":
+            L["xch"] = gdist.ColorGradExchange(L["bucket"], L["names"])
+            L["sinks"]["_color_exchange"] = L["xch"]
+        L["overlap"] = mode == "dense" and not args.unfused and not args.no_overlap
+        if L["overlap"]:   # parameter order of the bucket: means, sh, scaling_raw, rotation_raw, opacity_raw -> the tail starts at parameter 2
+            L["sinks"]["_early_ready"] = lambda: L["early"].__setitem__("h", L["bucket"].all_reduce_mean_tail_async(2))
+        # fused SH backward + Adam: with the dense exchanges (all-reduce variants / sharded Adam) the SH gradient has to exist as a tensor
+        L["sh_adam_ok"] = not args.unfused_adam and not args.unfused and mode in ("single", "colour")
+        return L
+
+    leg = make_leg(main_mode)
+    cur = {"leg": leg}
 
     def step(with_adam=True):
+        L = cur["leg"]
+        sinks, bucket, xch, sharded = L["sinks"], L["bucket"], L["xch"], L["sharded"]
         i = counter["i"]
         counter["i"] += 1
         cam = cams[(i * world + rank) % len(cams)]  # every step, every rank: another camera
         # the SH tensor's Adam step rides on the SH backward (no 192 MB gradient round trip); the other groups are stepped below
-        fused_sh = with_adam and sh_adam_ok
+        fused_sh = with_adam and L["sh_adam_ok"]
         if xch is not None:   # the step's whole camera batch, in rank order (every rank knows the schedule)
             xch.begin_step(torch.stack([cams[(i * world + r) % len(cams)].viewmat for r in range(world)]))
         target = targets[i % len(targets)]
@@ -360,16 +389,20 @@ def main():
             if xch is not None:
                 xch.finish()   # colours were all-gathered and the SH backward ran over every camera inside backward(); the rest was all-reduced under it
             elif world > 1:
-                if args.sparse_allreduce and not args.unfused:
+                if L["mode"] == "sparse" and not args.unfused:
                     # rows no camera of the step sees are zero on every rank: only the union of the visible rows travels
                     bucket.all_reduce_mean_rows((out.aux["radii_full"] > 0).all(-1))
-                elif overlap:
-                    bucket.all_reduce_mean_head(early["h"])   # means + SH now; scaling / rotation / opacity have been travelling since
-                    early["h"] = None
+                elif L["overlap"]:
+                    bucket.all_reduce_mean_head(L["early"]["h"])   # means + SH now; scaling / rotation / opacity have been travelling since
+                    L["early"]["h"] = None
                 else:
                     bucket.all_reduce_mean()
             if with_adam:
+                if strategy is not None:
+                    strategy.post_backward(1001 + i, out)   # MCMC: noise injection (+ relocation / growth on refine iterations: none in this range)
                 opt.step(1001 + i, skip_sh=fused_sh)  # past the shN warm-up (fused_adam.cpp:66-70): all six groups are updated
+                if strategy is not None:
+                    strategy.scheduler.step()
         counter["isects"].append(out.n_isects)
 
     def timed(n, with_adam):
@@ -429,6 +462,41 @@ def main():
     timer.enabled = False
     all_ms = timer.mean_ms()
     all_ms.update(blend_ms)                  # the blend ops keep their timed-region figures
+    # names used by the report below: the MAIN leg's configuration
+    names, bucket, xch, sharded, overlap, sh_adam_ok = leg["names"], leg["bucket"], leg["xch"], leg["sharded"], leg["overlap"], leg["sh_adam_ok"]
+    main_exchange_bytes = int(getattr(bucket, "last_reduced_bytes", 0)) if world > 1 else 0
+
+    # ---- N > 1: the other gradient exchange, in the same process group, right behind the contract's leg (outside its timed region) ----
+    # north_star words the exchange as "an RCCL all-reduce of per-Gaussian gradients": that is the dense leg; the colour-gradient exchange is
+    # the optimisation on top.  One invocation on a node yields both: W warm-up + K timed iterations each.
+    exchange_variants = None
+    if world > 1 and main_mode in ("colour", "dense") and not args.unfused and not args.no_exchange_variants:
+        other_mode = "dense" if main_mode == "colour" else "colour"
+        cur["leg"] = make_leg(other_mode)      # a second bucket over the same parameters: p.grad now points into it
+        for _ in range(args.warmup):
+            step(True)
+        other_ms = timed(args.steps, True) / args.steps * 1e3
+        other_bytes = int(getattr(cur["leg"]["bucket"], "last_reduced_bytes", 0))
+        exchange_variants = {main_mode: {"ms_per_step": round(elapsed / args.steps * 1e3, 4), "bytes_exchanged_per_rank": main_exchange_bytes},
+                             other_mode: {"ms_per_step": round(other_ms, 4), "bytes_exchanged_per_rank": other_bytes},
+                             "what": "the same training iteration with the other gradient exchange (colour = all-gather of 3 floats per (camera, Gaussian) + SH "
+                                     "backward over all cameras + all-reduce of the other 11 floats; dense = one all-reduce of the flat 59-float bucket, its "
+                                     "scaling / rotation / opacity tail travelling under the SH backward); W warm-up + K timed iterations each"}
+        cur["leg"] = leg
+        for p_, o_ in zip(bucket.params, bucket.offsets):   # p.grad back into the main leg's bucket
+            p_.grad = bucket.flat[o_:o_ + p_.numel()].view_as(p_)
+    # ---- configs[4]: one refine event of the MCMC strategy (relocation of dead Gaussians + growth up to the cap), every 100th iteration upstream ----
+    mcmc_refine_ms = None
+    if strategy is not None:
+        for _ in range(2):   # (the first call pays torch's one-time set-up of nonzero / multinomial at this size)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_rel = strategy.relocate_gs()
+            n_new = strategy.add_new_gs()
+            torch.cuda.synchronize()
+        mcmc_refine_ms = {"ms": round((time.perf_counter() - t0) * 1e3, 3), "relocated": int(n_rel), "added": int(n_new), "every_iterations": strategy.params.refine_every,
+                          "what": "relocate_gs + add_new_gs (mcmc.cpp:114-340) on the bench scene: random opacities in [0.1, 0.9] leave no dead Gaussian and the model "
+                                  "is at its cap, so this is the cost of the dead-Gaussian scan; a training run relocates ~1 % (tools/mcmc_time.py: 9.3 ms at 5 M)"}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -492,12 +560,14 @@ def main():
                        "cameras": "cfg2 pose only" if args.fixed_camera else "%d poses (cfg2 + a 0.4 m orbit around it), a different one every step" % len(cams),
                        "n_isects_mean": round(I, 1), "n_isects_min": min(isects_timed), "n_isects_max": max(isects_timed),
                        "gaussian_order": "as generated (random): --random-order" if args.random_order else "Morton order of the positions (gsx.layout; the same Gaussians as generated, permuted once before the timed region)",
-                       "cameras_per_step": world, "ranks": world, "backend": (dist.get_backend() if world > 1 else None),
+                       "cameras_per_step": world, "ranks": (dist.get_world_size() if world > 1 else 1), "backend": (dist.get_backend() if world > 1 else None),
+                       "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if (world > 1 and dist.get_backend() == "nccl") else None),
+                       "strategy": ("MCMC (noise injection every iteration, lr schedule; refine events timed separately: mcmc_refine)" if strategy is not None else "none (plain iteration)"),
                        "grad_exchange": ("none" if world == 1 else ("colour-gradient all-gather (3 floats / camera / Gaussian) + SH backward over all cameras on every rank; "
                                                                      "all-reduce of the other 11 floats under it" if xch is not None else "reduce-scatter + sharded Adam + all-gather" if sharded is not None else
                                          ("all-reduce of visible rows" if args.sparse_allreduce else
                                           ("dense all-reduce, scaling/rotation/opacity exchanged under the SH backward" if overlap else "dense all-reduce")))),
-                       "grad_exchange_bytes": int(getattr(bucket, "last_reduced_bytes", 0)) if world > 1 else 0,
+                       "grad_exchange_bytes": main_exchange_bytes,
                        "grad_bucket_bytes": bucket.nbytes(),
                        "host_syncs_per_step": round(host_syncs / (args.steps * len(elapsed_all)), 2),
                        "intersect_protocol": ("guarded lists (include/gsx.h): the host never reads n_isects on the render path; it confirms the count inside "
@@ -525,29 +595,39 @@ def main():
                            "unit": "T lane-op/s", "frac": round(lane_ops / VALU_PEAK_LANE_OPS, 4), "valu_insts_per_launch": c}
         if valu:
             result["roofline_valu"] = dict(valu, source=pmc.get("source"))
+        if exchange_variants is not None:
+            result["grad_exchange_variants"] = exchange_variants
+        if mcmc_refine_ms is not None:
+            result["mcmc_refine"] = mcmc_refine_ms
+            result["ms_per_step_with_refine_amortised"] = round(ms_per_step + mcmc_refine_ms["ms"] / mcmc_refine_ms["every_iterations"], 4)
         if fwd_bwd_ms is not None:
             result["fwd_bwd"] = {"ms_per_frame": round(fwd_bwd_ms, 4), "frames_per_s": round(world * 1e3 / fwd_bwd_ms, 3),
                                  "what": "render + fused loss + backward (+ gradient all-reduce), no optimizer; same camera sequence"}
-        if world == 1 and not args.no_order_ablation and not args.unfused:
-            # the other memory order, same scene: a fresh model / optimizer, W warm-up + K timed training iterations (outside the contract's region)
+        if world == 1 and not args.no_order_ablation and not args.unfused and strategy is None:
+            # the two memory orders of the same scene on equal footing: a fresh model / optimizer each, W warm-up iterations, then three
+            # alternating pairs of K-step legs (both models have trained the same number of iterations at every pair); medians.  A single
+            # 20-step leg is inside the run-to-run noise of the effect (a few per cent), and the contract's own model has trained longer.
+            from gsx import layout
+
+            def fresh(sc_):
+                m_ = scenes.to_splat_data(sc_, dev)
+                for p_ in m_.params():
+                    p_.requires_grad_(True)
+                b_ = gdist.GradBucket([getattr(m_, n) for n in names])
+                return {"m": m_, "b": b_, "s": b_.sinks(tuple(names)), "o": optim.FusedAdam.for_splat_data(m_)}
+
             other = dict(scene_as_generated)
             if args.random_order:
-                from gsx import layout
                 o2 = layout.morton_order(other["means"])
                 for k in ("means", "quats", "scales", "opacities", "sh"):
                     other[k] = other[k][o2].contiguous()
-            m2 = scenes.to_splat_data(other, dev)
-            for p_ in m2.params():
-                p_.requires_grad_(True)
-            b2 = gdist.GradBucket([getattr(m2, n) for n in names])
-            s2 = b2.sinks(tuple(names))
-            o2pt = optim.FusedAdam.for_splat_data(m2)
+            runs = {"this": fresh(scene), "other": fresh(other)}
 
-            def step2(i):
+            def step2(R, i):
                 cam = cams[i % len(cams)]
-                s2["_sh_adam"] = o2pt.begin_fused_sh_step(1001 + i) if sh_adam_ok else None
+                R["s"]["_sh_adam"] = R["o"].begin_fused_sh_step(1001 + i) if sh_adam_ok else None
                 for attempt in range(4):
-                    out2 = rasterizer.rasterize_fused(cam, m2, bg, grad_sinks=s2, guarded=guarded)
+                    out2 = rasterizer.rasterize_fused(cam, R["m"], bg, grad_sinks=R["s"], guarded=guarded)
                     l2 = gloss.photometric_loss(out2.render_hwc, targets[i % len(targets)], 0.2) if fused_loss else (out2.image - targets[i % len(targets)]).abs().mean()
                     try:
                         l2.backward()
@@ -555,18 +635,28 @@ def main():
                     except rasterizer.IsectCapacityMiss:
                         if attempt == 3:
                             raise
-                o2pt.step(1001 + i, skip_sh=s2["_sh_adam"] is not None)
-            for i in range(args.warmup):
-                step2(i)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(args.steps):
-                step2(i)
-            torch.cuda.synchronize()
-            result["order_ablation"] = {"order": "Morton order of the positions" if args.random_order else "as generated (random)",
-                                        "ms_per_step": round((time.perf_counter() - t0) / args.steps * 1e3, 4),
-                                        "what": "the same training iteration on the same Gaussians stored in the other memory order (fresh model and optimizer)"}
-            del m2, b2, s2, o2pt
+                R["o"].step(1001 + i, skip_sh=R["s"]["_sh_adam"] is not None)
+            for R in runs.values():
+                for i in range(args.warmup):
+                    step2(R, i)
+            legs, k2 = {"this": [], "other": []}, args.warmup
+            for _ in range(3):
+                for key in ("this", "other"):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for i in range(k2, k2 + args.steps):
+                        step2(runs[key], i)
+                    torch.cuda.synchronize()
+                    legs[key].append((time.perf_counter() - t0) / args.steps * 1e3)
+                k2 += args.steps
+            med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731
+            this_order, other_order = ("as generated (random)", "Morton order of the positions") if args.random_order else ("Morton order of the positions", "as generated (random)")
+            result["order_ablation"] = {"order": other_order, "ms_per_step": round(med(legs["other"]), 4),
+                                        "this_order": this_order, "this_order_ms_per_step": round(med(legs["this"]), 4),
+                                        "legs_ms_this_order": [round(v, 4) for v in legs["this"]], "legs_ms_other_order": [round(v, 4) for v in legs["other"]],
+                                        "what": "the same training iteration on the same Gaussians stored in either memory order: a fresh model and optimizer each, "
+                                                "W warm-up iterations, then three alternating pairs of K-step legs outside the contract's region; medians"}
+            del runs
         if world == 1 and not args.no_cpu_baseline:
             threads = os.cpu_count() or 1
             dt, i_cpu = cpu_baseline(scene, threads)

@@ -179,6 +179,7 @@ class ShardedAdam:
     def __init__(self, optimizer, bucket=None):
         self.opt, self.bucket = optimizer, bucket
         self._bounds = None   # (n, lo, hi) of the partition the moments were last updated under
+        self._gen = getattr(optimizer, "reindex_generation", 0)   # the optimizer's row order those bounds refer to
 
     @staticmethod
     def _merge_owned_rows(t, lo, hi):
@@ -234,6 +235,13 @@ class ShardedAdam:
         per = (n + world - 1) // world
         lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
         even = n % world == 0
+        gen = getattr(self.opt, "reindex_generation", 0)
+        if self._bounds is not None and gen != self._gen:
+            # rows were permuted or removed (FusedAdam.select_state) while this rank held current moments only for ITS rows: a same-size
+            # re-index would silently apply the old ownership bounds to other Gaussians.  merge_moments() before the surgery clears the bounds.
+            raise RuntimeError("ShardedAdam: the optimizer state was re-indexed (select_state) between two steps without merge_moments(); wire "
+                               "strategy.before_reindex = sharded.merge_moments (trainer.Trainer does) or call it before the surgery")
+        self._gen = gen
         if self._bounds is not None and self._bounds[0] != n:
             # the partition moves: bring every rank's moments up to date under the OLD partition before rows change owner.
             # (rows appended or reset by the densification strategy since are zero on every rank; merging zeros keeps them zero)

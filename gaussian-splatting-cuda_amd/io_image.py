@@ -3,8 +3,10 @@ save_image of the reference (src/core/image_io.cpp:112-345, src/core/camera.cpp:
 
 Same size rules: `res_div` in {1, 2, 4, 8} divides both sides (integer division, at least 1 px); `max_width` > 0 then bounds
 the LONGER side, keeping the aspect ratio with the reference's integer arithmetic (image_io.cpp:152-161, 190-203); alpha is
-dropped, 1- and 2-channel files are expanded to RGB.  The down-sampling filter is Pillow's box/bilinear reduction, not OIIO's
-resampler: resized pixels agree only approximately with the reference's (full-resolution loads are bit-identical)."""
+dropped, 1- and 2-channel files are expanded to RGB.  Down-sampling restates the reference's call
+`OIIO::ImageBufAlgo::resample(dst, src, /*interpolate=*/true)` (image_io.cpp:33-49): OpenImageIO is a vcpkg dependency that is not in
+this image, so `resample_oiio` follows its published algorithm (imagebufalgo_xform.cpp `resample_`, imagebuf.cpp `interppixel_`,
+fmath.h `bilerp`) in float32 and is pinned by hand-computed fixtures (tests/test_io.py), not against the library."""
 import numpy as np
 import torch
 from PIL import Image
@@ -23,6 +25,37 @@ def target_size(w, h, res_div=1, max_width=0):
     return nw, nh
 
 
+def resample_oiio(src, nw, nh):
+    """OIIO::ImageBufAlgo::resample(dst, src, interpolate=true) for uint8 [H,W,C] -> [nh,nw,C], in the library's float32 arithmetic:
+    destination pixel (x, y) samples the source at the position of its CENTRE, ((x + 0.5) / nw * w, (y + 0.5) / nh * h), by bilinear
+    interpolation between the four texel centres around it (interppixel: position - 0.5, floor / frac, texels outside the image are
+    black); texels are read as v * (1/255) and the result is stored as (uint8)(clamp(f * 255 + 0.5))."""
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    h, w = src.shape[:2]
+    f32 = np.float32
+    srcf = src.astype(f32) * f32(1.0 / 255.0)
+
+    def axis(n_dst, n_src):
+        s = (np.arange(n_dst, dtype=f32) + f32(0.5)) * (f32(1.0) / f32(n_dst))      # (x - dstfx + 0.5) * dstpixelwidth
+        pos = s * f32(n_src) - f32(0.5)                                             # srcfx + s * srcfw, then interppixel's -0.5
+        tex = np.floor(pos)
+        return tex.astype(np.int64), (pos - tex).astype(f32)
+
+    xt, xf = axis(nw, w)
+    yt, yf = axis(nh, h)
+
+    def texel(yy, xx):   # WrapBlack: zero outside the data window
+        ok = ((yy >= 0) & (yy < h))[:, None] & ((xx >= 0) & (xx < w))[None, :]
+        v = srcf[np.clip(yy, 0, h - 1)[:, None], np.clip(xx, 0, w - 1)[None, :]]
+        return np.where(ok[..., None], v, f32(0.0))
+
+    v0, v1, v2, v3 = texel(yt, xt), texel(yt, xt + 1), texel(yt + 1, xt), texel(yt + 1, xt + 1)
+    s, t = xf[None, :, None], yf[:, None, None]
+    s1, t1 = f32(1.0) - s, f32(1.0) - t
+    out = t1 * (s1 * v0 + s * v1) + t * (s1 * v2 + s * v3)                           # fmath.h bilerp
+    return np.clip(out * f32(255.0) + f32(0.5), f32(0.0), f32(255.0)).astype(np.uint8)
+
+
 def load_image(path, res_div=1, max_width=0):
     """-> uint8 array [H, W, 3]."""
     try:
@@ -33,9 +66,10 @@ def load_image(path, res_div=1, max_width=0):
     im = im.convert("RGB")  # drops alpha, expands grey (+alpha) to RGB
     w, h = im.size
     nw, nh = target_size(w, h, res_div, max_width)
+    a = np.ascontiguousarray(np.asarray(im, dtype=np.uint8))
     if (nw, nh) != (w, h):
-        im = im.resize((nw, nh), Image.Resampling.BOX if (w % nw == 0 and h % nh == 0) else Image.Resampling.BILINEAR, reducing_gap=None)
-    return np.ascontiguousarray(np.asarray(im, dtype=np.uint8))
+        a = resample_oiio(a, nw, nh)
+    return a
 
 
 def load_and_get_image(path, res_div=1, max_width=0, device="cpu"):

@@ -29,6 +29,7 @@ class FusedAdam:
         self.groups = [{"name": n, "lr": float(lrs[n])} for n in GROUPS]
         self.betas, self.eps, self.skip_sh_steps = betas, eps, skip_sh_steps
         self.state = {}   # "means" | "sh" | "scaling" | "rotation" | "opacity" -> exp_avg / exp_avg_sq; step counts per group
+        self.reindex_generation = 0   # bumped whenever rows are permuted / removed (select_state): distributed.ShardedAdam checks it
 
     @staticmethod
     def for_splat_data(model, means_lr=0.00016, shs_lr=0.0025, scaling_lr=0.005, rotation_lr=0.001, opacity_lr=0.05,
@@ -76,7 +77,8 @@ class FusedAdam:
                     st[k] = torch.cat([st[k], z], 0)
 
     def select_state(self, indices):
-        """Keep only the given Gaussians (MCMC::remove_gaussians, mcmc.cpp:404-444)."""
+        """Keep only the given Gaussians (MCMC::remove_gaussians, mcmc.cpp:404-444) — or permute them (MCMC.reorder_spatially)."""
+        self.reindex_generation += 1
         for key, st in self.state.items():
             if isinstance(st, dict):
                 st["exp_avg"] = st["exp_avg"].index_select(0, indices)

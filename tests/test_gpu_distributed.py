@@ -48,6 +48,9 @@ def _worker(rank, world, port, out_dir, sharded, exchange="colors"):
         if it == 9:   # before the first refinement step: only Adam has amplified the rounding so far
             torch.cuda.synchronize()
             np.save(os.path.join(out_dir, "early_%s_%d.npy" % (tag, rank)), torch.cat([p.detach().reshape(-1) for p in model.params()]).cpu().numpy())
+        if it == 23:  # three iterations after the first refinement (relocation + growth + Morton reorder at it = 20): row by row
+            torch.cuda.synchronize()
+            np.save(os.path.join(out_dir, "mid_%s_%d.npy" % (tag, rank)), torch.cat([p.detach().reshape(p.shape[0], -1) for p in model.params()], 1).cpu().numpy())
     torch.cuda.synchronize()
     flat = torch.cat([p.detach().reshape(-1) for p in model.params()]).cpu().numpy()
     np.save(os.path.join(out_dir, "params_%s_%d.npy" % (tag, rank)), flat)
@@ -83,4 +86,36 @@ def test_two_rank_color_exchange_matches_row_all_reduce(tmp_path):
     assert r.shape == a.shape
     ea, er = np.load(tmp_path / "early_0_0.npy"), np.load(tmp_path / "early_rows_0.npy")
     assert np.linalg.norm(ea - er) / np.linalg.norm(er) < 1e-4
+    # across the first refinement (relocation, growth, Morton reorder): the two runs hold the same Gaussians row by row — tight — except
+    # where a last-bit difference of an opacity moved ONE multinomial draw to the neighbouring Gaussian (then that row, and the rows the
+    # reorder shifts with it, differ): at most a few rows, never the model
+    ma, mr = np.load(tmp_path / "mid_0_0.npy"), np.load(tmp_path / "mid_rows_0.npy")
+    assert ma.shape == mr.shape and ma.shape[0] > 2000
+    key = lambda m: np.lexsort(np.round(m[:, :3], 3).T[::-1])   # noqa: E731  (rows as a set: sorted by position)
+    sa, sr = ma[key(ma)], mr[key(mr)]
+    row_err = np.abs(sa - sr).max(1) / (np.abs(sr).max(1) + 1e-6)
+    assert (row_err > 1e-3).mean() < 0.02, float((row_err > 1e-3).mean())
     assert np.linalg.norm(a - r) / np.linalg.norm(r) < 5e-2
+
+
+def test_bench_two_ranks_times_both_gradient_exchanges():
+    """`python bench.py --gpus 2` (self-launch, two ranks on GPU 0 over gloo: functional check of the N > 1 path the driver's SCALE run takes
+    over RCCL): one invocation must yield the contract's line with the colour-gradient exchange AND the dense all-reduce leg, guarded lists
+    agreed across the ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GSX_BENCH_ALL_RANKS_ON_DEVICE0="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--scene", "small", "--steps", "3",
+                        "--warmup", "2", "--no-fwd-bwd"], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["config"]["backend"] == "gloo"
+    v = d["grad_exchange_variants"]
+    assert v["colour"]["ms_per_step"] > 0 and v["dense"]["ms_per_step"] > 0
+    assert v["dense"]["bytes_exchanged_per_rank"] > 0 and v["colour"]["bytes_exchanged_per_rank"] > 0   # (S-small has SH degree 0: no SH gradient to save)
+    assert "guarded" in d["config"]["intersect_protocol"]   # (S-small has K = 1: no fused front end, so its renders fall back to the exact lists)

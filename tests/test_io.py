@@ -187,6 +187,35 @@ def test_image_io_sizes_and_round_trip(tmp_path):
         io_image.load_image(str(tmp_path / "missing.png"))
 
 
+def test_resample_restates_oiio_resample_interpolate():
+    """io_image.resample_oiio = OIIO::ImageBufAlgo::resample(dst, src, interpolate = true) as the reference calls it
+    (src/core/image_io.cpp:33-49).  OpenImageIO is not in this image (vcpkg dependency): pinned by fixtures computed by hand from its
+    published algorithm — sample the source at the destination pixel's CENTRE, bilinear between the four texel centres, texels as
+    v / 255, store (uint8)(f * 255 + 0.5)."""
+    import gsx  # noqa: F401
+    from gsx import io_image
+    # (1) exact halving: the centre of a destination pixel sits on the corner shared by a 2 x 2 source block: weights 1/4 each
+    src = np.array([[[10], [20], [7], [9]], [[30], [41], [1], [2]]], np.uint8)              # [H=2, W=4, C=1]
+    out = io_image.resample_oiio(src, 2, 1)
+    # (10 + 20 + 30 + 41) / 4 = 25.25 -> +0.5 -> 25 ; (7 + 9 + 1 + 2) / 4 = 4.75 -> +0.5 -> 5
+    assert out.shape == (1, 2, 1) and out[0, :, 0].tolist() == [25, 5]
+    # (2) 5 -> 3 along x, one row: centres at 5/6, 15/6, 25/6 -> minus 0.5 -> 1/3 (texel 0, frac 1/3), 2 (texel 2, frac 0), 11/3 (texel 3, frac 2/3)
+    row = np.array([[[0], [90], [77], [30], [120]]], np.uint8)
+    out = io_image.resample_oiio(row, 3, 1)
+    # y: one source row -> centre 0.5 -> minus 0.5 -> texel 0, frac 0 (the row below is outside: weight 0)
+    # 2/3 * 0 + 1/3 * 90 = 30 ; 77 ; 1/3 * 30 + 2/3 * 120 = 90
+    assert out[0, :, 0].tolist() == [30, 77, 90]
+    # (3) 3 -> 2 along y, three channels: centres at 0.75, 2.25 -> 0.25 (texel 0, frac 1/4), 1.75 (texel 1, frac 3/4)
+    col = np.array([[[0, 255, 8]], [[100, 155, 8]], [[200, 55, 9]]], np.uint8)
+    out = io_image.resample_oiio(col, 1, 2)
+    # 0.75 * 0 + 0.25 * 100 = 25 ; 0.75 * 255 + 0.25 * 155 = 230 ; 8        |  0.25 * 100 + 0.75 * 200 = 175 ; 0.25 * 155 + 0.75 * 55 = 80 ; 8.75 -> 9
+    assert out[:, 0, :].tolist() == [[25, 230, 8], [175, 80, 9]]
+    # (4) identity size: every pixel samples its own centre
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 256, (7, 5, 3), dtype=np.uint8)
+    assert np.array_equal(io_image.resample_oiio(a, 5, 7), a)
+
+
 def test_colmap_text_reader_matches_binary(tmp_path):
     import gsx  # noqa: F401
     from gsx import io_colmap
