@@ -404,6 +404,8 @@ def main():
                 if strategy is not None:
                     strategy.scheduler.step()
         counter["isects"].append(out.n_isects)
+        if out.lists is not None:
+            counter["max_seg"] = max(counter.get("max_seg", 0), int(out.lists.confirm()[1]))
 
     def timed(n, with_adam):
         torch.cuda.synchronize()
@@ -559,6 +561,7 @@ def main():
             "config": {"workload": workload, "n_gaussians": N, "width": W, "height": H, "sh_degree": deg,
                        "cameras": "cfg2 pose only" if args.fixed_camera else "%d poses (cfg2 + a 0.4 m orbit around it), a different one every step" % len(cams),
                        "n_isects_mean": round(I, 1), "n_isects_min": min(isects_timed), "n_isects_max": max(isects_timed),
+                       "largest_tile_segment": counter.get("max_seg"),
                        "gaussian_order": "as generated (random): --random-order" if args.random_order else "Morton order of the positions (gsx.layout; the same Gaussians as generated, permuted once before the timed region)",
                        "cameras_per_step": world, "ranks": (dist.get_world_size() if world > 1 else 1), "backend": (dist.get_backend() if world > 1 else None),
                        "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if (world > 1 and dist.get_backend() == "nccl") else None),

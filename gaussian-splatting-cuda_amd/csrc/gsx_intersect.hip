@@ -861,7 +861,7 @@ __global__ __launch_bounds__(ISECT_BLOCK) void ranked_finalize_kernel(int64_t ca
 // costs three launches for them).  out[i] = sum(in[0..i)), in[n-1] is ignored and out[n-1] = grand total.
 __global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t n, const uint32_t* __restrict__ in, int32_t* __restrict__ out,
                                                         uint32_t* __restrict__ max_count, int64_t capacity, int64_t seg_bound,
-                                                        int32_t* __restrict__ lists_status) {
+                                                        int32_t* __restrict__ lists_status, unsigned long long* __restrict__ host_word) {
     // exclusive scan of n - 1 counts, out[n - 1] = total.  Runs in 64 bits: a frame with more than 2^31 - 1 intersections does not
     // wrap silently — every offset saturates at INT32_MAX and the total is written as -1, which both consumers reject (the fill's
     // n_isects guard in the C ABI, the shim's TORCH_CHECK): such a scene needs the device-wide sort's int64 scan.
@@ -911,6 +911,13 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t n, const uint32
         const unsigned long long total = s_carry;
         const bool ok = total <= (unsigned long long)capacity && (seg_bound <= 0 || (int64_t)s_max <= seg_bound);
         *lists_status = ok ? (int32_t)total : -1;
+    }
+    // The host's copy of (n_isects | largest segment << 32): ONE 8-byte store into the caller's pinned memory through its device alias,
+    // instead of two 4-byte copy launches behind this kernel (each ~5 us of stream time between the count and the key scatter).
+    if (host_word != nullptr && threadIdx.x == 0) {
+        const unsigned long long total = s_carry;
+        const unsigned long long lo = total > 0x7FFFFFFFull ? 0xFFFFFFFFull : total;
+        __hip_atomic_store(host_word, lo | ((unsigned long long)(max_count != nullptr ? s_max : 0u) << 32), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1109,10 +1116,18 @@ extern "C" int gsx_intersect_bin_count_guarded(uint32_t C, uint32_t N, const flo
     // offsets[t] = intersections before (camera, tile) t; offsets[nseg] = n_isects
     // (the largest segment lands in the slack word behind the counts; it travels to the host in the upper half of the pinned word)
     uint32_t* max_count = (uint32_t*)((char*)workspace + bin_hist_bytes(C, n_tiles) + align_up((size_t)(nseg + 1) * 4, 256));
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, nseg + 1, (const uint32_t*)counts, tile_offsets, max_count, capacity, max_segment,
-                       lists_status);
+    // the pinned host word (low 32 bits: n_isects, 0xFFFFFFFF = more than 2^31 - 1; high 32 bits: keys of the largest (camera, tile) segment)
+    // is written by bin_scan itself when the memory has a device alias (hipHostMalloc / hipHostRegister: torch's pinned tensors), else copied
+    unsigned long long* host_alias = nullptr;
     if (n_isects_host_pinned) {
-        *n_isects_host_pinned = 0;  // low 32 bits: n_isects (-1 = more than 2^31 - 1), high 32 bits: keys of the largest (camera, tile) segment
+        *n_isects_host_pinned = 0;
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, n_isects_host_pinned, 0) == hipSuccess && dp != nullptr) host_alias = (unsigned long long*)dp;
+        else (void)hipGetLastError();
+    }
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, nseg + 1, (const uint32_t*)counts, tile_offsets, max_count, capacity, max_segment,
+                       lists_status, host_alias);
+    if (n_isects_host_pinned && host_alias == nullptr) {
         (void)hipMemcpyAsync(n_isects_host_pinned, tile_offsets + nseg, 4, hipMemcpyDeviceToHost, st);
         (void)hipMemcpyAsync((char*)n_isects_host_pinned + 4, max_count, 4, hipMemcpyDeviceToHost, st);
     }
@@ -1158,9 +1173,13 @@ extern "C" int gsx_intersect_bin_fill(uint32_t C, uint32_t N, const float* means
     const KeyDepthIdx kt{idx_bits};
     hipLaunchKernelGGL(tile_sort_wave_kernel<KeyDepthIdx>, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, n_tiles, bit_width_u32(n_tiles), kt,
                        tile_offsets, keys, flatten_ids, isect_ids, n_isects);
-    hipLaunchKernelGGL(tile_sort_kernel<KeyDepthIdx>, dim3(nseg), dim3(ISECT_BLOCK), 0, st, n_tiles, bit_width_u32(n_tiles), kt, tile_offsets,
-                       keys, flatten_ids, isect_ids, n_isects);
-    if (n_isects > TSORT_CAP) {   // a segment above 4096 keys needs at least that many intersections
+    // (`max_segment` > 0 is the caller's bound on the largest segment: the kernels for larger segments are not launched at all — a frame
+    // that outgrows the bound is refilled / rendered again, as documented for the giant-segment passes)
+    const int64_t seg_cap = std::min<int64_t>(max_segment > 0 ? max_segment : n_isects, n_isects);
+    if (seg_cap > TSORT_WAVE_CAP)
+        hipLaunchKernelGGL(tile_sort_kernel<KeyDepthIdx>, dim3(nseg), dim3(ISECT_BLOCK), 0, st, n_tiles, bit_width_u32(n_tiles), kt, tile_offsets,
+                           keys, flatten_ids, isect_ids, n_isects);
+    if (seg_cap > TSORT_CAP) {   // a segment above 4096 keys needs at least that many intersections
         const size_t big_lds = (size_t)(TSORT_BIG_CAP + TSORT_BIG_CAP / 32) * 8;
         static const bool attr_set = [&] {
             return hipFuncSetAttribute((const void*)tile_sort_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds) == hipSuccess;

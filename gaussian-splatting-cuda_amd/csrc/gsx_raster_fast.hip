@@ -413,8 +413,13 @@ static_assert(FCH == 128, "raster_fwd_quad_kernel: four byte lists of FCH entrie
 template <int KIND>
 __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_quad_kernel(RasterArgs a, float* __restrict__ render_colors,
                                                                             float* __restrict__ render_alphas, int32_t* __restrict__ last_ids) {
-    __shared__ float4 s_rec[2][FCH + 1][4];   // AoS records, double buffered; [FCH] = the null record
-    __shared__ float4 s_cull[2][FCH];
+    // AoS records, double buffered; [FCH] = the null record.  Pitch FIVE float4 (80 B): [0..3] the record, [4] = (rad2, k2, -, -) of the
+    // footprint test.  A ds_read_b128 is served in groups of 16 lanes, and in the step loop a group holds lanes of TWO DPP rows reading
+    // two different records: with a 64 B pitch their 4-bank windows coincide whenever the two list indices agree mod 4 (one extra LDS
+    // cycle in a quarter of the group accesses: SQ_LDS_BANK_CONFLICT = 33 % of the kernel's LDS cycles in round 3); with 80 B they
+    // coincide only for indices 16 apart.  The per-lane reads of the binning (stride = pitch) are conflict-free for the same reason
+    // (64 B: four-way), and the cull plane of round 3 lives in the pad.
+    __shared__ float4 s_rec[2][FCH + 1][5];
     __shared__ float s_bounds[4][4];
     __shared__ int s_wdone[2][4];
     // [wave][block][FCH]: indices into the chunk's records, consumed by the wave that wrote them (4 x FCH = 512 B per wave: one ds_write_b64 per
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_quad_kernel(Rast
             if (no_cull) sr.cull.z = INFINITY;
             sr.r1.y -= LOG2_K999; sr.r2.w *= K999; sr.r3.x *= K999; sr.r3.y *= K999;
             s_rec[buf][tid][0] = sr.r0; s_rec[buf][tid][1] = sr.r1; s_rec[buf][tid][2] = sr.r2; s_rec[buf][tid][3] = sr.r3;
-            s_cull[buf][tid] = sr.cull;
+            s_rec[buf][tid][4] = make_float4(sr.cull.z, sr.cull.w, 0.f, 0.f);
         }
         if (lane == 0) s_wdone[buf][wave] = wave_done ? 1 : 0;
         __syncthreads();
@@ -529,8 +534,8 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_quad_kernel(Rast
         for (int32_t sub = 0; sub < chunk_size; sub += 64) {
             uint32_t hits = 0u;
             if (sub + (int32_t)lane < chunk_size) {
-                const float4 c = s_cull[buf][sub + lane];
-                const float4 q0 = s_rec[buf][sub + lane][0], q1 = s_rec[buf][sub + lane][1];   // (.., .., l00, l01), (l11, ..)
+                const float4 q0 = s_rec[buf][sub + lane][0], q1 = s_rec[buf][sub + lane][1], q4 = s_rec[buf][sub + lane][4];   // (u0, v0, l00, l01), (l11, ..), (rad2, k2)
+                const float4 c = make_float4(q0.x, q0.y, q4.x, q4.y);
                 if (KIND == CAM_PERFECT_PINHOLE) {
                     hits = footprint_hits_2x2(c, q0.z, q0.w, q1.x, xr, yr);
                 } else {

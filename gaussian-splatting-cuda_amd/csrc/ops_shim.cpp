@@ -716,7 +716,10 @@ static std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile
     int64_t capacity = 0, seg_bound = 0;
     if (hint > 0 && n_elements) {
         capacity = std::min<int64_t>(hint + hint / 8 + 4096, 0x7FFFFFFFll);
-        seg_bound = std::max<int64_t>(hint_seg + hint_seg / 4, 16384);   // (16384: no giant-segment launches at all)
+        // bound on the largest (camera, tile) segment the fill is launched for, in the tiers of its sort kernels: <= 1024 keys: the one-wave
+        // sort alone; <= 4096: + the block sort; <= 16384: + the 1024-thread sort; above: + giant-segment merge passes for exactly this bound
+        const int64_t sb = hint_seg + hint_seg / 4;
+        seg_bound = sb <= 1024 ? 1024 : (sb <= 4096 ? 4096 : std::max<int64_t>(sb, 16384));
     }
     const bool guarded = lists != nullptr && capacity > 0;
 
