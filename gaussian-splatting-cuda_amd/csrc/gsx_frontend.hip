@@ -26,6 +26,7 @@ void set_error(const char* msg);
 int check_launch(const char* what);
 const char* test_switch(const char* name);
 size_t raster_fwd_fast_workspace_bytes(uint32_t C, uint32_t N);
+int32_t* raster_fwd_fast_heads(const float4* packed, uint32_t C, uint32_t N);
 
 constexpr int FE_BLOCK = 256;
 
@@ -34,6 +35,7 @@ struct FrontendOut {
     int32_t* radii; float* means2d; float* depths; float* conics;   // projection [1,N,2] [1,N,2] [1,N] [1,N,3]
     float* colors;                                                   // [1,N,3]
     float4* packed;                                                  // [N] x 64 B records
+    int32_t* heads;                                                  // [N] list heads of the backward's record chains: -1 (empty)
 };
 
 // STAGE != 0: the wave's 64 coefficient rows — one contiguous 64 * K * 12 B span — are streamed into LDS with fully coalesced 16 B / lane
@@ -135,6 +137,7 @@ __global__ __launch_bounds__(FE_BLOCK) void frontend_kernel(uint32_t N, uint32_t
         }
     }
     if (!in_range) return;
+    out.heads[gid] = -1;
     float* col = out.colors + (size_t)gid * 3;
     if (!visible) {
         out.radii[(size_t)gid * 2] = 0; out.radii[(size_t)gid * 2 + 1] = 0;   // as upstream, only radii is written for a culled Gaussian
@@ -217,8 +220,8 @@ extern "C" int gsx_frontend_fused(uint32_t N, uint32_t K, uint32_t degrees_to_us
         return GSX_ERR_INVALID_ARGUMENT;
     }
     if (workspace_bytes < raster_fwd_fast_workspace_bytes(1, N)) { set_error("frontend_fused: workspace too small (gsx_rasterize_fwd_workspace_bytes)"); return GSX_ERR_WORKSPACE_TOO_SMALL; }
-    FrontendOut out{scales, quats, opacities, radii, means2d, depths, conics, colors,
-                    (float4*)(((uintptr_t)fwd_workspace + 255) & ~(uintptr_t)255)};   // the blend forward's workspace layout
+    float4* packed_base = (float4*)(((uintptr_t)fwd_workspace + 255) & ~(uintptr_t)255);   // the blend forward's workspace layout
+    FrontendOut out{scales, quats, opacities, radii, means2d, depths, conics, colors, packed_base, raster_fwd_fast_heads(packed_base, 1, N)};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((N + FE_BLOCK - 1) / FE_BLOCK), block(FE_BLOCK);
     const bool distorted = cams->radial || cams->tangential || cams->thin_prism;

@@ -123,6 +123,7 @@ GSX_DEV uint32_t butterfly_value_of_lane(uint32_t lane) {
 const uint8_t* launch_raster_fwd_fast(int kind, RasterArgs a, float* renders, float* alphas, int32_t* last_ids, void* workspace,
                                       size_t workspace_bytes, hipStream_t st, bool records_ready = false);
 size_t raster_fwd_fast_workspace_bytes(uint32_t C, uint32_t N);
+int32_t* raster_fwd_fast_heads(const float4* packed, uint32_t C, uint32_t N);   // the list-head array inside the forward workspace (see its layout)
 // returns false (nothing launched) when no sufficient workspace was supplied: the caller falls back to the generic kernels
 bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, const int32_t* last_ids,
                             const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats,

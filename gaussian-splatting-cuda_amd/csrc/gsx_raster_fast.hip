@@ -605,9 +605,13 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_quad_kernel(Rast
 
 // forward workspace, from its 256 B aligned base: packed records [C*N] x 64 B | fisheye: "no chart" bytes [C*N] | tile flags
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
-size_t raster_fwd_fast_workspace_bytes(uint32_t C, uint32_t N) { return 256 + (size_t)C * N * 64 + align256((size_t)C * N) + FAST_FLAG_BYTES; }
+// ... | list heads [C*N] int32 of the backward's per-(camera, Gaussian) record chains: set to -1 by whoever packs the records (the fused front
+// end, pack_records_kernel) and put back to -1 by the gather kernel that walks the chains, so a backward on the forward's workspace needs
+// no memset launch
+size_t raster_fwd_fast_workspace_bytes(uint32_t C, uint32_t N) { return 256 + (size_t)C * N * 64 + align256((size_t)C * N) + FAST_FLAG_BYTES + align256((size_t)C * N * 4); }
 static uint8_t* ws_bad(const float4* packed, uint32_t C, uint32_t N) { return (uint8_t*)packed + (size_t)C * N * 64; }
 static uint8_t* ws_flags(const float4* packed, uint32_t C, uint32_t N) { return ws_bad(packed, C, N) + align256((size_t)C * N); }
+int32_t* raster_fwd_fast_heads(const float4* packed, uint32_t C, uint32_t N) { return (int32_t*)(ws_flags(packed, C, N) + FAST_FLAG_BYTES); }
 
 // packs the records (and, for a fisheye, flags the tiles the fast kernels must leave to the reference-order kernels)
 static const float4* pack_into(int kind, RasterArgs& a, void* base, hipStream_t st, int32_t* heads = nullptr) {
@@ -628,8 +632,8 @@ const uint8_t* launch_raster_fwd_fast(int kind, RasterArgs a, float* renders, fl
     (void)workspace_bytes;
     const uint32_t n_tiles = a.tw * a.th;
     const dim3 grid(((n_tiles + 7u) / 8u) * 8u, a.C), block(RB);
-    if (records_ready) a.packed = (const float4*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);   // written by the fused front end
-    else pack_into(kind, a, workspace, st);
+    if (records_ready) a.packed = (const float4*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);   // written by the fused front end (records + list heads)
+    else pack_into(kind, a, workspace, st, raster_fwd_fast_heads((const float4*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), a.C, a.N));
     // Which forward kernel: four lists per wave pay where a Gaussian that reaches a quadrant misses part of its four blocks — small
     // footprints.  Measured (tools/fwd_quad_ab.py, same box): S-1M (3.4 tiles per Gaussian) 0.272 -> 0.232 ms, its fisheye twin 0.320 ->
     // 0.265; S-5M @4K (5.3 tiles) -5 .. +7 %, a saturated scene (5.9) +3 %, large footprints with 32-pixel lists +18 % (every block sees
@@ -1248,7 +1252,7 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
 // One thread per Gaussian; colours / opacities are per camera, means / quats / scales are shared by the cameras.
 template <int KIND>
 __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const float4* __restrict__ ws_rec,
-                                                             const int32_t* __restrict__ ws_head, float* __restrict__ v_means,
+                                                             int32_t* __restrict__ ws_head, float* __restrict__ v_means,
                                                              float* __restrict__ v_quats, float* __restrict__ v_scales,
                                                              float* __restrict__ v_colors, float* __restrict__ v_opacities) {
     const uint32_t gi = blockIdx.x * 256u + threadIdx.x;
@@ -1262,6 +1266,7 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
     for (uint32_t c = 0; c < a.C; ++c) {
         const size_t g = (size_t)c * a.N + gi;
         int32_t it = ws_head[g];
+        if (it >= 0) ws_head[g] = -1;   // the chain is consumed: the head array is empty again for the next backward on this workspace
         if (it < 0) {  // no tile touched this (camera, Gaussian): every output element is written, none needs a pre-fill
             v_colors[g * 3] = 0.f; v_colors[g * 3 + 1] = 0.f; v_colors[g * 3 + 2] = 0.f;
             v_opacities[g] = 0.f;
@@ -1375,10 +1380,10 @@ bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, 
     const dim3 grid(((n_tiles + 7u) / 8u) * 8u, a.C), block(RB);
     float4* ws_rec = (float4*)workspace;
     int32_t* ws_head = (int32_t*)((char*)workspace + align256(((size_t)a.n_isects << (2 * a.lshift)) * 64));   // lists per 32 x 32 pixels: four record slots per entry
-    if (packed_from_fwd) {  // the forward of the same inputs left its packed records (and tile flags) with the caller: only the list heads are reset
+    if (packed_from_fwd) {  // the forward of the same inputs left its packed records, tile flags and (empty) list heads with the caller
         a.packed = packed_from_fwd;
         if (kind == CAM_OPENCV_FISHEYE) a.tile_flags = ws_flags(packed_from_fwd, a.C, a.N);
-        (void)hipMemsetAsync(ws_head, 0xFF, (size_t)a.C * a.N * 4, st);
+        ws_head = raster_fwd_fast_heads(packed_from_fwd, a.C, a.N);   // all -1: set by the packer, restored by every gather
     } else {
         pack_into(kind, a, (char*)ws_head + align256((size_t)a.C * a.N * 4), st, ws_head);  // also sets every list head to -1
     }
@@ -1401,7 +1406,7 @@ bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, 
     }
 #undef GSX_BLEND_BWD
     // the moments -> gradient map only involves the camera pose: one instance serves every camera model
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_bwd_gather_kernel<CAM_PERFECT_PINHOLE>), ggrid, gblock, 0, st, a, ws_rec, ws_head, v_means, v_quats, v_scales,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_bwd_gather_kernel<CAM_PERFECT_PINHOLE>), ggrid, gblock, 0, st, a, (const float4*)ws_rec, ws_head, v_means, v_quats, v_scales,
                        v_colors, v_opacities);
     return true;
 }
