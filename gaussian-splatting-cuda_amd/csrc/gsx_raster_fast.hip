@@ -274,8 +274,10 @@ template <int KIND>
 __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(RasterArgs a, float* __restrict__ render_colors,
                                                              float* __restrict__ render_alphas,
                                                              int32_t* __restrict__ last_ids) {
-    __shared__ float4 s_rec[2][FCH][4];   // AoS records, double buffered
-    __shared__ float4 s_cull[2][FCH];     // (u0, v0, rad2, k2): per-lane cull reads are conflict-free on this plane
+    // AoS records, double buffered, pitch FIVE float4 (80 B): [0..3] the record, [4] = (rad2, k2, -, -) of the footprint test.  The per-lane
+    // reads of the culling pass have the pitch as their stride: 80 B spreads a 16-lane group of a ds_read_b128 over all 64 banks (64 B: four-way
+    // conflicts); the step loop reads one record wave-uniformly either way.  (Layout shared with raster_fwd_quad_kernel.)
+    __shared__ float4 s_rec[2][FCH][5];
     __shared__ float s_bounds[4][4];
     __shared__ int s_wdone[2][4];
     const uint32_t cid = blockIdx.y;
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
             if (no_cull) sr.cull.z = INFINITY;
             sr.r1.y -= LOG2_K999; sr.r2.w *= K999; sr.r3.x *= K999; sr.r3.y *= K999;
             s_rec[buf][tid][0] = sr.r0; s_rec[buf][tid][1] = sr.r1; s_rec[buf][tid][2] = sr.r2; s_rec[buf][tid][3] = sr.r3;
-            s_cull[buf][tid] = sr.cull;
+            s_rec[buf][tid][4] = make_float4(sr.cull.z, sr.cull.w, 0.f, 0.f);
         }
         if (lane == 0) s_wdone[buf][wave] = wave_done ? 1 : 0;
         __syncthreads();
@@ -348,8 +350,8 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
             // one candidate Gaussian per lane: does its footprint touch this wave's quadrant?
             bool hit = false;
             if (sub + (int32_t)lane < chunk_size) {
-                const float4 c = s_cull[buf][sub + lane];
-                const float4 q0 = s_rec[buf][sub + lane][0], q1 = s_rec[buf][sub + lane][1];   // (.., .., l00, l01), (l11, ..)
+                const float4 q0 = s_rec[buf][sub + lane][0], q1 = s_rec[buf][sub + lane][1], q4 = s_rec[buf][sub + lane][4];   // (u0, v0, l00, l01), (l11, ..), (rad2, k2)
+                const float4 c = make_float4(q0.x, q0.y, q4.x, q4.y);
                 hit = footprint_hits(c, q0.z, q0.w, q1.x, wb[0], wb[1], wb[2], wb[3]);
             }
             unsigned long long todo = __builtin_amdgcn_ballot_w64(hit);
