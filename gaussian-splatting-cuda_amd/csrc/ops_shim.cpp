@@ -111,17 +111,31 @@ static std::map<HintKey, uint32_t> g_hint_last_n;
 
 static HintKey hint_key_any(const HintKey& k) { return std::make_tuple(std::get<0>(k), std::get<1>(k), 0u, std::get<3>(k), std::get<4>(k)); }
 
-static void hint_lookup(const HintKey& key, int64_t& hint, int64_t& hint_seg, int64_t* last_total = nullptr) {
-    std::lock_guard<std::mutex> lock(g_hint_mutex);
+// (g_hint_mutex held) the hint of `key`: its own running maxima, else those of the same (device, C, tile grid) at the previous Gaussian count
+static void hint_lookup_locked(const HintKey& key, int64_t& hint, int64_t& hint_seg) {
     const HintKey any = hint_key_any(key);
     auto it = g_hints.find(key);
     hint = hint_seg = 0;
     if (it != g_hints.end()) {
         hint = it->second.first; hint_seg = it->second.second;
     } else if ((it = g_hints.find(any)) != g_hints.end() && g_hint_last_n[any] > 0) {
-        const double grow = std::min(2.0, std::max(1.0, (double)std::get<2>(key) / (double)g_hint_last_n[any]));
-        hint = (int64_t)((double)it->second.first * grow); hint_seg = (int64_t)((double)it->second.second * grow);
+        // the last call of this (device, C, tile grid) at another Gaussian count stands in, scaled — if the counts are close (a growth step);
+        // a model 1.5x larger or smaller than that call's is a different scene: no hint, the exact protocol runs once
+        const double ratio = (double)std::get<2>(key) / (double)g_hint_last_n[any];
+        if (ratio <= 1.5 && ratio >= 0.67) {
+            const double grow = std::max(1.0, ratio);
+            // ... and what stands in is that shape's running MAXIMUM over its cameras (its last call alone may have been a light view)
+            auto prev = g_hints.find(std::make_tuple(std::get<0>(key), std::get<1>(key), g_hint_last_n[any], std::get<3>(key), std::get<4>(key)));
+            const std::pair<int64_t, int64_t> base = prev != g_hints.end() ? std::make_pair(std::max(prev->second.first, it->second.first), std::max(prev->second.second, it->second.second))
+                                                                           : it->second;
+            hint = (int64_t)((double)base.first * grow); hint_seg = (int64_t)((double)base.second * grow);
+        }
     }
+}
+
+static void hint_lookup(const HintKey& key, int64_t& hint, int64_t& hint_seg, int64_t* last_total = nullptr) {
+    std::lock_guard<std::mutex> lock(g_hint_mutex);
+    hint_lookup_locked(key, hint, hint_seg);
     if (last_total) {
         auto lt = g_last.find(key);
         *last_total = lt != g_last.end() ? lt->second.first : hint;
@@ -131,15 +145,21 @@ static void hint_lookup(const HintKey& key, int64_t& hint, int64_t& hint_seg, in
 static void hint_update(const HintKey& key, int64_t n_isects, int64_t max_seg) {
     std::lock_guard<std::mutex> lock(g_hint_mutex);
     if (g_hints.size() > 4096) { g_hints.clear(); g_last.clear(); }   // (a long run that resizes thousands of times: start over rather than grow without bound)
+    if (g_hints.find(key) == g_hints.end()) {   // a new shape inherits what stood in for it (a grown model keeps the maxima over its cameras)
+        int64_t h0 = 0, s0 = 0;
+        hint_lookup_locked(key, h0, s0);
+        g_hints[key] = std::make_pair(h0, s0);
+    }
     auto& h = g_hints[key];
-    h.first = std::max<int64_t>(n_isects, h.first - h.first / 128);  // running maximum with a slow decay
-    h.second = std::max<int64_t>(max_seg, h.second - h.second / 128);
+    // running maxima with a slow decay (a few hundred calls to forget an outlier view: a dataset's cameras come round every few hundred
+    // iterations, and under the guarded protocol a miss costs a whole repeated iteration, not just a second fill)
+    h.first = std::max<int64_t>(n_isects, h.first - h.first / 512);
+    h.second = std::max<int64_t>(max_seg, h.second - h.second / 512);
     const HintKey any = hint_key_any(key);
     g_hints[any] = std::make_pair(n_isects, max_seg);
     g_last[key] = std::make_pair(n_isects, max_seg);
     g_hint_last_n[any] = std::get<2>(key);
 }
-
 
 // Handle of one guarded intersection (include/gsx.h "guarded lists"): the lists were filled optimistically into `capacity` slots and the
 // blend kernels read the verdict from `status` on the device; the host reads the same verdict here, whenever it likes, and must do so
@@ -715,7 +735,7 @@ static std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile
     ranked = ranked && n_elements && gsx_intersect_ranked_supported(C, N);
     int64_t capacity = 0, seg_bound = 0;
     if (hint > 0 && n_elements) {
-        capacity = std::min<int64_t>(hint + hint / 8 + 4096, 0x7FFFFFFFll);
+        capacity = std::min<int64_t>(hint + hint / 4 + 4096, 0x7FFFFFFFll);   // 25 % head room: 288 GB of HBM make slots cheaper than repeats
         // bound on the largest (camera, tile) segment the fill is launched for, in the tiers of its sort kernels: <= 1024 keys: the one-wave
         // sort alone; <= 4096: + the block sort; <= 16384: + the 1024-thread sort; above: + giant-segment merge passes for exactly this bound
         const int64_t sb = hint_seg + hint_seg / 4;

@@ -344,7 +344,9 @@ class GutRenderFunction(torch.autograd.Function):
         if fe is None:
             colors = ops.sh_colors_fwd(sh_degree, means_c, viewmat, sh_c, radii)
         # tile size of the intersection lists: 32-px lists only on the fast blend path (global-shutter pinhole) — see _LIST_TILE_STATE
-        lt_key = (means_c.shape[0], width, height, means_c.device.index)
+        # (keyed by the image shape, not by the Gaussian count: a model that grows by 5 % every hundred iterations keeps its choice — with N in
+        # the key every growth step fell back to 16-px lists for one heavy frame, on a capacity hint from the start of the training)
+        lt_key = (width, height, means_c.device.index)
         # (and only with the fused front end: its records carry each Gaussian's rectangle of 16-px tiles, which a 16-px tile needs to take
         # exactly the reference's entries out of its 32-px parent's list)
         list_tile = _list_tile_for(lt_key) if (camera_model == ops.CameraModelType.PINHOLE and fe is not None) else TILE_SIZE

@@ -10,6 +10,9 @@
 
 One process per GPU; rank r renders camera `cams[(it * world + r) % len(cams)]`.  Every rank holds a full replica and applies
 the identical update (the strategy's random draws come from a generator seeded identically on all ranks)."""
+import os
+import sys
+
 import torch
 import torch.distributed as dist
 
@@ -94,8 +97,10 @@ class Trainer:
             try:
                 gloss.backward(loss)
                 break
-            except rasterizer.IsectCapacityMiss:
+            except rasterizer.IsectCapacityMiss as e:
                 self.capacity_misses += 1
+                if os.environ.get("GSX_LOG_CAPACITY_MISSES"):
+                    print("iteration %d (%d Gaussians): %s" % (it, self.model.means.shape[0], e), file=sys.stderr)
                 if attempt == 3:
                     raise
         if self.sharded is not None:

@@ -6,7 +6,7 @@
 #   4. bench.py --scene 5m                                                -> bench_s5m.json
 #   5. examples/train_garden_standin.py 4000 (twice)                      -> garden_standin.json
 # Usage: bash tools/profile_round.sh r02
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/$tag
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
