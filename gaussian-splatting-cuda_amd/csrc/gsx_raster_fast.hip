@@ -511,6 +511,9 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_quad_kernel(Rast
     int32_t g_pre = 0;
     bool have = (int32_t)tid < FCH && range_start + (int32_t)tid < range_end;
     if (have) g_pre = a.flatten_ids[range_start + (int32_t)tid];
+#ifdef GSX_STATS
+    uint32_t st_tot[4] = {0u, 0u, 0u, 0u};
+#endif
     for (int32_t b = 0; b < n_chunks; ++b) {
         const int buf = b & 1;
         const int32_t chunk_start = range_start + FCH * b;
@@ -558,6 +561,10 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_quad_kernel(Rast
         const uint32_t steps = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the lists are private to the wave
         GSX_STAT_ADD(0, steps);
+        GSX_STAT_ADD(4, cnt[0] + cnt[1] + cnt[2] + cnt[3]);      // sum of the four lists' lengths: / (4 x steps) = how full the four rows run
+#ifdef GSX_STATS
+        st_tot[0] += cnt[0]; st_tot[1] += cnt[1]; st_tot[2] += cnt[2]; st_tot[3] += cnt[3];
+#endif
         uint32_t cur = 0xFFFFFFFFu;   // record index (inside the chunk) of the last Gaussian this pixel took
         uint32_t t_next = my_list[0];
         for (uint32_t k = 0; k < steps; ++k) {
@@ -596,6 +603,7 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_quad_kernel(Rast
         cur_idx = cur != 0xFFFFFFFFu ? (uint32_t)chunk_start + cur : cur_idx;
         if (__builtin_amdgcn_ballot_w64(thr < INFINITY) == 0ull) wave_done = true;   // all 64 pixels finished
     }
+    GSX_STAT_ADD(5, max(max(st_tot[0], st_tot[1]), max(st_tot[2], st_tot[3])));   // steps if the lists ran on across chunk boundaries (per wave and tile: the longest list)
     if (inside) {
         render_alphas[pix] = 1.f - T;
         render_colors[pix * 3] = bg ? out_r + T * bg[0] : out_r;

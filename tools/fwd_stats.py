@@ -15,9 +15,9 @@ def main():
     out = os.path.join(ROOT, "gpurun_out", "libgsx_stats.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     srcs = [os.path.join(csrc, f) for f in ["gsx_capi.hip", "gsx_sh.hip", "gsx_projection.hip", "gsx_intersect.hip",
-                                             "gsx_raster.hip", "gsx_raster_fast.hip", "gsx_mcmc.hip", "gsx_adam.hip", "gsx_ssim.hip"]]
+                                             "gsx_raster.hip", "gsx_raster_fast.hip", "gsx_frontend.hip", "gsx_mcmc.hip", "gsx_adam.hip", "gsx_ssim.hip"]]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                           "-DGSX_STATS", "-o", out] + srcs)
+                           "-fno-slp-vectorize", "-DGSX_STATS", "-o", out] + srcs)
     # swap the library the extension binds to: preload the stats build under the same soname
     lib = ctypes.CDLL(out, mode=ctypes.RTLD_GLOBAL)
     import gsx  # noqa: F401
@@ -30,10 +30,9 @@ def main():
         o = rasterizer.rasterize(cam, model, scene["background"].to(dev))
     buf = (ctypes.c_ulonglong * 16)()   # gsx_debug_read_stats copies all 16 counters
     lib.gsx_debug_read_stats(buf, 1)
-    names = ["wave-Gaussian evaluations", "cull candidates (wave x Gaussian)", "evaluations with >=1 contributing lane",
-             "contributing (pixel,Gaussian) pairs", "survivors skipped by wave early-exit",
-             "4x4 blocks with a contributing lane (sum)", "row-queue steps, 4x4 blocks (max per 64-batch)",
-             "row-queue steps, 8x2 strips (max per 64-batch)"]
+    names = ["wave steps (one-list kernel: wave-Gaussian evaluations; four-list kernel: compositing steps)", "cull candidates (wave x Gaussian)",
+             "steps with >=1 contributing lane", "contributing (pixel,Gaussian) pairs",
+             "four-list kernel: sum of the four lists' lengths", "four-list kernel: steps if the lists ran on across chunk boundaries"]
     I = o.n_isects
     print("n_isects", I, " 4*I =", 4 * I)
     for n, v in zip(names, buf):
