@@ -289,6 +289,9 @@ __global__ __launch_bounds__(NT, 4) void loss_fwd_kernel(int H, int W, float cha
     const size_t q_stride = (size_t)gridDim.z * 3 * npix;
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     float l1 = 0.f, ss = 0.f;
+    // (Round 4 tried to software-pipeline the staging — the global loads of channel c + 1 issued right after the horizontal pass of channel c,
+    // held in 14 registers across the vertical pass: the kernel sits at its 128-VGPR cap (4 waves / SIMD for two 512-thread blocks per CU),
+    // the prefetch registers spilled (92 B of scratch per lane) and the forward went from 0.063 to 0.074 ms.  Not kept.)
     for (int c = 0; c < 3; ++c) {
         const size_t plane = ((size_t)blockIdx.z * 3 + c) * npix;
         const float* rbase = render + (size_t)blockIdx.z * npix * 3 + c;
