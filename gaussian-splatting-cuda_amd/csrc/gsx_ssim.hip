@@ -387,20 +387,43 @@ __global__ __launch_bounds__(NT) void loss_bwd_kernel(int H, int W, float l1_coe
     const size_t q_stride = (size_t)gridDim.z * 3 * npix;
     const float up = grad_scale * (grad_loss ? grad_loss[0] : 1.f);
     float g[4][3];
-    for (int c = 0; c < 3; ++c) {
+    // Staging is software-pipelined over the three channels: the loads of channel c + 1's three maps are issued right after the horizontal
+    // pass of channel c (which frees sD) and land in 21 registers while the vertical pass and the output arithmetic of channel c run (the
+    // kernel has the room: 74 VGPRs of 128; the forward, at its cap, does not — see loss_fwd_kernel).
+    constexpr int NS = (SY * SX + NT - 1) / NT;   // staged elements per thread and map (7)
+    float pm[3][NS];
+    auto fetch = [&](int c) {
         const size_t plane = ((size_t)blockIdx.z * 3 + c) * npix;
-        for (int i = threadIdx.x; i < SY * SX; i += NT) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int i = threadIdx.x + k * NT;
             const int ly = i / SX, lx = i - ly * SX;
             const int gy = ty0 + ly - HALO, gx = tx0 + lx - HALO;
-            const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
+            const bool in = i < SY * SX && gx >= 0 && gx < W && gy >= 0 && gy < H;
             const size_t idx = plane + (size_t)gy * W + gx;
-            sD[0][ly][lx] = in ? maps[idx] : 0.f;   // (plain loads: neighbouring tiles share the halo lines through L2; nontemporal loads: 0.044 -> 0.055 ms)
-            sD[1][ly][lx] = in ? maps[q_stride + idx] : 0.f;
-            sD[2][ly][lx] = in ? maps[2 * q_stride + idx] : 0.f;
+            pm[0][k] = in ? maps[idx] : 0.f;   // (plain loads: neighbouring tiles share the halo lines through L2; nontemporal loads: 0.044 -> 0.055 ms)
+            pm[1][k] = in ? maps[q_stride + idx] : 0.f;
+            pm[2][k] = in ? maps[2 * q_stride + idx] : 0.f;
         }
-        __syncthreads();
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int i = threadIdx.x + k * NT;
+            if (i < SY * SX) {
+                const int ly = i / SX, lx = i - ly * SX;
+                sD[0][ly][lx] = pm[0][k]; sD[1][ly][lx] = pm[1][k]; sD[2][ly][lx] = pm[2][k];
+            }
+        }
+    };
+    fetch(0);
+    stash();
+    __syncthreads();
+    for (int c = 0; c < 3; ++c) {
+        const size_t plane = ((size_t)blockIdx.z * 3 + c) * npix;
         hconv3(sD, sC);
         __syncthreads();
+        if (c < 2) fetch(c + 1);   // in flight during the vertical pass
         float s[4][3];
         vconv<3>(sC, x, y0, s);
 #pragma unroll
@@ -417,6 +440,10 @@ __global__ __launch_bounds__(NT) void loss_bwd_kernel(int H, int W, float l1_coe
                 v = (raw >= 0.f && raw <= 1.f) ? v * up : 0.f;  // clamp backward (inclusive bounds, as torch)
             }
             g[j][c] = v;
+        }
+        if (c < 2) {
+            stash();           // sD is free since the barrier above; sC is still being read by slower waves: the next hconv3 waits below
+            __syncthreads();
         }
     }
 #pragma unroll
