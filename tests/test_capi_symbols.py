@@ -37,6 +37,25 @@ def test_argument_validation_without_gpu():
     assert lib.gsx_spherical_harmonics_fwd(ctypes.c_uint32(3), ctypes.c_uint32(0), ctypes.c_uint32(16), None, None, None, None, None) == 0
 
 
+def test_guarded_entry_points_validate_their_arguments_without_gpu():
+    """ABI 4 (include/gsx.h "guarded lists"): null pointers / missing workspaces are rejected before any launch."""
+    import torch  # noqa: F401
+    c = ctypes
+    lib = c.CDLL(os.path.join(ROOT, "gaussian-splatting-cuda_amd", "libgsx.so"))
+    lib.gsx_last_error.restype = c.c_char_p
+    rc = lib.gsx_intersect_bin_count_guarded(c.c_uint32(1), c.c_uint32(16), None, None, c.c_uint32(16), c.c_uint32(4), c.c_uint32(4), None, None, None,
+                                             None, c.c_size_t(0), c.c_int64(100), c.c_int64(0), None, None)
+    assert rc == -1 and b"null" in lib.gsx_last_error()
+    rc = lib.gsx_rasterize_to_pixels_from_world_3dgs_fwd_guarded(c.c_uint32(4), c.c_int64(8), None, None, None, None, c.c_uint32(3), None, None, None, c.c_uint32(16),
+                                                                 c.c_uint32(16), c.c_uint32(16), None, None, None, None, None, None, None, None, c.c_size_t(0),
+                                                                 c.c_int(0), None, c.c_int64(0), None)
+    assert rc == -1
+    rc = lib.gsx_rasterize_to_pixels_from_world_3dgs_bwd_guarded(c.c_uint32(4), c.c_int64(8), None, None, None, None, c.c_uint32(3), None, None, None, c.c_uint32(16),
+                                                                 c.c_uint32(16), c.c_uint32(16), None, None, None, None, None, None, None, None, None, None, None,
+                                                                 None, None, None, c.c_size_t(0), None, None, None)
+    assert rc == -1
+
+
 def test_ops_module_imports_and_mirrors_ops_h():
     import gsx  # noqa: F401
     from gsx import ops

@@ -253,3 +253,41 @@ def test_color_grad_exchange_equals_dense_all_reduce(tmp_path, sh_first):
         exp = full if exp is None else exp + full
     exp = exp / world
     np.testing.assert_allclose(b0, exp, rtol=2e-5, atol=2e-6)
+
+
+def _agree_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import gsx  # noqa: F401
+    from gsx import distributed as gdist
+    gdist.init_from_env(backend="gloo")
+    agree = gdist.ListsAgreement()
+    # iteration 1: every rank's lists were complete; iteration 2: rank 1 overflowed -> every rank repeats; iteration 3: all complete again
+    got = [agree(True), agree(rank != 1), agree(True)]
+    # ShardedAdam: a same-size re-index of the optimizer state without merge_moments() must be refused
+    p = torch.zeros(8, 3, requires_grad=True)
+
+    class _Opt:   # the two members ShardedAdam.step reads before it touches a collective
+        reindex_generation = 0
+        state = {}
+    sh = gdist.ShardedAdam(_Opt())
+    sh._bounds, sh._gen = (8, 0, 4), 0
+    _Opt.reindex_generation = 1
+    refused = False
+    try:
+        sh.step(1, gdist.GradBucket([p]))
+    except RuntimeError as e:
+        refused = "re-indexed" in str(e)
+    np.save(os.path.join(out_dir, "agree_%d.npy" % rank), np.array(got + [refused, agree.disagreements], dtype=np.int64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_lists_agreement_and_reindex_guard(tmp_path):
+    """distributed.ListsAgreement: the guarded intersection lists of an N-rank step are repeated on EVERY rank when ANY rank overflowed (a MIN
+    all-reduce of one int on the host); ShardedAdam refuses a re-indexed optimizer state whose moments were not merged first."""
+    world = 2
+    mp.spawn(_agree_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "agree_0.npy"), np.load(tmp_path / "agree_1.npy")
+    assert a[:3].tolist() == [1, 0, 1] and b[:3].tolist() == [1, 0, 1]   # both ranks repeat iteration 2
+    assert a[3] == 1 and b[3] == 1                                       # the guard fired on both
+    assert a[4] == 1 and b[4] == 0                                       # rank 0 repeated because of the OTHER rank
