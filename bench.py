@@ -53,7 +53,7 @@ def algorithmic_bytes(N, C, I, P, tiles, deg, K):  # noqa: E741  (SURVEY.md §8d
         "splat_activations_projection_ut": N * (12 + 40 + 44) + 32 * N * C,   # raw parameters in, activated copies + the projection's outputs out
         "splat_activations_bwd": N * (40 + 44 + 40),
         # the fused front end (csrc/gsx_frontend.hip): raw parameters + active SH bases in; activated copies, projection, colours, 64 B record out
-        "frontend_fused": N * (12 + 12 + 16 + 4 + 12 * nb) + N * (32 + 32 + 12 + 64),
+        "frontend_fused": N * (12 + 12 + 16 + 4 + 12 * nb) + N * (32 + 20 + 12 + 64),   # (the render path's call: no conics)
         "intersect_tile": 20 * N * C + 12 * N * C + (28 * N * C + 12 * I) + 144 * I,
         "intersect_offset": 8 * I + 4 * tiles,
         # binned variant = both reference ops in one pipeline: priced at the reference's algorithmic bytes for the two
@@ -77,10 +77,11 @@ class OpTimer:
                       "intersect_offset", "rasterize_to_pixels_from_world_3dgs_fwd", "rasterize_to_pixels_from_world_3dgs_bwd",
                       "sh_colors_fwd", "sh_colors_bwd", "sh_colors_bwd_adam", "splat_activations_fwd", "splat_activations_projection_ut", "splat_activations_bwd",
                       "photometric_loss_fwd", "photometric_loss_bwd", "intersect_tile_binned", "adam_step", "adam_step_split", "adam_step_multi",
-                      "frontend_fused", "rasterize_fwd_packed", "intersect_tile_binned_guarded"]
+                      "frontend_fused", "frontend_fused_render", "rasterize_fwd_packed", "intersect_tile_binned_guarded"]
         # the blend forward on records the front end already packed is the same operator: one row in the table; so is the binned
         # intersection under the guarded protocol (the same kernels; the exact protocol's row additionally contains the host's wait for n_isects)
-        self.alias = {"rasterize_fwd_packed": "rasterize_to_pixels_from_world_3dgs_fwd", "intersect_tile_binned_guarded": "intersect_tile_binned"}
+        self.alias = {"rasterize_fwd_packed": "rasterize_to_pixels_from_world_3dgs_fwd", "intersect_tile_binned_guarded": "intersect_tile_binned",
+                      "frontend_fused_render": "frontend_fused"}
         self.host_delay_us = 0.0   # --host-delay-us: busy-wait after every intersection call (a slow / busy host between the count and the blend launch)
         self.orig = {n: getattr(ops_mod, n) for n in self.names}
         self.events = {n: [] for n in self.names}
@@ -105,7 +106,7 @@ class OpTimer:
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             r = fn(*a, **k)
-            if name == "frontend_fused" and r[8] is None:   # not supported for these arguments: nothing ran
+            if key == "frontend_fused" and r[8] is None:   # not supported for these arguments: nothing ran
                 return r
             e.record()
             self.events[key].append((s, e))
@@ -283,6 +284,9 @@ def main():
     assert world == max(1, args.gpus), "--gpus must equal WORLD_SIZE (torch.distributed.run sets it; a bare `python bench.py --gpus N` launches itself)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # `multi`: the step runs a gradient exchange.  N > 1 — or the diagnostic GSX_SINGLE_RANK_GROUP=1 (gsx.distributed.init_from_env): a process
+    # group of ONE rank whose collectives are executed all the same, i.e. the whole N > 1 code path through RCCL on a 1-GPU box
+    multi = world > 1 or gdist.SINGLE_RANK_COLLECTIVES
 
     scene = {"small": scenes.scene_small, "1m": scenes.scene_1m, "5m": scenes.scene_5m}[args.scene]()
     # Memory order of the Gaussians.  The scene generator emits them in random order; gsx stores a model in Morton order of the positions
@@ -298,7 +302,7 @@ def main():
     model = scenes.to_splat_data(scene, dev)
     for p in model.params():
         p.requires_grad_(True)
-    main_mode = ("single" if world == 1 else "sharded" if args.sharded_adam else "sparse" if args.sparse_allreduce else
+    main_mode = ("single" if not multi else "sharded" if args.sharded_adam else "sparse" if args.sparse_allreduce else
                  "dense" if (args.dense_allreduce or args.unfused or args.no_overlap) else "colour")
     poses = [scene["viewmat"].clone()] if args.fixed_camera else camera_poses(scene)
     cams = [rasterizer.Camera(viewmat=vm.to(dev), K=scene["K"].to(dev), width=W, height=H) for vm in poses]
@@ -325,7 +329,7 @@ def main():
     timer.host_delay_us = args.host_delay_us
     counter = {"i": 0, "isects": [], "repeated": 0}
     guarded = not (args.exact_lists or args.unfused)
-    lists_agree = gdist.ListsAgreement() if (guarded and world > 1) else None   # a frame that overflowed on any rank is repeated on every rank
+    lists_agree = gdist.ListsAgreement() if (guarded and multi) else None   # a frame that overflowed on any rank is repeated on every rank
 
     def make_leg(mode):
         """One gradient-exchange configuration over the SAME model and optimizer: the flat gradient bucket (re-points every p.grad), the
@@ -388,7 +392,7 @@ def main():
         else:
             if xch is not None:
                 xch.finish()   # colours were all-gathered and the SH backward ran over every camera inside backward(); the rest was all-reduced under it
-            elif world > 1:
+            elif multi:
                 if L["mode"] == "sparse" and not args.unfused:
                     # rows no camera of the step sees are zero on every rank: only the union of the visible rows travels
                     bucket.all_reduce_mean_rows((out.aux["radii_full"] > 0).all(-1))
@@ -409,18 +413,18 @@ def main():
 
     def timed(n, with_adam):
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
             step(with_adam)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -466,13 +470,13 @@ def main():
     all_ms.update(blend_ms)                  # the blend ops keep their timed-region figures
     # names used by the report below: the MAIN leg's configuration
     names, bucket, xch, sharded, overlap, sh_adam_ok = leg["names"], leg["bucket"], leg["xch"], leg["sharded"], leg["overlap"], leg["sh_adam_ok"]
-    main_exchange_bytes = int(getattr(bucket, "last_reduced_bytes", 0)) if world > 1 else 0
+    main_exchange_bytes = int(getattr(bucket, "last_reduced_bytes", 0)) if multi else 0
 
     # ---- N > 1: the other gradient exchange, in the same process group, right behind the contract's leg (outside its timed region) ----
     # north_star words the exchange as "an RCCL all-reduce of per-Gaussian gradients": that is the dense leg; the colour-gradient exchange is
     # the optimisation on top.  One invocation on a node yields both: W warm-up + K timed iterations each.
     exchange_variants = None
-    if world > 1 and main_mode in ("colour", "dense") and not args.unfused and not args.no_exchange_variants:
+    if multi and main_mode in ("colour", "dense") and not args.unfused and not args.no_exchange_variants:
         other_mode = "dense" if main_mode == "colour" else "colour"
         cur["leg"] = make_leg(other_mode)      # a second bucket over the same parameters: p.grad now points into it
         for _ in range(args.warmup):
@@ -563,10 +567,10 @@ def main():
                        "n_isects_mean": round(I, 1), "n_isects_min": min(isects_timed), "n_isects_max": max(isects_timed),
                        "largest_tile_segment": counter.get("max_seg"),
                        "gaussian_order": "as generated (random): --random-order" if args.random_order else "Morton order of the positions (gsx.layout; the same Gaussians as generated, permuted once before the timed region)",
-                       "cameras_per_step": world, "ranks": (dist.get_world_size() if world > 1 else 1), "backend": (dist.get_backend() if world > 1 else None),
-                       "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if (world > 1 and dist.get_backend() == "nccl") else None),
+                       "cameras_per_step": world, "single_rank_group": bool(gdist.SINGLE_RANK_COLLECTIVES and world == 1), "ranks": (dist.get_world_size() if multi else 1), "backend": (dist.get_backend() if multi else None),
+                       "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if (multi and dist.get_backend() == "nccl") else None),
                        "strategy": ("MCMC (noise injection every iteration, lr schedule; refine events timed separately: mcmc_refine)" if strategy is not None else "none (plain iteration)"),
-                       "grad_exchange": ("none" if world == 1 else ("colour-gradient all-gather (3 floats / camera / Gaussian) + SH backward over all cameras on every rank; "
+                       "grad_exchange": ("none" if not multi else ("colour-gradient all-gather (3 floats / camera / Gaussian) + SH backward over all cameras on every rank; "
                                                                      "all-reduce of the other 11 floats under it" if xch is not None else "reduce-scatter + sharded Adam + all-gather" if sharded is not None else
                                          ("all-reduce of visible rows" if args.sparse_allreduce else
                                           ("dense all-reduce, scaling/rotation/opacity exchanged under the SH backward" if overlap else "dense all-reduce")))),
@@ -606,7 +610,7 @@ def main():
         if fwd_bwd_ms is not None:
             result["fwd_bwd"] = {"ms_per_frame": round(fwd_bwd_ms, 4), "frames_per_s": round(world * 1e3 / fwd_bwd_ms, 3),
                                  "what": "render + fused loss + backward (+ gradient all-reduce), no optimizer; same camera sequence"}
-        if world == 1 and not args.no_order_ablation and not args.unfused and strategy is None:
+        if not multi and not args.no_order_ablation and not args.unfused and strategy is None:
             # the two memory orders of the same scene on equal footing: a fresh model / optimizer each, W warm-up iterations, then three
             # alternating pairs of K-step legs (both models have trained the same number of iterations at every pair); medians.  A single
             # 20-step leg is inside the run-to-run noise of the effect (a few per cent), and the contract's own model has trained longer.
@@ -660,7 +664,7 @@ def main():
                                         "what": "the same training iteration on the same Gaussians stored in either memory order: a fresh model and optimizer each, "
                                                 "W warm-up iterations, then three alternating pairs of K-step legs outside the contract's region; medians"}
             del runs
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             threads = os.cpu_count() or 1
             dt, i_cpu = cpu_baseline(scene, threads)
             try:
@@ -673,7 +677,7 @@ def main():
                                       "sample": "oracle (CPU restatement, OpenMP) forward+backward (no loss, no Adam) of ONE full frame of "
                                                 "the same workload, cfg2 camera (%d isects): %.2f s" % (i_cpu, dt)}
         print(json.dumps(result))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

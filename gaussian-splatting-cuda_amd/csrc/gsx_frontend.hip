@@ -148,9 +148,11 @@ __global__ __launch_bounds__(FE_BLOCK) void frontend_kernel(uint32_t N, uint32_t
     reinterpret_cast<int2*>(out.radii)[gid] = make_int2((int32_t)p.radius_x, (int32_t)p.radius_y);
     reinterpret_cast<float2*>(out.means2d)[gid] = make_float2(p.im.x, p.im.y);
     out.depths[gid] = p.depth;
-    out.conics[(size_t)gid * 3] = p.c11 * p.ood;
-    out.conics[(size_t)gid * 3 + 1] = -p.c01 * p.ood;
-    out.conics[(size_t)gid * 3 + 2] = p.c00 * p.ood;
+    if (out.conics) {   // optional: nothing downstream of the render path reads them
+        out.conics[(size_t)gid * 3] = p.c11 * p.ood;
+        out.conics[(size_t)gid * 3 + 1] = -p.c01 * p.ood;
+        out.conics[(size_t)gid * 3 + 2] = p.c00 * p.ood;
+    }
 
     // ---- SH colours (sh_colors_fwd_direct_kernel, verbatim) ----
     if (!STAGE) {
@@ -215,7 +217,7 @@ extern "C" int gsx_frontend_fused(uint32_t N, uint32_t K, uint32_t degrees_to_us
     }
     if (N == 0) return GSX_OK;
     if (!means || !rotation_raw || !scaling_raw || !opacity_raw || !coeffs || !cams->viewmats0 || !cams->Ks || !scales || !quats || !opacities ||
-        !radii || !means2d || !depths || !conics || !colors || !fwd_workspace) {
+        !radii || !means2d || !depths || !colors || !fwd_workspace) {
         set_error("frontend_fused: null pointer");
         return GSX_ERR_INVALID_ARGUMENT;
     }

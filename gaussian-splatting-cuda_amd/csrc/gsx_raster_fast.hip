@@ -1260,6 +1260,9 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
 // Sum the moment records of every (camera, Gaussian) (lists built by raster_bwd_fast_kernel) and apply the chain
 // rule once: moments -> (B0, B1, h, a_i, u0, v0, m_z) -> (A, m) -> (M, mu) -> (quat, scale) (Utils.cuh:104-158).
 // One thread per Gaussian; colours / opacities are per camera, means / quats / scales are shared by the cameras.
+// (111 VGPRs, 4 waves per SIMD — set by the chain rule, not by the walk.  Holding the allocation to 5 / 6 / 8 waves (launch bounds; 52 / 128 /
+// 184 B of scratch per lane) measured +0.010 / +0.026 / +0.054 ms on the S-1M step: the kernel moves ~240 MB — 64 B records at scattered
+// slots — in ~66 us and is near what such a read pattern gets from HBM, more chains in flight do not help it.)
 template <int KIND>
 __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const float4* __restrict__ ws_rec,
                                                              int32_t* __restrict__ ws_head, float* __restrict__ v_means,
@@ -1282,6 +1285,13 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
             v_opacities[g] = 0.f;
             continue;
         }
+        if (!any) {   // issued before the walk: these loads fly with the first record's
+            raw.mu = {a.means[(size_t)gi * 3], a.means[(size_t)gi * 3 + 1], a.means[(size_t)gi * 3 + 2]};
+            raw.q = reinterpret_cast<const float4*>(a.quats)[gi];
+            raw.sc = {a.scales[(size_t)gi * 3], a.scales[(size_t)gi * 3 + 1], a.scales[(size_t)gi * 3 + 2]};
+            any = true;
+        }
+        raw.opac = a.opacities[g];
         float Mo[15];
 #pragma unroll
         for (int k = 0; k < 15; ++k) Mo[k] = 0.f;
@@ -1294,13 +1304,6 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
             Mo[12] += r3.x; Mo[13] += r3.y; Mo[14] += r3.z;
             it = __float_as_int(r3.w);
         }
-        if (!any) {
-            raw.mu = {a.means[(size_t)gi * 3], a.means[(size_t)gi * 3 + 1], a.means[(size_t)gi * 3 + 2]};
-            raw.q = reinterpret_cast<const float4*>(a.quats)[gi];
-            raw.sc = {a.scales[(size_t)gi * 3], a.scales[(size_t)gi * 3 + 1], a.scales[(size_t)gi * 3 + 2]};
-            any = true;
-        }
-        raw.opac = a.opacities[g];
         v_colors[g * 3] = Mo[0]; v_colors[g * 3 + 1] = Mo[1]; v_colors[g * 3 + 2] = Mo[2];
         v_opacities[g] = Mo[3] / raw.opac;
         const ShutterPoses sp(a.cams.viewmats0 + c * 16, nullptr);

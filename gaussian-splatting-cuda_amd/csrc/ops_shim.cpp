@@ -621,7 +621,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tenso
     const at::Tensor opacity_raw, const at::Tensor viewmats0, const at::Tensor Ks, const uint32_t image_width, const uint32_t image_height,
     const float eps2d, const float near_plane, const float far_plane, const float radius_clip, const gsplat::CameraModelType camera_model,
     const UnscentedTransformParameters ut_params, const at::optional<at::Tensor> radial_coeffs, const at::optional<at::Tensor> tangential_coeffs,
-    const at::optional<at::Tensor> thin_prism_coeffs) {
+    const at::optional<at::Tensor> thin_prism_coeffs, const bool want_conics) {
     GSX_DEVICE_GUARD(means);
     GSX_CHECK_INPUT(means); GSX_CHECK_INPUT(sh); GSX_CHECK_INPUT(scaling_raw); GSX_CHECK_INPUT(rotation_raw); GSX_CHECK_INPUT(opacity_raw);
     TORCH_CHECK(means.scalar_type() == at::kFloat && sh.scalar_type() == at::kFloat, "float32 only");
@@ -637,14 +637,14 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tenso
     at::Tensor radii = at::empty({C, N, 2}, means.options().dtype(at::kInt));
     at::Tensor means2d = at::empty({C, N, 2}, means.options());
     at::Tensor depths = at::empty({C, N}, means.options());
-    at::Tensor conics = at::empty({C, N, 3}, means.options());
+    at::Tensor conics = want_conics ? at::empty({C, N, 3}, means.options()) : at::empty({0}, means.options());   // (nothing on the render path reads them)
     at::Tensor colors = at::empty({C, N, 3}, means.options());
     const size_t fwsb = gsx_rasterize_fwd_workspace_bytes(C, N);
     at::Tensor fws = at::empty({(int64_t)fwsb}, means.options().dtype(at::kByte));
     check(gsx_frontend_fused(N, K, degrees_to_use, means.data_ptr<float>(), rotation_raw.data_ptr<float>(), scaling_raw.data_ptr<float>(),
                              opacity_raw.data_ptr<float>(), sh.data_ptr<float>(), &cams, image_width, image_height, eps2d, near_plane, far_plane,
                              radius_clip, &ut, scales.data_ptr<float>(), quats.data_ptr<float>(), opac.data_ptr<float>(), radii.data_ptr<int32_t>(),
-                             means2d.data_ptr<float>(), depths.data_ptr<float>(), conics.data_ptr<float>(), colors.data_ptr<float>(), fws.data_ptr(),
+                             means2d.data_ptr<float>(), depths.data_ptr<float>(), want_conics ? conics.data_ptr<float>() : nullptr, colors.data_ptr<float>(), fws.data_ptr(),
                              fwsb, cur_stream()), "frontend_fused");
     return std::make_tuple(scales, quats, opac, radii, means2d, depths, conics, colors, fws);
 }
@@ -743,7 +743,8 @@ static std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile
     }
     const bool guarded = lists != nullptr && capacity > 0;
 
-    at::Tensor tiles_per_gauss = at::empty_like(depths, depths.options().dtype(at::kInt));
+    // (the guarded entry's callers never look at tiles_per_gauss: the count kernel then skips that 4 B / Gaussian store)
+    at::Tensor tiles_per_gauss = lists ? at::empty({0}, depths.options().dtype(at::kInt)) : at::empty_like(depths, depths.options().dtype(at::kInt));
     at::Tensor offsets = at::empty({(int64_t)C * tile_height * tile_width + 1}, depths.options().dtype(at::kInt));
     const size_t cwb = gsx_intersect_bin_count_workspace_bytes(C, tile_width, tile_height);
     at::Tensor cws = at::empty({(int64_t)cwb}, depths.options().dtype(at::kByte));
@@ -751,7 +752,7 @@ static std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile
     at::Tensor status;
     if (guarded) status = at::empty({1}, depths.options().dtype(at::kInt));
     check(gsx_intersect_bin_count_guarded(C, N, n_elements ? means2d.data_ptr<float>() : nullptr, n_elements ? radii.data_ptr<int32_t>() : nullptr, tile_size,
-                                          tile_width, tile_height, n_elements ? tiles_per_gauss.data_ptr<int32_t>() : nullptr, offsets.data_ptr<int32_t>(),
+                                          tile_width, tile_height, (n_elements && !lists) ? tiles_per_gauss.data_ptr<int32_t>() : nullptr, offsets.data_ptr<int32_t>(),
                                           n_host.data_ptr<int64_t>(), cws.data_ptr(), cwb, capacity, ranked ? 0 : seg_bound,
                                           guarded ? status.data_ptr<int32_t>() : nullptr, st), "intersect_tile_binned(count)");
     auto total_ready = std::make_shared<at::cuda::CUDAEvent>();
@@ -828,7 +829,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile_binned
     return intersect_tile_binned_core(means2d, radii, depths, C, tile_size, tile_width, tile_height, want_isect_ids, nullptr);
 }
 
-// the guarded protocol: (tiles_per_gauss, flatten_ids [capacity], isect_offsets, handle)
+// the guarded protocol: (tiles_per_gauss [empty: not produced], flatten_ids [capacity], isect_offsets, handle)
 std::tuple<at::Tensor, at::Tensor, at::Tensor, std::shared_ptr<IsectLists>> intersect_tile_binned_guarded(const at::Tensor means2d, const at::Tensor radii,
                                                                                                           const at::Tensor depths, const uint32_t C,
                                                                                                           const uint32_t tile_size, const uint32_t tile_width,
@@ -1055,7 +1056,17 @@ PYBIND11_MODULE(_gsx_ops, m) {
           py::arg("image_width"), py::arg("image_height"), py::arg("tile_size"), py::arg("viewmats0"), py::arg("viewmats1"), py::arg("Ks"),
           py::arg("camera_model"), py::arg("ut_params"), py::arg("rs_type"), py::arg("radial_coeffs"), py::arg("tangential_coeffs"),
           py::arg("thin_prism_coeffs"), py::arg("tile_offsets"), py::arg("flatten_ids"), py::arg("fwd_ws"), py::arg("lists") = std::shared_ptr<IsectLists>());
-    m.def("frontend_fused", &gsx_ext::frontend_fused);
+    // frontend_fused(…): all outputs; frontend_fused_render(…): the render path's call — `conics` (read by nothing downstream) comes back empty
+    m.def("frontend_fused", [](uint32_t deg, at::Tensor means, at::Tensor sh, at::Tensor sr, at::Tensor rr, at::Tensor orw, at::Tensor vm, at::Tensor Ks,
+                               uint32_t w, uint32_t h, float eps2d, float nearp, float farp, float clip, gsplat::CameraModelType cm,
+                               UnscentedTransformParameters ut, at::optional<at::Tensor> rad, at::optional<at::Tensor> tang, at::optional<at::Tensor> prism) {
+        return gsx_ext::frontend_fused(deg, means, sh, sr, rr, orw, vm, Ks, w, h, eps2d, nearp, farp, clip, cm, ut, rad, tang, prism, true);
+    });
+    m.def("frontend_fused_render", [](uint32_t deg, at::Tensor means, at::Tensor sh, at::Tensor sr, at::Tensor rr, at::Tensor orw, at::Tensor vm, at::Tensor Ks,
+                                      uint32_t w, uint32_t h, float eps2d, float nearp, float farp, float clip, gsplat::CameraModelType cm,
+                                      UnscentedTransformParameters ut, at::optional<at::Tensor> rad, at::optional<at::Tensor> tang, at::optional<at::Tensor> prism) {
+        return gsx_ext::frontend_fused(deg, means, sh, sr, rr, orw, vm, Ks, w, h, eps2d, nearp, farp, clip, cm, ut, rad, tang, prism, false);
+    });
     m.def("rasterize_to_pixels_from_world_3dgs_bwd",
           [](const at::Tensor means, const at::Tensor quats, const at::Tensor scales, const at::Tensor colors, const at::Tensor opacities,
              const at::optional<at::Tensor> backgrounds, const at::optional<at::Tensor> masks, uint32_t image_width, uint32_t image_height,

@@ -6,23 +6,59 @@ All six parameter gradients live in ONE flat fp32 bucket (59 floats per Gaussian
 sh0 3, shN 45, scaling 3, rotation 4, opacity 1) allocated once; `.grad` of every parameter is a view into it,
 so autograd accumulates straight into the bucket and the step issues a single large all-reduce — on MI355X's
 point-to-point xGMI mesh one big message lets RCCL spread the reduce-scatter/all-gather over all 7 links."""
+import contextlib
 import os
+import sys
 
 import torch
 import torch.distributed as dist
 
 
+# A process group of ONE rank skips every collective (nothing to exchange).  True = run them all the same: the whole N > 1 code path —
+# bucket all-reduces, colour-gradient all-gather, in-place reduce-scatter / all-gather of ShardedAdam, the gloo side group — through the
+# real backend on a 1-GPU box (RCCL's argument checks, stream hand-over, in-place aliasing rules; results must equal the plain step's).
+# Set by init_from_env when GSX_SINGLE_RANK_GROUP=1 (tests/test_gpu_distributed.py, `GSX_SINGLE_RANK_GROUP=1 python bench.py`).
+SINGLE_RANK_COLLECTIVES = False
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """gloo reports its mesh ("[Gloo] Rank 0 is connected to 7 peer ranks. ...") on STDOUT, from C++, whenever a gloo group is created.  A
+    launcher that reads rank 0's stdout as the program's result (bench.py: ONE JSON line) must not find that there: while a group is being
+    created, file descriptor 1 points at stderr."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
+def active():
+    """True when the step has a gradient exchange to run."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or SINGLE_RANK_COLLECTIVES)
+
+
 def init_from_env(backend=None):
     """torch.distributed.run contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment."""
+    global SINGLE_RANK_COLLECTIVES
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if world == 1 and os.environ.get("GSX_SINGLE_RANK_GROUP") == "1" and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        SINGLE_RANK_COLLECTIVES = True
+    if (world > 1 or SINGLE_RANK_COLLECTIVES) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" IS RCCL on ROCm
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        with _stdout_to_stderr():
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 
@@ -73,7 +109,7 @@ class GradBucket:
     def all_reduce_mean(self, async_op=False):
         """Mean of the bucket over the ranks.  async_op=True returns a handle whose wait() completes the MEAN (the division is part
         of the collective on RCCL, applied in wait() otherwise), so work that does not read the gradients can be enqueued meanwhile."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not active():
             return None
         self.last_reduced_bytes = self.nbytes()
         if async_op:
@@ -86,7 +122,7 @@ class GradBucket:
         """Starts the mean all-reduce of the bucket from parameter `first_param` to the end and returns a handle (wait() completes it).
         The render backward produces the scaling / rotation / opacity gradients (the last three parameters: 8 of the 59 floats per
         Gaussian) BEFORE the SH backward, so their exchange runs under it: rasterize_fused(grad_sinks={..., "_early_ready": callback})."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not active():
             return None
         self._tail_from = self.offsets[first_param]
         return _MeanHandle(self.flat[self._tail_from:])
@@ -106,7 +142,7 @@ class GradBucket:
         rank.  Only the union of the visible rows travels: one small MAX all-reduce of the mask, then ONE all-reduce of the
         compacted rows (at S-1M a camera sees ~40 % of the Gaussians: 94 MB instead of 236 MB over xGMI, where the ring is
         per-link bound).  Falls back to the dense collective when the union exceeds `dense_above` of the rows."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not active():
             return None
         n = self.params[0].shape[0]
         assert all(p.shape[0] == n for p in self.params), "row compaction needs per-Gaussian parameters"
@@ -369,8 +405,9 @@ class ListsAgreement:
 
     def __init__(self):
         self.group = None
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            self.group = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+        if active():
+            with _stdout_to_stderr():
+                self.group = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
         self._flag = torch.zeros(1, dtype=torch.int32)
         self.disagreements = 0   # iterations repeated because some OTHER rank overflowed
 

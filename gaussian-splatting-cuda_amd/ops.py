@@ -51,6 +51,7 @@ sh_colors_bwd = _C.sh_colors_bwd
 sh_colors_bwd_adam = _C.sh_colors_bwd_adam
 splat_activations_fwd = _C.splat_activations_fwd
 splat_activations_projection_ut = _C.splat_activations_projection_ut
+frontend_fused_render = _C.frontend_fused_render   # the same launch without the conics output (rasterize_fused)
 frontend_fused = _C.frontend_fused            # activations -> UT projection -> SH colours -> packed records, one kernel (gsx_frontend.hip)
 rasterize_fwd_packed = _C.rasterize_fwd_packed
 splat_activations_bwd = _C.splat_activations_bwd

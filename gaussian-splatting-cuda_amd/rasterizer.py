@@ -326,8 +326,8 @@ class GutRenderFunction(torch.autograd.Function):
         if scaling_modifier == 1.0 and FUSED_FRONTEND:
             # the whole per-Gaussian front end in ONE kernel: activations -> projection -> SH colours -> packed blend records
             # (same values as the separate launches below; an undefined workspace = camera / SH layout not supported)
-            fe = ops.frontend_fused(sh_degree, means_c, sh_c, sr, rr, orw, viewmat, K, width, height, EPS2D, NEAR_PLANE, FAR_PLANE, RADIUS_CLIP,
-                                    camera_model, ut, radial, tangential, None)
+            fe = ops.frontend_fused_render(sh_degree, means_c, sh_c, sr, rr, orw, viewmat, K, width, height, EPS2D, NEAR_PLANE, FAR_PLANE, RADIUS_CLIP,
+                                           camera_model, ut, radial, tangential, None)
             if fe[8] is None:
                 fe = None
         if fe is not None:

@@ -41,18 +41,19 @@ class Trainer:
         dev = model.means.device
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.multi = gdist.active()   # a gradient exchange runs (N > 1, or the one-rank diagnostic group of distributed.SINGLE_RANK_COLLECTIVES)
         gen = torch.Generator(device=dev)
         gen.manual_seed(seed)
         for p in model.params():
             p.requires_grad_(True)
-        self.exchange = exchange if (self.world > 1 and not sharded_adam) else None
-        self.fused_sh_adam = fused_sh_adam and not sharded_adam and (self.world == 1 or self.exchange == "colors")
+        self.exchange = exchange if (self.multi and not sharded_adam) else None
+        self.fused_sh_adam = fused_sh_adam and not sharded_adam and (not self.multi or self.exchange == "colors")
         self.strategy = MCMC(model, self.params, scene_scale, gen)
         self.strategy.on_resize = self._rebuild_bucket
         self._rebuild_bucket(model)
-        self.sharded = gdist.ShardedAdam(self.strategy.optimizer) if (sharded_adam and self.world > 1) else None
+        self.sharded = gdist.ShardedAdam(self.strategy.optimizer) if (sharded_adam and self.multi) else None
         self.guarded, self.capacity_misses = guarded_lists, 0
-        self._lists_agree = gdist.ListsAgreement() if (guarded_lists and self.world > 1) else None
+        self._lists_agree = gdist.ListsAgreement() if (guarded_lists and self.multi) else None
         if self._lists_agree is not None:
             self.sinks["_lists_agree"] = self._lists_agree
         if self.sharded is not None:   # rows change owner when the strategy permutes / removes them: complete the moments on every rank first
@@ -112,7 +113,7 @@ class Trainer:
         else:
             if self.exchange == "colors":
                 self.xch.finish()
-            elif self.world > 1:  # only rows some camera of the step saw are non-zero: compacted all-reduce
+            elif self.multi:  # only rows some camera of the step saw are non-zero: compacted all-reduce
                 self.bucket.all_reduce_mean_rows((out.aux["radii_full"] > 0).all(-1))
             self._add_regularisers()  # identical on every rank (functions of the replicated parameters): added after the reduction
             self.strategy.post_backward(it, out)

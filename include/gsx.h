@@ -178,8 +178,8 @@ int gsx_rasterize_to_pixels_from_world_3dgs_bwd(uint32_t N, int64_t n_isects, co
  * traffic per visible Gaussian at SH degree 3 instead of ~470 B over four launches).  Outputs bit-identical to gsx_splat_activations_projection_ut
  * + gsx_sh_colors_fwd; records equal to rounding to the ones the blend forward packs for itself.  `fwd_workspace` (gsx_rasterize_fwd_workspace_bytes(1, N)) is then
  * handed to gsx_rasterize_to_pixels_from_world_3dgs_fwd_packed(..., records_ready = 1) and later to ..._bwd_packed.  Outputs: scales
- * [N,3], quats [N,4], opacities [N] (activated), radii int32 [1,N,2], means2d [1,N,2], depths [1,N], conics [1,N,3] (only radii for a
- * culled Gaussian, as the projection), colors [1,N,3] (zero rows for culled Gaussians).  gsx_frontend_fused_supported: 1 when the
+ * [N,3], quats [N,4], opacities [N] (activated), radii int32 [1,N,2], means2d [1,N,2], depths [1,N], conics [1,N,3] or NULL (not
+ * written: nothing on the render path reads them) (only radii for a culled Gaussian, as the projection), colors [1,N,3] (zero rows for culled Gaussians).  gsx_frontend_fused_supported: 1 when the
  * camera block / SH layout qualify (C == 1, PINHOLE with or without distortion, GLOBAL shutter, (K*3) % 4 == 0, 16 B aligned coeffs). */
 int gsx_frontend_fused_supported(uint32_t K, uint32_t degrees_to_use, const gsx_cameras* cams, const float* coeffs);
 int gsx_frontend_fused(uint32_t N, uint32_t K, uint32_t degrees_to_use, const float* means, const float* rotation_raw,

@@ -47,10 +47,12 @@ def test_bare_python_bench_gpus_2_launches_two_ranks():
 def test_under_torch_distributed_run_it_does_not_relaunch():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
            BENCH, "--gpus", "2", "--backend", "gloo", "--launch-check"]
-    r = subprocess.run(cmd, env=_env(), cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout[-3000:]
+    r = subprocess.run(cmd, env=_env(), cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert _last_json(r.stdout)["n_gpus"] == 2
-    assert r.stdout.count('"launch_check"') == 1   # one JSON line, from rank 0
+    # the job's stdout is the ONE JSON line of rank 0: gloo's own "[Gloo] Rank r is connected to ..." (printed on stdout by the library when a
+    # group is created, on every rank) is diverted to stderr (gsx.distributed._stdout_to_stderr)
+    assert [ln for ln in r.stdout.splitlines() if ln.strip()] == [json.dumps({"launch_check": True, "n_gpus": 2, "backend": "gloo"})], r.stdout
 
 
 def test_single_gpu_launch_check_needs_no_process_group():

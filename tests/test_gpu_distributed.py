@@ -112,10 +112,94 @@ def test_bench_two_ranks_times_both_gradient_exchanges():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--scene", "small", "--steps", "3",
                         "--warmup", "2", "--no-fwd-bwd"], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
-    line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
-    d = json.loads(line)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines[:5]   # stdout of the whole job = the contract's ONE JSON line (gloo's "[Gloo] Rank r is connected to ..." goes to stderr)
+    d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["config"]["backend"] == "gloo"
     v = d["grad_exchange_variants"]
     assert v["colour"]["ms_per_step"] > 0 and v["dense"]["ms_per_step"] > 0
     assert v["dense"]["bytes_exchanged_per_rank"] > 0 and v["colour"]["bytes_exchanged_per_rank"] > 0   # (S-small has SH degree 0: no SH gradient to save)
     assert "guarded" in d["config"]["intersect_protocol"]   # (S-small has K = 1: no fused front end, so its renders fall back to the exact lists)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# RCCL on the 1-GPU box: a process group of ONE rank with every collective executed (gsx.distributed.SINGLE_RANK_COLLECTIVES).  The
+# mean over one rank is the identity, so each exchange must leave what the plain single-GPU step leaves — and RCCL's argument checks,
+# the hand-over between torch's stream and RCCL's, the in-place reduce-scatter / all-gather aliasing and the gloo side group under an
+# nccl default group are exercised by the real library, not by gloo.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _single_rank_worker(_, port, out_dir, mode):
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if mode != "plain":
+        os.environ["GSX_SINGLE_RANK_GROUP"] = "1"
+    import torch.distributed as dist
+    import gsx  # noqa: F401
+    from gsx import distributed as gdist
+    from gsx import parameters, rasterizer, scenes, trainer
+    from tests.test_gpu_training import _scene
+    torch.cuda.set_device(0)
+    rank, _, world = gdist.init_from_env(backend="nccl")
+    assert world == 1 and gdist.active() == (mode != "plain")
+    if mode != "plain":
+        assert dist.get_backend() == "nccl"
+    dev = "cuda:0"
+    sc, gt_model, cams = _scene(dev, N=3000, K=16)    # SH degree 3: the fused front end, guarded lists and the fused SH backward + Adam all run
+    bg = sc["background"].to(dev)
+    with torch.no_grad():
+        images = [rasterizer.rasterize_fused(c, gt_model, bg).image.clone() for c in cams]
+    g = torch.Generator().manual_seed(9)
+    model = scenes.to_splat_data(dict(sc), dev)
+    model.sh = (gt_model.sh + 0.3 * torch.randn(gt_model.sh.shape, generator=g).to(dev)).contiguous()
+    model.opacity_raw = (gt_model.opacity_raw - 0.5).contiguous()
+    prm = parameters.OptimizationParameters(iterations=200, start_refine=100, refine_every=100, stop_refine=150, max_cap=3000, sh_degree_interval=1000)
+    kw = {"plain": {}, "colors": {"exchange": "colors"}, "rows": {"exchange": "rows"}, "sharded": {"sharded_adam": True}}[mode]
+    tr = trainer.Trainer(model, cams, images, prm, bg, seed=3, **kw)
+    if mode == "colors":
+        assert tr.xch is not None and tr._lists_agree is not None and tr._lists_agree.group is not None
+    if mode == "sharded":
+        assert tr.sharded is not None
+    for it in range(1, 13):
+        tr.train_step(it)
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, "single_%s.npy" % mode), torch.cat([p.detach().reshape(-1) for p in model.params()]).cpu().numpy())
+    if mode != "plain":
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_single_rank_rccl_group_runs_every_exchange(tmp_path):
+    res = {}
+    for mode in ("plain", "colors", "rows", "sharded"):
+        mp.spawn(_single_rank_worker, args=(_free_port(), str(tmp_path), mode), nprocs=1, join=True)
+        res[mode] = np.load(tmp_path / ("single_%s.npy" % mode))
+        assert np.isfinite(res[mode]).all()
+    ref = res["plain"]
+    for mode in ("colors", "rows", "sharded"):
+        # (same kernels, same sums; the exchanges order a few additions differently and the backward's record chains follow launch order:
+        #  Adam amplifies last bits over 12 steps — a dropped or doubled exchange would be 1e-2)
+        rel = float(np.linalg.norm(res[mode] - ref) / np.linalg.norm(ref))
+        assert rel < 2e-4, (mode, rel)
+
+
+@pytest.mark.parametrize("extra", [[], ["--sharded-adam"], ["--sparse-allreduce"]])
+def test_bench_single_rank_group_over_rccl(extra):
+    """`GSX_SINGLE_RANK_GROUP=1 python bench.py`: the N > 1 bench path (both gradient-exchange legs, guarded-list agreement) through RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GSX_SINGLE_RANK_GROUP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--scene", "small", "--steps", "3", "--warmup", "2", "--no-fwd-bwd"] + extra,
+                       env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines[:5]   # (the gloo side group of the guarded-list agreement reports its mesh on stderr, not here)
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["single_rank_group"] and d["config"]["backend"] == "nccl" and d["config"]["rccl_version"]
+    if not extra:
+        v = d["grad_exchange_variants"]
+        assert v["colour"]["ms_per_step"] > 0 and v["dense"]["ms_per_step"] > 0
