@@ -260,6 +260,17 @@ def main():
         sys.stdout.flush()
         os.execv(cmd[0], cmd)
 
+    # The job's stdout is the contract's ONE JSON line.  Libraries underneath write there too, from C, on every rank — RCCL its version banner
+    # ("RCCL version : ... / HIP version : ... / Librccl path : ...", flushed at exit, i.e. BEHIND the result), gloo its mesh report — so the
+    # result keeps a private duplicate of the original stdout and file descriptor 1 points at stderr from here on.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+    def emit(obj):
+        result_out.write(json.dumps(obj) + "\n")
+        result_out.flush()
+
     import gsx  # noqa: F401
     from gsx import distributed as gdist
     from gsx import loss as gloss
@@ -275,7 +286,7 @@ def main():
             dist.all_reduce(tt)
             assert int(tt.item()) == world
         if rank == 0:
-            print(json.dumps({"launch_check": True, "n_gpus": world, "backend": dist.get_backend() if world > 1 else None}))
+            emit({"launch_check": True, "n_gpus": world, "backend": dist.get_backend() if world > 1 else None})
         if world > 1:
             dist.destroy_process_group()
         return
@@ -676,7 +687,7 @@ def main():
             result["cpu_baseline"] = {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": threads, "kind": "port",
                                       "sample": "oracle (CPU restatement, OpenMP) forward+backward (no loss, no Adam) of ONE full frame of "
                                                 "the same workload, cfg2 camera (%d isects): %.2f s" % (i_cpu, dt)}
-        print(json.dumps(result))
+        emit(result)
     if multi:
         dist.barrier()
         dist.destroy_process_group()
