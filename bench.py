@@ -31,6 +31,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# multi-process GPU work on this host needs dmabuf IPC (RCCL's peer mappings fail with `hipIpcGetMemHandle: invalid argument` otherwise); read by
+# the HSA runtime when it starts, i.e. before the first HIP call of this process — a value the launcher exported wins
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

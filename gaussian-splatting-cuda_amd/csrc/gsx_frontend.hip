@@ -35,7 +35,7 @@ struct FrontendOut {
     int32_t* radii; float* means2d; float* depths; float* conics;   // projection [1,N,2] [1,N,2] [1,N] [1,N,3]
     float* colors;                                                   // [1,N,3]
     float4* packed;                                                  // [N] x 64 B records
-    int32_t* heads;                                                  // [N] list heads of the backward's record chains: -1 (empty)
+    int32_t* heads;                                                  // [4][N] heads of the backward's record chains (gsx_raster_common.hpp: NSUB planes): -1 (empty)
 };
 
 // STAGE != 0: the wave's 64 coefficient rows — one contiguous 64 * K * 12 B span — are streamed into LDS with fully coalesced 16 B / lane
@@ -137,7 +137,8 @@ __global__ __launch_bounds__(FE_BLOCK) void frontend_kernel(uint32_t N, uint32_t
         }
     }
     if (!in_range) return;
-    out.heads[gid] = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out.heads[(size_t)k * N + gid] = -1;   // four planes (gsx_raster_common.hpp: NSUB chains, one camera)
     float* col = out.colors + (size_t)gid * 3;
     if (!visible) {
         out.radii[(size_t)gid * 2] = 0; out.radii[(size_t)gid * 2 + 1] = 0;   // as upstream, only radii is written for a culled Gaussian

@@ -36,6 +36,7 @@ struct RasterArgs {
     // and the host, which reads the same verdict later, renders it again.  nullptr = `n_isects` is exact (the reference's protocol).
     const int32_t* lists_status;
     int64_t n_isects_expected;   // list-density estimate for launch decisions (kernel variants); = n_isects when exact
+    uint32_t chain_mask;         // backward: NSUB - 1 = NSUB record chains per (camera, Gaussian), 0 = one (see tile_chain)
 };
 
 // end of the LAST list of the frame (every other list ends where the next one starts); `ok` = false: overflowed frame, all lists empty
@@ -61,6 +62,14 @@ GSX_DEV void tile_list_range(const RasterArgs& a, uint32_t cid, uint32_t tile_x,
     end = (cid == a.C - 1 && lt == n_lt - 1) ? total : toff[lt + 1];
     if (!ok) end = start;
 }
+// The backward chains the moment records of a (camera, Gaussian) for the gather kernel.  On frames of large footprints (a Gaussian
+// covering w x h tiles has a chain of w h records) the walk — a pointer chase, one dependent 64 B load per record, the longest chain of a
+// wave is what the wave takes — dominated the backward: such frames use NSUB chains per Gaussian, chosen by the parity of the pixel tile
+// (four chains of ~w h / 4 records, walked side by side with four record loads in flight per thread).  Frames of small footprints keep
+// ONE chain (a.chain_mask = 0): their gather is bound by the bytes it moves, and three more heads per Gaussian are just more bytes.
+// Head array: NSUB planes of [C*N] int32, plane c = heads of chain c (-1 = empty); only the planes of the frame's chains are read.
+constexpr int NSUB = 4;
+GSX_DEV uint32_t tile_chain(const RasterArgs& a, uint32_t tile_x, uint32_t tile_y) { return ((tile_x & 1u) | ((tile_y & 1u) << 1)) & a.chain_mask; }
 GSX_DEV int32_t tile_record_slot(const RasterArgs& a, int32_t isect, uint32_t tile_x, uint32_t tile_y) {
     return a.lshift ? (isect << 2) | (int32_t)(((tile_y & 1u) << 1) | (tile_x & 1u)) : isect;
 }
@@ -123,7 +132,7 @@ GSX_DEV uint32_t butterfly_value_of_lane(uint32_t lane) {
 const uint8_t* launch_raster_fwd_fast(int kind, RasterArgs a, float* renders, float* alphas, int32_t* last_ids, void* workspace,
                                       size_t workspace_bytes, hipStream_t st, bool records_ready = false);
 size_t raster_fwd_fast_workspace_bytes(uint32_t C, uint32_t N);
-int32_t* raster_fwd_fast_heads(const float4* packed, uint32_t C, uint32_t N);   // the list-head array inside the forward workspace (see its layout)
+int32_t* raster_fwd_fast_heads(const float4* packed, uint32_t C, uint32_t N);   // the chain-head array [C*N][NSUB] inside the forward workspace (see its layout)
 // returns false (nothing launched) when no sufficient workspace was supplied: the caller falls back to the generic kernels
 bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, const int32_t* last_ids,
                             const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats,

@@ -72,7 +72,11 @@ __global__ __launch_bounds__(256) void pack_records_kernel(RasterArgs a, float4*
     const uint32_t n = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
     if (n >= a.N) return;
     const size_t g = (size_t)c * a.N + n;
-    if (heads) heads[g] = -1;  // backward: empty moment-record list
+    if (heads) {  // backward: empty moment-record chains (NSUB planes)
+        const size_t cn = (size_t)a.C * a.N;
+#pragma unroll
+        for (int k = 0; k < NSUB; ++k) heads[(size_t)k * cn + g] = -1;
+    }
     RawG raw;
     raw.g = (int32_t)g;
     raw.mu = {a.means[(size_t)n * 3], a.means[(size_t)n * 3 + 1], a.means[(size_t)n * 3 + 2]};
@@ -615,10 +619,10 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_quad_kernel(Rast
 
 // forward workspace, from its 256 B aligned base: packed records [C*N] x 64 B | fisheye: "no chart" bytes [C*N] | tile flags
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
-// ... | list heads [C*N] int32 of the backward's per-(camera, Gaussian) record chains: set to -1 by whoever packs the records (the fused front
-// end, pack_records_kernel) and put back to -1 by the gather kernel that walks the chains, so a backward on the forward's workspace needs
-// no memset launch
-size_t raster_fwd_fast_workspace_bytes(uint32_t C, uint32_t N) { return 256 + (size_t)C * N * 64 + align256((size_t)C * N) + FAST_FLAG_BYTES + align256((size_t)C * N * 4); }
+// ... | chain heads [NSUB][C*N] int32 of the backward's per-(camera, Gaussian) record chains: set to -1 by whoever packs the records (the
+// fused front end, pack_records_kernel) and put back to -1 by the gather kernel that walks the chains, so a backward on the forward's
+// workspace needs no memset launch
+size_t raster_fwd_fast_workspace_bytes(uint32_t C, uint32_t N) { return 256 + (size_t)C * N * 64 + align256((size_t)C * N) + FAST_FLAG_BYTES + align256((size_t)C * N * 4 * NSUB); }
 static uint8_t* ws_bad(const float4* packed, uint32_t C, uint32_t N) { return (uint8_t*)packed + (size_t)C * N * 64; }
 static uint8_t* ws_flags(const float4* packed, uint32_t C, uint32_t N) { return ws_bad(packed, C, N) + align256((size_t)C * N); }
 int32_t* raster_fwd_fast_heads(const float4* packed, uint32_t C, uint32_t N) { return (int32_t*)(ws_flags(packed, C, N) + FAST_FLAG_BYTES); }
@@ -840,7 +844,7 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
         // one thread per touched Gaussian of the chunk: 64 B moment record at its sorted index, chained per Gaussian
         if ((int32_t)tid < chunk_size && ((s_touched[tid >> 6] >> (tid & 63u)) & 1ull)) {
             const int32_t isect = tile_record_slot(a, chunk_end - (int32_t)tid, tile_x, tile_y);
-            const int32_t prev = atomicExch(&ws_head[s_gid[tid]], isect);
+            const int32_t prev = atomicExch(&ws_head[(size_t)tile_chain(a, tile_x, tile_y) * a.C * a.N + s_gid[tid]], isect);
             float4* rec = ws_rec + (size_t)isect * 4;
             nt_store4(make_float4(s_acc[0][tid], s_acc[1][tid], s_acc[2][tid], s_acc[3][tid]), rec);   // (nontemporal: see raster_bwd_gq_kernel)
             nt_store4(make_float4(s_acc[4][tid], s_acc[5][tid], s_acc[6][tid], s_acc[7][tid]), rec + 1);
@@ -1244,7 +1248,7 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
         // one thread per touched Gaussian of the super-chunk: 64 B moment record at its sorted index, chained per Gaussian
         if ((int32_t)tid < chunk_size && s_acc[15][tid] > 0.f) {
             const int32_t isect = tile_record_slot(a, chunk_end - (int32_t)tid, tile_x, tile_y);
-            const int32_t prev = atomicExch(&ws_head[s_gid[tid]], isect);
+            const int32_t prev = atomicExch(&ws_head[(size_t)tile_chain(a, tile_x, tile_y) * a.C * a.N + s_gid[tid]], isect);
             float4* rec = ws_rec + (size_t)isect * 4;
             // nontemporal: 64 B written once at a scattered slot and read once by the gather kernel — as ordinary stores the records
             // push the kernel's own working set (lists, packed records, pixel inputs) out of L2: S-1M 0.573 -> 0.526 ms, S-5M @4K 2.17 ->
@@ -1263,7 +1267,7 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
 // (111 VGPRs, 4 waves per SIMD — set by the chain rule, not by the walk.  Holding the allocation to 5 / 6 / 8 waves (launch bounds; 52 / 128 /
 // 184 B of scratch per lane) measured +0.010 / +0.026 / +0.054 ms on the S-1M step: the kernel moves ~240 MB — 64 B records at scattered
 // slots — in ~66 us and is near what such a read pattern gets from HBM, more chains in flight do not help it.)
-template <int KIND>
+template <int KIND, int NCH>
 __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const float4* __restrict__ ws_rec,
                                                              int32_t* __restrict__ ws_head, float* __restrict__ v_means,
                                                              float* __restrict__ v_quats, float* __restrict__ v_scales,
@@ -1276,16 +1280,22 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
     bool any = false;
     RawG raw;
     raw.g = (int32_t)gi;
+    const size_t cn = (size_t)a.C * a.N;
     for (uint32_t c = 0; c < a.C; ++c) {
         const size_t g = (size_t)c * a.N + gi;
-        int32_t it = ws_head[g];
-        if (it >= 0) ws_head[g] = -1;   // the chain is consumed: the head array is empty again for the next backward on this workspace
-        if (it < 0) {  // no tile touched this (camera, Gaussian): every output element is written, none needs a pre-fill
+        int32_t it[NCH];
+        int32_t all = -1;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) { it[k] = ws_head[(size_t)k * cn + g]; all &= it[k]; }
+        if (all < 0) {  // every chain empty (an index has its sign bit clear): no tile touched this (camera, Gaussian) — every output element is written, none needs a pre-fill
             v_colors[g * 3] = 0.f; v_colors[g * 3 + 1] = 0.f; v_colors[g * 3 + 2] = 0.f;
             v_opacities[g] = 0.f;
             continue;
         }
-        if (!any) {   // issued before the walk: these loads fly with the first record's
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)   // the chains are consumed: the head array is empty again for the next backward on this workspace
+            if (it[k] >= 0) ws_head[(size_t)k * cn + g] = -1;
+        if (!any) {   // issued before the walk: these loads fly with the first records'
             raw.mu = {a.means[(size_t)gi * 3], a.means[(size_t)gi * 3 + 1], a.means[(size_t)gi * 3 + 2]};
             raw.q = reinterpret_cast<const float4*>(a.quats)[gi];
             raw.sc = {a.scales[(size_t)gi * 3], a.scales[(size_t)gi * 3 + 1], a.scales[(size_t)gi * 3 + 2]};
@@ -1295,14 +1305,49 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
         float Mo[15];
 #pragma unroll
         for (int k = 0; k < 15; ++k) Mo[k] = 0.f;
-        while (it >= 0) {
-            const float4* rec = ws_rec + (size_t)it * 4;
-            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-            Mo[0] += r0.x; Mo[1] += r0.y; Mo[2] += r0.z; Mo[3] += r0.w;
-            Mo[4] += r1.x; Mo[5] += r1.y; Mo[6] += r1.z; Mo[7] += r1.w;
-            Mo[8] += r2.x; Mo[9] += r2.y; Mo[10] += r2.z; Mo[11] += r2.w;
-            Mo[12] += r3.x; Mo[13] += r3.y; Mo[14] += r3.z;
-            it = __float_as_int(r3.w);
+        if (NCH == 1) {
+            int32_t cur = it[0];
+            while (cur >= 0) {
+                const float4* rec = ws_rec + (size_t)cur * 4;
+                const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+                Mo[0] += r0.x; Mo[1] += r0.y; Mo[2] += r0.z; Mo[3] += r0.w;
+                Mo[4] += r1.x; Mo[5] += r1.y; Mo[6] += r1.z; Mo[7] += r1.w;
+                Mo[8] += r2.x; Mo[9] += r2.y; Mo[10] += r2.z; Mo[11] += r2.w;
+                Mo[12] += r3.x; Mo[13] += r3.y; Mo[14] += r3.z;
+                cur = __float_as_int(r3.w);
+            }
+        } else {
+            // the chains side by side: every round issues the record loads of all chains some lane still walks before any is consumed
+            // (a lane whose chain k has ended re-reads a record of one of its live chains — same line, no new traffic — and ignores it)
+            while (all >= 0) {
+                int32_t live = it[0];
+#pragma unroll
+                for (int k = 1; k < NCH; ++k) live = max(live, it[k]);
+                float4 r[NCH][4];
+                bool on[NCH];
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    on[k] = it[k] >= 0;
+                    if (__builtin_amdgcn_ballot_w64(on[k]) != 0ull) {
+                        const float4* rec = ws_rec + (size_t)(on[k] ? it[k] : live) * 4;
+                        r[k][0] = rec[0]; r[k][1] = rec[1]; r[k][2] = rec[2]; r[k][3] = rec[3];
+                    } else {
+                        r[k][0] = r[k][1] = r[k][2] = r[k][3] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+                all = -1;
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    if (on[k]) {
+                        Mo[0] += r[k][0].x; Mo[1] += r[k][0].y; Mo[2] += r[k][0].z; Mo[3] += r[k][0].w;
+                        Mo[4] += r[k][1].x; Mo[5] += r[k][1].y; Mo[6] += r[k][1].z; Mo[7] += r[k][1].w;
+                        Mo[8] += r[k][2].x; Mo[9] += r[k][2].y; Mo[10] += r[k][2].z; Mo[11] += r[k][2].w;
+                        Mo[12] += r[k][3].x; Mo[13] += r[k][3].y; Mo[14] += r[k][3].z;
+                        it[k] = __float_as_int(r[k][3].w);
+                    }
+                    all &= it[k];
+                }
+            }
         }
         v_colors[g * 3] = Mo[0]; v_colors[g * 3 + 1] = Mo[1]; v_colors[g * 3 + 2] = Mo[2];
         v_opacities[g] = Mo[3] / raw.opac;
@@ -1379,8 +1424,8 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
 }
 
 size_t raster_bwd_fast_workspace_bytes(uint32_t C, uint32_t N, int64_t n_isects) {
-    // moment records (64 B per intersection) + list heads (4 B per (camera, Gaussian)) + the forward's layout, 256 B aligned
-    return align256((size_t)n_isects * 64) + align256((size_t)C * N * 4) + raster_fwd_fast_workspace_bytes(C, N);
+    // moment records (64 B per intersection) + chain heads (NSUB x 4 B per (camera, Gaussian)) + the forward's layout, 256 B aligned
+    return align256((size_t)n_isects * 64) + align256((size_t)C * N * 4 * NSUB) + raster_fwd_fast_workspace_bytes(C, N);
 }
 
 bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, const int32_t* last_ids,
@@ -1398,10 +1443,14 @@ bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, 
         if (kind == CAM_OPENCV_FISHEYE) a.tile_flags = ws_flags(packed_from_fwd, a.C, a.N);
         ws_head = raster_fwd_fast_heads(packed_from_fwd, a.C, a.N);   // all -1: set by the packer, restored by every gather
     } else {
-        pack_into(kind, a, (char*)ws_head + align256((size_t)a.C * a.N * 4), st, ws_head);  // also sets every list head to -1
+        pack_into(kind, a, (char*)ws_head + align256((size_t)a.C * a.N * 4 * NSUB), st, ws_head);  // also sets every chain head to -1
     }
     *tile_flags_out = a.tile_flags;
     const dim3 ggrid((a.N + 255u) / 256u), gblock(256);
+    // record chains per (camera, Gaussian): NSUB on frames of large footprints — lists per 32 x 32 pixels are chosen for exactly those, or more
+    // than 8 tiles per Gaussian on average — else one (gsx_raster_common.hpp: tile_chain; GSX_BWD_CHAINS=1|4 forces it: tests, A/B)
+    a.chain_mask = (a.lshift != 0u || a.n_isects_expected > 8 * (int64_t)a.C * (int64_t)a.N) ? (uint32_t)(NSUB - 1) : 0u;
+    if (const char* e = test_switch("GSX_BWD_CHAINS")) a.chain_mask = atoi(e) > 1 ? (uint32_t)(NSUB - 1) : 0u;
     // Two backward kernels, same records and gather: Gaussian-major (the default; S-1M 0.49 vs 0.86 ms, S-5M @4K 1.9 vs 2.5 ms, garden
     // stand-in 248 vs 226 it/s) and pixel-major (GSX_BWD=pm forces it: tests, tools).
     const bool force_pm = [] { const char* e = test_switch("GSX_BWD"); return e && std::string(e) == "pm"; }();   // read per launch: the tests switch it
@@ -1419,8 +1468,12 @@ bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, 
     }
 #undef GSX_BLEND_BWD
     // the moments -> gradient map only involves the camera pose: one instance serves every camera model
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_bwd_gather_kernel<CAM_PERFECT_PINHOLE>), ggrid, gblock, 0, st, a, (const float4*)ws_rec, ws_head, v_means, v_quats, v_scales,
-                       v_colors, v_opacities);
+    if (a.chain_mask)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_bwd_gather_kernel<CAM_PERFECT_PINHOLE, NSUB>), ggrid, gblock, 0, st, a, (const float4*)ws_rec, ws_head, v_means, v_quats,
+                           v_scales, v_colors, v_opacities);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_bwd_gather_kernel<CAM_PERFECT_PINHOLE, 1>), ggrid, gblock, 0, st, a, (const float4*)ws_rec, ws_head, v_means, v_quats,
+                           v_scales, v_colors, v_opacities);
     return true;
 }
 

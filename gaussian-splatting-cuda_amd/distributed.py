@@ -53,6 +53,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_PORT", "29533")
         SINGLE_RANK_COLLECTIVES = True
     if (world > 1 or SINGLE_RANK_COLLECTIVES) and not dist.is_initialized():
+        # this host's driver only supports dmabuf IPC: without it RCCL's peer mappings fail with `hipIpcGetMemHandle: invalid argument`
+        # (read by the HSA runtime when the first rank-to-rank mapping is made; a value the launcher exported wins)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" IS RCCL on ROCm
         if backend == "nccl":

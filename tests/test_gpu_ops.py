@@ -257,6 +257,48 @@ def test_blend_backward_variants_vs_oracle(gsx_mod, variant):
         assert e < 1e-3, (variant, name, e)
 
 
+@pytest.mark.parametrize("variant", ["pm", "gq"])
+def test_blend_backward_record_chains(gsx_mod, variant):
+    """The backward chains its moment records per Gaussian — one chain on frames of small footprints, four (by tile parity) on frames of large
+    ones (gsx_raster_common.hpp: tile_chain).  Both forced on a scene of LARGE footprints (chains of tens of records), both kernels:
+    the oracle's gradients either way, the same sums up to the order of the additions, and a second backward on the same forward
+    workspace (the gather must have put every head back to -1) repeats the first."""
+    _, ops, _, scenes = gsx_mod
+    sc = scenes.scene_frustum(1_500, 256, 192, 300.0, (1.5, 6.0), sh_degree=0, seed=11)
+    sc["scales"] = sc["scales"] * 20.0   # footprints of many tiles
+    H, W = sc["height"], sc["width"]
+    rng = np.random.default_rng(2)
+    v_rc = rng.standard_normal((1, H, W, 3)).astype(np.float32)
+    v_ra = rng.standard_normal((1, H, W, 1)).astype(np.float32)
+    o = oracle_pipeline(sc, v_render_colors=v_rc, v_render_alphas=v_ra)
+    b = _blend_inputs(sc, o)
+    assert b["fl"].shape[0] > 12 * 1_500   # more than 12 tiles per Gaussian on average
+    args = (b["means"], b["quats"], b["scales"], b["colors"], b["opac"], b["bg"], None, W, H, 16, b["viewmat"], None, b["K"],
+            ops.CameraModelType.PINHOLE, ops.UnscentedTransformParameters(), ops.ShutterType.GLOBAL, None, None, None, b["off"], b["fl"])
+    fwd = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args, keep_ws=True)
+    ws = fwd[3]
+    old = {k: os.environ.get(k) for k in ("GSX_BWD", "GSX_BWD_CHAINS")}
+    res = {}
+    try:
+        os.environ["GSX_BWD"] = variant
+        for chains in ("1", "4", "4"):   # (the third run: the heads the second one consumed are empty again)
+            os.environ["GSX_BWD_CHAINS"] = chains
+            g = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, fwd[1], fwd[2], t(v_rc), t(v_ra), fwd_ws=ws)
+            res.setdefault(chains, []).append([np32(x) for x in g])
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    names = ["v_means", "v_quats", "v_scales", "v_colors", "v_opacities"]
+    for chains, runs in res.items():
+        for name, g in zip(names, runs[0]):
+            assert rel_l2(g, o[name]) < 1e-3, (variant, chains, name, rel_l2(g, o[name]))
+    for name, g1, g4, g4b in zip(names, res["1"][0], res["4"][0], res["4"][1]):
+        assert rel_l2(g4, g1) < 1e-5 and rel_l2(g4b, g4) < 1e-5, (variant, name, rel_l2(g4, g1), rel_l2(g4b, g4))
+
+
 def test_rasterize_autograd_end_to_end(gsx_mod):
     """gs::training::rasterize mirror: image parity with the oracle pipeline and gradients that flow to every
     raw parameter through the activations."""
