@@ -9,8 +9,9 @@
 // pack_records, ~470 B of HBM traffic per Gaussian).  Here one lane owns one Gaussian from its raw parameters to its record:
 //     reads   means 12 + scaling_raw 12 + rotation_raw 16 + opacity_raw 4 + the active SH bases 12 (deg+1)^2     (236 B at degree 3)
 //     writes  scales 12 + quats 16 + opacities 4 (the activated copies the backward and the operators read) + radii 8 + means2d 8 +
-//             depths 4 + conics 12 + colours 12 + record 64                                                      (140 B)
-// = 376 B per visible Gaussian at degree 3; a culled Gaussian stops after the projection (84 B: its SH row is never fetched, its record
+//             depths 4 + conics 12 (optional: the render path passes NULL, nothing downstream reads them) + colours 12 + record 64
+//             (140 B) + the four empty chain heads of the backward's record lists, 16 B
+// = 376 B per visible Gaussian at degree 3 (+ 16 B of heads); a culled Gaussian stops after the projection (84 B: its SH row is never fetched, its record
 // never written — no tile list can name it).  Every value is computed by the same device functions, in the same order of operations, as
 // the separate operators (ut_project, ShBasis::eval, store_packed_record): activated parameters, projection and colours are bit-identical;
 // the records agree to the last bit or two (the compiler contracts a few a*b+c of make_record differently in the two kernels) (tests/test_gpu_fused.py).
