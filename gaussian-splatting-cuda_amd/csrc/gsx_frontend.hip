@@ -47,6 +47,9 @@ struct FrontendOut {
 // Taken when the active bases are the whole row and rows are multiples of 16 B (K = (deg + 1)^2, K * 3 % 4 == 0: degree 3 with K = 16 —
 // two halves —, degree 1 with K = 4 — whole tile); otherwise the lane loads the active part of its row itself.  Rows of culled Gaussians
 // are not fetched either way.  GSX_FE_STAGE=0|1|2 (test switch) forces a variant.
+// (Round 4, not kept: the rows in two COLUMN halves — bases 0..7, then 8..15, the colour accumulated per half in the same order, bit-identical —
+// leaves 24 instead of 48 coefficient registers live: 96 VGPRs, 5 instead of 4 waves per SIMD, and 0.081 -> 0.090 ms: the 96 B half-row runs
+// use half of every 192 B the memory system moves per pass; occupancy is not what bounds this kernel.)
 template <int KIND, int DEG, int STAGE>
 __global__ __launch_bounds__(FE_BLOCK) void frontend_kernel(uint32_t N, uint32_t K, const float* __restrict__ means,
                                                             const float* __restrict__ rotation_raw, const float* __restrict__ scaling_raw,
