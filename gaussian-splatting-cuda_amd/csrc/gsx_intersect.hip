@@ -111,8 +111,9 @@ __global__ __launch_bounds__(ISECT_BLOCK) void isect_offset_kernel(int64_t n_ise
 //   3. scan     exclusive scan of the C*tiles totals = the reference's isect_offsets (+ the grand total = n_isects);
 //   4. scatter  the same blocks reload (tile offset + block prefix) as LDS cursors, claim slots with returning LDS atomics and
 //               write 64-bit keys (depth bits << idx_bits | flatten index) into their tile's segment — unordered inside it;
-//   5. sort     one wave per tile (up to 1024 keys; a 256-thread block up to 4096; a 1024-thread block with 132 KB of LDS up to
-//               16384): merge sort of the segment in LDS; larger segments: 16384-key LDS-sorted chunks + merge-path passes by many
+//   5. sort     one wave per tile up to 1024 keys: a bitonic network on the keys in REGISTERS (tile_sort_wave_regs_kernel: exchanges through
+//               DPP and the LDS crossbar, no LDS memory; round 4 — the LDS merge sort it replaces still serves calls that want isect_ids);
+//               a 256-thread block up to 4096 keys, a 1024-thread block with 132 KB of LDS up to 16384: merge sort of the segment in LDS; larger segments: 16384-key LDS-sorted chunks + merge-path passes by many
 //               blocks (giant_* kernels).  Then flatten_ids = low bits, isect_ids (on request) = (camera|tile) << 32 | depth bits.
 //               Keys are unique, so the result is exactly the stable sort upstream.
 //      Frames with heavy tiles: the ranked variant (4-byte depth ranks as keys, bitmap sort for tiles above 4096 keys), further down.
@@ -380,6 +381,138 @@ __global__ __launch_bounds__(256) void tile_sort_wave_kernel(uint32_t n_segments
         }
     }
 }
+
+// ---- one wave per segment, keys in REGISTERS: bitonic network over 64 lanes x E keys, exchanges through DPP / the LDS crossbar ----
+// The LDS merge sort above moves every key through LDS memory log2(64) + 1 times and half of its LDS cycles are bank conflicts (cursor
+// positions are data dependent).  A bitonic network needs no memory at all: lane l holds E keys; an exchange at element distance >= E is
+// "same register, lane l ^ j" — quad_perm / row_ror DPP moves for j = 1, 2, 8, ds_swizzle / ds_bpermute (the LDS crossbar: no bank, no
+// conflict) for j = 4, 16, 32 — and below E it is a compare-exchange between two registers of the lane.  21 cross-lane steps and
+// 6 log2(E) + log2(E)(log2(E)+1)/2 local ones; the direction of a step is a compile-time constant or a lane bit.  The input may
+// sit in the registers in ANY order (it is unsorted), so the keys are loaded striped (coalesced); the output is in blocked order
+// (element lane E + e) and takes one trip through LDS to leave coalesced.
+template <int M> GSX_DEV uint32_t lane_xor_u32(uint32_t v, uint32_t lane) {
+    if (M == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);        // quad_perm [1,0,3,2]
+    if (M == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);        // quad_perm [2,3,0,1]
+    if (M == 4) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);                         // lane ^ 4
+    if (M == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true);       // row_ror:8 = lane ^ 8 inside the row
+    if (M == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);                        // lane ^ 16
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ^ 32u) << 2), (int)v);                  // lane ^ 32
+}
+template <int M> GSX_DEV uint64_t lane_xor(uint64_t v, uint32_t lane) {
+    return ((uint64_t)lane_xor_u32<M>((uint32_t)(v >> 32), lane) << 32) | (uint64_t)lane_xor_u32<M>((uint32_t)v, lane);
+}
+template <int M> GSX_DEV uint32_t lane_xor(uint32_t v, uint32_t lane) { return lane_xor_u32<M>(v, lane); }
+
+// (64-bit keys compare with v_cmp_lt_u64: 6.5 cycles per wave instruction on gfx950 against 2 x 4.3 for a v_sub_co / v_subb_co borrow chain,
+//  tools/valu_probe.hip; a key step = 2 moves (DPP 4.3 each, ds_swizzle 9.0) + the compare + 2 v_cndmask (4.6) ~ 25-34 cycles)
+template <typename K> GSX_DEV bool key_lt(K a, K b) { return a < b; }
+
+// one cross-lane step: partner = lane ^ JL; `keep_min` (per lane): this lane keeps the smaller key of each pair
+template <int E, int JL, typename K> GSX_DEV void bitonic_cross(K (&r)[E], uint32_t lane, bool keep_min) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const K o = lane_xor<JL>(r[e], lane);
+        const bool take = key_lt(o, r[e]) == keep_min;   // (equal keys are the padding: either choice is the same value)
+        r[e] = take ? o : r[e];
+    }
+}
+// the local steps of a stage: element distances JE = E/2 .. 1 inside the lane, all in direction `asc` (per lane)
+template <int E, typename K> GSX_DEV void bitonic_local(K (&r)[E], bool asc) {
+#pragma unroll
+    for (int je = E / 2; je >= 1; je >>= 1)
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if ((e & je) == 0) {
+                const K x = r[e], y = r[e | je];
+                const bool sw = key_lt(y, x) == asc;
+                r[e] = sw ? y : x;
+                r[e | je] = sw ? x : y;
+            }
+}
+template <int E, typename K> GSX_DEV void bitonic_sort_regs(K (&r)[E], uint32_t lane) {
+    // stages of size k (elements) <= E: inside the lane, direction by the element index (compile time) — and by lane bit 0 at k = E
+#pragma unroll
+    for (int k = 2; k <= E; k <<= 1)
+#pragma unroll
+        for (int je = k / 2; je >= 1; je >>= 1)
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if ((e & je) == 0) {
+                    const bool asc = k < E ? ((e & k) == 0) : ((lane & 1u) == 0u);
+                    const K x = r[e], y = r[e | je];
+                    const bool sw = key_lt(y, x) == asc;
+                    r[e] = sw ? y : x;
+                    r[e | je] = sw ? x : y;
+                }
+    // stages of 2, 4, ..., 64 lanes (k = 2E .. 64E elements): direction = lane bit KL (the last stage: ascending everywhere)
+#define GSX_BITONIC_STAGE(KL, ...)                                                        \
+    {                                                                                     \
+        const bool asc = KL >= 64 || (lane & (uint32_t)KL) == 0u;                         \
+        __VA_ARGS__                                                                       \
+        bitonic_local<E>(r, asc);                                                         \
+    }
+#define GSX_X(JL) bitonic_cross<E, JL>(r, lane, asc == ((lane & (uint32_t)JL) == 0u));
+    GSX_BITONIC_STAGE(2, GSX_X(1))
+    GSX_BITONIC_STAGE(4, GSX_X(2) GSX_X(1))
+    GSX_BITONIC_STAGE(8, GSX_X(4) GSX_X(2) GSX_X(1))
+    GSX_BITONIC_STAGE(16, GSX_X(8) GSX_X(4) GSX_X(2) GSX_X(1))
+    GSX_BITONIC_STAGE(32, GSX_X(16) GSX_X(8) GSX_X(4) GSX_X(2) GSX_X(1))
+    GSX_BITONIC_STAGE(64, GSX_X(32) GSX_X(16) GSX_X(8) GSX_X(4) GSX_X(2) GSX_X(1))
+#undef GSX_X
+#undef GSX_BITONIC_STAGE
+}
+
+// (k = E needs the lane's direction at the END of the local sort: for E == 1 there is no local stage)
+template <int E, class KT>
+GSX_DEV void tile_sort_regs_segment(const KT& kt, typename KT::T* __restrict__ keys, int32_t* __restrict__ flatten_ids, int64_t begin, int n,
+                                    uint32_t lane, uint32_t* s_out) {
+    using K = typename KT::T;
+    K r[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {   // striped: coalesced, and the network does not care where an unsorted key starts
+        const int i = e * 64 + (int)lane;
+        r[e] = i < n ? keys[begin + i] : ~(K)0;
+    }
+    bitonic_sort_regs<E>(r, lane);
+    // blocked (lane E + e) -> striped through LDS (pad: one word after every 32), then coalesced stores
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = (int)lane * E + e;
+        s_out[i + (i >> 5)] = KT::kDeferred ? (uint32_t)r[e] : (uint32_t)kt.id(r[e]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = e * 64 + (int)lane;
+        if (i < n) {
+            const uint32_t v = s_out[i + (i >> 5)];
+            if (KT::kDeferred) keys[begin + i] = (K)v;   // in place: the whole segment was read before the sort
+            else flatten_ids[begin + i] = (int32_t)v;
+        }
+    }
+}
+
+template <class KT>
+__global__ __launch_bounds__(256) void tile_sort_wave_regs_kernel(uint32_t n_segments, KT kt, const int32_t* __restrict__ tile_offsets,
+                                                                  typename KT::T* __restrict__ keys, int32_t* __restrict__ flatten_ids,
+                                                                  int64_t capacity) {
+    __shared__ uint32_t s_all[4][TSORT_WAVE_CAP + TSORT_WAVE_CAP / 32];
+    const uint32_t seg = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (seg >= n_segments) return;
+    const int64_t begin = tile_offsets[seg];
+    const int n = (int)(tile_offsets[seg + 1] - tile_offsets[seg]);
+    if (n <= 0 || n > TSORT_WAVE_CAP || begin + n > capacity) return;
+    uint32_t* s_out = s_all[threadIdx.x >> 6];
+    const uint32_t lane = threadIdx.x & 63u;
+    if (n <= 64) tile_sort_regs_segment<1>(kt, keys, flatten_ids, begin, n, lane, s_out);
+    else if (n <= 128) tile_sort_regs_segment<2>(kt, keys, flatten_ids, begin, n, lane, s_out);
+    else if (n <= 256) tile_sort_regs_segment<4>(kt, keys, flatten_ids, begin, n, lane, s_out);
+    else if (n <= 512) tile_sort_regs_segment<8>(kt, keys, flatten_ids, begin, n, lane, s_out);
+    else tile_sort_regs_segment<16>(kt, keys, flatten_ids, begin, n, lane, s_out);
+}
+
+static bool wave_sort_merge_forced() { const char* e = test_switch("GSX_WAVE_SORT"); return e != nullptr && strcmp(e, "merge") == 0; }   // read per launch
 
 template <class KT>
 __global__ __launch_bounds__(ISECT_BLOCK) void tile_sort_kernel(uint32_t n_tiles, uint32_t tile_n_bits, KT kt,
@@ -1171,8 +1304,13 @@ extern "C" int gsx_intersect_bin_fill(uint32_t C, uint32_t N, const float* means
                        (const uint32_t*)nullptr, (float)tile_size, tile_width, tile_height, idx_bits, tile_offsets, (const uint32_t*)count_workspace,
                        keys, (uint32_t)n_isects);
     const KeyDepthIdx kt{idx_bits};
-    hipLaunchKernelGGL(tile_sort_wave_kernel<KeyDepthIdx>, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, n_tiles, bit_width_u32(n_tiles), kt,
-                       tile_offsets, keys, flatten_ids, isect_ids, n_isects);
+    // segments up to 1024 keys: one wave each — the register bitonic network (isect_ids, which need the sorted depth bits, keep the LDS
+    // merge sort; GSX_WAVE_SORT=merge (test switch) forces it: second implementation in the tests)
+    if (isect_ids == nullptr && !wave_sort_merge_forced())
+        hipLaunchKernelGGL(tile_sort_wave_regs_kernel<KeyDepthIdx>, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, kt, tile_offsets, keys, flatten_ids, n_isects);
+    else
+        hipLaunchKernelGGL(tile_sort_wave_kernel<KeyDepthIdx>, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, n_tiles, bit_width_u32(n_tiles), kt,
+                           tile_offsets, keys, flatten_ids, isect_ids, n_isects);
     // (`max_segment` > 0 is the caller's bound on the largest segment: the kernels for larger segments are not launched at all — a frame
     // that outgrows the bound is refilled / rendered again, as documented for the giant-segment passes)
     const int64_t seg_cap = std::min<int64_t>(max_segment > 0 ? max_segment : n_isects, n_isects);
@@ -1332,8 +1470,11 @@ extern "C" int gsx_intersect_bin_fill_ranked(uint32_t C, uint32_t N, const float
     hipLaunchKernelGGL(bin_scatter_kernel<uint32_t>, dim3(bin_nb(), C), dim3(BIN_BLOCK), lds, st, N, per_block, means2d, radii, depths, ranks,
                        (float)tile_size, tile_width, tile_height, 0u, tile_offsets, (const uint32_t*)count_workspace, keys, (uint32_t)n_isects);
     const KeyRank kt{order, depths};
-    hipLaunchKernelGGL(tile_sort_wave_kernel<KeyRank>, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, n_tiles, bit_width_u32(n_tiles), kt, tile_offsets,
-                       keys, flatten_ids, isect_ids, n_isects);
+    if (!wave_sort_merge_forced())   // (deferred keys: the sorted ranks stay in place, ranked_finalize_kernel turns them into ids / isect_ids)
+        hipLaunchKernelGGL(tile_sort_wave_regs_kernel<KeyRank>, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, kt, tile_offsets, keys, flatten_ids, n_isects);
+    else
+        hipLaunchKernelGGL(tile_sort_wave_kernel<KeyRank>, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, n_tiles, bit_width_u32(n_tiles), kt, tile_offsets,
+                           keys, flatten_ids, isect_ids, n_isects);
     hipLaunchKernelGGL(tile_sort_kernel<KeyRank>, dim3(nseg), dim3(ISECT_BLOCK), 0, st, n_tiles, bit_width_u32(n_tiles), kt, tile_offsets,
                        keys, flatten_ids, isect_ids, n_isects);
     if (n_isects > TSORT_CAP) {

@@ -378,9 +378,15 @@ def test_intersect_tile_binned_equals_sorted_path(C, N, W, H, rmax, nq, fill, mo
     assert torch.equal(ids, ids2) and torch.equal(flat, flat2)
     _, ids3, flat3, off3 = ops.intersect_tile_binned(means2d, radii, depths, C, 16, tw, th, False)
     assert ids3.numel() == 0 and torch.equal(flat, flat3) and torch.equal(off, off3)
+    # (segments up to 1024 keys: the call above sorts them with the register bitonic network, the one with isect_ids with the LDS merge
+    #  sort; forced here once more without isect_ids)
+    monkeypatch.setenv("GSX_WAVE_SORT", "merge")
+    _, _, flat4, off4 = ops.intersect_tile_binned(means2d, radii, depths, C, 16, tw, th, False)
+    monkeypatch.delenv("GSX_WAVE_SORT")
+    assert torch.equal(flat, flat4) and torch.equal(off, off4)
     seg = torch.cat([off.flatten(), torch.tensor([flat.numel()], device=off.device, dtype=off.dtype)])
     seg = seg[1:] - seg[:-1]
-    assert ops.shim_ranked_calls(True) == (2 if fill == "ranked" else 0)
+    assert ops.shim_ranked_calls(True) == (3 if fill == "ranked" else 0)
     if N == 30000:
         assert int(seg.max()) > 4096                                         # beyond the 4096-key block sort
     if N in (20000, 50000):

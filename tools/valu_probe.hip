@@ -21,6 +21,10 @@ template <int OP> __global__ void k(float* out, int iters, float seed) {
             if (OP == 9) { asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cmp_lt_f32 vcc, %1, %8\n v_cmp_lt_f32 vcc, %2, %8\n v_cmp_lt_f32 vcc, %3, %8\n v_cmp_lt_f32 vcc, %4, %8\n v_cmp_lt_f32 vcc, %5, %8\n v_cmp_lt_f32 vcc, %6, %8\n v_cmp_lt_f32 vcc, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc"); }
             if (OP == 10) { asm volatile("v_min_f32 %0, %0, %8\n v_min_f32 %1, %1, %8\n v_min_f32 %2, %2, %8\n v_min_f32 %3, %3, %8\n v_min_f32 %4, %4, %8\n v_min_f32 %5, %5, %8\n v_min_f32 %6, %6, %8\n v_min_f32 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)); }
             if (OP == 11) { asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %8, vcc\n v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %8, vcc\n v_cmp_lt_f32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %8, vcc\n v_cmp_lt_f32 vcc, %6, %8\n v_cndmask_b32 %7, %7, %8, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc"); }
+            if (OP == 13) { asm volatile("v_cmp_lt_u64 vcc, %0, %2\n v_cmp_lt_u64 vcc, %1, %3\n v_cmp_lt_u64 vcc, %2, %0\n v_cmp_lt_u64 vcc, %3, %1\n v_cmp_lt_u64 vcc, %0, %3\n v_cmp_lt_u64 vcc, %1, %2\n v_cmp_lt_u64 vcc, %2, %1\n v_cmp_lt_u64 vcc, %3, %0" : "+v"(*(double*)&a0), "+v"(*(double*)&a2), "+v"(*(double*)&a4), "+v"(*(double*)&a6) : : "vcc"); }
+            if (OP == 14) { asm volatile("v_sub_co_u32 %8, vcc, %0, %2\n v_subb_co_u32 %8, vcc, %1, %3, vcc\n v_sub_co_u32 %8, vcc, %4, %6\n v_subb_co_u32 %8, vcc, %5, %7, vcc\n v_sub_co_u32 %8, vcc, %2, %0\n v_subb_co_u32 %8, vcc, %3, %1, vcc\n v_sub_co_u32 %8, vcc, %6, %4\n v_subb_co_u32 %8, vcc, %7, %5, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a0) : : "vcc"); }
+            if (OP == 15) { asm volatile("ds_swizzle_b32 %0, %0 offset:0x101F\n ds_swizzle_b32 %1, %1 offset:0x101F\n ds_swizzle_b32 %2, %2 offset:0x101F\n ds_swizzle_b32 %3, %3 offset:0x101F\n ds_swizzle_b32 %4, %4 offset:0x101F\n ds_swizzle_b32 %5, %5 offset:0x101F\n ds_swizzle_b32 %6, %6 offset:0x101F\n ds_swizzle_b32 %7, %7 offset:0x101F\n s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)); }
+            if (OP == 16) { asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %4, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)); }
             if (OP == 12) { asm volatile("v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)); }
         }
     }
@@ -44,6 +48,7 @@ int main() {
         run<0>("v_fma_f32", d, w); run<1>("v_mul_f32", d, w); run<5>("v_pk_fma_f32", d, w); run<2>("v_exp_f32", d, w); run<6>("v_rcp_f32", d, w);
         run<3>("v_add_f32_dpp row_shr", d, w); run<4>("v_permlane32_swap", d, w); run<7>("v_cndmask_b32 vcc", d, w);
         run<8>("v_cndmask_b32 sgpr", d, w); run<9>("v_cmp_lt_f32", d, w); run<10>("v_min_f32", d, w); run<11>("cmp+cndmask pairs", d, w); run<12>("v_mov_b32", d, w);
+        run<13>("v_cmp_lt_u64", d, w); run<14>("v_sub_co/v_subb_co", d, w); run<15>("ds_swizzle_b32", d, w); run<16>("v_mov_b32_dpp quad", d, w);
     }
     return 0;
 }
