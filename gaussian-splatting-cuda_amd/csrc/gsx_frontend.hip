@@ -94,7 +94,7 @@ __global__ __launch_bounds__(FE_BLOCK) void frontend_kernel(uint32_t N, uint32_t
             else { const float o = 1.f / len; q = {q.w * o, q.x * o, q.y * o, q.z * o}; }
         }
         // ---- projection ----
-        visible = ut_project<KIND>(cam, sp, mean, scale, q, true, opacity, W, H, eps2d, near_plane, far_plane, radius_clip, ut, p);
+        visible = ut_project<KIND, true>(cam, sp, mean, scale, q, true, opacity, W, H, eps2d, near_plane, far_plane, radius_clip, ut, p);
     }
     float row[NQ * 4];
     if (STAGE) {

@@ -12,7 +12,10 @@ struct UtProjOut { float radius_x, radius_y; f2 im; float depth, c00, c01, c11, 
 
 // `q` is the glm-normalised quaternion (w, x, y, z).  Returns false when the Gaussian is culled (the caller writes radii = 0 only, as
 // upstream); true: `o` holds radii (as floats), the 2-D mean, the depth, the blurred covariance, 1/det and the compensation.
-template <int KIND>
+// GLOBAL_SHUTTER = true: the caller guarantees cams.shutter == GLOBAL (the fused front end): world_to_image is then its first projection alone —
+// the same instructions on that path, but the rolling-shutter iteration (ten slerps with acos / sin per sigma point, unrolled seven
+// times) is not compiled into the kernel at all.
+template <int KIND, bool GLOBAL_SHUTTER = false>
 GSX_DEV bool ut_project(const Camera<KIND>& cam, const ShutterPoses& sp, const f3 mean, const f3 scale, const quat q, const bool has_opacity,
                         const float opacity_in, const uint32_t W, const uint32_t H, const float eps2d, const float near_plane, const float far_plane,
                         const float radius_clip, const gsx_ut_params& ut, UtProjOut& o) {
@@ -46,7 +49,8 @@ GSX_DEV bool ut_project(const Camera<KIND>& cam, const ShutterPoses& sp, const f
             pt = (i <= 3) ? (mean + delta) : (mean - delta);
         }
         f2 ip;
-        const bool pv = cam.world_to_image(pt, sp, ut.in_image_margin_factor, ip);
+        const bool pv = GLOBAL_SHUTTER ? cam.project(quat_rotate(sp.q0, pt) + sp.t0, ut.in_image_margin_factor, ip)
+                                       : cam.world_to_image(pt, sp, ut.in_image_margin_factor, ip);
         if (require_all) {
             if (!pv) return false;
         } else {
