@@ -1253,7 +1253,9 @@ extern "C" int gsx_intersect_bin_count_guarded(uint32_t C, uint32_t N, const flo
     // is written by bin_scan itself when the memory has a device alias (hipHostMalloc / hipHostRegister: torch's pinned tensors), else copied
     unsigned long long* host_alias = nullptr;
     if (n_isects_host_pinned) {
-        *n_isects_host_pinned = 0;
+        // all ones = "not written yet" (no frame produces it: the high half is a segment size <= 2^31): a host that would rather not put
+        // an event into the stream polls the word — its HIGH half changes last on either path below
+        *n_isects_host_pinned = -1;
         void* dp = nullptr;
         if (hipHostGetDevicePointer(&dp, n_isects_host_pinned, 0) == hipSuccess && dp != nullptr) host_alias = (unsigned long long*)dp;
         else (void)hipGetLastError();

@@ -16,6 +16,7 @@
 #include <ATen/hip/HIPEvent.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -166,21 +167,63 @@ static void hint_update(const HintKey& key, int64_t n_isects, int64_t max_seg) {
 // (confirm) before it applies anything irreversible to a frame rendered from these lists.  confirm() waits for the 8-byte word the count
 // copied to pinned memory — by then hundreds of microseconds of queued kernels sit behind that copy, so the wait does not drain the stream —
 // and feeds the capacity hints.
+// The pinned host word of one count (n_isects | largest segment << 32): a slot of a process-wide ring of HOST-COHERENT pinned memory
+// (hipHostMallocCoherent: the device's system-scope store is visible to the CPU without a release at kernel end).  The count leaves all
+// ones in it until the device has written it, so the host POLLS the word: no event is recorded behind the count — an event's
+// system-scope release between bin_scan and the key scatter cost ~6 us of idle GPU per frame (kernel trace, round 4).
+struct HostWord {
+    static constexpr uint64_t kSlots = 4096;
+    volatile uint64_t* p = nullptr;
+    uint64_t ticket = 0;
+    static uint64_t* ring() {
+        static uint64_t* base = [] {
+            void* q = nullptr;
+            TORCH_CHECK(hipHostMalloc(&q, kSlots * sizeof(uint64_t), hipHostMallocCoherent | hipHostMallocPortable | hipHostMallocMapped) == hipSuccess && q != nullptr,
+                        "gsx: hipHostMalloc of the host-word ring failed");
+            return (uint64_t*)q;
+        }();
+        return base;
+    }
+    static std::atomic<uint64_t>& counter() { static std::atomic<uint64_t> c{0}; return c; }
+    static HostWord take() {
+        HostWord w;
+        w.ticket = counter().fetch_add(1);
+        w.p = ring() + (w.ticket % kSlots);
+        *w.p = ~0ull;
+        return w;
+    }
+    bool ready() const { return (uint32_t)(__atomic_load_n(p, __ATOMIC_ACQUIRE) >> 32) != 0xFFFFFFFFu; }
+    // waits for the device's store (by polling; a word that does not arrive within 20 s means the stream died: synchronise to surface the error)
+    uint64_t wait() const {
+        TORCH_CHECK(counter().load() - ticket <= kSlots, "gsx: an intersection handle was confirmed after ", kSlots, " later intersections (its host word was reused)");
+        const auto t0 = std::chrono::steady_clock::now();
+        uint32_t spins = 0;
+        while (!ready()) {
+            if ((++spins & 1023u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+                C10_HIP_CHECK(hipDeviceSynchronize());
+                TORCH_CHECK(ready(), "gsx: the intersection count never reached the host");
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        return __atomic_load_n(p, __ATOMIC_ACQUIRE);
+    }
+};
+
 struct IsectLists {
-    at::Tensor n_host;    // pinned: n_isects | largest segment << 32
+    HostWord n_host;      // pinned: n_isects | largest segment << 32
     at::Tensor status;    // device int32 [1]: n_isects, or -1 = lists incomplete (frame renders empty); undefined = exact lists (cold call)
-    std::shared_ptr<at::cuda::CUDAEvent> ready;
     HintKey key;
     int64_t capacity = 0, seg_bound = 0, expected = 0;
     bool ranked = false, confirmed = false, complete = true;
     int64_t n_isects = 0, max_seg = 0;
 
-    bool is_ready() const { return confirmed || ready->query(); }
+    bool is_ready() const { return confirmed || n_host.ready(); }
     std::tuple<int64_t, int64_t, bool> confirm() {
         if (!confirmed) {
-            if (!ready->query()) g_stats.guarded_waits++;   // the host got here before the GPU passed the count
-            ready->synchronize();
-            const uint64_t word = (uint64_t)n_host.data_ptr<int64_t>()[0];
+            if (!n_host.ready()) g_stats.guarded_waits++;   // the host got here before the GPU passed the count
+            const uint64_t word = n_host.wait();
             n_isects = (int64_t)(word & 0xFFFFFFFFull); max_seg = (int64_t)(word >> 32);
             TORCH_CHECK(n_isects <= 0x7FFFFFFFll, "intersect_tile: more than 2^31 - 1 intersections (tile offsets are int32, as upstream's isect_offsets)");
             hint_update(key, n_isects, max_seg);
@@ -748,15 +791,17 @@ static std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile
     at::Tensor offsets = at::empty({(int64_t)C * tile_height * tile_width + 1}, depths.options().dtype(at::kInt));
     const size_t cwb = gsx_intersect_bin_count_workspace_bytes(C, tile_width, tile_height);
     at::Tensor cws = at::empty({(int64_t)cwb}, depths.options().dtype(at::kByte));
-    at::Tensor n_host = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+    const HostWord n_host = HostWord::take();
     at::Tensor status;
     if (guarded) status = at::empty({1}, depths.options().dtype(at::kInt));
     check(gsx_intersect_bin_count_guarded(C, N, n_elements ? means2d.data_ptr<float>() : nullptr, n_elements ? radii.data_ptr<int32_t>() : nullptr, tile_size,
                                           tile_width, tile_height, (n_elements && !lists) ? tiles_per_gauss.data_ptr<int32_t>() : nullptr, offsets.data_ptr<int32_t>(),
-                                          n_host.data_ptr<int64_t>(), cws.data_ptr(), cwb, capacity, ranked ? 0 : seg_bound,
+                                          (int64_t*)n_host.p, cws.data_ptr(), cwb, capacity, ranked ? 0 : seg_bound,
                                           guarded ? status.data_ptr<int32_t>() : nullptr, st), "intersect_tile_binned(count)");
-    auto total_ready = std::make_shared<at::cuda::CUDAEvent>();
-    total_ready->record(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
+    if (const char* e = gsx_test_switch("GSX_COUNT_EVENT"); e && e[0] == '1') {   // A/B tool: what rounds 2 .. 4 did here — an event behind the count
+        at::cuda::CUDAEvent ev;
+        ev.record(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
+    }
     at::Tensor ranks, order;
     if (ranked) {
         ranks = at::empty({(int64_t)n_elements}, depths.options().dtype(at::kInt));
@@ -791,15 +836,14 @@ static std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> intersect_tile
     at::Tensor isect_offsets = offsets.narrow(0, 0, (int64_t)C * tile_height * tile_width).view({(int64_t)C, (int64_t)tile_height, (int64_t)tile_width});
     g_stats.binned_calls++;
     if (guarded) {   // nobody waits: the consumers read the verdict on the device, the host confirms later
-        lists->n_host = n_host; lists->status = status; lists->ready = total_ready; lists->key = key;
+        lists->n_host = n_host; lists->status = status; lists->key = key;
         lists->capacity = capacity; lists->seg_bound = seg_bound; lists->ranked = ranked;
         lists->expected = last_total > 0 ? std::min(last_total, capacity) : capacity;
         g_stats.guarded_calls++;
         return std::make_tuple(tiles_per_gauss, isect_ids, flatten_ids, isect_offsets);
     }
-    total_ready->synchronize();
+    const uint64_t word = n_host.wait();   // the exact protocol: the host waits for the count here, every call
     g_stats.host_syncs++;
-    const uint64_t word = (uint64_t)n_host.data_ptr<int64_t>()[0];
     const int64_t n_isects = (int64_t)(word & 0xFFFFFFFFull), max_seg = (int64_t)(word >> 32);
     TORCH_CHECK(n_isects <= 0x7FFFFFFFll, "intersect_tile: more than 2^31 - 1 intersections (tile offsets are int32, as upstream's isect_offsets)");
     hint_update(key, n_isects, max_seg);

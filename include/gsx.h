@@ -30,8 +30,10 @@ extern "C" {
  *      NULL radii / colors; ranked fill entry points added.
  *   3  additions only: gsx_frontend_fused(_supported), gsx_rasterize_to_pixels_from_world_3dgs_fwd_packed, gsx_intersect_tile_fill_packed.
  *   4  additions only: the guarded list protocol (no host read of n_isects on the render path): gsx_intersect_bin_count_guarded,
- *      gsx_rasterize_to_pixels_from_world_3dgs_{fwd,bwd}_guarded. */
-#define GSX_ABI_VERSION 4
+ *      gsx_rasterize_to_pixels_from_world_3dgs_{fwd,bwd}_guarded.
+ *   5  gsx_intersect_bin_count(_guarded) store all ones into the pinned host word before they launch anything, and its high half is what the
+ *      device writes last: the word can be POLLED by the host (no event in the stream); gsx_frontend_fused accepts NULL conics. */
+#define GSX_ABI_VERSION 5
 
 typedef enum gsx_status {
     GSX_OK = 0,
@@ -254,7 +256,9 @@ int gsx_intersect_bin_fill(uint32_t C, uint32_t N, const float* means2d, const i
  * when it does not.  The blend entry points below take that word: the last list ends at the total instead of at the host's `n_isects` (which is
  * then only the capacity of flatten_ids), and a frame whose verdict is -1 is rendered with EMPTY lists (background, zero gradients: no
  * unwritten slot of flatten_ids is ever read).  The host reads the same verdict whenever it likes — the pinned word of bin_count still
- * arrives — and renders an overflowed frame again with enough room BEFORE it applies anything irreversible (an optimizer step).
+ * arrives: it holds all ones until the device has written it (high half last), so the host may poll it (host-coherent pinned memory:
+ * hipHostMallocCoherent) instead of recording an event behind the count, which would put a system-scope release between the count and
+ * the key scatter — and renders an overflowed frame again with enough room BEFORE it applies anything irreversible (an optimizer step).
  * Same results as the exact protocol whenever the verdict is >= 0; nothing blocks between the count and the blend. */
 int gsx_intersect_bin_count_guarded(uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, uint32_t tile_size,
                                     uint32_t tile_width, uint32_t tile_height, int32_t* tiles_per_gauss, int32_t* tile_offsets,
