@@ -504,11 +504,19 @@ __global__ __launch_bounds__(256) void splat_activations_bwd_kernel(uint32_t N, 
                                                                     const float* __restrict__ v_scales, const float* __restrict__ v_quats,
                                                                     const float* __restrict__ v_opacities,
                                                                     float* __restrict__ v_scaling_raw, float* __restrict__ v_rotation_raw,
-                                                                    float* __restrict__ v_opacity_raw) {
+                                                                    float* __restrict__ v_opacity_raw, float scale_reg, float opacity_reg) {
+    // scale_reg / opacity_reg != 0: the gradients of the MCMC strategy's regularisers scale_reg * mean(exp(s_raw)) and opacity_reg *
+    // mean(sigmoid(o_raw)) (trainer.cpp:103-127 adds them to the loss) are added where exp(s) and sigmoid'(o) are formed anyway —
+    // the caller passes reg / numel — instead of six elementwise launches behind the backward
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= N) return;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) v_scaling_raw[(size_t)i * 3 + k] = v_scales[(size_t)i * 3 + k] * expf(scaling_raw[(size_t)i * 3 + k]);
+    for (int k = 0; k < 3; ++k) {
+        const float e = expf(scaling_raw[(size_t)i * 3 + k]);
+        float g = v_scales[(size_t)i * 3 + k] * e;
+        if (scale_reg != 0.f) g = fmaf(scale_reg, e, g);
+        v_scaling_raw[(size_t)i * 3 + k] = g;
+    }
     const float4 q = reinterpret_cast<const float4*>(rotation_raw)[i];
     const float4 g = reinterpret_cast<const float4*>(v_quats)[i];
     const float nrm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
@@ -523,7 +531,10 @@ __global__ __launch_bounds__(256) void splat_activations_bwd_kernel(uint32_t N, 
     }
     reinterpret_cast<float4*>(v_rotation_raw)[i] = o;
     const float sg = 1.f / (1.f + expf(-opacity_raw[i]));
-    v_opacity_raw[i] = v_opacities[i] * sg * (1.f - sg);
+    const float ds = sg * (1.f - sg);
+    float go = v_opacities[i] * sg * (1.f - sg);
+    if (opacity_reg != 0.f) go = fmaf(opacity_reg, ds, go);
+    v_opacity_raw[i] = go;
 }
 
 
@@ -678,12 +689,20 @@ extern "C" int gsx_splat_activations_fwd(uint32_t N, const float* scaling_raw, c
 extern "C" int gsx_splat_activations_bwd(uint32_t N, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
                                          const float* v_scales, const float* v_quats, const float* v_opacities, float* v_scaling_raw,
                                          float* v_rotation_raw, float* v_opacity_raw, void* stream) {
+    return gsx_splat_activations_bwd_reg(N, scaling_raw, rotation_raw, opacity_raw, v_scales, v_quats, v_opacities, v_scaling_raw, v_rotation_raw,
+                                         v_opacity_raw, 0.f, 0.f, stream);
+}
+
+extern "C" int gsx_splat_activations_bwd_reg(uint32_t N, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                                             const float* v_scales, const float* v_quats, const float* v_opacities, float* v_scaling_raw,
+                                             float* v_rotation_raw, float* v_opacity_raw, float scale_reg_per_element, float opacity_reg_per_element,
+                                             void* stream) {
     if (N == 0) return GSX_OK;
     if (!scaling_raw || !rotation_raw || !opacity_raw || !v_scales || !v_quats || !v_opacities || !v_scaling_raw || !v_rotation_raw || !v_opacity_raw) {
         set_error("splat_activations_bwd: null pointer");
         return GSX_ERR_INVALID_ARGUMENT;
     }
     hipLaunchKernelGGL(splat_activations_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, scaling_raw, rotation_raw,
-                       opacity_raw, v_scales, v_quats, v_opacities, v_scaling_raw, v_rotation_raw, v_opacity_raw);
+                       opacity_raw, v_scales, v_quats, v_opacities, v_scaling_raw, v_rotation_raw, v_opacity_raw, scale_reg_per_element, opacity_reg_per_element);
     return check_launch("splat_activations_bwd");
 }

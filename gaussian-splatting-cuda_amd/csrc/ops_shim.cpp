@@ -709,7 +709,8 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> splat_activations_bwd(const at::T
                                                                      const at::Tensor v_quats, const at::Tensor v_opacities,
                                                                      const at::optional<at::Tensor> out_scaling,
                                                                      const at::optional<at::Tensor> out_rotation,
-                                                                     const at::optional<at::Tensor> out_opacity) {
+                                                                     const at::optional<at::Tensor> out_opacity, const double scale_reg_per_element,
+                                                                     const double opacity_reg_per_element) {
     GSX_DEVICE_GUARD(scaling_raw);
     GSX_CHECK_INPUT(scaling_raw); GSX_CHECK_INPUT(rotation_raw); GSX_CHECK_INPUT(opacity_raw);
     GSX_CHECK_INPUT(v_scales); GSX_CHECK_INPUT(v_quats); GSX_CHECK_INPUT(v_opacities);
@@ -718,9 +719,10 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> splat_activations_bwd(const at::T
     at::Tensor gr = (out_rotation.has_value() && out_rotation->defined()) ? out_rotation.value() : at::empty_like(rotation_raw);
     at::Tensor go = (out_opacity.has_value() && out_opacity->defined()) ? out_opacity.value() : at::empty_like(opacity_raw);
     GSX_CHECK_INPUT(gs); GSX_CHECK_INPUT(gr); GSX_CHECK_INPUT(go);
-    check(gsx_splat_activations_bwd(N, scaling_raw.data_ptr<float>(), rotation_raw.data_ptr<float>(), opacity_raw.data_ptr<float>(),
-                                    v_scales.data_ptr<float>(), v_quats.data_ptr<float>(), v_opacities.data_ptr<float>(),
-                                    gs.data_ptr<float>(), gr.data_ptr<float>(), go.data_ptr<float>(), cur_stream()), "splat_activations_bwd");
+    check(gsx_splat_activations_bwd_reg(N, scaling_raw.data_ptr<float>(), rotation_raw.data_ptr<float>(), opacity_raw.data_ptr<float>(),
+                                        v_scales.data_ptr<float>(), v_quats.data_ptr<float>(), v_opacities.data_ptr<float>(),
+                                        gs.data_ptr<float>(), gr.data_ptr<float>(), go.data_ptr<float>(), (float)scale_reg_per_element,
+                                        (float)opacity_reg_per_element, cur_stream()), "splat_activations_bwd");
     return std::make_tuple(gs, gr, go);
 }
 
@@ -1153,7 +1155,9 @@ PYBIND11_MODULE(_gsx_ops, m) {
     m.def("sh_colors_bwd_adam", &gsx_ext::sh_colors_bwd_adam);
     m.def("splat_activations_fwd", &gsx_ext::splat_activations_fwd);
     m.def("splat_activations_projection_ut", &gsx_ext::splat_activations_projection_ut);
-    m.def("splat_activations_bwd", &gsx_ext::splat_activations_bwd);
+    m.def("splat_activations_bwd", &gsx_ext::splat_activations_bwd, py::arg("scaling_raw"), py::arg("rotation_raw"), py::arg("opacity_raw"), py::arg("v_scales"),
+          py::arg("v_quats"), py::arg("v_opacities"), py::arg("out_scaling") = at::optional<at::Tensor>(), py::arg("out_rotation") = at::optional<at::Tensor>(),
+          py::arg("out_opacity") = at::optional<at::Tensor>(), py::arg("scale_reg_per_element") = 0.0, py::arg("opacity_reg_per_element") = 0.0);
     m.def("intersect_tile_binned", &gsx_ext::intersect_tile_binned);
     m.def("intersect_tile_binned_guarded", &gsx_ext::intersect_tile_binned_guarded);
     m.def("shim_guarded_stats", [](bool reset) {  // (guarded intersect calls, confirms that had to wait for the GPU, frames whose lists were incomplete)

@@ -402,8 +402,10 @@ class GutRenderFunction(torch.autograd.Function):
         s = sinks or {}
         # scaling / rotation / opacity gradients only need the blend backward: they are finished first, so that a multi-GPU caller can
         # start exchanging them ("_early_ready" callback) while the SH backward — 81 % of the gradient bytes — is still running
+        # "_regularisers" = (scale_reg / numel, opacity_reg / numel): the MCMC strategy's two regulariser gradients ride on this kernel
+        reg = s.get("_regularisers") or (0.0, 0.0)
         g_s, g_r, g_o = ops.splat_activations_bwd(sr, rr, orw, v_scales, v_quats, v_opac.reshape(-1), s.get("scaling_raw"),
-                                                 s.get("rotation_raw"), s.get("opacity_raw"))
+                                                 s.get("rotation_raw"), s.get("opacity_raw"), float(reg[0]), float(reg[1]))
         if ctx.lists is not None and not getattr(ctx, "lists_checked", False):
             # Guarded lists: the one place the host looks at the frame's intersection count — with the forward, the loss and the blend
             # backward (~0.9 ms at S-1M) queued behind the 8-byte copy it waits for, so the stream never drains.  Everything so far only

@@ -24,7 +24,7 @@ from .strategy import MCMC, OptimizationParameters
 
 class Trainer:
     def __init__(self, model, cameras, images, params: OptimizationParameters = None, background=None, scene_scale=1.0, seed=0,
-                 sharded_adam=False, exchange="colors", fused_sh_adam=True, guarded_lists=True):
+                 sharded_adam=False, exchange="colors", fused_sh_adam=True, guarded_lists=True, fused_regularisers=True):
         """cameras: list of rasterizer.Camera; images: list of [3,H,W] ground-truth tensors on the device.
         sharded_adam (world > 1): reduce-scatter -> Adam on this rank's 1/world of the Gaussians -> all-gather of the parameters
         (distributed.ShardedAdam) instead of all-reduce + replicated Adam.
@@ -34,8 +34,13 @@ class Trainer:
         (gsx_sh_colors_bwd_adam: the SH gradient is never written); needs the complete SH gradient on this rank, i.e. one GPU or the
         colour exchange.  Refine iterations keep the separate step: relocation / growth run between backward and optimizer there.
         guarded_lists: render with rasterize_fused(guarded=True) — no host read of n_isects per iteration (include/gsx.h "guarded lists");
-        an iteration whose intersection lists outgrew their capacity is repeated before its optimizer step (`capacity_misses` counts them)."""
-        self.model, self.cameras, self.images = model, cameras, images
+        an iteration whose intersection lists outgrew their capacity is repeated before its optimizer step (`capacity_misses` counts them).
+        fused_regularisers: the gradients of the strategy's scale / opacity regularisers are added inside the render backward's
+        activation-Jacobian kernel (same values as the separate elementwise ops of _add_regularisers up to the rounding of one fma)."""
+        self.model, self.cameras = model, cameras
+        # dense [3,H,W] once, here: a target that is a permuted view (e.g. a clamped render: torch.clamp keeps the HWC strides of its input) would
+        # otherwise be copied by the loss in EVERY iteration (13 MB per frame at 1296x840: 14 us of the garden stand-in's 2.2 ms)
+        self.images = [im if im.is_contiguous() else im.contiguous() for im in images]
         self.params = params or OptimizationParameters()
         self.bg = background
         dev = model.means.device
@@ -53,6 +58,7 @@ class Trainer:
         self._rebuild_bucket(model)
         self.sharded = gdist.ShardedAdam(self.strategy.optimizer) if (sharded_adam and self.multi) else None
         self.guarded, self.capacity_misses = guarded_lists, 0
+        self.fused_regularisers = fused_regularisers
         self._lists_agree = gdist.ListsAgreement() if (guarded_lists and self.multi) else None
         if self._lists_agree is not None:
             self.sinks["_lists_agree"] = self._lists_agree
@@ -73,8 +79,17 @@ class Trainer:
         if getattr(self, "_lists_agree", None) is not None:
             self.sinks["_lists_agree"] = self._lists_agree
 
+    def _regulariser_coefficients(self):
+        """(scale_reg / numel, opacity_reg / numel): what rasterize_fused's backward adds inside the activation-Jacobian kernel
+        (sinks["_regularisers"]) — the same gradients as _add_regularisers, without its six elementwise launches."""
+        p, m = self.params, self.model
+        return (p.scale_reg / m.scaling_raw.numel() if p.scale_reg > 0.0 else 0.0,
+                p.opacity_reg / m.opacity_raw.numel() if p.opacity_reg > 0.0 else 0.0)
+
     @torch.no_grad()
     def _add_regularisers(self):
+        if self.sinks.get("_regularisers") is not None:   # already inside the gradients (fused into the render backward)
+            return
         p, m = self.params, self.model
         if p.scale_reg > 0.0:   # d/ds_raw [reg * mean(exp(s_raw))]
             m.scaling_raw.grad.add_(torch.exp(m.scaling_raw), alpha=p.scale_reg / m.scaling_raw.numel())
@@ -88,6 +103,7 @@ class Trainer:
             self.xch.begin_step(torch.stack([self.cameras[(it * self.world + r) % len(self.cameras)].viewmat for r in range(self.world)]))
         fuse = self.fused_sh_adam and it < self.params.iterations and not self.strategy.is_refining(it)
         gt = self.images[i]
+        self.sinks["_regularisers"] = self._regulariser_coefficients() if self.fused_regularisers else None
         for attempt in range(4):
             self.sinks["_sh_adam"] = self.strategy.optimizer.begin_fused_sh_step(it) if fuse else None
             fuse = self.sinks["_sh_adam"] is not None

@@ -32,7 +32,7 @@ extern "C" {
  *   4  additions only: the guarded list protocol (no host read of n_isects on the render path): gsx_intersect_bin_count_guarded,
  *      gsx_rasterize_to_pixels_from_world_3dgs_{fwd,bwd}_guarded.
  *   5  gsx_intersect_bin_count(_guarded) store all ones into the pinned host word before they launch anything, and its high half is what the
- *      device writes last: the word can be POLLED by the host (no event in the stream); gsx_frontend_fused accepts NULL conics. */
+ *      device writes last: the word can be POLLED by the host (no event in the stream); gsx_frontend_fused accepts NULL conics; gsx_splat_activations_bwd_reg added. */
 #define GSX_ABI_VERSION 5
 
 typedef enum gsx_status {
@@ -384,6 +384,12 @@ int gsx_splat_activations_fwd(uint32_t N, const float* scaling_raw, const float*
 int gsx_splat_activations_bwd(uint32_t N, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
                               const float* v_scales, const float* v_quats, const float* v_opacities, float* v_scaling_raw,
                               float* v_rotation_raw, float* v_opacity_raw, void* stream);
+/* The same with the gradients of the MCMC strategy's two regularisers added in place (scale_reg * mean(exp(scaling_raw)) and opacity_reg *
+ * mean(sigmoid(opacity_raw)): /root/reference/src/training/trainer.cpp:103-127 adds them to the loss): pass reg / numel of the tensor; 0 = none. */
+int gsx_splat_activations_bwd_reg(uint32_t N, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                                  const float* v_scales, const float* v_quats, const float* v_opacities, float* v_scaling_raw,
+                                  float* v_rotation_raw, float* v_opacity_raw, float scale_reg_per_element, float opacity_reg_per_element,
+                                  void* stream);
 
 #ifdef __cplusplus
 }

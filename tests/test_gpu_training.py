@@ -100,3 +100,42 @@ def test_mcmc_relocate_moves_dead_gaussians_onto_live_ones():
     m0 = model.means.detach().clone()
     mc.inject_noise()
     assert float((model.means.detach() - m0).abs().max()) > 0.0
+
+
+@pytest.mark.gpu
+def test_fused_regularisers_equal_the_separate_ones():
+    """Trainer(fused_regularisers=True) adds the scale / opacity regulariser gradients inside the render backward's activation kernel;
+    False adds them with elementwise ops behind the backward (trainer.cpp:103-127 puts both terms into the loss): same parameters after
+    a few iterations, and one call of the operator alone matches the closed form."""
+    import gsx  # noqa: F401
+    from gsx import ops, parameters, rasterizer, scenes, trainer
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(1)
+    n = 1000
+    sr, rr, orw = torch.randn(n, 3, generator=g).to(dev), torch.randn(n, 4, generator=g).to(dev), torch.randn(n, generator=g).to(dev)
+    vs, vq, vo = torch.randn(n, 3, generator=g).to(dev), torch.randn(n, 4, generator=g).to(dev), torch.randn(n, generator=g).to(dev)
+    a = ops.splat_activations_bwd(sr, rr, orw, vs, vq, vo)
+    b = ops.splat_activations_bwd(sr, rr, orw, vs, vq, vo, None, None, None, 0.01 / sr.numel(), 0.02 / orw.numel())
+    sg = torch.sigmoid(orw)
+    assert torch.equal(a[1], b[1])
+    assert torch.allclose(b[0], a[0] + 0.01 / sr.numel() * torch.exp(sr), rtol=1e-6, atol=1e-9)
+    assert torch.allclose(b[2], a[2] + 0.02 / orw.numel() * sg * (1 - sg), rtol=1e-6, atol=1e-9)
+    res = []
+    for fused in (False, True):
+        sc, gt_model, cams = _scene(dev, N=3000, K=16)
+        bg = sc["background"].to(dev)
+        with torch.no_grad():
+            images = [rasterizer.rasterize_fused(c, gt_model, bg).image.clone() for c in cams]
+        gg = torch.Generator().manual_seed(9)
+        model = scenes.to_splat_data(dict(sc), dev)
+        model.sh = (gt_model.sh + 0.3 * torch.randn(gt_model.sh.shape, generator=gg).to(dev)).contiguous()
+        prm = parameters.OptimizationParameters(iterations=200, start_refine=100, refine_every=100, stop_refine=150, max_cap=3000, sh_degree_interval=1000)
+        assert prm.scale_reg > 0 and prm.opacity_reg > 0
+        tr = trainer.Trainer(model, cams, images, prm, bg, seed=3, fused_regularisers=fused)
+        assert all(im.is_contiguous() for im in tr.images)   # (the clamped renders above are HWC-strided views: made dense once)
+        for it in range(1, 11):
+            tr.train_step(it)
+        torch.cuda.synchronize()
+        res.append(torch.cat([p.detach().reshape(-1) for p in model.params()]))
+    rel = float((res[0] - res[1]).norm() / res[0].norm())
+    assert rel < 1e-5, rel
