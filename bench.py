@@ -22,6 +22,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` 
 timing) and `cpu_baseline` (the CPU oracle timed on one full frame of the same workload, ~10 s on 8 cores).
 """
 import argparse
+import gc
 import json
 import math
 import os
@@ -426,6 +427,13 @@ def main():
             counter["max_seg"] = max(counter.get("max_seg", 0), int(out.lists.confirm()[1]))
 
     def timed(n, with_adam):
+        # The cyclic garbage collector stays out of the timed region (as any long-running training loop arranges: gsx.trainer.Trainer.train does
+        # the same): a full collection over this process's ~10^5 live objects takes a few milliseconds, the host runs at most one iteration
+        # ahead of the GPU, and a 20-step region is 25 ms — one collection inside it showed up as +0.08 ms per step on the driver's kind of run
+        # (first bench of a fresh box: ms_per_step 1.325 against gpu_ms_per_step 1.248; tools/host_time.py: the host needs 0.2 - 0.26 ms per step).
+        # Nothing here allocates cycles; reference counting frees everything the steps create.
+        gc.collect()
+        gc.disable()
         torch.cuda.synchronize()
         if multi:
             dist.barrier()
@@ -438,6 +446,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        gc.enable()
         if multi:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)

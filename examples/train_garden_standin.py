@@ -92,6 +92,9 @@ def main():
     eval_idx = list(range(0, N_CAMS, 8))
     ev = lambda: metrics.evaluate(model, [cams[i] for i in eval_idx], [images[i] for i in eval_idx], bg)  # noqa: E731
     before = ev()
+    import gc
+    gc.collect()
+    gc.freeze()   # as Trainer.train(): the dataset and modules leave the collector's young generations — its collections inside the loop stay short
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     marks = {}
