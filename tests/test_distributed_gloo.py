@@ -291,3 +291,48 @@ def test_lists_agreement_and_reindex_guard(tmp_path):
     assert a[:3].tolist() == [1, 0, 1] and b[:3].tolist() == [1, 0, 1]   # both ranks repeat iteration 2
     assert a[3] == 1 and b[3] == 1                                       # the guard fired on both
     assert a[4] == 1 and b[4] == 0                                       # rank 0 repeated because of the OTHER rank
+
+
+def _single_rank_worker(_, port, out_dir):
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GSX_SINGLE_RANK_GROUP="1")
+    import gsx  # noqa: F401
+    from gsx import distributed as gdist
+    assert not gdist.active()
+    r, lr, w = gdist.init_from_env(backend="gloo")
+    assert (r, w) == (0, 1) and gdist.SINGLE_RANK_COLLECTIVES and gdist.active() and dist.get_world_size() == 1
+    g = torch.Generator().manual_seed(3)
+    params = [torch.zeros(40, 3, requires_grad=True), torch.zeros(40, 16, 3, requires_grad=True), torch.zeros(40, requires_grad=True)]
+    bucket = gdist.GradBucket(params)
+    vals = [torch.randn(p.shape, generator=g) for p in params]
+    for p, v in zip(params, vals):
+        p.grad.copy_(v)
+    bucket.last_reduced_bytes = 0
+    bucket.all_reduce_mean()                       # executed (a group of one rank would normally skip it): the mean over one rank
+    assert bucket.last_reduced_bytes == bucket.nbytes()
+    h = bucket.all_reduce_mean_tail_async(1)
+    assert h is not None
+    bucket.all_reduce_mean_head(h)
+    vis = torch.zeros(40, dtype=torch.bool)
+    vis[::3] = True
+    for p in params:                               # rows no camera sees are zero, as after a render backward
+        p.grad[~vis] = 0
+    expect = [p.grad.clone() for p in params]
+    bucket.all_reduce_mean_rows(vis)
+    assert bucket.last_reduced_bytes < bucket.nbytes()
+    for p, e in zip(params, expect):
+        assert torch.equal(p.grad, e)
+    agree = gdist.ListsAgreement()
+    assert agree.group is not None and agree(True) is True and agree(False) is False
+    open(os.path.join(out_dir, "single_ok"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_single_rank_group_executes_the_collectives(tmp_path, capfd):
+    """GSX_SINGLE_RANK_GROUP=1: a process group of ONE rank whose collectives run all the same (the diagnostic that puts the N > 1 code
+    path through RCCL on a 1-GPU box; here over gloo) — and gloo's mesh report does not land on stdout."""
+    mp.spawn(_single_rank_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "single_ok").read_text() == "ok"
+    out = capfd.readouterr().out
+    assert "[Gloo]" not in out, out
