@@ -372,6 +372,17 @@ template <int KIND> struct Camera {
 // ---------------------------------------------------------------------------------------------
 // wave64 helpers
 // ---------------------------------------------------------------------------------------------
+// inclusive prefix sum over the 64 lanes with DPP row operations (no LDS traffic: six adds)
+GSX_DEV uint32_t wave_incl_scan_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // Sum over the 64 lanes of a wave using DPP row operations (no LDS traffic); result valid in lane 63.
 GSX_DEV float wave_sum_to_lane63(float v) {
     // within rows of 16 lanes

@@ -28,6 +28,7 @@ int check_launch(const char* what);
 const char* test_switch(const char* name);
 size_t raster_fwd_fast_workspace_bytes(uint32_t C, uint32_t N);
 int32_t* raster_fwd_fast_heads(const float4* packed, uint32_t C, uint32_t N);
+uint32_t* raster_fwd_fast_alloc(const float4* packed, uint32_t C, uint32_t N);
 
 constexpr int FE_BLOCK = 256;
 
@@ -36,7 +37,9 @@ struct FrontendOut {
     int32_t* radii; float* means2d; float* depths; float* conics;   // projection [1,N,2] [1,N,2] [1,N] [1,N,3]
     float* colors;                                                   // [1,N,3]
     float4* packed;                                                  // [N] x 64 B records
-    int32_t* heads;                                                  // [4][N] heads of the backward's record chains (gsx_raster_common.hpp: NSUB planes): -1 (empty)
+    int32_t* heads;                                                  // head planes of the backward's records (gsx_raster_common.hpp), RANGE mode: plane 0 [N] first slot, plane 1 [N] cursor
+    uint32_t* alloc;                                                 // word [1] = mode of the planes; from word 64 on: the waves' slot totals (ranges), scanned into first slots behind this kernel
+    int ranges;                                                      // 1: plane 0 = offset of the Gaussian's record run inside its wave, plane 1 = 0; 0: the four planes = -1 (empty chains)
 };
 
 // STAGE != 0: the wave's 64 coefficient rows — one contiguous 64 * K * 12 B span — are streamed into LDS with fully coalesced 16 B / lane
@@ -65,7 +68,6 @@ __global__ __launch_bounds__(FE_BLOCK) void frontend_kernel(uint32_t N, uint32_t
     const uint32_t gid = blockIdx.x * FE_BLOCK + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const bool in_range = gid < N;
-    if (!STAGE && !in_range) return;
     const Camera<KIND> cam(cams, 0, W, H);
     const ShutterPoses sp(cams.viewmats0, nullptr);
 
@@ -96,6 +98,22 @@ __global__ __launch_bounds__(FE_BLOCK) void frontend_kernel(uint32_t N, uint32_t
         // ---- projection ----
         visible = ut_project<KIND, true>(cam, sp, mean, scale, q, true, opacity, W, H, eps2d, near_plane, far_plane, radius_clip, ut, p);
     }
+    // ---- the rectangle of 16-pixel tiles the intersection derives from (means2d, radii); on frames of large footprints (out.ranges) the
+    //      backward's records of a Gaussian get that many consecutive slots: offset inside the wave here, the waves' totals scanned later ----
+    uint32_t rect_x = 0u, rect_y = 0u;
+    int32_t head0 = -1;   // chains: an empty chain
+    if (visible) {
+        rect_x = tile16_range(p.im.x, (float)(int32_t)p.radius_x, (W + 15u) / 16u);
+        rect_y = tile16_range(p.im.y, (float)(int32_t)p.radius_y, (H + 15u) / 16u);
+    }
+    if (out.ranges) {   // (uniform; all 64 lanes are alive here: no lane has returned yet)
+        const uint32_t n_slots = visible ? ((rect_x >> 16) - (rect_x & 0xFFFFu)) * ((rect_y >> 16) - (rect_y & 0xFFFFu)) : 0u;
+        const uint32_t incl = wave_incl_scan_u32(n_slots);
+        if (lane == 63u) out.alloc[64u + (blockIdx.x * FE_BLOCK + threadIdx.x) / 64u] = incl;
+        head0 = (int32_t)(incl - n_slots);
+    }
+    if (gid == 0u) out.alloc[1] = out.ranges ? 1u : 0u;   // REC_MODE_RANGES / REC_MODE_CHAINS
+
     float row[NQ * 4];
     if (STAGE) {
         // ---- the wave's coefficient rows -> LDS -> this lane's registers (only the rows of visible Gaussians are fetched) ----
@@ -141,8 +159,13 @@ __global__ __launch_bounds__(FE_BLOCK) void frontend_kernel(uint32_t N, uint32_t
         }
     }
     if (!in_range) return;
+    out.heads[gid] = head0;                        // chains: an empty chain; ranges: offset of the run inside the wave
+    if (out.ranges) {
+        out.heads[(size_t)N + gid] = 0;            // ranges: plane 1 = records claimed so far
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) out.heads[(size_t)k * N + gid] = -1;   // four planes (gsx_raster_common.hpp: NSUB chains, one camera)
+        for (int k = 1; k < 4; ++k) out.heads[(size_t)k * N + gid] = -1;   // chains: the backward may use all four planes (gsx_raster_common.hpp: NSUB)
+    }
     float* col = out.colors + (size_t)gid * 3;
     if (!visible) {
         out.radii[(size_t)gid * 2] = 0; out.radii[(size_t)gid * 2 + 1] = 0;   // as upstream, only radii is written for a culled Gaussian
@@ -195,8 +218,29 @@ __global__ __launch_bounds__(FE_BLOCK) void frontend_kernel(uint32_t N, uint32_t
     raw.opac = opacity;
     const CamFrame cf = make_cam_frame(sp);
     // + the rectangle of 16-pixel tiles the intersection derives from (means2d, radii): read by the blend only under 32-pixel lists
-    store_packed_record(raw, cf, out.packed + (size_t)gid * 4, tile16_range(p.im.x, (float)(int32_t)p.radius_x, (W + 15u) / 16u),
-                        tile16_range(p.im.y, (float)(int32_t)p.radius_y, (H + 15u) / 16u));
+    store_packed_record(raw, cf, out.packed + (size_t)gid * 4, rect_x, rect_y);
+}
+
+// the waves' slot totals -> first slot of every wave (exclusive scan in place, one block: 15 625 waves at 1 M Gaussians)
+__global__ __launch_bounds__(1024) void wave_first_slot_kernel(uint32_t n_waves, uint32_t* __restrict__ w) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0u;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_waves; base += 1024u) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n_waves ? w[i] : 0u;
+        const uint32_t incl = wave_incl_scan_u32(v);
+        if (lane == 63u) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = s_carry;
+        for (uint32_t k = 0; k < wave; ++k) before += s_wave[k];
+        if (i < n_waves) w[i] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023u) s_carry = before + incl;
+        __syncthreads();
+    }
 }
 
 }  // namespace gsx
@@ -214,7 +258,7 @@ extern "C" int gsx_frontend_fused(uint32_t N, uint32_t K, uint32_t degrees_to_us
                                   const float* scaling_raw, const float* opacity_raw, const float* coeffs, const gsx_cameras* cams,
                                   uint32_t image_width, uint32_t image_height, float eps2d, float near_plane, float far_plane, float radius_clip,
                                   const gsx_ut_params* ut, float* scales, float* quats, float* opacities, int32_t* radii, float* means2d,
-                                  float* depths, float* conics, float* colors, void* fwd_workspace, size_t workspace_bytes, void* stream) {
+                                  float* depths, float* conics, float* colors, void* fwd_workspace, size_t workspace_bytes, int record_ranges, void* stream) {
     if (!cams || !ut) { set_error("frontend_fused: cams/ut is null"); return GSX_ERR_INVALID_ARGUMENT; }
     if (!gsx_frontend_fused_supported(K, degrees_to_use, cams, coeffs)) {
         set_error("frontend_fused: one global-shutter pinhole camera, SH rows of whole 16 B vectors (gsx_frontend_fused_supported)");
@@ -228,7 +272,7 @@ extern "C" int gsx_frontend_fused(uint32_t N, uint32_t K, uint32_t degrees_to_us
     }
     if (workspace_bytes < raster_fwd_fast_workspace_bytes(1, N)) { set_error("frontend_fused: workspace too small (gsx_rasterize_fwd_workspace_bytes)"); return GSX_ERR_WORKSPACE_TOO_SMALL; }
     float4* packed_base = (float4*)(((uintptr_t)fwd_workspace + 255) & ~(uintptr_t)255);   // the blend forward's workspace layout
-    FrontendOut out{scales, quats, opacities, radii, means2d, depths, conics, colors, packed_base, raster_fwd_fast_heads(packed_base, 1, N)};
+    FrontendOut out{scales, quats, opacities, radii, means2d, depths, conics, colors, packed_base, raster_fwd_fast_heads(packed_base, 1, N), raster_fwd_fast_alloc(packed_base, 1, N), record_ranges ? 1 : 0};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((N + FE_BLOCK - 1) / FE_BLOCK), block(FE_BLOCK);
     const bool distorted = cams->radial || cams->tangential || cams->thin_prism;
@@ -249,5 +293,6 @@ extern "C" int gsx_frontend_fused(uint32_t N, uint32_t K, uint32_t degrees_to_us
 #undef GSX_FE_DEG
 #undef GSX_FE_ST
 #undef GSX_FE
+    if (record_ranges) hipLaunchKernelGGL(wave_first_slot_kernel, dim3(1), dim3(1024), 0, st, (N + 63u) / 64u, out.alloc + 64);
     return check_launch("frontend_fused");
 }

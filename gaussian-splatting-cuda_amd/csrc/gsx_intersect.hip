@@ -721,16 +721,6 @@ __global__ __launch_bounds__(1024) void giant_merge_kernel(const int4* __restric
 // writing its ranks into a C*N-bit bitmap in LDS (128 KB at 1 M) and reading the set bits back in order: no comparison, no merge
 // passes, any segment size (tile_sort_bitmap_kernel, ~5 us + 3 ps per key per CU).  Lighter tiles take the merge sorts above with
 // 4-byte keys.  flatten_ids = order[rank]; the result is the same total order, bit for bit.
-// inclusive prefix sum over the 64 lanes with DPP row operations (no LDS traffic: six adds)
-GSX_DEV uint32_t wave_incl_scan_u32(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1, 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2, 3
-    return v;
-}
 
 GSX_DEV uint32_t rank_key_of(const int32_t* __restrict__ radii, const float* __restrict__ depths, uint32_t i) {
     const int2 r = reinterpret_cast<const int2*>(radii)[i];

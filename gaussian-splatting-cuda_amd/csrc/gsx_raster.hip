@@ -525,6 +525,7 @@ static int fill_args(RasterArgs& a, uint32_t N, int64_t n_isects, const float* m
     const char* rf = test_switch("GSX_LIST_RECT");   // tests only: "0" shows what the 32-px lists would composite without the rectangle filter
     a.rect_filter = (rf != nullptr && strcmp(rf, "0") == 0) ? 0u : 1u;
     a.chain_mask = 0u;
+    a.rec_capacity = 0;
     a.cams = *cams;
     a.tile_offsets = tile_offsets; a.flatten_ids = flatten_ids;
     a.packed = nullptr;

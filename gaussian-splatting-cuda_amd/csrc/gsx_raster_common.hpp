@@ -37,6 +37,7 @@ struct RasterArgs {
     const int32_t* lists_status;
     int64_t n_isects_expected;   // list-density estimate for launch decisions (kernel variants); = n_isects when exact
     uint32_t chain_mask;         // backward: NSUB - 1 = NSUB record chains per (camera, Gaussian), 0 = one (see tile_chain)
+    int64_t rec_capacity;        // backward: record slots behind ws_rec (ranges: a slot beyond it is never written)
 };
 
 // end of the LAST list of the frame (every other list ends where the next one starts); `ok` = false: overflowed frame, all lists empty
@@ -48,6 +49,7 @@ GSX_DEV int32_t lists_total(const RasterArgs& a, bool& ok) {
     return tot;
 }
 
+__host__ __device__ inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 constexpr size_t FAST_FLAG_BYTES = 262144;  // capacity of the tile-flag plane (C * tiles); larger grids take the generic kernels
 
 
@@ -68,7 +70,18 @@ GSX_DEV void tile_list_range(const RasterArgs& a, uint32_t cid, uint32_t tile_x,
 // (four chains of ~w h / 4 records, walked side by side with four record loads in flight per thread).  Frames of small footprints keep
 // ONE chain (a.chain_mask = 0): their gather is bound by the bytes it moves, and three more heads per Gaussian are just more bytes.
 // Head array: NSUB planes of [C*N] int32, plane c = heads of chain c (-1 = empty); only the planes of the frame's chains are read.
+//
+// RANGES (round 4, mode word = 1: the fused front end packed the workspace of a frame of large footprints): the front end knows every
+// Gaussian's rectangle of 16-pixel tiles, i.e. an upper bound of the records the backward can write for it, and gives every Gaussian that
+// many CONSECUTIVE record slots: plane 0 = its offset inside its wave of 64 Gaussians (a DPP scan), the waves' totals are scanned by one
+// small launch behind the front end into "first slot of wave w" (no atomics: 15 k returning adds on one allocator word cost 145 us).
+// Plane 1 = records claimed so far (0): the backward claims slot first + (returning add on plane 1) — no chain link —, the gather reads
+// [first, first + count) as one contiguous run (neighbouring Gaussians' runs are neighbours in memory: it streams instead of chasing
+// 64 B pointers; a run longer than a few records is summed by the whole wave) and puts the count back to 0.  Chains remain the layout of
+// frames of small footprints (nothing to gain there: S-1M's gather is bound by its bytes) and of workspaces packed by
+// pack_records_kernel (the operator-level entry points: no rectangles there).
 constexpr int NSUB = 4;
+constexpr uint32_t REC_MODE_CHAINS = 0u, REC_MODE_RANGES = 1u;
 GSX_DEV uint32_t tile_chain(const RasterArgs& a, uint32_t tile_x, uint32_t tile_y) { return ((tile_x & 1u) | ((tile_y & 1u) << 1)) & a.chain_mask; }
 GSX_DEV int32_t tile_record_slot(const RasterArgs& a, int32_t isect, uint32_t tile_x, uint32_t tile_y) {
     return a.lshift ? (isect << 2) | (int32_t)(((tile_y & 1u) << 1) | (tile_x & 1u)) : isect;
@@ -132,7 +145,8 @@ GSX_DEV uint32_t butterfly_value_of_lane(uint32_t lane) {
 const uint8_t* launch_raster_fwd_fast(int kind, RasterArgs a, float* renders, float* alphas, int32_t* last_ids, void* workspace,
                                       size_t workspace_bytes, hipStream_t st, bool records_ready = false);
 size_t raster_fwd_fast_workspace_bytes(uint32_t C, uint32_t N);
-int32_t* raster_fwd_fast_heads(const float4* packed, uint32_t C, uint32_t N);   // the chain-head array [C*N][NSUB] inside the forward workspace (see its layout)
+int32_t* raster_fwd_fast_heads(const float4* packed, uint32_t C, uint32_t N);
+uint32_t* raster_fwd_fast_alloc(const float4* packed, uint32_t C, uint32_t N);   // word [1] = REC_MODE_* of the head planes; from word 64 on: first record slot of every wave of 64 Gaussians (ranges)   // the chain-head array [C*N][NSUB] inside the forward workspace (see its layout)
 // returns false (nothing launched) when no sufficient workspace was supplied: the caller falls back to the generic kernels
 bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, const int32_t* last_ids,
                             const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats,

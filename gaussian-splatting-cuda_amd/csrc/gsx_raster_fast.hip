@@ -72,10 +72,11 @@ __global__ __launch_bounds__(256) void pack_records_kernel(RasterArgs a, float4*
     const uint32_t n = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
     if (n >= a.N) return;
     const size_t g = (size_t)c * a.N + n;
-    if (heads) {  // backward: empty moment-record chains (NSUB planes)
+    if (heads) {  // backward: empty moment-record chains (NSUB planes), mode word = chains
         const size_t cn = (size_t)a.C * a.N;
 #pragma unroll
         for (int k = 0; k < NSUB; ++k) heads[(size_t)k * cn + g] = -1;
+        if (g == 0) reinterpret_cast<uint32_t*>(heads + (align256(cn * 4 * NSUB) >> 2))[1] = 0u;
     }
     RawG raw;
     raw.g = (int32_t)g;
@@ -618,14 +619,38 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_quad_kernel(Rast
 }
 
 // forward workspace, from its 256 B aligned base: packed records [C*N] x 64 B | fisheye: "no chart" bytes [C*N] | tile flags
-static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 // ... | chain heads [NSUB][C*N] int32 of the backward's per-(camera, Gaussian) record chains: set to -1 by whoever packs the records (the
 // fused front end, pack_records_kernel) and put back to -1 by the gather kernel that walks the chains, so a backward on the forward's
 // workspace needs no memset launch
-size_t raster_fwd_fast_workspace_bytes(uint32_t C, uint32_t N) { return 256 + (size_t)C * N * 64 + align256((size_t)C * N) + FAST_FLAG_BYTES + align256((size_t)C * N * 4 * NSUB); }
+// ... | 256 B: word [1] = the mode of the head planes (0 = chains, 1 = ranges: see gsx_raster_common.hpp) | ranges: first record slot of every wave of 64 Gaussians
+static size_t head_planes_bytes(uint32_t C, uint32_t N) { return align256((size_t)C * N * 4 * NSUB) + 256 + align256((((size_t)C * N + 63) / 64 + 64) * 4); }   // the planes + the mode word + the waves' first slots (ranges)
+size_t raster_fwd_fast_workspace_bytes(uint32_t C, uint32_t N) { return 256 + (size_t)C * N * 64 + align256((size_t)C * N) + FAST_FLAG_BYTES + head_planes_bytes(C, N); }
 static uint8_t* ws_bad(const float4* packed, uint32_t C, uint32_t N) { return (uint8_t*)packed + (size_t)C * N * 64; }
 static uint8_t* ws_flags(const float4* packed, uint32_t C, uint32_t N) { return ws_bad(packed, C, N) + align256((size_t)C * N); }
 int32_t* raster_fwd_fast_heads(const float4* packed, uint32_t C, uint32_t N) { return (int32_t*)(ws_flags(packed, C, N) + FAST_FLAG_BYTES); }
+uint32_t* raster_fwd_fast_alloc(const float4* packed, uint32_t C, uint32_t N) { return (uint32_t*)((char*)raster_fwd_fast_heads(packed, C, N) + align256((size_t)C * N * 4 * NSUB)); }   // [1] mode word; + 64 words: the waves' first slots
+
+// mode of the head planes behind `ws_head` (REC_MODE_*: written by whoever packed the workspace); wave-uniform scalar load
+GSX_DEV bool record_ranges(const RasterArgs& a, const int32_t* ws_head) {
+    return reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ws_head) + align256((size_t)a.C * a.N * 4 * NSUB))[1] == REC_MODE_RANGES;
+}
+// ranges: first slot of the run of (camera, Gaussian) g = first slot of its wave of 64 Gaussians + its offset inside the wave (plane 0)
+GSX_DEV int32_t range_first_slot(const RasterArgs& a, const int32_t* ws_head, size_t g) {
+    const uint32_t* wave_first = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ws_head) + align256((size_t)a.C * a.N * 4 * NSUB) + 256);
+    return (int32_t)wave_first[g >> 6] + ws_head[g];
+}
+// slot of the moment record of (tile, list entry `isect`) for (camera, Gaussian) g, claimed with ONE returning atomic either way:
+// ranges — the next slot of the Gaussian's own run (no link); chains — the entry's tile-major slot, linked in front of the Gaussian's chain
+GSX_DEV int32_t claim_record_slot(const RasterArgs& a, int32_t* ws_head, bool ranges, int32_t g, int32_t isect, uint32_t tile_x, uint32_t tile_y, int32_t& link) {
+    const size_t cn = (size_t)a.C * a.N;
+    if (ranges) {
+        link = -1;
+        return range_first_slot(a, ws_head, (size_t)g) + atomicAdd(&ws_head[cn + (size_t)g], 1);   // plane 1 = records claimed so far
+    }
+    const int32_t slot = tile_record_slot(a, isect, tile_x, tile_y);
+    link = atomicExch(&ws_head[(size_t)tile_chain(a, tile_x, tile_y) * cn + (size_t)g], slot);
+    return slot;
+}
 
 // packs the records (and, for a fisheye, flags the tiles the fast kernels must leave to the reference-order kernels)
 static const float4* pack_into(int kind, RasterArgs& a, void* base, hipStream_t st, int32_t* heads = nullptr) {
@@ -711,6 +736,7 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
     __shared__ float s_bounds[4][4];
     __shared__ int32_t s_blockmax;
     const uint32_t cid = blockIdx.y;
+    const bool ranges = record_ranges(a, ws_head);   // how this workspace's head planes are used (gsx_raster_common.hpp)
     uint32_t tile_id;
     if (!swizzled_tile(blockIdx.x, a.tw * a.th, tile_id)) return;
     if (a.masks != nullptr && !a.masks[(size_t)cid * a.th * a.tw + tile_id]) return;  // Bwd.cu:84-86
@@ -843,13 +869,15 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
 
         // one thread per touched Gaussian of the chunk: 64 B moment record at its sorted index, chained per Gaussian
         if ((int32_t)tid < chunk_size && ((s_touched[tid >> 6] >> (tid & 63u)) & 1ull)) {
-            const int32_t isect = tile_record_slot(a, chunk_end - (int32_t)tid, tile_x, tile_y);
-            const int32_t prev = atomicExch(&ws_head[(size_t)tile_chain(a, tile_x, tile_y) * a.C * a.N + s_gid[tid]], isect);
+            int32_t prev;
+            const int32_t isect = claim_record_slot(a, ws_head, ranges, s_gid[tid], chunk_end - (int32_t)tid, tile_x, tile_y, prev);
             float4* rec = ws_rec + (size_t)isect * 4;
+            if ((int64_t)isect < a.rec_capacity) {   // (always, by construction: a run never exceeds the Gaussian's tile rectangle)
             nt_store4(make_float4(s_acc[0][tid], s_acc[1][tid], s_acc[2][tid], s_acc[3][tid]), rec);   // (nontemporal: see raster_bwd_gq_kernel)
             nt_store4(make_float4(s_acc[4][tid], s_acc[5][tid], s_acc[6][tid], s_acc[7][tid]), rec + 1);
             nt_store4(make_float4(s_acc[8][tid], s_acc[9][tid], s_acc[10][tid], s_acc[11][tid]), rec + 2);
             nt_store4(make_float4(s_acc[12][tid], s_acc[13][tid], s_acc[14][tid], __int_as_float(prev)), rec + 3);
+            }
         }
     }
 }
@@ -1019,6 +1047,7 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
     __shared__ float s_bounds[4][4];
     __shared__ int32_t s_blockmax;
     const uint32_t cid = blockIdx.y;
+    const bool ranges = record_ranges(a, ws_head);   // how this workspace's head planes are used (gsx_raster_common.hpp)
     uint32_t tile_id;
     if (!swizzled_tile(blockIdx.x, a.tw * a.th, tile_id)) return;
     if (a.masks != nullptr && !a.masks[(size_t)cid * a.th * a.tw + tile_id]) return;  // Bwd.cu:84-86
@@ -1247,9 +1276,10 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
 
         // one thread per touched Gaussian of the super-chunk: 64 B moment record at its sorted index, chained per Gaussian
         if ((int32_t)tid < chunk_size && s_acc[15][tid] > 0.f) {
-            const int32_t isect = tile_record_slot(a, chunk_end - (int32_t)tid, tile_x, tile_y);
-            const int32_t prev = atomicExch(&ws_head[(size_t)tile_chain(a, tile_x, tile_y) * a.C * a.N + s_gid[tid]], isect);
+            int32_t prev;
+            const int32_t isect = claim_record_slot(a, ws_head, ranges, s_gid[tid], chunk_end - (int32_t)tid, tile_x, tile_y, prev);
             float4* rec = ws_rec + (size_t)isect * 4;
+            if ((int64_t)isect < a.rec_capacity) {   // (always, by construction: a run never exceeds the Gaussian's tile rectangle)
             // nontemporal: 64 B written once at a scattered slot and read once by the gather kernel — as ordinary stores the records
             // push the kernel's own working set (lists, packed records, pixel inputs) out of L2: S-1M 0.573 -> 0.526 ms, S-5M @4K 2.17 ->
             // 2.03, garden stand-in 1.28 -> 1.20 (same-box A/B; nontemporal LOADS in the gather measured flat)
@@ -1257,6 +1287,7 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
             nt_store4(make_float4(s_acc[4][tid], s_acc[5][tid], s_acc[6][tid], s_acc[7][tid]), rec + 1);
             nt_store4(make_float4(s_acc[8][tid], s_acc[9][tid], s_acc[10][tid], s_acc[11][tid]), rec + 2);
             nt_store4(make_float4(s_acc[12][tid], s_acc[13][tid], s_acc[14][tid], __int_as_float(prev)), rec + 3);
+            }
         }
     }
 }
@@ -1272,8 +1303,11 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
                                                              int32_t* __restrict__ ws_head, float* __restrict__ v_means,
                                                              float* __restrict__ v_quats, float* __restrict__ v_scales,
                                                              float* __restrict__ v_colors, float* __restrict__ v_opacities) {
-    const uint32_t gi = blockIdx.x * 256u + threadIdx.x;
-    if (gi >= a.N) return;
+    const uint32_t gi_raw = blockIdx.x * 256u + threadIdx.x;
+    const bool in = gi_raw < a.N;                       // (no early return: the long runs of the range mode are summed by the whole wave)
+    const uint32_t gi = in ? gi_raw : a.N - 1u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool ranges = record_ranges(a, ws_head);
     float geo[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) geo[k] = 0.f;
@@ -1283,71 +1317,121 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
     const size_t cn = (size_t)a.C * a.N;
     for (uint32_t c = 0; c < a.C; ++c) {
         const size_t g = (size_t)c * a.N + gi;
-        int32_t it[NCH];
-        int32_t all = -1;
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) { it[k] = ws_head[(size_t)k * cn + g]; all &= it[k]; }
-        if (all < 0) {  // every chain empty (an index has its sign bit clear): no tile touched this (camera, Gaussian) — every output element is written, none needs a pre-fill
-            v_colors[g * 3] = 0.f; v_colors[g * 3 + 1] = 0.f; v_colors[g * 3 + 2] = 0.f;
-            v_opacities[g] = 0.f;
-            continue;
-        }
-#pragma unroll
-        for (int k = 0; k < NCH; ++k)   // the chains are consumed: the head array is empty again for the next backward on this workspace
-            if (it[k] >= 0) ws_head[(size_t)k * cn + g] = -1;
-        if (!any) {   // issued before the walk: these loads fly with the first records'
-            raw.mu = {a.means[(size_t)gi * 3], a.means[(size_t)gi * 3 + 1], a.means[(size_t)gi * 3 + 2]};
-            raw.q = reinterpret_cast<const float4*>(a.quats)[gi];
-            raw.sc = {a.scales[(size_t)gi * 3], a.scales[(size_t)gi * 3 + 1], a.scales[(size_t)gi * 3 + 2]};
-            any = true;
-        }
-        raw.opac = a.opacities[g];
         float Mo[15];
 #pragma unroll
         for (int k = 0; k < 15; ++k) Mo[k] = 0.f;
-        if (NCH == 1) {
-            int32_t cur = it[0];
-            while (cur >= 0) {
-                const float4* rec = ws_rec + (size_t)cur * 4;
-                const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-                Mo[0] += r0.x; Mo[1] += r0.y; Mo[2] += r0.z; Mo[3] += r0.w;
-                Mo[4] += r1.x; Mo[5] += r1.y; Mo[6] += r1.z; Mo[7] += r1.w;
-                Mo[8] += r2.x; Mo[9] += r2.y; Mo[10] += r2.z; Mo[11] += r2.w;
-                Mo[12] += r3.x; Mo[13] += r3.y; Mo[14] += r3.z;
-                cur = __float_as_int(r3.w);
+        bool touched = false;
+        auto load_raw = [&]() {   // issued before the records are read: these loads fly with the first records'
+            if (!any) {
+                raw.mu = {a.means[(size_t)gi * 3], a.means[(size_t)gi * 3 + 1], a.means[(size_t)gi * 3 + 2]};
+                raw.q = reinterpret_cast<const float4*>(a.quats)[gi];
+                raw.sc = {a.scales[(size_t)gi * 3], a.scales[(size_t)gi * 3 + 1], a.scales[(size_t)gi * 3 + 2]};
+                any = true;
+            }
+            raw.opac = a.opacities[g];
+        };
+#define GSX_ADD_REC(M, R0, R1, R2, R3)                                                         \
+        M[0] += R0.x; M[1] += R0.y; M[2] += R0.z; M[3] += R0.w;                                \
+        M[4] += R1.x; M[5] += R1.y; M[6] += R1.z; M[7] += R1.w;                                \
+        M[8] += R2.x; M[9] += R2.y; M[10] += R2.z; M[11] += R2.w;                              \
+        M[12] += R3.x; M[13] += R3.y; M[14] += R3.z;
+        if (ranges) {
+            // ---- ranges: the records of this (camera, Gaussian) are the slots [first, cursor) ----
+            constexpr int32_t RUN_T = 12;   // longer runs are summed by the whole wave
+            const int32_t n = in ? ws_head[cn + g] : 0;   // plane 1: records the backward claimed
+            const int32_t first = n > 0 ? range_first_slot(a, ws_head, g) : 0, cursor = first + n;
+            touched = n > 0;
+            if (touched) {
+                ws_head[cn + g] = 0;   // the run is consumed: the count is back at 0 for the next backward on this workspace
+                load_raw();
+            }
+            if (n > 0 && n <= RUN_T) {
+                for (int32_t r = first; r < cursor; r += 2) {   // two records in flight
+                    const float4* p0 = ws_rec + (size_t)r * 4;
+                    const bool two = r + 1 < cursor;
+                    const float4* p1 = two ? p0 + 4 : p0;
+                    const float4 a0 = p0[0], a1 = p0[1], a2 = p0[2], a3 = p0[3];
+                    const float4 b0 = p1[0], b1 = p1[1], b2 = p1[2], b3 = p1[3];
+                    GSX_ADD_REC(Mo, a0, a1, a2, a3)
+                    if (two) { GSX_ADD_REC(Mo, b0, b1, b2, b3) }
+                }
+            }
+            for (unsigned long long longs = __builtin_amdgcn_ballot_w64(n > RUN_T); longs != 0ull; longs &= longs - 1ull) {
+                const int src = __builtin_ctzll(longs);
+                const int32_t f = __builtin_amdgcn_readlane(first, src), nl = __builtin_amdgcn_readlane(n, src);
+                float part[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) part[k] = 0.f;
+                for (int32_t r = (int32_t)lane; r < nl; r += 64) {   // 64 consecutive records per round: 4 KB, coalesced
+                    const float4* p0 = ws_rec + (size_t)(f + r) * 4;
+                    const float4 a0 = p0[0], a1 = p0[1], a2 = p0[2], a3 = p0[3];
+                    GSX_ADD_REC(part, a0, a1, a2, a3)
+                }
+                const float tot = butterfly_reduce16(part);   // lane 16 row + 4 quad holds the total of value 4 quad + {0,2,1,3}[row]
+#pragma unroll
+                for (int v = 0; v < 15; ++v) {
+                    const int row = ((v & 3) == 1) ? 2 : (((v & 3) == 2) ? 1 : (v & 3));
+                    const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), row * 16 + (v >> 2) * 4));
+                    Mo[v] += ((int)lane == src) ? t : 0.f;
+                }
             }
         } else {
-            // the chains side by side: every round issues the record loads of all chains some lane still walks before any is consumed
-            // (a lane whose chain k has ended re-reads a record of one of its live chains — same line, no new traffic — and ignores it)
-            while (all >= 0) {
-                int32_t live = it[0];
+            int32_t it[NCH];
+            int32_t all = -1;
 #pragma unroll
-                for (int k = 1; k < NCH; ++k) live = max(live, it[k]);
-                float4 r[NCH][4];
-                bool on[NCH];
+            for (int k = 0; k < NCH; ++k) { it[k] = in ? ws_head[(size_t)k * cn + g] : -1; all &= it[k]; }
+            touched = all >= 0;   // some chain has a record (an index has its sign bit clear)
+            if (touched) {
 #pragma unroll
-                for (int k = 0; k < NCH; ++k) {
-                    on[k] = it[k] >= 0;
-                    if (__builtin_amdgcn_ballot_w64(on[k]) != 0ull) {
-                        const float4* rec = ws_rec + (size_t)(on[k] ? it[k] : live) * 4;
-                        r[k][0] = rec[0]; r[k][1] = rec[1]; r[k][2] = rec[2]; r[k][3] = rec[3];
-                    } else {
-                        r[k][0] = r[k][1] = r[k][2] = r[k][3] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
+                for (int k = 0; k < NCH; ++k)   // the chains are consumed: the head array is empty again for the next backward on this workspace
+                    if (it[k] >= 0) ws_head[(size_t)k * cn + g] = -1;
+                load_raw();
+            }
+            if (NCH == 1) {
+                int32_t cur = it[0];
+                while (cur >= 0) {
+                    const float4* rec = ws_rec + (size_t)cur * 4;
+                    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+                    GSX_ADD_REC(Mo, r0, r1, r2, r3)
+                    cur = __float_as_int(r3.w);
                 }
-                all = -1;
+            } else {
+                // the chains side by side: every round issues the record loads of all chains some lane still walks before any is consumed
+                // (a lane whose chain k has ended re-reads a record of one of its live chains — same line, no new traffic — and ignores it)
+                while (all >= 0) {
+                    int32_t live = it[0];
 #pragma unroll
-                for (int k = 0; k < NCH; ++k) {
-                    if (on[k]) {
-                        Mo[0] += r[k][0].x; Mo[1] += r[k][0].y; Mo[2] += r[k][0].z; Mo[3] += r[k][0].w;
-                        Mo[4] += r[k][1].x; Mo[5] += r[k][1].y; Mo[6] += r[k][1].z; Mo[7] += r[k][1].w;
-                        Mo[8] += r[k][2].x; Mo[9] += r[k][2].y; Mo[10] += r[k][2].z; Mo[11] += r[k][2].w;
-                        Mo[12] += r[k][3].x; Mo[13] += r[k][3].y; Mo[14] += r[k][3].z;
-                        it[k] = __float_as_int(r[k][3].w);
+                    for (int k = 1; k < NCH; ++k) live = max(live, it[k]);
+                    float4 r[NCH][4];
+                    bool on[NCH];
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) {
+                        on[k] = it[k] >= 0;
+                        if (__builtin_amdgcn_ballot_w64(on[k]) != 0ull) {
+                            const float4* rec = ws_rec + (size_t)(on[k] ? it[k] : live) * 4;
+                            r[k][0] = rec[0]; r[k][1] = rec[1]; r[k][2] = rec[2]; r[k][3] = rec[3];
+                        } else {
+                            r[k][0] = r[k][1] = r[k][2] = r[k][3] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
                     }
-                    all &= it[k];
+                    all = -1;
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) {
+                        if (on[k]) {
+                            GSX_ADD_REC(Mo, r[k][0], r[k][1], r[k][2], r[k][3])
+                            it[k] = __float_as_int(r[k][3].w);
+                        }
+                        all &= it[k];
+                    }
                 }
             }
+        }
+#undef GSX_ADD_REC
+        if (!in) continue;
+        if (!touched) {  // no tile touched this (camera, Gaussian): every output element is written, none needs a pre-fill
+            v_colors[g * 3] = 0.f; v_colors[g * 3 + 1] = 0.f; v_colors[g * 3 + 2] = 0.f;
+            v_opacities[g] = 0.f;
+            continue;
         }
         v_colors[g * 3] = Mo[0]; v_colors[g * 3 + 1] = Mo[1]; v_colors[g * 3 + 2] = Mo[2];
         v_opacities[g] = Mo[3] / raw.opac;
@@ -1418,6 +1502,7 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
 #pragma unroll
         for (int k = 0; k < 3; ++k) geo[7 + k] += -isv[k] * (r.Mt[k][0] * vMt[k][0] + r.Mt[k][1] * vMt[k][1] + r.Mt[k][2] * vMt[k][2]);
     }
+    if (!in) return;
     v_means[(size_t)gi * 3] = geo[0]; v_means[(size_t)gi * 3 + 1] = geo[1]; v_means[(size_t)gi * 3 + 2] = geo[2];
     reinterpret_cast<float4*>(v_quats)[gi] = make_float4(geo[3], geo[4], geo[5], geo[6]);
     v_scales[(size_t)gi * 3] = geo[7]; v_scales[(size_t)gi * 3 + 1] = geo[8]; v_scales[(size_t)gi * 3 + 2] = geo[9];
@@ -1425,7 +1510,7 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
 
 size_t raster_bwd_fast_workspace_bytes(uint32_t C, uint32_t N, int64_t n_isects) {
     // moment records (64 B per intersection) + chain heads (NSUB x 4 B per (camera, Gaussian)) + the forward's layout, 256 B aligned
-    return align256((size_t)n_isects * 64) + align256((size_t)C * N * 4 * NSUB) + raster_fwd_fast_workspace_bytes(C, N);
+    return align256((size_t)n_isects * 64) + head_planes_bytes(C, N) + raster_fwd_fast_workspace_bytes(C, N);
 }
 
 bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, const int32_t* last_ids,
@@ -1443,9 +1528,11 @@ bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, 
         if (kind == CAM_OPENCV_FISHEYE) a.tile_flags = ws_flags(packed_from_fwd, a.C, a.N);
         ws_head = raster_fwd_fast_heads(packed_from_fwd, a.C, a.N);   // all -1: set by the packer, restored by every gather
     } else {
-        pack_into(kind, a, (char*)ws_head + align256((size_t)a.C * a.N * 4 * NSUB), st, ws_head);  // also sets every chain head to -1
+        pack_into(kind, a, (char*)ws_head + head_planes_bytes(a.C, a.N), st, ws_head);  // also sets every chain head to -1 (and the mode word behind the planes to chains)
     }
     *tile_flags_out = a.tile_flags;
+    a.rec_capacity = a.n_isects << (2 * a.lshift);
+    a.rect_filter = 1u;   // (GSX_LIST_RECT=0 is a forward-only demonstration: a record run is sized by the Gaussian's tile rectangle)
     const dim3 ggrid((a.N + 255u) / 256u), gblock(256);
     // record chains per (camera, Gaussian): NSUB on frames of large footprints — lists per 32 x 32 pixels are chosen for exactly those, or more
     // than 8 tiles per Gaussian on average — else one (gsx_raster_common.hpp: tile_chain; GSX_BWD_CHAINS=1|4 forces it: tests, A/B)

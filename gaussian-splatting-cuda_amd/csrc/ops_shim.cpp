@@ -664,7 +664,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tenso
     const at::Tensor opacity_raw, const at::Tensor viewmats0, const at::Tensor Ks, const uint32_t image_width, const uint32_t image_height,
     const float eps2d, const float near_plane, const float far_plane, const float radius_clip, const gsplat::CameraModelType camera_model,
     const UnscentedTransformParameters ut_params, const at::optional<at::Tensor> radial_coeffs, const at::optional<at::Tensor> tangential_coeffs,
-    const at::optional<at::Tensor> thin_prism_coeffs, const bool want_conics) {
+    const at::optional<at::Tensor> thin_prism_coeffs, const bool want_conics, const bool record_ranges = false) {
     GSX_DEVICE_GUARD(means);
     GSX_CHECK_INPUT(means); GSX_CHECK_INPUT(sh); GSX_CHECK_INPUT(scaling_raw); GSX_CHECK_INPUT(rotation_raw); GSX_CHECK_INPUT(opacity_raw);
     TORCH_CHECK(means.scalar_type() == at::kFloat && sh.scalar_type() == at::kFloat, "float32 only");
@@ -688,7 +688,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tenso
                              opacity_raw.data_ptr<float>(), sh.data_ptr<float>(), &cams, image_width, image_height, eps2d, near_plane, far_plane,
                              radius_clip, &ut, scales.data_ptr<float>(), quats.data_ptr<float>(), opac.data_ptr<float>(), radii.data_ptr<int32_t>(),
                              means2d.data_ptr<float>(), depths.data_ptr<float>(), want_conics ? conics.data_ptr<float>() : nullptr, colors.data_ptr<float>(), fws.data_ptr(),
-                             fwsb, cur_stream()), "frontend_fused");
+                             fwsb, record_ranges ? 1 : 0, cur_stream()), "frontend_fused");
     return std::make_tuple(scales, quats, opac, radii, means2d, depths, conics, colors, fws);
 }
 
@@ -1110,8 +1110,9 @@ PYBIND11_MODULE(_gsx_ops, m) {
     });
     m.def("frontend_fused_render", [](uint32_t deg, at::Tensor means, at::Tensor sh, at::Tensor sr, at::Tensor rr, at::Tensor orw, at::Tensor vm, at::Tensor Ks,
                                       uint32_t w, uint32_t h, float eps2d, float nearp, float farp, float clip, gsplat::CameraModelType cm,
-                                      UnscentedTransformParameters ut, at::optional<at::Tensor> rad, at::optional<at::Tensor> tang, at::optional<at::Tensor> prism) {
-        return gsx_ext::frontend_fused(deg, means, sh, sr, rr, orw, vm, Ks, w, h, eps2d, nearp, farp, clip, cm, ut, rad, tang, prism, false);
+                                      UnscentedTransformParameters ut, at::optional<at::Tensor> rad, at::optional<at::Tensor> tang, at::optional<at::Tensor> prism,
+                                      bool record_ranges) {   // record_ranges: the backward's records in one contiguous run per Gaussian (frames of large footprints)
+        return gsx_ext::frontend_fused(deg, means, sh, sr, rr, orw, vm, Ks, w, h, eps2d, nearp, farp, clip, cm, ut, rad, tang, prism, false, record_ranges);
     });
     m.def("rasterize_to_pixels_from_world_3dgs_bwd",
           [](const at::Tensor means, const at::Tensor quats, const at::Tensor scales, const at::Tensor colors, const at::Tensor opacities,

@@ -326,8 +326,11 @@ class GutRenderFunction(torch.autograd.Function):
         if scaling_modifier == 1.0 and FUSED_FRONTEND:
             # the whole per-Gaussian front end in ONE kernel: activations -> projection -> SH colours -> packed blend records
             # (same values as the separate launches below; an undefined workspace = camera / SH layout not supported)
+            # frames of large footprints (the ones that get lists per 32 x 32 pixels: _LIST_TILE_STATE, from the previous frames' statistics) keep the
+            # backward's moment records of a Gaussian in one contiguous run of slots instead of a chain (gsx_raster_common.hpp: "ranges")
+            ranges = camera_model == ops.CameraModelType.PINHOLE and _list_tile_for((width, height, means_c.device.index)) != TILE_SIZE
             fe = ops.frontend_fused_render(sh_degree, means_c, sh_c, sr, rr, orw, viewmat, K, width, height, EPS2D, NEAR_PLANE, FAR_PLANE, RADIUS_CLIP,
-                                           camera_model, ut, radial, tangential, None)
+                                           camera_model, ut, radial, tangential, None, ranges)
             if fe[8] is None:
                 fe = None
         if fe is not None:

@@ -32,7 +32,7 @@ extern "C" {
  *   4  additions only: the guarded list protocol (no host read of n_isects on the render path): gsx_intersect_bin_count_guarded,
  *      gsx_rasterize_to_pixels_from_world_3dgs_{fwd,bwd}_guarded.
  *   5  gsx_intersect_bin_count(_guarded) store all ones into the pinned host word before they launch anything, and its high half is what the
- *      device writes last: the word can be POLLED by the host (no event in the stream); gsx_frontend_fused accepts NULL conics; gsx_splat_activations_bwd_reg added. */
+ *      device writes last: the word can be POLLED by the host (no event in the stream); gsx_frontend_fused accepts NULL conics and takes `record_ranges`; gsx_splat_activations_bwd_reg added. */
 #define GSX_ABI_VERSION 5
 
 typedef enum gsx_status {
@@ -182,13 +182,16 @@ int gsx_rasterize_to_pixels_from_world_3dgs_bwd(uint32_t N, int64_t n_isects, co
  * handed to gsx_rasterize_to_pixels_from_world_3dgs_fwd_packed(..., records_ready = 1) and later to ..._bwd_packed.  Outputs: scales
  * [N,3], quats [N,4], opacities [N] (activated), radii int32 [1,N,2], means2d [1,N,2], depths [1,N], conics [1,N,3] or NULL (not
  * written: nothing on the render path reads them) (only radii for a culled Gaussian, as the projection), colors [1,N,3] (zero rows for culled Gaussians).  gsx_frontend_fused_supported: 1 when the
- * camera block / SH layout qualify (C == 1, PINHOLE with or without distortion, GLOBAL shutter, (K*3) % 4 == 0, 16 B aligned coeffs). */
+ * camera block / SH layout qualify (C == 1, PINHOLE with or without distortion, GLOBAL shutter, (K*3) % 4 == 0, 16 B aligned coeffs).
+ * record_ranges = 1 (frames of large footprints: the caller's choice, e.g. whenever it builds lists per 32 x 32 pixels): the backward's per-(tile,
+ * Gaussian) moment records of a Gaussian then occupy one contiguous run of slots sized by its rectangle of 16-pixel tiles, which the
+ * gather streams; 0: they are chained per Gaussian (csrc/gsx_raster_common.hpp).  Same gradients either way. */
 int gsx_frontend_fused_supported(uint32_t K, uint32_t degrees_to_use, const gsx_cameras* cams, const float* coeffs);
 int gsx_frontend_fused(uint32_t N, uint32_t K, uint32_t degrees_to_use, const float* means, const float* rotation_raw,
                        const float* scaling_raw, const float* opacity_raw, const float* coeffs, const gsx_cameras* cams,
                        uint32_t image_width, uint32_t image_height, float eps2d, float near_plane, float far_plane, float radius_clip,
                        const gsx_ut_params* ut, float* scales, float* quats, float* opacities, int32_t* radii, float* means2d,
-                       float* depths, float* conics, float* colors, void* fwd_workspace, size_t workspace_bytes, void* stream);
+                       float* depths, float* conics, float* colors, void* fwd_workspace, size_t workspace_bytes, int record_ranges, void* stream);
 /* The blend forward for a caller whose workspace already holds the packed records of exactly these inputs (records_ready = 1: written
  * by gsx_frontend_fused; 0 = gsx_rasterize_to_pixels_from_world_3dgs_fwd). */
 int gsx_rasterize_to_pixels_from_world_3dgs_fwd_packed(uint32_t N, int64_t n_isects, const float* means,

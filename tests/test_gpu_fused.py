@@ -234,6 +234,18 @@ def test_frontend_fused_is_bit_identical_to_the_separate_operators(mods, deg, di
     ga = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, a[1], a[2], v_rc, v_ra, fwd_ws=ws)
     gb = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, a[1], a[2], v_rc, v_ra)
     assert all(rel_l2(x.cpu().numpy(), y.cpu().numpy()) < 1e-5 for x, y in zip(ga, gb))
+    # the render path's variant with the backward's records in RANGES (one contiguous run of slots per Gaussian, sized by its tile rectangle:
+    # gsx_raster_common.hpp) instead of chains: the same gradients, and a second backward on the same workspace (the gather has put every
+    # count back to 0) repeats the first
+    if not distorted:
+        fe_r = ops.frontend_fused_render(deg, model.means, model.sh, sr, rr, orw, vm, K, W, H, 0.3, 0.01, 1e4, 0.0, cm, ut, radial, tang, None, True)
+        ws_r = fe_r[8]
+        a_r = ops.rasterize_fwd_packed(*args, ws_r)
+        assert torch.equal(a_r[0], a[0]) and torch.equal(a_r[2], a[2])
+        gr1 = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, a_r[1], a_r[2], v_rc, v_ra, fwd_ws=ws_r)
+        gr2 = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, a_r[1], a_r[2], v_rc, v_ra, fwd_ws=ws_r)
+        for x, y, z in zip(gr1, gr2, ga):
+            assert rel_l2(x.cpu().numpy(), z.cpu().numpy()) < 1e-5 and rel_l2(y.cpu().numpy(), x.cpu().numpy()) < 1e-5
     # a camera the front end does not take: undefined workspace, the caller falls back
     fish = ops.frontend_fused(deg, model.means, model.sh, sr, rr, orw, vm, K, W, H, 0.3, 0.01, 1e4, 0.0, ops.CameraModelType.FISHEYE, ut, None, None, None)
     assert fish[8] is None
