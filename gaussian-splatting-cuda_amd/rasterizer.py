@@ -49,7 +49,19 @@ def _list_tile_for(key):
     return _LIST_TILE_STATE.get(key, 16)
 
 
-def _list_tile_update(key, list_tile, n_isects, n_list_tiles):
+# list entries per Gaussian of the previous frame of a problem shape (at its list granularity): above RANGES_ABOVE the next frame keeps the
+# backward's records in per-Gaussian runs even on 16-pixel lists (the same threshold at which the chained layout goes to four chains)
+_ENTRIES_PER_GAUSSIAN = {}
+RANGES_ABOVE = 8.0
+
+
+def _record_ranges_for(key):
+    return _list_tile_for(key) != TILE_SIZE or _ENTRIES_PER_GAUSSIAN.get(key, 0.0) > RANGES_ABOVE
+
+
+def _list_tile_update(key, list_tile, n_isects, n_list_tiles, n_gaussians=0):
+    if n_gaussians > 0:
+        _ENTRIES_PER_GAUSSIAN[key] = n_isects / n_gaussians
     density = n_isects / max(1, n_list_tiles)
     if list_tile == 16 and density >= LIST_TILE_UP:
         _LIST_TILE_STATE[key] = 32
@@ -326,9 +338,9 @@ class GutRenderFunction(torch.autograd.Function):
         if scaling_modifier == 1.0 and FUSED_FRONTEND:
             # the whole per-Gaussian front end in ONE kernel: activations -> projection -> SH colours -> packed blend records
             # (same values as the separate launches below; an undefined workspace = camera / SH layout not supported)
-            # frames of large footprints (the ones that get lists per 32 x 32 pixels: _LIST_TILE_STATE, from the previous frames' statistics) keep the
+            # frames of large footprints (lists per 32 x 32 pixels, or more than RANGES_ABOVE list entries per Gaussian: the previous frames' statistics) keep the
             # backward's moment records of a Gaussian in one contiguous run of slots instead of a chain (gsx_raster_common.hpp: "ranges")
-            ranges = camera_model == ops.CameraModelType.PINHOLE and _list_tile_for((width, height, means_c.device.index)) != TILE_SIZE
+            ranges = camera_model == ops.CameraModelType.PINHOLE and _record_ranges_for((width, height, means_c.device.index))
             fe = ops.frontend_fused_render(sh_degree, means_c, sh_c, sr, rr, orw, viewmat, K, width, height, EPS2D, NEAR_PLANE, FAR_PLANE, RADIUS_CLIP,
                                            camera_model, ut, radial, tangential, None, ranges)
             if fe[8] is None:
@@ -361,10 +373,10 @@ class GutRenderFunction(torch.autograd.Function):
             # the frame's verdict on the device, backward() confirms it on the host before anything irreversible
             _, flatten_ids, isect_offsets, lists = ops.intersect_tile_binned_guarded(means2d, radii, depths, 1, list_tile, tw, th)
             if lists.confirmed:   # first call of a problem shape: the exact protocol ran
-                _list_tile_update(lt_key, list_tile, int(lists.confirm()[0]), tw * th)
+                _list_tile_update(lt_key, list_tile, int(lists.confirm()[0]), tw * th, means_c.shape[0])
         else:
             _, _, flatten_ids, isect_offsets = ops.intersect_tile_binned(means2d, radii, depths, 1, list_tile, tw, th, False)
-            _list_tile_update(lt_key, list_tile, int(flatten_ids.shape[0]), tw * th)
+            _list_tile_update(lt_key, list_tile, int(flatten_ids.shape[0]), tw * th, means_c.shape[0])
         opac2 = opac.unsqueeze(0)
         if fe is not None:   # the records of exactly these inputs are already in fe_ws
             renders, alphas, last_ids = ops.rasterize_fwd_packed(
@@ -381,7 +393,7 @@ class GutRenderFunction(torch.autograd.Function):
         ctx.extra = (bg, width, height, sh_degree, scaling_modifier, camera_model, radial, tangential, grad_sinks, ut)
         ctx.list_tile = list_tile
         ctx.lists = lists
-        ctx.lt_update = (lt_key, list_tile, tw * th)
+        ctx.lt_update = (lt_key, list_tile, tw * th, means_c.shape[0])
         GutRenderFunction.last_lists = lists   # picked up by rasterize_fused right after apply() (a handle is not a tensor output)
         ctx.mark_non_differentiable(radii, means2d, depths, flatten_ids, isect_offsets)
         ctx.set_materialize_grads(False)  # no zero tensors for the outputs nobody differentiates (six fill launches per step)
@@ -417,7 +429,7 @@ class GutRenderFunction(torch.autograd.Function):
             # repeats the iteration when any rank overflowed — the collectives below stay matched).
             n_is, _, ok = ctx.lists.confirm()
             ctx.lists_checked = True
-            _list_tile_update(ctx.lt_update[0], ctx.lt_update[1], int(n_is), ctx.lt_update[2])
+            _list_tile_update(ctx.lt_update[0], ctx.lt_update[1], int(n_is), ctx.lt_update[2], ctx.lt_update[3])
             if s.get("_lists_agree") is not None:
                 ok = s["_lists_agree"](ok)
             if not ok:
