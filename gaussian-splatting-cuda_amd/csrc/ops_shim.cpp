@@ -22,6 +22,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <tuple>
 
 #include "../../include/gsx.h"
@@ -206,6 +207,7 @@ struct HostWord {
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif
+            if (spins > 8192u && (spins & 255u) == 0u) std::this_thread::yield();   // a long wait (cold start, a deep queue): leave the core to others now and then
         }
         return __atomic_load_n(p, __ATOMIC_ACQUIRE);
     }
