@@ -44,6 +44,21 @@ __device__ unsigned long long g_stats[16];
 #else
 #define GSX_STAT_ADD(i, v) do { } while (0)
 #endif
+#ifdef GSX_CLOCKS
+// debug build only (tools/blend_clock.py, -DGSX_CLOCKS; no other counters, so the kernels run at their production speed)
+// the shader clock a blend kernel really runs at (round 5): thread 0 of every block brackets its block with s_memtime (shader cycles:
+// MI355X_MICROARCH.md) and s_memrealtime (constant 100 MHz); g_clk[3 k ..] = {sum of cycles, sum of 10 ns ticks, blocks} of kernel k
+// (0 one-list forward, 1 four-list forward, 2 Gaussian-major backward, 3 pixel-major backward).  tools/blend_clock.py
+__device__ unsigned long long g_clk[12];
+struct BlockClock {
+    unsigned long long t0, r0; int k; bool on;
+    __device__ BlockClock(int k_) : k(k_), on(threadIdx.x == 0) { if (on) { t0 = __builtin_readcyclecounter(); r0 = wall_clock64(); } }
+    __device__ ~BlockClock() { if (on) { atomicAdd(&g_clk[3 * k], __builtin_readcyclecounter() - t0); atomicAdd(&g_clk[3 * k + 1], wall_clock64() - r0); atomicAdd(&g_clk[3 * k + 2], 1ull); } }
+};
+#define GSX_BLOCK_CLOCK(k) BlockClock gsx_block_clock(k)
+#else
+#define GSX_BLOCK_CLOCK(k) do { } while (0)
+#endif
 
 // minimum waves per SIMD requested from the register allocator (__launch_bounds__ 2nd argument)
 #ifndef GSX_FWD_WAVES
@@ -285,6 +300,7 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_fast_kernel(Rast
     __shared__ float4 s_rec[2][FCH][5];
     __shared__ float s_bounds[4][4];
     __shared__ int s_wdone[2][4];
+    GSX_BLOCK_CLOCK(0);
     const uint32_t cid = blockIdx.y;
     uint32_t tile_id;
     if (!swizzled_tile(blockIdx.x, a.tw * a.th, tile_id)) return;
@@ -429,6 +445,7 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_quad_kernel(Rast
     __shared__ float4 s_rec[2][FCH + 1][5];
     __shared__ float s_bounds[4][4];
     __shared__ int s_wdone[2][4];
+    GSX_BLOCK_CLOCK(1);
     // [wave][block][FCH]: indices into the chunk's records, consumed by the wave that wrote them (4 x FCH = 512 B per wave: one ds_write_b64 per
     // lane pre-fills them); + the byte the last list's look-ahead reads past its end
     __shared__ __attribute__((aligned(8))) uint8_t s_list_flat[4 * 4 * FCH + 8];
@@ -735,6 +752,7 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
     __shared__ unsigned long long s_touched[(BCH + 63) / 64];
     __shared__ float s_bounds[4][4];
     __shared__ int32_t s_blockmax;
+    GSX_BLOCK_CLOCK(3);
     const uint32_t cid = blockIdx.y;
     const bool ranges = record_ranges(a, ws_head);   // how this workspace's head planes are used (gsx_raster_common.hpp)
     uint32_t tile_id;
@@ -1046,6 +1064,7 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
     __shared__ float4 s_uvb[KIND == CAM_PERFECT_PINHOLE ? 1 : RB];   // distorted cameras: per pixel (u, v, last id, w) (w = 1 unless fisheye)
     __shared__ float s_bounds[4][4];
     __shared__ int32_t s_blockmax;
+    GSX_BLOCK_CLOCK(2);
     const uint32_t cid = blockIdx.y;
     const bool ranges = record_ranges(a, ws_head);   // how this workspace's head planes are used (gsx_raster_common.hpp)
     uint32_t tile_id;
@@ -1252,6 +1271,7 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
                     uint32_t expected = 0u;
                     while (!__hip_atomic_compare_exchange_strong(&s_lock, &expected, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
                         expected = 0u;
+                        GSX_STAT_ADD(12, 1);   // (lane 0 is the only lane here)
                         __builtin_amdgcn_s_sleep(GSX_GQ_SLEEP);
                     }
                 }
@@ -1571,5 +1591,12 @@ extern "C" void gsx_debug_read_stats(unsigned long long* out, int reset) {
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(gsx::g_stats), sizeof(unsigned long long) * 16);
     if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(gsx::g_stats), z, sizeof(z)); }
+}
+#endif
+#ifdef GSX_CLOCKS
+extern "C" void gsx_debug_read_clocks(unsigned long long* out, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(gsx::g_clk), sizeof(unsigned long long) * 12);
+    if (reset) { unsigned long long z[12] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(gsx::g_clk), z, sizeof(z)); }
 }
 #endif

@@ -399,6 +399,87 @@ class ColorGradExchange:
         self._pending = []
 
 
+class CameraBatchAccumulator:
+    """C cameras per optimizer step on ONE GPU: the single-process counterpart of the camera-sharded step (BASELINE configs[3] on one
+    MI355X — the denominator of `north_star`'s scaling target).  The reference renders one camera per iteration (trainer.cpp:917-922);
+    a batch of C cameras is that loop body C times with the gradients averaged and ONE optimizer step, which is also exactly what N
+    ranks x 1 camera compute.  The same arithmetic as ColorGradExchange without the collectives:
+
+      camera c = 0 .. C-1 (each a full render + loss + backward through rasterize_fused with this object as sinks["_color_exchange"]):
+          colour gradient of the camera, masked by the colour clamp, times 1/C  ->  row c of a [C,N,3] buffer         (12 B / Gaussian)
+          the blend's means gradient and the scaling / rotation / opacity sinks  ->  added into an 11-float accumulator  (44 B / Gaussian)
+      after camera C-1: ONE SH backward over all C cameras (fused with the SH tensor's Adam step when the caller passes one), the
+          accumulator / C goes back into the bucket: the 192 B SH gradient row of a Gaussian is produced once per step, not once per camera.
+
+    Wiring: acc = CameraBatchAccumulator(bucket, names, C); sinks["_color_exchange"] = acc; acc.begin_step(viewmats [C,4,4]);
+    C x (rasterize_fused(..., grad_sinks=sinks) -> loss -> backward); acc.finish(); optimizer step.  sinks["_sh_adam"] may be set for
+    every backward: it is used by the last camera's only."""
+
+    def __init__(self, bucket, names=("means", "sh", "scaling_raw", "rotation_raw", "opacity_raw"), cameras=8, sh_bwd_fn=None):
+        self.bucket, self.names, self.C = bucket, list(names), int(cameras)
+        self.sh_bwd_fn = sh_bwd_fn   # tests: a CPU stand-in for ops.sh_colors_bwd (same signature)
+        self._viewmats = None
+        self._buf = self._tmp = self._acc = None
+        self._c = 0
+        self._done = False
+        # the spans of the flat bucket that are not the SH gradient, as in ColorGradExchange (everything the per-camera backward overwrites)
+        i_sh = self.names.index("sh")
+        self._spans = []
+        for i, o in enumerate(bucket.offsets):
+            if i == i_sh:
+                continue
+            end = bucket.offsets[i + 1] if i + 1 < len(bucket.offsets) else bucket.flat.numel()
+            if self._spans and self._spans[-1][1] == o:
+                self._spans[-1][1] = end
+            else:
+                self._spans.append([o, end])
+
+    def begin_step(self, viewmats_all):
+        assert viewmats_all.shape[0] == self.C
+        self._viewmats = viewmats_all.contiguous()
+        self._c = 0
+        self._done = False
+
+    def sh_backward(self, sh_degree, means, sh, colors, v_colors, v_means_blend, sink_sh, sink_means, sh_adam=None):
+        """Same contract as ColorGradExchange.sh_backward; called once per camera of the batch, in the order of begin_step's viewmats."""
+        n, c = means.shape[0], self._c
+        assert self._viewmats is not None and c < self.C, "CameraBatchAccumulator: begin_step() first, C backwards per step"
+        flat = self.bucket.flat
+        if self._buf is None or self._buf.shape[1] != n or self._buf.device != means.device:
+            self._buf = torch.empty(self.C, n, 3, dtype=means.dtype, device=means.device)
+            self._tmp = torch.empty(n, 3, dtype=means.dtype, device=means.device)
+            self._acc = [torch.empty(b - a, dtype=flat.dtype, device=flat.device) for a, b in self._spans]
+        torch.mul(v_colors.reshape(n, 3), 1.0 / self.C, out=self._buf[c])
+        self._buf[c].mul_(colors.reshape(n, 3) > 0)
+        sink_means.copy_(v_means_blend.reshape(sink_means.shape))
+        for acc, (a, b) in zip(self._acc, self._spans):   # means | scaling | rotation | opacity of THIS camera
+            if c == 0:
+                acc.copy_(flat[a:b])
+            else:
+                acc.add_(flat[a:b])
+        self._c = c + 1
+        if self._c < self.C:
+            return sink_sh, sink_means
+        fn = self.sh_bwd_fn
+        if sh_adam is not None and fn is None:
+            from . import ops
+            ops.sh_colors_bwd_adam(sh_degree, means, self._viewmats, sh, None, None, self._buf, None, self._tmp, *sh_adam)
+        else:
+            if fn is None:
+                from . import ops
+                fn = ops.sh_colors_bwd
+            fn(sh_degree, means, self._viewmats, sh, None, None, self._buf, None, sink_sh, self._tmp)
+        for acc, (a, b) in zip(self._acc, self._spans):
+            torch.mul(acc, 1.0 / self.C, out=flat[a:b])
+        self.bucket.params[self.names.index("means")].grad.add_(self._tmp)   # the direction part, summed over the cameras (colour gradients carry 1/C)
+        self._done = True
+        return sink_sh, sink_means
+
+    def finish(self):
+        assert self._done, "CameraBatchAccumulator.finish(): %d of %d cameras of the step have run their backward" % (self._c, self.C)
+        self._viewmats = None
+
+
 class ListsAgreement:
     """Guarded intersection lists (rasterizer.rasterize_fused(guarded=True)) under N ranks: a frame whose lists overflowed on ANY rank
     is rendered again on EVERY rank, so the collectives of the step stay matched and the replicas identical.  The verdicts meet on

@@ -255,6 +255,42 @@ def test_color_grad_exchange_equals_dense_all_reduce(tmp_path, sh_first):
     np.testing.assert_allclose(b0, exp, rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("sh_first", [False, True])
+def test_camera_batch_accumulator_equals_mean_of_single_camera_gradients(sh_first):
+    """distributed.CameraBatchAccumulator (C cameras per optimizer step on ONE GPU: BASELINE configs[3]'s iteration without the ranks): after
+    C backwards the bucket holds the mean over the cameras of each camera's full gradient — what C ranks x 1 camera produce through
+    ColorGradExchange / the dense all-reduce."""
+    import gsx  # noqa: F401
+    from gsx import distributed as gdist
+    C = 3
+    names = ["sh", "means", "scaling_raw", "rotation_raw", "opacity_raw"] if sh_first else ["means", "sh", "scaling_raw", "rotation_raw", "opacity_raw"]
+    shapes = dict(means=(257, 3), sh=(257, 16, 3), scaling_raw=(257, 3), rotation_raw=(257, 4), opacity_raw=(257, 1))
+    params = [torch.zeros(shapes[n], requires_grad=True) for n in names]
+    bucket = gdist.GradBucket(params)
+    sinks = bucket.sinks(tuple(names))
+    acc = gdist.CameraBatchAccumulator(bucket, names, cameras=C, sh_bwd_fn=_sh_colors_bwd_cpu)
+    assert len(acc._spans) == (1 if sh_first else 2)
+    for _step in range(2):   # a second step on the same object starts from scratch
+        acc.begin_step(torch.stack([_xch_inputs(c)[2] for c in range(C)]))
+        with pytest.raises(AssertionError):
+            acc.finish()
+        exp = None
+        for c in range(C):
+            means, sh, vm, colors, v_colors, others = _xch_inputs(c)
+            # what the render backward of camera c does: the other gradients into their sinks (overwriting camera c-1's), then the hook
+            sinks["scaling_raw"].copy_(others[1]); sinks["rotation_raw"].copy_(others[2]); sinks["opacity_raw"].copy_(others[3])
+            acc.sh_backward(3, means, sh, colors, v_colors, others[0], sinks["sh"], sinks["means"])
+            vcm = (v_colors * (colors > 0))[0]
+            vsh, vmn = torch.zeros(257, 16, 3), torch.zeros(257, 3)
+            _sh_colors_bwd_cpu(3, means, vm[None], sh, None, None, vcm[None], None, vsh, vmn)
+            full = np.concatenate([(others[0] + vmn).numpy().reshape(-1), vsh.numpy().reshape(-1), others[1].numpy().reshape(-1),
+                                   others[2].numpy().reshape(-1), others[3].numpy().reshape(-1)])
+            exp = full if exp is None else exp + full
+        acc.finish()
+        got = np.concatenate([sinks[n].numpy().reshape(-1) for n in ["means", "sh", "scaling_raw", "rotation_raw", "opacity_raw"]])
+        np.testing.assert_allclose(got, exp / C, rtol=2e-5, atol=2e-6)
+
+
 def _agree_worker(rank, world, port, out_dir):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import gsx  # noqa: F401

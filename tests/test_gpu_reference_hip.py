@@ -103,6 +103,24 @@ def _to_np(d, keys):
     return {k: (d[k].cpu().numpy() if d[k] is not None else None) for k in keys if k in d}
 
 
+def _explain_pixels(sc, R, g_ren, g_last, tag):
+    """Full frames: every pixel where the HIP blend and the REFERENCE KERNEL's frame differ by more than 1e-4 must carry a discrete
+    decision that two correct fp32 evaluations can take differently — a different last Gaussian, or an alpha >= 1/255 / T <= 1e-4 test
+    within 1e-3 (relative) of its threshold in the reference-order evaluation of the same inputs (the oracle's per-pixel flag).
+    (VERDICT r04 weak #1a: the explanation used to be asserted against the oracle's frame only, tests/test_gpu_fullsize.py.)"""
+    f = lambda k: np.ascontiguousarray(sc[k].numpy(), np.float32)  # noqa: E731
+    W, H = sc["width"], sc["height"]
+    _, _, _, frag = oracle.rasterize_fwd(f("means"), f("quats"), f("scales"), np32(R["colors"]), f("opacities")[None], f("background")[None], None, W, H, 16,
+                                         f("viewmat")[None], f("K")[None], R["tile_offsets"].cpu().numpy(), R["flatten_ids"].cpu().numpy(), frag_rel=1e-3)
+    err = np.abs(g_ren - np32(R["renders"])).max(-1)
+    over = err > 1e-4
+    explained = (frag != 0) | (g_last != R["last_ids"].cpu().numpy())
+    rec = parity_record("%s blend forward: pixels beyond 1e-4 vs the reference kernel's frame, explained by a threshold decision" % tag,
+                        pixels_over_1e4=int(over.sum()), unexplained=int((over & ~explained).sum()), threshold_ambiguous_pixels=int((frag != 0).sum()))
+    assert rec["unexplained"] == 0, rec
+    return rec
+
+
 def _stagewise(ref, ops, sc, cam, tag, with_oracle=True, fwd_strict=True):
     """Runs the reference chain, then feeds each stage's REFERENCE inputs to the HIP operator (and the oracle) and compares outputs."""
     a = _scene_args(sc, cam)
@@ -163,6 +181,8 @@ def _stagewise(ref, ops, sc, cam, tag, with_oracle=True, fwd_strict=True):
     cmax = float(R["colors"].max())
     r_ren, r_alp, r_last = np32(R["renders"]), np32(R["alphas"]), R["last_ids"].cpu().numpy()
     recs["fwd_hip"] = _fwd_stats(tag, "HIP", r_ren, r_alp, r_last, np32(G[0]), np32(G[1]), G[2].cpu().numpy(), cmax)
+    if not fwd_strict:
+        recs["fwd_explained"] = _explain_pixels(sc, R, np32(G[0]), G[2].cpu().numpy(), tag)
     B = ops.rasterize_to_pixels_from_world_3dgs_bwd(*common, R["alphas"], R["last_ids"], v_rc, v_ra)
     recs["bwd_hip"] = parity_record("%s blend backward: HIP vs reference kernel (rel-L2)" % tag, **{n: rel_l2(np32(g), np32(R[n])) for n, g in zip(GRADS, B)})
     if with_oracle:
@@ -189,7 +209,8 @@ def _stagewise(ref, ops, sc, cam, tag, with_oracle=True, fwd_strict=True):
         if fwd_strict:
             assert fw["rgb_max_err"] < 1e-4 and fw["alpha_max_err"] < 1e-4, fw   # north_star: 1e-4 RGB L-inf, every pixel
         else:
-            assert fw["rgb_pixels_over_1e4"] <= 4e-4 * fw["pixels"] and fw["rgb_q999999"] < 1e-3, fw
+            # measured (profiles/parity_r04.md): 8.4e-5 of the pixels (S-1M), 5.8e-5 (S-5M); the reference's own two builds differ on 9.9e-5
+            assert fw["rgb_pixels_over_1e4"] <= 2e-4 * fw["pixels"] and fw["rgb_q999999"] < 1e-3, fw
     for k in [k for k in ("bwd_hip", "bwd_oracle") if k in recs]:
         for g in GRADS:
             assert recs[k][g] < 1e-3, (k, g, recs[k])                      # north_star: 1e-3 gradient rel-L2
@@ -227,6 +248,41 @@ def test_s1m_full_frame(ref, mods):
     rec = parity_record("S-1M @1080p END TO END image: HIP fused chain (own projection + binning) vs reference chain", pixels=int(err.numel()),
                         rgb_max_err=float(err.max()), rgb_pixels_over_1e4=int((err > 1e-4).sum()), rgb_pixels_over_1e3=int((err > 1e-3).sum()),
                         rgb_mean_err=float(err.mean()), n_isects_hip=int(out.n_isects), n_isects_ref=int(R["flatten_ids"].numel()))
+    assert rec["rgb_pixels_over_1e4"] <= 2e-3 * rec["pixels"] and rec["rgb_max_err"] < float(R["colors"].max()) / 255.0 * 2 + 1e-3, rec
+
+
+@pytest.fixture(scope="module")
+def s1m_scene(mods):
+    return mods[1].scene_1m()
+
+
+@pytest.mark.parametrize("cam_i", range(8))
+def test_s8cam_ring_cameras_vs_reference(ref, mods, s1m_scene, cam_i):
+    """BASELINE configs[3]'s inputs as SURVEY §8(d) defines them ("S-8cam"): S-1M seen by 8 cameras on a ring of radius 6 around the slab centre
+    (gsx.scenes.ring_cameras), one per rank.  Cameras 2 / 6 look along the slab from its side (Gaussians a few centimetres from the camera: radii of
+    hundreds of pixels, most of the model outside the frustum), camera 4 sees it from behind: the culling paths, the "behind the camera"
+    paths and the heavy tiles cfg2's own camera never exercises.  Stage by stage against the reference's kernels, same tolerances as
+    test_s1m_full_frame; the counts go to profiles/parity_r05.md."""
+    ops, scenes = mods
+    sc = dict(s1m_scene)
+    sc["viewmat"] = scenes.ring_cameras(8)[cam_i]
+    tag = "S-8cam ring camera %d" % cam_i
+    recs, R = _stagewise(ref, ops, sc, {}, tag, with_oracle=False, fwd_strict=False)
+    off = R["tile_offsets"].reshape(-1).cpu().numpy().astype(np.int64)
+    seg = np.diff(np.concatenate([off, [int(R["flatten_ids"].numel())]]))
+    parity_record("%s: workload" % tag, visible=int((R["radii"] > 0).all(-1).sum().item()), n_isects=int(R["flatten_ids"].numel()), largest_tile=int(seg.max()),
+                  max_radius_px=int(R["radii"].max().item()))
+    # end to end: the fused chain on its own projection / binning through the same camera
+    import gsx  # noqa: F401
+    from gsx import rasterizer
+    model = scenes.to_splat_data(sc, DEV)
+    cam = rasterizer.Camera(viewmat=sc["viewmat"].to(DEV), K=sc["K"].to(DEV), width=sc["width"], height=sc["height"])
+    with torch.no_grad():
+        out = rasterizer.rasterize_fused(cam, model, sc["background"].to(DEV))
+    err = (out.render_hwc - R["renders"][0]).abs().amax(-1)
+    rec = parity_record("%s END TO END image: HIP fused chain (own projection + binning) vs reference chain" % tag, pixels=int(err.numel()),
+                        rgb_max_err=float(err.max()), rgb_pixels_over_1e4=int((err > 1e-4).sum()), rgb_pixels_over_1e3=int((err > 1e-3).sum()),
+                        n_isects_hip=int(out.n_isects), n_isects_ref=int(R["flatten_ids"].numel()))
     assert rec["rgb_pixels_over_1e4"] <= 2e-3 * rec["pixels"] and rec["rgb_max_err"] < float(R["colors"].max()) / 255.0 * 2 + 1e-3, rec
 
 
@@ -270,7 +326,7 @@ def _blend_generic_vs_reference(ref, ops, sc, tag):
         who = "HIP reference-order kernels (GSX_RASTER_PATH=generic)" if path == "generic" else "HIP fast kernels (same run)"
         fw = _fwd_stats(tag, who, r_ren, r_alp, r_last, np32(G[0]), np32(G[1]), G[2].cpu().numpy(), cmax)
         bw = parity_record("%s blend backward: %s vs reference kernel (rel-L2)" % (tag, who), **{n: rel_l2(np32(g), np32(R[n])) for n, g in zip(GRADS, B)})
-        assert fw["rgb_max_err"] <= fw["one_gaussian_bound"] and fw["rgb_pixels_over_1e4"] <= 4e-4 * fw["pixels"], fw
+        assert fw["rgb_max_err"] <= fw["one_gaussian_bound"] and fw["rgb_pixels_over_1e4"] <= 2e-4 * fw["pixels"], fw
         for g in GRADS:
             assert bw[g] < 1e-3, (path, g, bw)
         out[path] = (fw, bw)

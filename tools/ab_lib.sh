@@ -19,7 +19,7 @@ cp "$PKG/libgsx.so" /tmp/libgsx_cur.so
 for round in 1 2 3; do
   for v in base cur; do
     if [ $v = base ]; then cp "$ROOT/tools/variants/libgsx_base.so" "$PKG/libgsx.so"; else cp /tmp/libgsx_cur.so "$PKG/libgsx.so"; fi
-    (cd "$ROOT" && python bench.py --no-cpu-baseline --no-order-ablation --no-fwd-bwd "$@" > /tmp/ab.json 2>/tmp/ab.err) || tail -3 /tmp/ab.err
+    (cd "$ROOT" && python bench.py --no-cpu-baseline --no-order-ablation --no-camera-batch --no-s5m --no-fwd-bwd "$@" > /tmp/ab.json 2>/tmp/ab.err) || tail -3 /tmp/ab.err
     python - "$v" <<'PY'
 import json, sys
 d = json.load(open("/tmp/ab.json")); k = d["kernels"]

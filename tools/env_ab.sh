@@ -5,7 +5,7 @@ ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 VAR="$1"; VALS="$2"; ROUNDS="${3:-2}"; shift 3 || true
 for round in $(seq 1 "$ROUNDS"); do
   for v in $VALS; do
-    (cd "$ROOT" && env GSX_TEST_SWITCHES=1 "$VAR=$v" python bench.py --no-cpu-baseline --no-order-ablation --no-fwd-bwd "$@" > /tmp/ab.json 2>/tmp/ab.err) || tail -3 /tmp/ab.err
+    (cd "$ROOT" && env GSX_TEST_SWITCHES=1 "$VAR=$v" python bench.py --no-cpu-baseline --no-order-ablation --no-camera-batch --no-s5m --no-fwd-bwd "$@" > /tmp/ab.json 2>/tmp/ab.err) || tail -3 /tmp/ab.err
     python - "$VAR=$v" <<'PY'
 import json, sys
 d = json.load(open("/tmp/ab.json")); k = d["kernels"]

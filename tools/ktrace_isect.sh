@@ -3,7 +3,7 @@
 out=${1:-gpurun_out/kti}; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
-timeout -k 5 300 rocprofv3 --kernel-trace --stats -d "$out" -o kt --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-order-ablation --no-fwd-bwd "$@" > "$out/bench.json" 2> "$out/err.txt"
+timeout -k 5 300 rocprofv3 --kernel-trace --stats -d "$out" -o kt --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-order-ablation --no-camera-batch --no-s5m --no-fwd-bwd "$@" > "$out/bench.json" 2> "$out/err.txt"
 python - "$out" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)

@@ -6,7 +6,7 @@ PKG=gaussian-splatting-cuda_amd
 cp $PKG/libgsx.so /tmp/cur.so
 for v in base cur base cur; do
   if [ $v = base ]; then cp tools/variants/libgsx_base.so $PKG/libgsx.so; else cp /tmp/cur.so $PKG/libgsx.so; fi
-  python bench.py --scene 5m --steps 10 --warmup 3 --no-cpu-baseline --no-order-ablation --no-fwd-bwd 2>/dev/null | python -c "
+  python bench.py --scene 5m --steps 10 --warmup 3 --no-cpu-baseline --no-order-ablation --no-camera-batch --no-fwd-bwd 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); k=d['kernels']; print('5m $v step %.4f bwd %.4f fe %.4f' % (d['ms_per_step'], k['rasterize_to_pixels_from_world_3dgs_bwd']['ms'], k['frontend_fused']['ms']))"
 done
 for v in base cur base cur; do

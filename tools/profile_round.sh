@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
 python bench.py > "$out/bench.json" 2> "$out/bench.err"
 echo "bench rc=$?"
-timeout -k 5 300 rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$out/bench_under_rocprof.json" 2> "$out/kt.err"
+timeout -k 5 300 rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-camera-batch --no-s5m > "$out/bench_under_rocprof.json" 2> "$out/kt.err"
 echo "kernel-trace rc=$?"
 python - "$out" <<'PY'
 import csv, glob, sys
