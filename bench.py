@@ -663,8 +663,8 @@ def main():
                     out2 = rasterizer.rasterize_fused(cam, R["m"], bg, grad_sinks=R["s"], guarded=guarded)
                     l2 = gloss.photometric_loss(out2.render_hwc, targets[i % len(targets)], 0.2) if fused_loss else (out2.image - targets[i % len(targets)]).abs().mean()
                     try:
-                        l2.backward()
-                        break
+                        gloss.backward(l2)   # (cached unit gradient: a plain .backward() launches a 1-element fill per iteration — the
+                        break                # "FillFunctor per iteration" of round 4's kernel trace came from this leg, tools/find_fill.py)
                     except rasterizer.IsectCapacityMiss:
                         if attempt == 3:
                             raise

@@ -644,7 +644,7 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd_packed(
     return gsx_rasterize_to_pixels_from_world_3dgs_bwd_guarded(N, n_isects, means, quats, scales, colors, channels, opacities, backgrounds, masks,
                                                                image_width, image_height, tile_size, cams, ut, tile_offsets, flatten_ids,
                                                                render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales,
-                                                               v_colors, v_opacities, workspace, workspace_bytes, packed_records, nullptr, stream);
+                                                               v_colors, v_opacities, workspace, workspace_bytes, packed_records, nullptr, 0, stream);
 }
 
 extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd_guarded(
@@ -654,13 +654,14 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd_guarded(
     const int32_t* tile_offsets, const int32_t* flatten_ids, const float* render_alphas, const int32_t* last_ids,
     const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats, float* v_scales,
     float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes, const void* packed_records,
-    const int32_t* lists_status, void* stream) {
+    const int32_t* lists_status, int64_t n_isects_expected, void* stream) {
     (void)ut;
     RasterArgs a;
     int rc = fill_args(a, N, n_isects, means, quats, scales, colors, channels, opacities, backgrounds, masks, image_width,
                        image_height, tile_size, cams, tile_offsets, flatten_ids, "bwd");
     if (rc != GSX_OK) return rc;
     a.lists_status = lists_status;
+    if (lists_status != nullptr && n_isects_expected > 0) a.n_isects_expected = n_isects_expected;   // as the forward: launch decisions from the estimate, not the capacity
     if (!render_alphas || !last_ids || !v_render_colors || !v_means || !v_quats || !v_scales || !v_colors || !v_opacities) {
         set_error("rasterize bwd: null pointer");
         return GSX_ERR_INVALID_ARGUMENT;

@@ -591,7 +591,9 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_quad_kernel(Rast
         uint32_t t_next = my_list[0];
         for (uint32_t k = 0; k < steps; ++k) {
             // one compositing step: every lane evaluates the Gaussian of ITS block's list for its pixel (same instruction sequence as
-            // raster_fwd_fast_kernel's)
+            // raster_fwd_fast_kernel's).  (Round 5, measured and not kept: the record address 80 t + base as two v_lshl_add_u32 instead of hipcc's
+            // v_and + v_mad_u32_u24 — the pattern probe prices an isolated v_mad_u32_u24 at 4 plain instructions — A/B 0.1970 -> 0.1978 ms:
+            // the step is co-limited by its 15 LDS cycles per wave, DESIGN.md §4 / NOTES.md.)
             const uint32_t t = t_next;
             t_next = my_list[k + 1];                     // (one past the end at the last step: inside the LDS arrays, never used)
             const float4* rp = s_rec[buf][t];
@@ -1000,7 +1002,7 @@ GSX_DEV void gq_row(const GmLaneRec& g, const GmRowPix& px, const float (&du)[4]
         if (CLAMP) alpha = fminf(0.999f, alpha);
         const bool valid = (g.idx <= px.binf[h]) && (alpha >= ALPHA_MIN);
         al[h] = valid ? alpha : 0.f;
-        P[h] = ra[h] = __builtin_amdgcn_rcpf(1.f - al[h]);
+        P[h] = ra[h] = __builtin_amdgcn_rcpf(1.f - al[h]);   // (round 5: the four reciprocals as one asm run of v_rcp_f32 — A/B 0.5421 -> 0.5449 ms, not kept)
     }
     row_scan4_mul(P);
     float T[4], fac[4], cv[4], e[4], S[4];
@@ -1358,9 +1360,15 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
         if (ranges) {
             // ---- ranges: the records of this (camera, Gaussian) are the slots [first, cursor) ----
             constexpr int32_t RUN_T = 12;   // longer runs are summed by the whole wave
-            const int32_t n = in ? ws_head[cn + g] : 0;   // plane 1: records the backward claimed
-            const int32_t first = n > 0 ? range_first_slot(a, ws_head, g) : 0, cursor = first + n;
-            touched = n > 0;
+            const int32_t n_claimed = in ? ws_head[cn + g] : 0;   // plane 1: records the backward claimed
+            const int32_t first = n_claimed > 0 ? range_first_slot(a, ws_head, g) : 0;
+            // the same bound as the writers' guard (claim_record_slot's callers): a slot at or beyond rec_capacity was never written.  By
+            // construction no run reaches it (a run is at most the Gaussian's rectangle of 16-px tiles, the slots are their sum); if the
+            // invariant ever broke — a workspace packed for another frame — the gradient would lose records either way, but the gather must not
+            // read unwritten or out-of-bounds memory on top of it
+            const int32_t n = (int32_t)min((int64_t)n_claimed, max((int64_t)0, a.rec_capacity - (int64_t)first));
+            const int32_t cursor = first + n;
+            touched = n_claimed > 0;
             if (touched) {
                 ws_head[cn + g] = 0;   // the run is consumed: the count is back at 0 for the next backward on this workspace
                 load_raw();

@@ -100,7 +100,7 @@ static ShimStats g_stats;
 
 // ---- capacity hints of the binned intersection -------------------------------------------------------------------------------
 // The ONLY state the shim keeps between calls: a process-wide map {(device, C, N, tile grid) -> recent maxima of n_isects and of the
-// largest tile segment}, mutex protected, decaying slowly so that one outlier view does not pin memory for ever.  It never changes a
+// largest tile segment}, mutex protected, over a sliding window of frames so that one outlier view does not pin memory for ever.  It never changes a
 // result: it sizes the optimistic fill (exact protocol: outputs narrowed / fill repeated on a miss; guarded protocol: the frame is
 // rendered again on a miss).  A model that grows (densification changes N every few hundred iterations) would start cold after every
 // resize: the entry with N = 0 holds the last call of the same (device, C, tile grid) at any N and stands in, scaled by the ratio of
@@ -110,6 +110,8 @@ static std::mutex g_hint_mutex;
 static std::map<HintKey, std::pair<int64_t, int64_t>> g_hints;   // (n_isects, largest segment)
 static std::map<HintKey, std::pair<int64_t, int64_t>> g_last;    // the last confirmed frame of the shape, undecayed (launch decisions)
 static std::map<HintKey, uint32_t> g_hint_last_n;
+struct HintWindow { int64_t cur_n, cur_seg, prev_n, prev_seg; uint32_t count; };
+static std::map<HintKey, HintWindow> g_hint_win;                 // the two windows behind g_hints' maxima (hint_update)
 
 static HintKey hint_key_any(const HintKey& k) { return std::make_tuple(std::get<0>(k), std::get<1>(k), 0u, std::get<3>(k), std::get<4>(k)); }
 
@@ -146,17 +148,25 @@ static void hint_lookup(const HintKey& key, int64_t& hint, int64_t& hint_seg, in
 
 static void hint_update(const HintKey& key, int64_t n_isects, int64_t max_seg) {
     std::lock_guard<std::mutex> lock(g_hint_mutex);
-    if (g_hints.size() > 4096) { g_hints.clear(); g_last.clear(); }   // (a long run that resizes thousands of times: start over rather than grow without bound)
+    if (g_hints.size() > 4096) { g_hints.clear(); g_last.clear(); g_hint_win.clear(); }   // (a long run that resizes thousands of times: start over rather than grow without bound)
     if (g_hints.find(key) == g_hints.end()) {   // a new shape inherits what stood in for it (a grown model keeps the maxima over its cameras)
         int64_t h0 = 0, s0 = 0;
         hint_lookup_locked(key, h0, s0);
         g_hints[key] = std::make_pair(h0, s0);
     }
     auto& h = g_hints[key];
-    // running maxima with a slow decay (a few hundred calls to forget an outlier view: a dataset's cameras come round every few hundred
-    // iterations, and under the guarded protocol a miss costs a whole repeated iteration, not just a second fill)
-    h.first = std::max<int64_t>(n_isects, h.first - h.first / 512);
-    h.second = std::max<int64_t>(max_seg, h.second - h.second / 512);
+    // Maxima over a sliding window of frames: the hint is the maximum of the current and the previous window of kHintWindow confirmed frames,
+    // so a heavy view is remembered for 1024 - 2048 frames — at least one round of a dataset's cameras — and an outlier is forgotten after that.
+    // (Rounds 2 - 4 decayed the maximum by 1/512 per frame: a view 1.5x the median was forgotten within ~200 frames, i.e. missed once per
+    // epoch on a dataset of a few hundred views; under the guarded protocol a miss costs a whole repeated iteration.  ADVICE r04.)
+    constexpr uint32_t kHintWindow = 1024;
+    auto wi = g_hint_win.find(key);
+    if (wi == g_hint_win.end()) wi = g_hint_win.emplace(key, HintWindow{0, 0, h.first, h.second, 0}).first;   // what the shape inherited counts as the previous window
+    HintWindow& w = wi->second;
+    w.cur_n = std::max(w.cur_n, n_isects); w.cur_seg = std::max(w.cur_seg, max_seg);
+    if (++w.count >= kHintWindow) { w.prev_n = w.cur_n; w.prev_seg = w.cur_seg; w.cur_n = n_isects; w.cur_seg = max_seg; w.count = 0; }
+    h.first = std::max(w.cur_n, w.prev_n);
+    h.second = std::max(w.cur_seg, w.prev_seg);
     const HintKey any = hint_key_any(key);
     g_hints[any] = std::make_pair(n_isects, max_seg);
     g_last[key] = std::make_pair(n_isects, max_seg);
@@ -517,7 +527,8 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
               last_ids.data_ptr<int32_t>(), v_render_colors.data_ptr<float>(),
               v_render_alphas.defined() ? v_render_alphas.data_ptr<float>() : nullptr,
               v_means.data_ptr<float>(), v_quats.data_ptr<float>(), v_scales.data_ptr<float>(), v_colors.data_ptr<float>(),
-              v_opacities.data_ptr<float>(), ws.data_ptr(), wsb, packed, guarded ? g_lists->status.data_ptr<int32_t>() : nullptr, cur_stream()),
+              v_opacities.data_ptr<float>(), ws.data_ptr(), wsb, packed, guarded ? g_lists->status.data_ptr<int32_t>() : nullptr,
+              guarded ? g_lists->expected : 0, cur_stream()),
           "rasterize_to_pixels_from_world_3dgs_bwd");
     return std::make_tuple(v_means, v_quats, v_scales, v_colors, v_opacities);
 }

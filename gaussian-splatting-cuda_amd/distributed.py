@@ -50,12 +50,22 @@ def init_from_env(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and os.environ.get("GSX_SINGLE_RANK_GROUP") == "1" and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:   # a free port of this host: two single-rank runs side by side must not meet on a fixed one
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
         SINGLE_RANK_COLLECTIVES = True
     if (world > 1 or SINGLE_RANK_COLLECTIVES) and not dist.is_initialized():
-        # this host's driver only supports dmabuf IPC: without it RCCL's peer mappings fail with `hipIpcGetMemHandle: invalid argument`
-        # (read by the HSA runtime when the first rank-to-rank mapping is made; a value the launcher exported wins)
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # this host's driver only supports dmabuf IPC: without it RCCL's peer mappings fail with `hipIpcGetMemHandle: invalid argument`.
+        # The HSA runtime reads the variable when it starts, i.e. with the process's first GPU call: a value the launcher exported wins
+        # (bench.py's self-launch and the driver's environment do); setting it here only helps a process that has not touched the GPU yet.
+        if "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ:
+            if world > 1 and torch.cuda.is_available() and torch.cuda.is_initialized():
+                print("gsx.distributed: HSA_ENABLE_IPC_MODE_LEGACY is not set and this process has already initialised the GPU runtime; export "
+                      "HSA_ENABLE_IPC_MODE_LEGACY=0 before the first GPU call or RCCL's peer mappings may fail (hipIpcGetMemHandle: invalid argument)",
+                      file=sys.stderr)
+            os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" IS RCCL on ROCm
         if backend == "nccl":
@@ -483,27 +493,108 @@ class CameraBatchAccumulator:
 class ListsAgreement:
     """Guarded intersection lists (rasterizer.rasterize_fused(guarded=True)) under N ranks: a frame whose lists overflowed on ANY rank
     is rendered again on EVERY rank, so the collectives of the step stay matched and the replicas identical.  The verdicts meet on
-    the HOST — a MIN all-reduce of one int over a gloo group (loopback TCP, tens of microseconds) — while every GPU still has the
-    forward, the loss and the blend backward queued: no device-side collective, no stream synchronisation.
+    the HOST while every GPU still has the forward, the loss and the blend backward queued: no device-side collective, no stream
+    synchronisation.
+
+    Transport.  Ranks of one node (the camera-sharded step is a single-node design: `north_star`) meet in a SHARED-MEMORY page: every rank
+    publishes (call number, verdict) in its own cache line and reads the others' — a few microseconds however many ranks there are.  (Round 4
+    used a MIN all-reduce of one int over a gloo group; measured with tools/lists_agree_time.py on an 8-core box: 0.25 ms with 2 ranks,
+    1.1 ms with 8 — as long as the iteration it guards.)  Ranks that do not share a host (or GSX_AGREE=gloo) keep the gloo all-reduce.
+    A rank that fails before it reaches its vote must still vote (`agree(False)` from the caller's exception path) or its peers wait: the
+    wait gives up after `timeout_s` with an error naming the silent ranks instead of hanging.
     Wiring: `sinks["_lists_agree"] = ListsAgreement()` (constructed collectively on every rank)."""
 
-    def __init__(self):
+    def __init__(self, timeout_s=120.0):
         self.group = None
-        if active():
-            with _stdout_to_stderr():
-                self.group = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
-        self._flag = torch.zeros(1, dtype=torch.int32)
+        self.timeout_s = float(timeout_s)
+        self._shm = self._slots = None
+        self._calls = 0
+        self.transport = "none"
         self.disagreements = 0   # iterations repeated because some OTHER rank overflowed
+        self._flag = torch.zeros(1, dtype=torch.int32)
+        if not active():
+            return
+        import datetime
+        import socket
+        with _stdout_to_stderr():
+            self.group = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=self.timeout_s))
+        self.transport = "gloo"
+        world, rank = dist.get_world_size(), dist.get_rank()
+        if os.environ.get("GSX_AGREE", "shm") != "shm":
+            return
+        try:
+            from multiprocessing import shared_memory
+            import numpy as np
+            hosts = [None] * world
+            dist.all_gather_object(hosts, socket.gethostname(), group=self.group)
+            same_host = all(h == hosts[0] for h in hosts)
+            name = [None]
+            if rank == 0 and same_host:
+                self._shm = shared_memory.SharedMemory(create=True, size=64 * world)   # one cache line per rank
+                self._shm.buf[:64 * world] = bytes(64 * world)
+                name[0] = self._shm.name
+            dist.broadcast_object_list(name, src=0, group=self.group)
+            if name[0] is not None:
+                if rank != 0:
+                    self._shm = shared_memory.SharedMemory(name=name[0])
+                    try:   # the segment belongs to rank 0: this process's resource tracker must not unlink it at exit
+                        from multiprocessing import resource_tracker
+                        resource_tracker.unregister(self._shm._name, "shared_memory")
+                    except Exception:  # noqa: BLE001
+                        pass
+                self._slots = np.ndarray((world, 8), dtype=np.int64, buffer=self._shm.buf)   # [rank][0] = (call number << 1) | verdict
+                self.transport = "shm"
+            dist.barrier(group=self.group)   # every rank has mapped the page before rank 0 can go away
+        except Exception:  # noqa: BLE001  (no /dev/shm, a sandbox without shared memory ...: the gloo path stays)
+            self._shm = self._slots = None
+            self.transport = "gloo"
 
     def __call__(self, ok):
         if self.group is None:
             return bool(ok)
-        self._flag[0] = 1 if ok else 0
-        dist.all_reduce(self._flag, op=dist.ReduceOp.MIN, group=self.group)
-        agreed = bool(int(self._flag[0]))
+        if self._slots is not None:
+            import time
+            self._calls += 1
+            n, me = self._calls, dist.get_rank()
+            # Slot of a rank (one 64 B cache line): word 0 = number of its latest call; words 1 / 2 = its verdicts of its latest odd / even call.
+            # The verdict is stored BEFORE the call number announces it (x86 keeps the order of stores and of loads).  A rank leaves call n
+            # only after it has seen EVERY rank's number reach n, so no rank can be more than one call ahead of the slowest one: while a slow
+            # rank still reads the verdicts of call n, a fast one may already have published call n + 1 — into the OTHER verdict word.
+            self._slots[me, 1 + (n & 1)] = 1 if ok else 0
+            self._slots[me, 0] = n
+            agreed, deadline, spins = True, None, 0
+            for r in range(dist.get_world_size()):
+                while int(self._slots[r, 0]) < n:
+                    spins += 1
+                    if spins & 0xFF == 0:
+                        now = time.monotonic()
+                        deadline = deadline or now + self.timeout_s
+                        if now > deadline:
+                            raise RuntimeError("ListsAgreement: rank %d did not vote on call %d within %.0f s (it failed before its vote, or hangs)" % (r, n, self.timeout_s))
+                        if spins > 1 << 16:
+                            time.sleep(0)   # long waits yield the core
+                agreed = agreed and bool(int(self._slots[r, 1 + (n & 1)]))
+        else:
+            self._flag[0] = 1 if ok else 0
+            dist.all_reduce(self._flag, op=dist.ReduceOp.MIN, group=self.group)
+            agreed = bool(int(self._flag[0]))
         if ok and not agreed:
             self.disagreements += 1
         return agreed
+
+    def close(self):
+        if self._shm is not None:
+            self._slots = None
+            try:
+                self._shm.close()
+                if dist.is_initialized() and dist.get_rank() == 0:
+                    self._shm.unlink()
+            except Exception:  # noqa: BLE001
+                pass
+            self._shm = None
+
+    def __del__(self):
+        self.close()
 
 
 def shard_cameras(cameras, rank, world):

@@ -12,6 +12,7 @@ radius_clip 0, tile 16, calc_compensations = antialiased, GLOBAL shutter, defaul
 """
 from dataclasses import dataclass, field
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -40,6 +41,14 @@ class IsectCapacityMiss(RuntimeError):
     with, so the kernels rendered it with EMPTY lists.  Raised from the render's backward BEFORE anything irreversible ran (the SH
     tensor's fused Adam step, a gradient exchange); the capacity hint has been raised: run the iteration again (trainer.Trainer and
     bench.py do)."""
+
+
+def _policy_key(width, height, device_index, n_gaussians):
+    """Key of the list-granularity / record-layout statistics: image shape, device and a COARSE size class of the model (its bit length:
+    a model growing by 5 % every hundred iterations keeps its key — it changes at doublings only — while two models of very different
+    size rendered at one resolution in the same process, e.g. training and the evaluation of another model, no longer steer each
+    other's choices: ADVICE r04)."""
+    return (width, height, device_index, int(n_gaussians).bit_length())
 
 
 def _list_tile_for(key):
@@ -325,8 +334,10 @@ def rasterize(camera: Camera, model: SplatData, bg_color: Optional[torch.Tensor]
 # Gradients can be written straight into caller-provided buffers (`grad_sinks`, e.g. the views of a flat
 # all-reduce bucket): no zero fill and no AccumulateGrad add pass over the 192 MB SH gradient.
 # ---------------------------------------------------------------------------------------------------------
+_TLS = threading.local()   # the guarded-lists handle of the render this THREAD just ran: forward() -> rasterize_fused (a handle is not a tensor output)
+
+
 class GutRenderFunction(torch.autograd.Function):
-    last_lists = None
 
     @staticmethod
     def forward(ctx, means, sh, scaling_raw, rotation_raw, opacity_raw, viewmat, K, bg, width, height, sh_degree, scaling_modifier,
@@ -340,7 +351,7 @@ class GutRenderFunction(torch.autograd.Function):
             # (same values as the separate launches below; an undefined workspace = camera / SH layout not supported)
             # frames of large footprints (lists per 32 x 32 pixels, or more than RANGES_ABOVE list entries per Gaussian: the previous frames' statistics) keep the
             # backward's moment records of a Gaussian in one contiguous run of slots instead of a chain (gsx_raster_common.hpp: "ranges")
-            ranges = camera_model == ops.CameraModelType.PINHOLE and _record_ranges_for((width, height, means_c.device.index))
+            ranges = camera_model == ops.CameraModelType.PINHOLE and _record_ranges_for(_policy_key(width, height, means_c.device.index, means_c.shape[0]))
             fe = ops.frontend_fused_render(sh_degree, means_c, sh_c, sr, rr, orw, viewmat, K, width, height, EPS2D, NEAR_PLANE, FAR_PLANE, RADIUS_CLIP,
                                            camera_model, ut, radial, tangential, None, ranges)
             if fe[8] is None:
@@ -361,7 +372,7 @@ class GutRenderFunction(torch.autograd.Function):
         # tile size of the intersection lists: 32-px lists only on the fast blend path (global-shutter pinhole) — see _LIST_TILE_STATE
         # (keyed by the image shape, not by the Gaussian count: a model that grows by 5 % every hundred iterations keeps its choice — with N in
         # the key every growth step fell back to 16-px lists for one heavy frame, on a capacity hint from the start of the training)
-        lt_key = (width, height, means_c.device.index)
+        lt_key = _policy_key(width, height, means_c.device.index, means_c.shape[0])
         # (and only with the fused front end: its records carry each Gaussian's rectangle of 16-px tiles, which a 16-px tile needs to take
         # exactly the reference's entries out of its 32-px parent's list)
         list_tile = _list_tile_for(lt_key) if (camera_model == ops.CameraModelType.PINHOLE and fe is not None) else TILE_SIZE
@@ -394,7 +405,7 @@ class GutRenderFunction(torch.autograd.Function):
         ctx.list_tile = list_tile
         ctx.lists = lists
         ctx.lt_update = (lt_key, list_tile, tw * th, means_c.shape[0])
-        GutRenderFunction.last_lists = lists   # picked up by rasterize_fused right after apply() (a handle is not a tensor output)
+        _TLS.last_lists = lists   # picked up by rasterize_fused right after apply()
         ctx.mark_non_differentiable(radii, means2d, depths, flatten_ids, isect_offsets)
         ctx.set_materialize_grads(False)  # no zero tensors for the outputs nobody differentiates (six fill launches per step)
         return renders, alphas, radii, means2d, depths, flatten_ids, isect_offsets
@@ -408,13 +419,21 @@ class GutRenderFunction(torch.autograd.Function):
         bg, width, height, sh_degree, scaling_modifier, camera_model, radial, tangential, sinks, ut = ctx.extra
         if v_renders is None:
             v_renders = torch.zeros(alphas.shape[:-1] + (3,), dtype=alphas.dtype, device=alphas.device)
-        v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_to_pixels_from_world_3dgs_bwd(
-            means, quats, scales, colors, opac2, bg, None, width, height, ctx.list_tile, viewmat, None, K, camera_model, ut,
-            ops.ShutterType.GLOBAL, radial, tangential, None, isect_offsets, flatten_ids, alphas, last_ids,
-            v_renders.contiguous(), None if v_alphas is None else v_alphas.contiguous(), fwd_ws=ctx.fwd_ws, lists=ctx.lists)
+        s = sinks or {}
+        try:
+            v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_to_pixels_from_world_3dgs_bwd(
+                means, quats, scales, colors, opac2, bg, None, width, height, ctx.list_tile, viewmat, None, K, camera_model, ut,
+                ops.ShutterType.GLOBAL, radial, tangential, None, isect_offsets, flatten_ids, alphas, last_ids,
+                v_renders.contiguous(), None if v_alphas is None else v_alphas.contiguous(), fwd_ws=ctx.fwd_ws, lists=ctx.lists)
+        except Exception:
+            # N ranks: the peers are (or will be) waiting for this rank's verdict on the frame's lists — a rank that fails before it votes must
+            # still vote, or they wait for the agreement's timeout (distributed.ListsAgreement)
+            if ctx.lists is not None and s.get("_lists_agree") is not None and not getattr(ctx, "lists_checked", False):
+                ctx.lists_checked = True
+                s["_lists_agree"](False)
+            raise
         if scaling_modifier != 1.0:
             v_scales = v_scales * scaling_modifier
-        s = sinks or {}
         # scaling / rotation / opacity gradients only need the blend backward: they are finished first, so that a multi-GPU caller can
         # start exchanging them ("_early_ready" callback) while the SH backward — 81 % of the gradient bytes — is still running
         # "_regularisers" = (scale_reg / numel, opacity_reg / numel): the MCMC strategy's two regulariser gradients ride on this kernel
@@ -473,11 +492,12 @@ def rasterize_fused(camera: Camera, model: SplatData, bg_color: Optional[torch.T
     cam_model = camera.camera_model if camera.camera_model is not None else ops.CameraModelType.PINHOLE
     bg = bg_color.reshape(1, -1).to(model.means.device).contiguous() if (bg_color is not None and bg_color.numel() > 0) else None
     radial, tangential = _distortion_args(camera, cam_model, model.means.device)
+    _TLS.last_lists = None   # (a forward that raises leaves nothing stale behind)
     renders, alphas, radii, means2d, depths, flatten_ids, isect_offsets = GutRenderFunction.apply(
         model.means, model.sh, model.scaling_raw, model.rotation_raw, model.opacity_raw, viewmat, K, bg, W, H, sh_degree,
         scaling_modifier, cam_model, radial, tangential, grad_sinks, guarded)
     out = RenderOutput()
-    out.lists, GutRenderFunction.last_lists = GutRenderFunction.last_lists, None
+    out.lists, _TLS.last_lists = getattr(_TLS, "last_lists", None), None
     out.render_hwc = renders  # [1,H,W,3] unclamped: what loss.photometric_loss consumes; out.image is derived on first access
     out.alpha = alphas.squeeze(0).permute(2, 0, 1)
     out.means2d, out.depths = means2d, depths.squeeze(0)

@@ -148,7 +148,9 @@ class Trainer:
             for it in range(start, start + n):
                 loss = self.train_step(it)
                 if log_every and it % log_every == 0 and self.rank == 0:
-                    print(f"iter {it}: loss {float(loss):.5f}  gaussians {self.model.means.shape[0]}")
+                    done = it - start + 1
+                    print(f"iter {it}: loss {float(loss):.5f}  gaussians {self.model.means.shape[0]}  repeated iterations (list capacity misses) "
+                          f"{self.capacity_misses} = {1e3 * self.capacity_misses / done:.2f} per 1000")
         finally:
             gc.unfreeze()
         return self.last_loss

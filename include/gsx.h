@@ -32,8 +32,10 @@ extern "C" {
  *   4  additions only: the guarded list protocol (no host read of n_isects on the render path): gsx_intersect_bin_count_guarded,
  *      gsx_rasterize_to_pixels_from_world_3dgs_{fwd,bwd}_guarded.
  *   5  gsx_intersect_bin_count(_guarded) store all ones into the pinned host word before they launch anything, and its high half is what the
- *      device writes last: the word can be POLLED by the host (no event in the stream); gsx_frontend_fused accepts NULL conics and takes `record_ranges`; gsx_splat_activations_bwd_reg added. */
-#define GSX_ABI_VERSION 5
+ *      device writes last: the word can be POLLED by the host (no event in the stream); gsx_frontend_fused accepts NULL conics and takes `record_ranges`; gsx_splat_activations_bwd_reg added.
+ *   6  gsx_rasterize_to_pixels_from_world_3dgs_bwd_guarded gained the positional `n_isects_expected` argument its forward twin already had: both
+ *      choose their kernel variants from the same estimate (round 4's backward saw the capacity — 25 % above it — on guarded lists). */
+#define GSX_ABI_VERSION 6
 
 typedef enum gsx_status {
     GSX_OK = 0,
@@ -269,7 +271,8 @@ int gsx_intersect_bin_count_guarded(uint32_t C, uint32_t N, const float* means2d
                                     int64_t max_segment, int32_t* lists_status, void* stream);
 /* gsx_rasterize_to_pixels_from_world_3dgs_{fwd,bwd}_packed on guarded lists: `n_isects` = capacity of flatten_ids (the backward's workspace
  * is sized by it), `lists_status` = the device word above (NULL = `n_isects` is exact: identical to the _packed entry points),
- * `n_isects_expected` = the caller's estimate of the total for launch decisions (which forward kernel; 0 = use the capacity). */
+ * `n_isects_expected` = the caller's estimate of the total for launch decisions (which forward kernel, how many record chains per Gaussian in
+ * the backward; 0 = use the capacity). */
 int gsx_rasterize_to_pixels_from_world_3dgs_fwd_guarded(uint32_t N, int64_t n_isects, const float* means,
                                                         const float* quats, const float* scales, const float* colors,
                                                         uint32_t channels, const float* opacities, const float* backgrounds,
@@ -289,7 +292,8 @@ int gsx_rasterize_to_pixels_from_world_3dgs_bwd_guarded(uint32_t N, int64_t n_is
                                                         const float* v_render_colors, const float* v_render_alphas,
                                                         float* v_means, float* v_quats, float* v_scales, float* v_colors,
                                                         float* v_opacities, void* workspace, size_t workspace_bytes,
-                                                        const void* packed_records, const int32_t* lists_status, void* stream);
+                                                        const void* packed_records, const int32_t* lists_status,
+                                                        int64_t n_isects_expected, void* stream);
 
 /* Ranked variant of the fill for frames with heavy tiles (same outputs, bit for bit; same reference interface).  The Gaussians of
  * the frame are ranked once by (depth bits, flatten index) — gsx_intersect_depth_ranks: ranks[c*N + n] = position in that order,

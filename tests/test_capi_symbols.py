@@ -18,7 +18,7 @@ def test_libgsx_exports_every_declared_symbol():
     assert len(names) >= 12
     for n in names:
         assert hasattr(lib, n), "libgsx.so does not export " + n
-    assert lib.gsx_abi_version() == 5   # include/gsx.h GSX_ABI_VERSION (history in the header)
+    assert lib.gsx_abi_version() == 6   # include/gsx.h GSX_ABI_VERSION (history in the header)
     lib.gsx_last_error.restype = ctypes.c_char_p
     assert isinstance(lib.gsx_last_error(), bytes)
 
@@ -52,7 +52,7 @@ def test_guarded_entry_points_validate_their_arguments_without_gpu():
     assert rc == -1
     rc = lib.gsx_rasterize_to_pixels_from_world_3dgs_bwd_guarded(c.c_uint32(4), c.c_int64(8), None, None, None, None, c.c_uint32(3), None, None, None, c.c_uint32(16),
                                                                  c.c_uint32(16), c.c_uint32(16), None, None, None, None, None, None, None, None, None, None, None,
-                                                                 None, None, None, c.c_size_t(0), None, None, None)
+                                                                 None, None, None, c.c_size_t(0), None, None, c.c_int64(0), None)
     assert rc == -1
 
 
