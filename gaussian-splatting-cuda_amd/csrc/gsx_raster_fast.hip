@@ -1296,21 +1296,41 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
         }
         __syncthreads();
 
-        // one thread per touched Gaussian of the super-chunk: 64 B moment record at its sorted index, chained per Gaussian
+        // the touched Gaussians of the super-chunk leave as 64 B moment records (at their sorted index / in their Gaussian's run, chained per
+        // Gaussian): one thread per record, four 16 B nontemporal stores.  The four quarters of a line reach HBM separately (WRITE_SIZE 436 MB
+        // for 215 MB of records at S-1M, profiles/r04_pmc_counters.md).  GSX_GQ_REC_4LANE (round 5, measured and not the default): four lanes
+        // per record, one quarter each, so that a wave instruction stores 16 whole lines — same-box A/B of the op 0.551 -> 0.568 ms (+3 %):
+        // the stores are not what the kernel waits for, the extra LDS reads / shuffles and 8 more VGPRs are paid on its critical path.
+#ifdef GSX_GQ_REC_4LANE
+        for (int32_t base = 0; base < chunk_size; base += RB / 4) {
+            const int32_t r = base + (int32_t)(tid >> 2);
+            const uint32_t q = tid & 3u;
+            const bool touched = r < chunk_size && s_acc[15][r & (GS - 1)] > 0.f;
+            int32_t prev = -1, isect = 0;
+            if (touched && q == 0u) isect = claim_record_slot(a, ws_head, ranges, s_gid[r], chunk_end - r, tile_x, tile_y, prev);
+            isect = __shfl(isect, (int)(lane & ~3u));   // the quad's first lane claimed the slot
+            prev = __shfl(prev, (int)(lane & ~3u));
+            if (touched && (int64_t)isect < a.rec_capacity) {   // (always, by construction: a run never exceeds the Gaussian's tile rectangle)
+                const float w3 = s_acc[4 * q + 3][r];            // (plane 15 is the pass counter: the record's last word is the chain link)
+                // nontemporal: 64 B written once at a scattered slot and read once by the gather kernel — as ordinary stores the records
+                // push the kernel's own working set (lists, packed records, pixel inputs) out of L2: S-1M 0.573 -> 0.526 ms, S-5M @4K 2.17 ->
+                // 2.03, garden stand-in 1.28 -> 1.20 (same-box A/B; nontemporal LOADS in the gather measured flat)
+                nt_store4(make_float4(s_acc[4 * q][r], s_acc[4 * q + 1][r], s_acc[4 * q + 2][r], q == 3u ? __int_as_float(prev) : w3), ws_rec + (size_t)isect * 4 + q);
+            }
+        }
+#else
         if ((int32_t)tid < chunk_size && s_acc[15][tid] > 0.f) {
             int32_t prev;
             const int32_t isect = claim_record_slot(a, ws_head, ranges, s_gid[tid], chunk_end - (int32_t)tid, tile_x, tile_y, prev);
             float4* rec = ws_rec + (size_t)isect * 4;
-            if ((int64_t)isect < a.rec_capacity) {   // (always, by construction: a run never exceeds the Gaussian's tile rectangle)
-            // nontemporal: 64 B written once at a scattered slot and read once by the gather kernel — as ordinary stores the records
-            // push the kernel's own working set (lists, packed records, pixel inputs) out of L2: S-1M 0.573 -> 0.526 ms, S-5M @4K 2.17 ->
-            // 2.03, garden stand-in 1.28 -> 1.20 (same-box A/B; nontemporal LOADS in the gather measured flat)
-            nt_store4(make_float4(s_acc[0][tid], s_acc[1][tid], s_acc[2][tid], s_acc[3][tid]), rec);
-            nt_store4(make_float4(s_acc[4][tid], s_acc[5][tid], s_acc[6][tid], s_acc[7][tid]), rec + 1);
-            nt_store4(make_float4(s_acc[8][tid], s_acc[9][tid], s_acc[10][tid], s_acc[11][tid]), rec + 2);
-            nt_store4(make_float4(s_acc[12][tid], s_acc[13][tid], s_acc[14][tid], __int_as_float(prev)), rec + 3);
+            if ((int64_t)isect < a.rec_capacity) {
+                nt_store4(make_float4(s_acc[0][tid], s_acc[1][tid], s_acc[2][tid], s_acc[3][tid]), rec);
+                nt_store4(make_float4(s_acc[4][tid], s_acc[5][tid], s_acc[6][tid], s_acc[7][tid]), rec + 1);
+                nt_store4(make_float4(s_acc[8][tid], s_acc[9][tid], s_acc[10][tid], s_acc[11][tid]), rec + 2);
+                nt_store4(make_float4(s_acc[12][tid], s_acc[13][tid], s_acc[14][tid], __int_as_float(prev)), rec + 3);
             }
         }
+#endif
     }
 }
 
