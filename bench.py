@@ -205,6 +205,10 @@ def load_pmc(workload_key):
 
 
 VALU_PEAK_LANE_OPS = 78.6e12  # fp32 vector lane-operations / s: 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz (157.3 TFLOP/s / 2)
+# what a stream of plain (non-packed) wave64 fp32 instructions really issues on this part: one per 2.25 cycles per SIMD at the 2.15 GHz the
+# chip sustains under it — in-kernel s_memtime / s_memrealtime, tools/valu_clock_probe.hip, profiles/r05_valu_issue.md (the blend kernels,
+# whose mix holds quarter-rate and DPP instructions, clock at 1.94 - 1.99 GHz)
+VALU_PEAK_MEASURED_LANE_OPS = 64.0 / 2.25 * 1024 * 2.15e9
 
 
 def self_launch_command(n, argv, port=None):
@@ -573,6 +577,12 @@ def main():
                     "frac": kernels[dom]["frac_hbm"], "traffic": pm.get("hbm_bytes"),
                     "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"], "avg_launch_ms": kernels[dom]["ms"],
                     "traffic_source": (pmc.get("source") if pm.get("hbm_bytes") else pmc.get("stale"))}
+        if pm.get("hbm_bytes") and pmc.get("n_isects"):
+            # the counters were collected on ONE frame (the cfg2 camera); the timed steps average other cameras: like for like = the algorithmic
+            # bytes of the counters' own frame
+            ab_pm = algorithmic_bytes(N, 1, pmc["n_isects"], P, tiles, deg, K)[dom]
+            roofline["traffic_n_isects"] = pmc["n_isects"]
+            roofline["traffic_over_algorithmic_same_frame"] = round(pm["hbm_bytes"] / ab_pm, 3)
         workload = {"1m": "S-1M (BASELINE configs[1]): 1M random Gaussians, SH deg 3, 1920x1080, one camera per GPU per iteration",
                     "5m": "S-5M (BASELINE configs[4]): 5M random Gaussians, SH deg 3, 3840x2160, one camera per GPU per iteration",
                     "small": "S-small (BASELINE configs[0]): 10k Gaussians, SH deg 0, 256x256"}[args.scene]
@@ -625,9 +635,12 @@ def main():
             if c:
                 lane_ops = c * 64.0 / (all_ms[n] * 1e-3)
                 valu[n] = {"bound": "valu", "achieved": round(lane_ops / 1e12, 2), "peak": round(VALU_PEAK_LANE_OPS / 1e12, 1),
-                           "unit": "T lane-op/s", "frac": round(lane_ops / VALU_PEAK_LANE_OPS, 4), "valu_insts_per_launch": c}
+                           "unit": "T lane-op/s", "frac": round(lane_ops / VALU_PEAK_LANE_OPS, 4), "valu_insts_per_launch": c,
+                           "peak_measured": round(VALU_PEAK_MEASURED_LANE_OPS / 1e12, 1), "frac_of_peak_measured": round(lane_ops / VALU_PEAK_MEASURED_LANE_OPS, 4)}
         if valu:
-            result["roofline_valu"] = dict(valu, source=pmc.get("source"))
+            result["roofline_valu"] = dict(valu, source=pmc.get("source"), peak_is="data sheet: 32 lanes/clk/SIMD at 2.4 GHz",
+                                           peak_measured_is="a plain wave64 fp32 stream on this part: 64 lanes per 2.25 cycles per SIMD at the 2.15 GHz sustained "
+                                                            "under it (in-kernel shader clock, profiles/r05_valu_issue.md)")
         if exchange_variants is not None:
             result["grad_exchange_variants"] = exchange_variants
         if mcmc_refine_ms is not None:

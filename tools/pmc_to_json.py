@@ -37,6 +37,9 @@ def main():
     entry = {
         "source": source,
         "blend_kernel_hash": gbuild.blend_kernel_hash(),   # bench.py reports these figures only while the blend sources still hash to this
+        # tile intersections of the frame the counters were collected on (tools/run_fwd_bwd.py renders the scene's own camera): bench.py prices
+        # the counter traffic against the algorithmic bytes AT THIS COUNT, not at the mean of its timed steps' other cameras
+        "n_isects": int(sys.argv[4]) if len(sys.argv) > 4 else None,
         "rasterize_to_pixels_from_world_3dgs_fwd": {"hbm_bytes": traffic(pack) + traffic(fwd), "valu_insts": int(fwd["SQ_INSTS_VALU"]),
                                                     "kernels": ("pack_records + " + fwd_name if pack else fwd_name + " (records packed by the fused front end)")},
         "rasterize_to_pixels_from_world_3dgs_bwd": {"hbm_bytes": traffic(bwd) + traffic(gather), "valu_insts": int(bwd["SQ_INSTS_VALU"]),

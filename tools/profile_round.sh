@@ -33,7 +33,7 @@ if [ -z "$SKIP_PMC" ]; then   # SKIP_PMC=1 only when the blend sources still has
   tail -3 "$out/pmc.log"
   # counter-derived figures of the blend ops, stamped with the hash of the blend sources they were measured on (bench.py drops them
   # as "stale" once the sources change); written to profiles/pmc.json on this box -> copied to $out/pmc.json for the merge back
-  python tools/pmc_to_json.py "$out/pmc/summary.txt" s1m_1080p "profiles/${tag}_pmc_counters.md (rocprofv3 --pmc, separate passes, tools/pmc_passes.sh; bench step with the cfg2 camera)" > "$out/pmc_entry.json" && cp profiles/pmc.json "$out/pmc.json"
+  python tools/pmc_to_json.py "$out/pmc/summary.txt" s1m_1080p "profiles/${tag}_pmc_counters.md (rocprofv3 --pmc, separate passes, tools/pmc_passes.sh; bench step with the cfg2 camera)" 3360791 > "$out/pmc_entry.json" && cp profiles/pmc.json "$out/pmc.json"
 fi
 python bench.py --scene 5m --steps 10 --warmup 3 --no-cpu-baseline > "$out/bench_s5m.json" 2> "$out/bench_s5m.err"
 echo "bench 5m rc=$?"
