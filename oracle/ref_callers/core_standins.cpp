@@ -12,42 +12,35 @@ using torch::indexing::None;
 using torch::indexing::Slice;
 
 namespace gs {
-    // src/core/camera.cpp:15-23
-    static torch::Tensor world_to_view(const torch::Tensor& R, const torch::Tensor& t) {
-        torch::Tensor w2c = torch::eye(4, torch::TensorOptions().dtype(torch::kFloat32).device(R.device()));
-        w2c.index_put_({Slice(0, 3), Slice(0, 3)}, R);
-        w2c.index_put_({Slice(0, 3), 3}, t);
-        return w2c.to(torch::TensorOptions().dtype(torch::kFloat32).device(torch::kCUDA)).unsqueeze(0).contiguous();
+    // [R | t; 0 0 0 1] as a [1,4,4] float32 tensor on the GPU: what src/core/camera.cpp:15-23 builds with index_put_
+    static torch::Tensor rigid_w2c(const torch::Tensor& R, const torch::Tensor& t) {
+        const auto f32 = torch::TensorOptions().dtype(torch::kFloat32).device(R.device());
+        const auto upper = torch::cat({R.to(f32), t.to(f32).reshape({3, 1})}, 1);
+        const auto last_row = torch::tensor({0.f, 0.f, 0.f, 1.f}, f32).reshape({1, 4});
+        return torch::cat({upper, last_row}, 0).to(torch::kCUDA).unsqueeze(0).contiguous();
     }
 
-    // src/core/camera.cpp:25-58
+    // the members src/core/camera.cpp:25-58 initialises (declaration order of include/core/camera.hpp), image size = camera size
     Camera::Camera(const torch::Tensor& R, const torch::Tensor& T, float focal_x, float focal_y, float center_x, float center_y,
                    const torch::Tensor radial_distortion, const torch::Tensor tangential_distortion, gsplat::CameraModelType camera_model_type,
                    const std::string& image_name, const std::filesystem::path& image_path, int camera_width, int camera_height, int uid)
         : _uid(uid), _focal_x(focal_x), _focal_y(focal_y), _center_x(center_x), _center_y(center_y), _R(R), _T(T),
           _radial_distortion(radial_distortion), _tangential_distortion(tangential_distortion), _camera_model_type(camera_model_type),
           _image_name(image_name), _image_path(image_path), _camera_width(camera_width), _camera_height(camera_height),
-          _image_width(camera_width), _image_height(camera_height), _world_view_transform{world_to_view(R, T)} {
-        auto c2w = torch::inverse(_world_view_transform.squeeze());
-        _cam_position = c2w.index({Slice(None, 3), 3}).contiguous().squeeze();
+          _image_width(camera_width), _image_height(camera_height), _world_view_transform{rigid_w2c(R, T)} {
+        _cam_position = torch::inverse(_world_view_transform[0]).index({Slice(None, 3), 3}).contiguous();
         _FoVx = focal2fov(_focal_x, _camera_width);
         _FoVy = focal2fov(_focal_y, _camera_height);
     }
 
-    // src/core/camera.cpp:82-103
-    torch::Tensor Camera::K() const {
-        const auto K = torch::zeros({1, 3, 3}, _world_view_transform.options());
-        auto [fx, fy, cx, cy] = get_intrinsics();
-        K[0][0][0] = fx;
-        K[0][1][1] = fy;
-        K[0][0][2] = cx;
-        K[0][1][2] = cy;
-        K[0][2][2] = 1.0f;
-        return K;
-    }
+    // [1,3,3] intrinsics of the (possibly resized) image on the view matrix's device — the values of src/core/camera.cpp:82-103
     std::tuple<float, float, float, float> Camera::get_intrinsics() const {
-        const float xs = float(_image_width) / float(_camera_width), ys = float(_image_height) / float(_camera_height);
-        return std::make_tuple(_focal_x * xs, _focal_y * ys, _center_x * xs, _center_y * ys);
+        const float sx = float(_image_width) / float(_camera_width), sy = float(_image_height) / float(_camera_height);
+        return {_focal_x * sx, _focal_y * sy, _center_x * sx, _center_y * sy};
+    }
+    torch::Tensor Camera::K() const {
+        const auto [fx, fy, cx, cy] = get_intrinsics();
+        return torch::tensor({fx, 0.f, cx, 0.f, fy, cy, 0.f, 0.f, 1.f}, torch::kFloat32).reshape({1, 3, 3}).to(_world_view_transform.device());
     }
 
     // src/core/splat_data.cpp:202-218

@@ -203,3 +203,72 @@ def test_bench_single_rank_group_over_rccl(extra):
     if not extra:
         v = d["grad_exchange_variants"]
         assert v["colour"]["ms_per_step"] > 0 and v["dense"]["ms_per_step"] > 0
+
+
+def test_camera_batch_accumulator_equals_mean_of_single_camera_steps():
+    """BASELINE configs[3] on ONE GPU (bench.py `cameras_per_step_1gpu`): C renders + losses + backwards through
+    distributed.CameraBatchAccumulator — colour gradients parked per camera, ONE SH backward over the C cameras — leave the mean over the
+    cameras of the gradients C separate single-camera steps produce; with the SH tensor's Adam step fused into that SH backward the
+    parameters after one iteration equal those of the unfused iteration (gradient written, all six groups stepped by the optimizer)."""
+    import gsx  # noqa: F401
+    from gsx import distributed as gdist
+    from gsx import loss as gloss
+    from gsx import optim, rasterizer, scenes
+    dev = "cuda:0"
+    sc = scenes.scene_small(seed=3, N=6000)
+    sc["sh"] = (torch.rand(6000, 16, 3, generator=torch.Generator().manual_seed(9)) - 0.5) * 0.3
+    sc["sh_degree"] = 3
+    W, H = sc["width"], sc["height"]
+    views = [scenes.look_at_viewmat((0.3 * k - 0.3, 0.1 * k, -0.2 * k), (0.0, 0.0, 2.5)) for k in range(3)]
+    cams = [rasterizer.Camera(viewmat=v.to(dev), K=sc["K"].to(dev), width=W, height=H) for v in views]
+    targets = [torch.rand(3, H, W, generator=torch.Generator().manual_seed(20 + k)).to(dev) for k in range(3)]
+    bg = sc["background"].to(dev)
+    names = ["sh", "means", "scaling_raw", "rotation_raw", "opacity_raw"]
+
+    def fresh():
+        m = scenes.to_splat_data(sc, dev)
+        for p in m.params():
+            p.requires_grad_(True)
+        b = gdist.GradBucket([getattr(m, n) for n in names])
+        return m, b, b.sinks(tuple(names))
+
+    # reference: C separate single-camera backwards, gradients averaged
+    m0, b0, s0 = fresh()
+    mean = torch.zeros_like(b0.flat)
+    for cam, tgt in zip(cams, targets):
+        out = rasterizer.rasterize_fused(cam, m0, bg, grad_sinks=s0)
+        gloss.backward(gloss.photometric_loss(out.render_hwc, tgt, 0.2))
+        mean += b0.flat
+    mean /= len(cams)
+    # the accumulator, SH gradient written (no fused Adam)
+    m1, b1, s1 = fresh()
+    acc = gdist.CameraBatchAccumulator(b1, names, cameras=len(cams))
+    s1["_color_exchange"] = acc
+    acc.begin_step(torch.stack([c.viewmat for c in cams]))
+    for cam, tgt in zip(cams, targets):
+        out = rasterizer.rasterize_fused(cam, m1, bg, grad_sinks=s1)
+        gloss.backward(gloss.photometric_loss(out.render_hwc, tgt, 0.2))
+    acc.finish()
+    for n, p in zip(names, b1.params):
+        o = b1.offsets[names.index(n)]
+        ref = mean[o:o + p.numel()]
+        rel = float((p.grad.reshape(-1) - ref).norm() / ref.norm().clamp_min(1e-30))
+        assert rel < 2e-5, (n, rel)
+    # one optimizer step either way: fused SH Adam inside the batched SH backward == gradient written + separate SH step
+    opt1 = optim.FusedAdam.for_splat_data(m1)
+    opt1.step(1500)
+    m2, b2, s2 = fresh()
+    opt2 = optim.FusedAdam.for_splat_data(m2)
+    acc2 = gdist.CameraBatchAccumulator(b2, names, cameras=len(cams))
+    s2["_color_exchange"] = acc2
+    acc2.begin_step(torch.stack([c.viewmat for c in cams]))
+    s2["_sh_adam"] = opt2.begin_fused_sh_step(1500)
+    assert s2["_sh_adam"] is not None
+    for cam, tgt in zip(cams, targets):
+        out = rasterizer.rasterize_fused(cam, m2, bg, grad_sinks=s2)
+        gloss.backward(gloss.photometric_loss(out.render_hwc, tgt, 0.2))
+    acc2.finish()
+    opt2.step(1500, skip_sh=True)
+    for p1, p2, n in zip(m1.params(), m2.params(), ["means", "sh", "scaling_raw", "rotation_raw", "opacity_raw"]):
+        d = float((p1.detach() - p2.detach()).abs().max())
+        assert d < 2e-6, (n, d)
