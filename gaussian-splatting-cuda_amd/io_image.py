@@ -66,7 +66,7 @@ def load_image(path, res_div=1, max_width=0):
     im = im.convert("RGB")  # drops alpha, expands grey (+alpha) to RGB
     w, h = im.size
     nw, nh = target_size(w, h, res_div, max_width)
-    a = np.ascontiguousarray(np.asarray(im, dtype=np.uint8))
+    a = np.array(im, dtype=np.uint8)   # (a writable copy: torch.from_numpy refuses to promise anything about PIL's read-only buffer)
     if (nw, nh) != (w, h):
         a = resample_oiio(a, nw, nh)
     return a
