@@ -235,12 +235,14 @@ def _worker_xch(rank, world, port, out_dir, sh_first):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sh_first", [False, True])
-def test_color_grad_exchange_equals_dense_all_reduce(tmp_path, sh_first):
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("sh_first,world", [(False, 2), (True, 2), (True, 8)])
+def test_color_grad_exchange_equals_dense_all_reduce(tmp_path, sh_first, world):
+    """world = 8: the node `north_star` names (one camera per rank on 8 GPUs), over gloo on the CPU."""
+    port = _free_port()
     mp.spawn(_worker_xch, args=(world, port, str(tmp_path), sh_first), nprocs=world, join=True)
-    b0, b1 = np.load(tmp_path / "xch_0.npy"), np.load(tmp_path / "xch_1.npy")
-    assert np.array_equal(b0, b1)   # bit-identical replicas: same gathered bits, same camera order
+    b0, b1 = np.load(tmp_path / "xch_0.npy"), np.load(tmp_path / ("xch_%d.npy" % (world - 1)))
+    for r in range(1, world):
+        assert np.array_equal(b0, np.load(tmp_path / ("xch_%d.npy" % r)))   # bit-identical replicas: same gathered bits, same camera order
     # expectation: every rank's own full gradient (local SH backward of its camera, clamp mask applied), averaged
     exp = None
     for r in range(world):
@@ -313,17 +315,22 @@ def _agree_worker(rank, world, port, out_dir):
         sh.step(1, gdist.GradBucket([p]))
     except RuntimeError as e:
         refused = "re-indexed" in str(e)
-    np.save(os.path.join(out_dir, "agree_%d.npy" % rank), np.array(got + [refused, agree.disagreements], dtype=np.int64))
+    np.save(os.path.join(out_dir, "agree_%d.npy" % rank), np.array(got + [refused, agree.disagreements, agree.transport == "shm"], dtype=np.int64))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_lists_agreement_and_reindex_guard(tmp_path):
-    """distributed.ListsAgreement: the guarded intersection lists of an N-rank step are repeated on EVERY rank when ANY rank overflowed (a MIN
-    all-reduce of one int on the host); ShardedAdam refuses a re-indexed optimizer state whose moments were not merged first."""
-    world = 2
+@pytest.mark.parametrize("world,transport", [(2, "shm"), (2, "gloo"), (8, "shm")])
+def test_lists_agreement_and_reindex_guard(tmp_path, monkeypatch, world, transport):
+    """distributed.ListsAgreement: the guarded intersection lists of an N-rank step are repeated on EVERY rank when ANY rank overflowed (the
+    verdicts meet in a shared-memory page, or in a MIN all-reduce over gloo); ShardedAdam refuses a re-indexed optimizer state whose moments
+    were not merged first."""
+    monkeypatch.setenv("GSX_AGREE", transport)
     mp.spawn(_agree_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     a, b = np.load(tmp_path / "agree_0.npy"), np.load(tmp_path / "agree_1.npy")
+    assert int(a[5]) == (1 if transport == "shm" else 0)   # the transport that was asked for ran
+    for r in range(2, world):
+        assert np.load(tmp_path / ("agree_%d.npy" % r))[:3].tolist() == [1, 0, 1]
     assert a[:3].tolist() == [1, 0, 1] and b[:3].tolist() == [1, 0, 1]   # both ranks repeat iteration 2
     assert a[3] == 1 and b[3] == 1                                       # the guard fired on both
     assert a[4] == 1 and b[4] == 0                                       # rank 0 repeated because of the OTHER rank
