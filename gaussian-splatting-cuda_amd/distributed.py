@@ -522,19 +522,25 @@ class ListsAgreement:
         world, rank = dist.get_world_size(), dist.get_rank()
         if os.environ.get("GSX_AGREE", "shm") != "shm":
             return
-        try:
-            from multiprocessing import shared_memory
-            import numpy as np
-            hosts = [None] * world
-            dist.all_gather_object(hosts, socket.gethostname(), group=self.group)
-            same_host = all(h == hosts[0] for h in hosts)
-            name = [None]
-            if rank == 0 and same_host:
+        # Every collective below is executed by EVERY rank whatever happens locally (a rank that cannot create or map the page reports it and all
+        # ranks fall back to gloo together): an exception on one rank must not leave its peers waiting in a collective it skipped.
+        from multiprocessing import shared_memory
+        import numpy as np
+        hosts = [None] * world
+        dist.all_gather_object(hosts, socket.gethostname(), group=self.group)
+        same_host = all(h == hosts[0] for h in hosts)
+        name = [None]
+        if rank == 0 and same_host:
+            try:
                 self._shm = shared_memory.SharedMemory(create=True, size=64 * world)   # one cache line per rank
                 self._shm.buf[:64 * world] = bytes(64 * world)
                 name[0] = self._shm.name
-            dist.broadcast_object_list(name, src=0, group=self.group)
-            if name[0] is not None:
+            except Exception:  # noqa: BLE001  (no /dev/shm, a sandbox without shared memory ...)
+                self._shm, name[0] = None, None
+        dist.broadcast_object_list(name, src=0, group=self.group)
+        mapped = 0
+        if name[0] is not None:
+            try:
                 if rank != 0:
                     self._shm = shared_memory.SharedMemory(name=name[0])
                     try:   # the segment belongs to rank 0: this process's resource tracker must not unlink it at exit
@@ -542,12 +548,17 @@ class ListsAgreement:
                         resource_tracker.unregister(self._shm._name, "shared_memory")
                     except Exception:  # noqa: BLE001
                         pass
-                self._slots = np.ndarray((world, 8), dtype=np.int64, buffer=self._shm.buf)   # [rank][0] = (call number << 1) | verdict
-                self.transport = "shm"
-            dist.barrier(group=self.group)   # every rank has mapped the page before rank 0 can go away
-        except Exception:  # noqa: BLE001  (no /dev/shm, a sandbox without shared memory ...: the gloo path stays)
-            self._shm = self._slots = None
-            self.transport = "gloo"
+                self._slots = np.ndarray((world, 8), dtype=np.int64, buffer=self._shm.buf)   # [rank][0] = call number, [1] / [2] = verdicts (see __call__)
+                mapped = 1
+            except Exception:  # noqa: BLE001
+                self._slots = None
+        flag = torch.tensor([mapped], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)   # every rank has mapped the page — or nobody uses it (also the barrier before rank 0 can go away)
+        if int(flag[0]) == 1:
+            self.transport = "shm"
+        else:
+            self._slots = None
+            self.close()
 
     def __call__(self, ok):
         if self.group is None:
@@ -571,8 +582,8 @@ class ListsAgreement:
                         deadline = deadline or now + self.timeout_s
                         if now > deadline:
                             raise RuntimeError("ListsAgreement: rank %d did not vote on call %d within %.0f s (it failed before its vote, or hangs)" % (r, n, self.timeout_s))
-                        if spins > 1 << 16:
-                            time.sleep(0)   # long waits yield the core
+                    if spins > 256:
+                        time.sleep(0)   # a peer that is ~100 us late may be waiting for a core (oversubscribed host): yield instead of spinning on
                 agreed = agreed and bool(int(self._slots[r, 1 + (n & 1)]))
         else:
             self._flag[0] = 1 if ok else 0
