@@ -996,11 +996,15 @@ template <bool CLAMP, bool ROWDV, bool FISH>
 GSX_DEV void gq_row(const GmLaneRec& g, const GmRowPix& px, const float (&du)[4], const float (&dv)[4], const float (&pw)[4], const float (&num2)[4],
                     const float (&rden)[4], float (&acc)[16], float (&T_out)[4], float (&tb_out)[4]) {
     float al[4], ra[4], P[4];
+    // (opaque copy: the clamped and the clamp-free instantiation of this function sit in the two arms of one branch, and hipcc otherwise hoists the
+    // four `idx <= last id` compares above it for the clamped arm AND recomputes them in the clamp-free one — 4 of a pass's 255 VALU)
+    int32_t idx = g.idx;
+    asm volatile("" : "+v"(idx));
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         float alpha = __builtin_amdgcn_exp2f(fmaf(-num2[h], rden[h], g.lo));
         if (CLAMP) alpha = fminf(0.999f, alpha);
-        const bool valid = (g.idx <= px.binf[h]) && (alpha >= ALPHA_MIN);
+        const bool valid = (idx <= px.binf[h]) && (alpha >= ALPHA_MIN);
         al[h] = valid ? alpha : 0.f;
         P[h] = ra[h] = __builtin_amdgcn_rcpf(1.f - al[h]);   // (round 5: the four reciprocals as one asm run of v_rcp_f32 — A/B 0.5421 -> 0.5449 ms, not kept)
     }
@@ -1218,6 +1222,8 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
 #pragma unroll 1
             for (uint32_t b0 = 0; b0 < n_list; b0 += 16) {
                 const bool have = b0 + pcol < n_list;
+                // (slot 0 for idle lanes, not the stale byte behind the list's end: an idle lane's alpha is 0, but its record still enters
+                // cv = colour . v_out and the additive scan — a stale slot beyond the staged records holds uninitialised LDS, NaN * 0 = NaN; tried in round 5)
                 const uint32_t slot = have ? (uint32_t)list[b0 + pcol] : 0u;
                 GmLaneRec g;
                 g.idx = chunk_end - (int32_t)slot;
@@ -1233,7 +1239,7 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
                     const float Ar = fmaf(dvr, fmaf(g.d5, dvr, g.d2), 1.f), Br = fmaf(g.d4, dvr, g.d1);
 #pragma unroll
                     for (int h = 0; h < 4; ++h) {
-                        du[h] = fmaf((float)h, su, du0); dv[h] = dvr;
+                        du[h] = h == 0 ? du0 : fmaf((float)h, su, du0); dv[h] = dvr;   // (h == 0 spelled out: hipcc emits fma(0, su, du0) otherwise)
                         const float t0 = fmaf(g.l00, du[h], t0r);
                         num2[h] = fmaf(t0, t0, t1sq);
                         rden[h] = __builtin_amdgcn_rcpf(fmaf(du[h], fmaf(g.d3, du[h], Br), Ar));
