@@ -103,7 +103,7 @@ def _to_np(d, keys):
     return {k: (d[k].cpu().numpy() if d[k] is not None else None) for k in keys if k in d}
 
 
-def _explain_pixels(sc, R, g_ren, g_last, tag):
+def _explain_pixels(sc, R, g_ren, g_last, tag, ocam):
     """Full frames: every pixel where the HIP blend and the REFERENCE KERNEL's frame differ by more than 1e-4 must carry a discrete
     decision that two correct fp32 evaluations can take differently — a different last Gaussian, or an alpha >= 1/255 / T <= 1e-4 test
     within a small relative window of its threshold in the reference-order evaluation of the same inputs (the oracle's per-pixel flag).
@@ -119,7 +119,7 @@ def _explain_pixels(sc, R, g_ren, g_last, tag):
     out = {}
     for window in (1e-3, 4e-3):
         _, _, _, frag = oracle.rasterize_fwd(f("means"), f("quats"), f("scales"), np32(R["colors"]), f("opacities")[None], f("background")[None], None, W, H, 16,
-                                             f("viewmat")[None], f("K")[None], R["tile_offsets"].cpu().numpy(), R["flatten_ids"].cpu().numpy(), frag_rel=window)
+                                             f("viewmat")[None], f("K")[None], R["tile_offsets"].cpu().numpy(), R["flatten_ids"].cpu().numpy(), frag_rel=window, **ocam)
         unexpl = over & ~((frag != 0) | last_differs)
         out["unexplained_w%g" % window] = int(unexpl.sum())
         out["unexplained_max_err_w%g" % window] = float(err[unexpl].max()) if unexpl.any() else 0.0
@@ -134,7 +134,7 @@ def _explain_pixels(sc, R, g_ren, g_last, tag):
         f64 = lambda k: np.ascontiguousarray(sc[k].numpy(), np.float64)  # noqa: E731
         r64 = oracle.rasterize_fwd(f64("means"), f64("quats"), f64("scales"), R["colors"].detach().cpu().numpy().astype(np.float64), f64("opacities")[None],
                                    f64("background")[None], None, W, H, 16, f64("viewmat")[None], f64("K")[None], R["tile_offsets"].cpu().numpy(),
-                                   R["flatten_ids"].cpu().numpy())[0]
+                                   R["flatten_ids"].cpu().numpy(), **ocam)[0]
         e_hip = np.abs(g_ren.astype(np.float64) - r64).max(-1)[unexpl]
         e_ref = np.abs(np32(R["renders"]).astype(np.float64) - r64).max(-1)[unexpl]
         out.update(unexplained_hip_vs_f64_max=float(e_hip.max()), unexplained_hip_vs_f64_mean=float(e_hip.mean()),
@@ -210,8 +210,11 @@ def _stagewise(ref, ops, sc, cam, tag, with_oracle=True, fwd_strict=True, over_f
     cmax = float(R["colors"][R["masks"]].max())   # (the reference leaves the colour rows of culled Gaussians unwritten: only visible ones count)
     r_ren, r_alp, r_last = np32(R["renders"]), np32(R["alphas"]), R["last_ids"].cpu().numpy()
     recs["fwd_hip"] = _fwd_stats(tag, "HIP", r_ren, r_alp, r_last, np32(G[0]), np32(G[1]), G[2].cpu().numpy(), cmax)
+    ocam_all = dict(camera_model=a["camera_model"], shutter=a["shutter"])   # the camera as the oracle takes it
+    for k in ("viewmats1", "radial", "tangential", "thin_prism"):
+        ocam_all[k] = None if cam.get(k) is None else np.asarray(cam[k], np.float32)
     if not fwd_strict:
-        recs["fwd_explained"] = _explain_pixels(sc, R, np32(G[0]), G[2].cpu().numpy(), tag)
+        recs["fwd_explained"] = _explain_pixels(sc, R, np32(G[0]), G[2].cpu().numpy(), tag, ocam_all)
     B = ops.rasterize_to_pixels_from_world_3dgs_bwd(*common, R["alphas"], R["last_ids"], v_rc, v_ra)
     recs["bwd_hip"] = parity_record("%s blend backward: HIP vs reference kernel (rel-L2)" % tag, **{n: rel_l2(np32(g), np32(R[n])) for n, g in zip(GRADS, B)})
     if with_oracle:
@@ -249,7 +252,7 @@ def _stagewise(ref, ops, sc, cam, tag, with_oracle=True, fwd_strict=True, over_f
         d64 = lambda t: t.detach().cpu().numpy().astype(np.float64)  # noqa: E731
         o64 = oracle.rasterize_bwd(f64("means"), f64("quats"), f64("scales"), d64(R["colors"]), f64("opacities")[None], f64("background")[None], None, W, H, 16,
                                    f64("viewmat")[None], f64("K")[None], R["tile_offsets"].cpu().numpy(), R["flatten_ids"].cpu().numpy(), d64(R["alphas"]),
-                                   R["last_ids"].cpu().numpy(), d64(v_rc), d64(v_ra))
+                                   R["last_ids"].cpu().numpy(), d64(v_rc), d64(v_ra), **ocam_all)
         hip64 = {n: rel_l2(np32(g).astype(np.float64), o) for n, g, o in zip(GRADS, B, o64)}
         ref64 = {n: rel_l2(np32(R[n]).astype(np.float64), o) for n, o in zip(GRADS, o64)}
         recs["bwd_f64"] = parity_record("%s blend backward: rel-L2 against the float64 evaluation of the same backward" % tag,
@@ -339,6 +342,21 @@ def test_s8cam_ring_cameras_vs_reference(ref, mods, s1m_scene, cam_i):
                         rgb_max_err=float(err.max()), rgb_pixels_over_1e4=int((err > 1e-4).sum()), rgb_pixels_over_1e3=int((err > 1e-3).sum()),
                         n_isects_hip=int(out.n_isects), n_isects_ref=int(R["flatten_ids"].numel()))
     assert rec["rgb_pixels_over_1e4"] <= 2e-3 * rec["pixels"] and rec["rgb_max_err"] < float(R["colors"][R["masks"]].max()) / 255.0 * 2 + 1e-3, rec
+
+
+@pytest.mark.parametrize("name", ["distorted_pinhole", "fisheye", "rolling_top_to_bottom"])
+def test_s1m_other_camera_models_vs_reference(ref, mods, s1m_scene, name):
+    """The BASELINE frame (S-1M, 1920 x 1080) through the camera models the small golden cases cover at 4 k Gaussians: an OpenCV-distorted pinhole and an equidistant
+    fisheye (both on the fast kernels: distorted charts, w-weighted moments) and a rolling shutter (the reference-order kernels), stage by stage against the
+    reference's kernels, full-frame tolerances."""
+    ops, scenes = mods
+    sc = dict(s1m_scene)
+    vm1 = scenes.look_at_viewmat((0.03, -0.02, 0.01), (0.02, 0.0, 6.0))[None].numpy()
+    cam = {"distorted_pinhole": dict(camera_model=ref_hip.PINHOLE, radial=np.array([[0.05, -0.02, 0.003, 0.0, 0.0, 0.0]], np.float32),
+                                     tangential=np.array([[0.002, -0.001]], np.float32), thin_prism=np.array([[0.001, 0.0, -0.001, 0.0]], np.float32)),
+           "fisheye": dict(camera_model=ref_hip.FISHEYE, radial=np.array([[0.02, -0.005, 0.001, 0.0]], np.float32)),
+           "rolling_top_to_bottom": dict(shutter=ref_hip.ROLLING_TOP_TO_BOTTOM, viewmats1=vm1)}[name]
+    _stagewise(ref, ops, sc, cam, "S-1M @1080p, %s" % name, with_oracle=False, fwd_strict=False, over_frac=6e-4, bwd_f64_yardstick=False)
 
 
 def test_s5m_4k_full_frame(ref, mods):
