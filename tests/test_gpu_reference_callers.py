@@ -6,7 +6,6 @@ else), the six parameter gradients within 1e-3 rel-L2, and the time per frame of
 gsx's own fused render (what a reference user gets on day one vs what the fused glue adds)."""
 import time
 
-import numpy as np
 import pytest
 import torch
 
