@@ -141,6 +141,7 @@ def test_fused_regularisers_equal_the_separate_ones():
     assert rel < 1e-5, rel
 
 
+@pytest.mark.gpu
 def test_train_colmap_example_end_to_end(tmp_path):
     """BASELINE configs[2] as a command (examples/train_colmap.py = the reference's `LichtFeld-Studio -d <capture> --images ... --iter ... --config ...`):
     a capture on disk — binary COLMAP sparse model + PNG images, written by the example's own synthetic-capture writer — goes through the COLMAP
