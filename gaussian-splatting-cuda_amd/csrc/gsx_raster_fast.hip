@@ -994,7 +994,7 @@ GSX_DEV void rows_reduce16(float (&x)[16], float (&z)[4]) {
 // d/dv0 (first-order a) and h (the b family's 1, du', dv') carry the matching powers of the pixel's w (as in raster_bwd_fast_kernel).
 template <bool CLAMP, bool ROWDV, bool FISH>
 GSX_DEV void gq_row(const GmLaneRec& g, const GmRowPix& px, const float (&du)[4], const float (&dv)[4], const float (&pw)[4], const float (&num2)[4],
-                    const float (&rden)[4], float (&acc)[16], float (&T_out)[4], float (&tb_out)[4]) {
+                    const float (&rden)[4], float su_, float su2, float (&acc)[16], float (&T_out)[4], float (&tb_out)[4]) {
     float al[4], ra[4], P[4];
     // (opaque copy: the clamped and the clamp-free instantiation of this function sit in the two arms of one branch, and hipcc otherwise hoists the
     // four `idx <= last id` compares above it for the clamped arm AND recomputes them in the clamp-free one — 4 of a pass's 255 VALU)
@@ -1018,11 +1018,14 @@ GSX_DEV void gq_row(const GmLaneRec& g, const GmRowPix& px, const float (&du)[4]
         S[h] = e[h] = cv[h] * fac[h];
     }
     row_scan4_add(S);
+    float awh[4], bwh[4];
+    (void)awh; (void)bwh;
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = 0.f;
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-        const float tbuf = (px.tb[h] + e[h]) - S[h];             // tail - v . (colour accumulated behind this Gaussian)
+        const float tbo = px.tb[h] - S[h];                       // what the NEXT Gaussian of the row starts from (S = inclusive sum of e over the row's lanes)
+        const float tbuf = tbo + e[h];                           // tail - v . (colour accumulated behind this Gaussian)
         const float v_alpha = fmaf(T[h], cv[h], ra[h] * tbuf);
         float av = al[h] * v_alpha;
         if (CLAMP) av = (al[h] < 0.999f) ? av : 0.f;             // clamped alpha carries no gradient (Bwd.cu:318)
@@ -1031,9 +1034,13 @@ GSX_DEV void gq_row(const GmLaneRec& g, const GmRowPix& px, const float (&du)[4]
         acc[0] = fmaf(fac[h], px.vr[h], acc[0]); acc[1] = fmaf(fac[h], px.vg[h], acc[1]); acc[2] = fmaf(fac[h], px.vb[h], acc[2]);
         acc[3] += av;
         if (ROWDV) {   // acc[6] / acc[8] / acc[11] collect sum aw, sum aw (again), sum bw here; the dv factors follow below
+#ifdef GSX_GQ_NO_HMOMENTS
             const float x7 = aw * du[h], x10 = bw * du[h];
             acc[4] = fmaf(x7, du[h], acc[4]); acc[7] += x7; acc[8] += aw;
             acc[9] += bw; acc[10] += x10; acc[12] = fmaf(x10, du[h], acc[12]);
+#else
+            awh[h] = aw; bwh[h] = bw;   // the du moments of the lane's four pixels are formed after the loop from moments in h (du[h] = du[0] + h su)
+#endif
         } else {
             const float x7 = aw * du[h], x8 = aw * dv[h], x10 = bw * du[h], x11 = bw * dv[h];
             acc[4] = fmaf(x7, du[h], acc[4]); acc[5] = fmaf(x7, dv[h], acc[5]); acc[6] = fmaf(x8, dv[h], acc[6]);
@@ -1045,9 +1052,22 @@ GSX_DEV void gq_row(const GmLaneRec& g, const GmRowPix& px, const float (&du)[4]
             }
             acc[12] = fmaf(x10, du[h], acc[12]); acc[13] = fmaf(x10, dv[h], acc[13]); acc[14] = fmaf(x11, dv[h], acc[14]);
         }
-        T_out[h] = T[h]; tb_out[h] = tbuf - e[h];
+        T_out[h] = T[h]; tb_out[h] = tbo;
     }
     if (ROWDV) {
+#ifndef GSX_GQ_NO_HMOMENTS
+        // A lane's four pixels are one image row: du[h] = du0 + h su.  With S0 = sum w, S1 = sum h w, S2 = sum h^2 w (h = 0 .. 3: constants)
+        //     sum w du = du0 S0 + su S1,     sum w du^2 = du0 (sum w du + su S1) + su^2 S2
+        // 12 VALU per weight family instead of 16 (three per pixel + the weight's own sum), no per-pixel products with du.
+        {
+            const float du0 = du[0];   // su_ = 1 / fx = du[h + 1] - du[h], su2 its square: wave-uniform, formed once per kernel
+            const float S0a = (awh[0] + awh[1]) + (awh[2] + awh[3]), S1a = fmaf(3.f, awh[3], fmaf(2.f, awh[2], awh[1])), S2a = fmaf(9.f, awh[3], fmaf(4.f, awh[2], awh[1]));
+            const float S0b = (bwh[0] + bwh[1]) + (bwh[2] + bwh[3]), S1b = fmaf(3.f, bwh[3], fmaf(2.f, bwh[2], bwh[1])), S2b = fmaf(9.f, bwh[3], fmaf(4.f, bwh[2], bwh[1]));
+            const float Aa = su_ * S1a, Ab = su_ * S1b;
+            acc[8] = S0a; acc[7] = fmaf(du0, S0a, Aa); acc[4] = fmaf(du0, acc[7] + Aa, su2 * S2a);
+            acc[9] = S0b; acc[10] = fmaf(du0, S0b, Ab); acc[12] = fmaf(du0, acc[10] + Ab, su2 * S2b);
+        }
+#endif
         const float d = dv[0], a0 = acc[8] * d, b0 = acc[9] * d;   // sum aw dv, sum bw dv
         acc[5] = acc[7] * d; acc[6] = a0 * d; acc[8] = a0;
         acc[11] = b0; acc[13] = acc[10] * d; acc[14] = b0 * d;
@@ -1139,7 +1159,7 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
     const int32_t per_super = (n_total + n_super - 1) / n_super;   // balanced super-chunks (<= GS)
 
     const uint32_t prow = lane >> 4, pcol = lane & 15u;            // this lane's pixel row of the block / its Gaussian column of the batch
-    const float su = 1.f / cam.fx, sv = 1.f / cam.fy;
+    const float su = 1.f / cam.fx, sv = 1.f / cam.fy, su_sq = su * su;
     const float prow_f = (float)prow;
     // plane of value z[j] after rows_reduce16: 4 j + {0,2,1,3}[row]
     const uint32_t zplane0 = (prow == 1u) ? 2u : (prow == 2u ? 1u : prow);
@@ -1265,8 +1285,10 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
                     }
                 }
                 float acc[16], T_out[4], tb_out[4];
-                if (clamp) gq_row<true, KIND == CAM_PERFECT_PINHOLE, KIND == CAM_OPENCV_FISHEYE>(g, px, du, dv, pw, num2, rden, acc, T_out, tb_out);
-                else gq_row<false, KIND == CAM_PERFECT_PINHOLE, KIND == CAM_OPENCV_FISHEYE>(g, px, du, dv, pw, num2, rden, acc, T_out, tb_out);
+                if (clamp) gq_row<true, KIND == CAM_PERFECT_PINHOLE, KIND == CAM_OPENCV_FISHEYE>(g, px, du, dv, pw, num2, rden, su, su_sq, acc, T_out, tb_out);
+                else gq_row<false, KIND == CAM_PERFECT_PINHOLE, KIND == CAM_OPENCV_FISHEYE>(g, px, du, dv, pw, num2, rden, su, su_sq, acc, T_out, tb_out);
+                // (round 5: instantiating the rest of the pass in both arms, so that their 24 results need not meet in the same registers, was tried
+                // for the clamp-free arm's four v_mov: 245 instead of 237 VALU per pass — the arms then disagree about more, not less)
                 acc[15] = 1.f;   // "listed" marker (summed like a moment: no separate LDS atomic)
                 // carries for this row's next pass: the values behind the row's last Gaussian
 #pragma unroll

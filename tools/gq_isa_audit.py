@@ -32,11 +32,28 @@ def main(path):
     exps = [i for i, l in enumerate(body) if "v_exp_f32" in l]
     first_exp = exps[0]
     header = max(i for i in range(first_exp) if re.match(r"\.LBB\d+_\d+:", body[i]) and "Depth=3" in " ".join(body[i:i + 3]))
-    cb = next(i for i in range(first_exp, len(body)) if "s_cbranch_vccz" in body[i])
-    target = body[cb].split()[-1]
-    t_idx = next(i for i, l in enumerate(body) if l.startswith(target + ":"))
-    clamp_end = next(i for i in range(cb + 1, len(body)) if re.match(r"\.LBB\d+_\d+:", body[i]))
-    seq = body[header:cb + 1] + body[clamp_end:t_idx]
+    # walk ONE pass along the clamp-free arm: take the clamp branch (s_cbranch_vccz: "no lane can reach alpha 0.999"), follow unconditional
+    # branches, fall through exec-mask skips (their bodies run for some lanes) and through the lock's spin loop; stop back at the header
+    labels = {l.split(":")[0]: i for i, l in enumerate(body) if re.match(r"\.LBB\d+_\d+:", l)}
+    seq, i, seen, took_clamp, target = [], header, set(), False, "?"
+    while i not in seen and i < len(body):
+        seen.add(i)
+        l = body[i].strip()
+        seq.append(body[i])
+        op = l.split()[0] if l else ""
+        if op == "s_cbranch_vccz" and not took_clamp and i > first_exp - 200:
+            took_clamp, target = True, l.split()[-1]
+            i = labels[target]
+            continue
+        if op == "s_branch":
+            i = labels[l.split()[-1]]
+            if i == header:
+                break
+            continue
+        if op.startswith("s_cbranch") and labels.get(l.split()[-1], -1) == header:
+            break
+        i += 1
+    clamp_lines = 0
     cls, ops = collections.Counter(), collections.Counter()
     for l in seq:
         l = l.strip()
@@ -48,7 +65,7 @@ def main(path):
         ops[(c, re.sub(r"_e32|_e64", "", m.group(1)))] += 1
     valu = sum(v for k, v in cls.items() if k not in ("LDS", "SALU / wait / branch", "other"))
     cyc = 2.3 * cls["plain VALU (2.3)"] + 8.2 * cls["quarter-rate (8.2)"] + 4.1 * cls["DPP (4.1 in runs)"] + 6.0 * cls["slow-pairing (4.1 - 8.7)"]
-    print("pass loop %s .. %s (clamp arm %d lines excluded): %d instructions, %d VALU, ~%.0f issue cycles" % (body[header].split(":")[0], target, clamp_end - cb - 1, sum(cls.values()), valu, cyc))
+    print("pass loop %s .. %s (clamp-free arm): %d instructions, %d VALU, ~%.0f issue cycles" % (body[header].split(":")[0], target, sum(cls.values()), valu, cyc))
     print(dict(cls))
     for (c, o), n in sorted(ops.items(), key=lambda kv: (kv[0][0], -kv[1])):
         print("%-26s %-26s %d" % (c, o, n))
