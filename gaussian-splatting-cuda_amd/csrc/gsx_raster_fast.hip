@@ -997,7 +997,7 @@ GSX_DEV void gq_row(const GmLaneRec& g, const GmRowPix& px, const float (&du)[4]
                     const float (&rden)[4], float su_, float su2, float (&acc)[16], float (&T_out)[4], float (&tb_out)[4]) {
     float al[4], ra[4], P[4];
     // (opaque copy: the clamped and the clamp-free instantiation of this function sit in the two arms of one branch, and hipcc otherwise hoists the
-    // four `idx <= last id` compares above it for the clamped arm AND recomputes them in the clamp-free one — 4 of a pass's 255 VALU)
+    // four `idx <= last id` compares above it for the clamped arm AND recomputes them in the clamp-free one — 4 of what were 255 VALU per pass)
     int32_t idx = g.idx;
     asm volatile("" : "+v"(idx));
 #pragma unroll

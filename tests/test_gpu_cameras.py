@@ -106,6 +106,57 @@ def test_fisheye(mods):
     _check(*res, o)
 
 
+def _opaque_scene(scenes, N=900, size=128, f=90.0, seed=29):
+    """A third of the Gaussians opaque (opacity 1.0, 0.9995, 0.9992) and large enough on screen (sigma ~ 10 px) that pixels next to
+    their centres see opacity x exp(-s) above 0.999: the alpha clamp of Fwd.cu:239 and the gradient mask of Bwd.cu:318 — a regime none
+    of the random scenes reaches (their opacities stop at 0.9) and one a trained model lives in (sigmoid(raw) -> 1)."""
+    sc = _scene(scenes, N=N, size=size, seed=seed, f=f)
+    g = torch.Generator().manual_seed(seed)
+    n_op = N // 3
+    sc["opacities"][:n_op] = torch.tensor([1.0, 0.9995, 0.9992])[torch.arange(n_op) % 3]
+    sc["scales"][:n_op] = torch.rand(n_op, 3, generator=g) * 0.2 + 0.2
+    perm = torch.randperm(N, generator=g)   # opaque and ordinary Gaussians interleaved in depth order AND in index order
+    for k in ("means", "quats", "scales", "opacities", "sh"):
+        sc[k] = sc[k][perm].contiguous()
+    return sc
+
+
+@pytest.mark.parametrize("bwd_kernel", ["pm", "gq"])
+@pytest.mark.parametrize("camera", ["pinhole", "distorted", "fisheye", "rolling"])
+def test_opaque_gaussians_alpha_clamp(mods, monkeypatch, camera, bwd_kernel):
+    """alpha = min(0.999, o exp(-s)) and `clamped alpha carries no gradient` on every kernel family: the fast path's forward kernels
+    (fixture) x its two backward kernels (their clamped instantiations: gq_row<true, ...>), the distorted / fisheye variants and the
+    reference-order kernels (rolling shutter).  The scene is shown to exercise the clamp: the oracle's gradients with the opacities
+    held just below 0.999 differ from the real ones by far more than the tolerance."""
+    ops, scenes = mods
+    monkeypatch.setenv("GSX_BWD", bwd_kernel)
+    sc = _opaque_scene(scenes, f=70.0 if camera == "fisheye" else 90.0)
+    v_rc, v_ra = _grads(128)
+    kw, run = {}, dict(cam_model=ops.CameraModelType.PINHOLE, shutter=ops.ShutterType.GLOBAL, viewmats1=None, radial=None, tangential=None, thin_prism=None)
+    if camera == "distorted":
+        run.update(radial=np.array([[0.05, -0.02, 0.003, 0.0, 0.0, 0.0]], np.float32), tangential=np.array([[0.002, -0.001]], np.float32))
+        kw = dict(camera_model=oracle.PINHOLE, radial=run["radial"], tangential=run["tangential"])
+    elif camera == "fisheye":
+        run.update(cam_model=ops.CameraModelType.FISHEYE, radial=np.array([[0.02, -0.005, 0.001, 0.0]], np.float32))
+        kw = dict(camera_model=oracle.FISHEYE, radial=run["radial"])
+    elif camera == "rolling":
+        vm1 = sc["viewmat"].clone()
+        vm1[0, 3], vm1[1, 3] = 0.03, -0.02
+        run.update(shutter=ops.ShutterType.ROLLING_TOP_TO_BOTTOM, viewmats1=vm1[None].numpy())
+        kw = dict(camera_model=oracle.PINHOLE, shutter=int(ops.ShutterType.ROLLING_TOP_TO_BOTTOM), viewmats1=vm1[None].numpy())
+    o = oracle_pipeline(sc, frag_rel=1e-3, v_render_colors=v_rc, v_render_alphas=v_ra, cam=kw)
+    below = dict(sc)
+    below["opacities"] = sc["opacities"].clamp(max=0.9989)
+    o_below = oracle_pipeline(below, v_render_colors=v_rc, v_render_alphas=v_ra, cam=kw, isect_override=(o["tile_offsets"], o["flatten_ids"]))
+    assert rel_l2(o_below["v_opacities"], o["v_opacities"]) > 0.03 and rel_l2(o_below["v_means"], o["v_means"]) > 0.005   # the clamp matters here (measured: 0.05 - 0.20 / 0.007 - 0.04)
+    res = _run_gpu(ops, sc, o, run["cam_model"], run["shutter"], run["viewmats1"], run["radial"], run["tangential"], run["thin_prism"], v_rc, v_ra)
+    _check(*res, o, min_ok=0.85)
+    clamped = (sc["opacities"] >= 0.9992).numpy() & (o["radii"] > 0).all(-1)[0]
+    assert clamped.sum() > 100
+    gv = np32(res[2][4]).reshape(-1)[clamped]
+    assert rel_l2(gv, o["v_opacities"].reshape(-1)[clamped]) < 1e-3   # the opaque Gaussians' own opacity gradients (what the mask removes terms from)
+
+
 def _wide_scene(N=3000, size=160, f=45.0, seed=21):
     """Gaussians all around the optical axis out to 100 degrees, seen by a ~200 degree fisheye (image radius / f = 1.78 rad)."""
     import math
