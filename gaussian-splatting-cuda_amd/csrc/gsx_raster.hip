@@ -253,6 +253,7 @@ __global__ __launch_bounds__(RB) void raster_bwd_kernel(RasterArgs a, const floa
     __shared__ int32_t s_id[RB];
     __shared__ int32_t s_touched[RB];
     __shared__ float4 s_sph[RB];
+    __shared__ float4 s_omu[HOIST ? RB : 1];   // global shutter: camera centre - mean of the staged Gaussians (v_gro (x) (o - mu) is folded per PIXEL, below)
     const uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y, cid = blockIdx.z;
     const uint32_t tile_id = tile_y * a.tw + tile_x;
     if (only_tiles != nullptr && !only_tiles[(size_t)cid * a.th * a.tw + tile_id]) return;  // the fast path handled this tile
@@ -318,6 +319,10 @@ __global__ __launch_bounds__(RB) void raster_bwd_kernel(RasterArgs a, const floa
             s_g[tid] = s;
             s_id[tid] = g;
             s_sph[tid] = cull_sphere(a, g);
+            if (HOIST) {
+                const int32_t gi = (a.C == 1) ? g : (int32_t)((uint32_t)g % a.N);
+                s_omu[tid] = make_float4(cam_org.x - a.means[(size_t)gi * 3], cam_org.y - a.means[(size_t)gi * 3 + 1], cam_org.z - a.means[(size_t)gi * 3 + 2], 0.f);
+            }
         }
         s_touched[tid] = 0;
 #pragma unroll
@@ -370,9 +375,15 @@ __global__ __launch_bounds__(RB) void raster_bwd_kernel(RasterArgs a, const floa
                     acc[7] = v_grd.x * ray_d.x; acc[8] = v_grd.x * ray_d.y; acc[9] = v_grd.x * ray_d.z;
                     acc[10] = v_grd.y * ray_d.x; acc[11] = v_grd.y * ray_d.y; acc[12] = v_grd.y * ray_d.z;
                     acc[13] = v_grd.z * ray_d.x; acc[14] = v_grd.z * ray_d.y; acc[15] = v_grd.z * ray_d.z;
-                    if (!HOIST) {
-                        // per-pixel origin: fold v_gro (x) (o - mu) into G now and keep v_gro for v_mean
-                        const f3 omu = ray_o - f3{s.r0.w, s.r1.w, s.r2.w};
+                    {
+                        // v_Mt = v_grd (x) d + v_gro (x) (o - mu) per PIXEL, as Bwd.cu:325-326 has it (v_gro is kept for v_mean).  Rounds 1 - 4 folded
+                        // the second product once per (tile, Gaussian) behind the sums when the origin is the same for every pixel: the two sums are
+                        // |gro| ~ depth / scale times larger than their total, and on needle-shaped Gaussians (scale ratios of several hundred) the
+                        // short axes' scale gradients lost 3e-3 to it (tests/test_gpu_reference_hip.py: regime "needles").  Pixel by pixel the two
+                        // products cancel before they are summed.
+                        f3 omu;
+                        if (HOIST) { const float4 om = s_omu[t]; omu = {om.x, om.y, om.z}; }
+                        else omu = ray_o - f3{s.r0.w, s.r1.w, s.r2.w};
                         acc[7] += v_gro.x * omu.x; acc[8] += v_gro.x * omu.y; acc[9] += v_gro.x * omu.z;
                         acc[10] += v_gro.y * omu.x; acc[11] += v_gro.y * omu.y; acc[12] += v_gro.y * omu.z;
                         acc[13] += v_gro.z * omu.x; acc[14] += v_gro.z * omu.y; acc[15] += v_gro.z * omu.z;
@@ -403,19 +414,10 @@ __global__ __launch_bounds__(RB) void raster_bwd_kernel(RasterArgs a, const floa
             out[0] = -(s.r0.x * v_gro.x + s.r1.x * v_gro.y + s.r2.x * v_gro.z);
             out[1] = -(s.r0.y * v_gro.x + s.r1.y * v_gro.y + s.r2.y * v_gro.z);
             out[2] = -(s.r0.z * v_gro.x + s.r1.z * v_gro.y + s.r2.z * v_gro.z);
-            // v_Mt(r,c) = G(r,c) + v_gro_r * omu_c   (Bwd.cu:325-326)
+            // v_Mt(r,c) = sum over the pixels of v_grd_r d_c + v_gro_r (o - mu)_c   (Bwd.cu:325-326)
             float vMt[3][3] = {{A[7], A[8], A[9]}, {A[10], A[11], A[12]}, {A[13], A[14], A[15]}};
             const float4 qraw = reinterpret_cast<const float4*>(a.quats)[gi];
             const f3 sc{a.scales[(size_t)gi * 3], a.scales[(size_t)gi * 3 + 1], a.scales[(size_t)gi * 3 + 2]};
-            if (HOIST) {
-                const f3 mu{a.means[(size_t)gi * 3], a.means[(size_t)gi * 3 + 1], a.means[(size_t)gi * 3 + 2]};
-                const f3 omu = cam_org - mu;
-                const float vgv[3] = {v_gro.x, v_gro.y, v_gro.z}, om[3] = {omu.x, omu.y, omu.z};
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) vMt[r][c] += vgv[r] * om[c];
-            }
             // quat_scale_to_preci_half_vjp (Utils.cuh:128-158): v_M = v_Mt^T is dL/d(R S), S = diag(1/s)
             const float isv[3] = {1.f / sc.x, 1.f / sc.y, 1.f / sc.z};
             float w = qraw.x, x = qraw.y, y = qraw.z, z = qraw.w;

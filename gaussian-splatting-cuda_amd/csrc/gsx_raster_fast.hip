@@ -128,11 +128,13 @@ __global__ __launch_bounds__(256) void tile_flag_kernel(RasterArgs a, const uint
 
 // alpha of one (pixel, Gaussian) pair: 16 VALU.  Record layout (== the packed 64 B record):
 //   r0 = (u0, v0, l00, l01)  r1 = (l11, lo, d1, d2)  r2 = (d3, d4, d5, red)  r3 = (green, blue, -, -)
-// Returns alpha; num2 = 0.5 log2(e) * grayDist * den' (scaled numerator), rden = 1/den'.
-GSX_DEV float fast_alpha(float u, float v, float4 r0, float4 r1, float4 r2, float& du, float& dv, float& num2, float& rden) {
-    du = u - r0.x; dv = v - r0.y;
+// Returns alpha; (x0, x1) = the whitened pixel offsets L (du, dv) (N = x0^2 + x1^2: the backward takes its moments in them, gsx_record.hpp),
+// num2 = 0.5 log2(e) * grayDist * den' (scaled numerator), rden = 1/den'.
+GSX_DEV float fast_alpha(float u, float v, float4 r0, float4 r1, float4 r2, float& x0, float& x1, float& num2, float& rden) {
+    const float du = u - r0.x, dv = v - r0.y;
     const float t0 = fmaf(r0.w, dv, r0.z * du);
     const float t1 = r1.x * dv;
+    x0 = t0; x1 = t1;
     num2 = fmaf(t0, t0, t1 * t1);
     const float den = fmaf(du, fmaf(r2.x, du, fmaf(r2.y, dv, r1.z)), fmaf(dv, fmaf(r2.z, dv, r1.w), 1.f));
     rden = __builtin_amdgcn_rcpf(den);
@@ -143,10 +145,11 @@ GSX_DEV float fast_alpha(float u, float v, float4 r0, float4 r1, float4 r2, floa
 // off axis (w <= 0).  With du' = u - w u0, dv' = v - w v0:  (A d) x g = du' B0 + dv' B1 and A d = w h + a0 du' + a1 dv', so the numerator
 // keeps its form and the denominator becomes w (w + d1 du' + d2 dv') + d3 du'^2 + d4 du' dv' + d5 dv'^2; the ratio does not depend
 // on the length of (u, v, w).  19 VALU.
-GSX_DEV float fast_alpha_ray(float u, float v, float w, float ww, float4 r0, float4 r1, float4 r2, float& du, float& dv, float& num2, float& rden) {
-    du = fmaf(-w, r0.x, u); dv = fmaf(-w, r0.y, v);
+GSX_DEV float fast_alpha_ray(float u, float v, float w, float ww, float4 r0, float4 r1, float4 r2, float& x0, float& x1, float& num2, float& rden) {
+    const float du = fmaf(-w, r0.x, u), dv = fmaf(-w, r0.y, v);
     const float t0 = fmaf(r0.w, dv, r0.z * du);
     const float t1 = r1.x * dv;
+    x0 = t0; x1 = t1;
     num2 = fmaf(t0, t0, t1 * t1);
     const float den = fmaf(du, fmaf(r2.x, du, fmaf(r2.y, dv, r1.z * w)), fmaf(dv, fmaf(r2.z, dv, r1.w * w), ww));
     rden = __builtin_amdgcn_rcpf(den);
@@ -718,6 +721,8 @@ const uint8_t* launch_raster_fwd_fast(int kind, RasterArgs a, float* renders, fl
 // pixel moments of each (camera, Gaussian)
 //     Ma = sum a {du^2, du dv, dv^2, du, dv},   Mb = sum b {1, du, dv, du^2, du dv, dv^2},
 //     a = (dL/dD) / den',  b = a D,
+// which the kernels take in the WHITENED offsets x0 = l00 du + l01 dv, x1 = l11 dv the alpha evaluation forms anyway (a thin footprint makes
+// the (du, dv) moments nearly rank one and loses the short axes' gradients to fp32; gsx_record.hpp: moments_to_gradients),
 // plus v_rgb[3] and the opacity term: 15 sums.  The coefficients of that linear map depend on the Gaussian and
 // the camera only — not on the tile — so the kernel accumulates moments and the chain rule runs ONCE per
 // (camera, Gaussian) afterwards (gsx_bwd_gather_kernel), not once per (tile, Gaussian).
@@ -843,9 +848,9 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
                 todo &= todo - 1ull;
                 const float4* rp = s_rec[t];
                 const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
-                float du, dv, num2, rden;
-                const float alpha = KIND == CAM_OPENCV_FISHEYE ? fast_alpha_ray(u, v, w, ww, r0, r1, r2, du, dv, num2, rden)
-                                                               : fast_alpha(u, v, r0, r1, r2, du, dv, num2, rden);
+                float x0, x1, num2, rden;   // (x0, x1): whitened pixel offsets — the moments are taken in them (gsx_record.hpp: moments_to_gradients)
+                const float alpha = KIND == CAM_OPENCV_FISHEYE ? fast_alpha_ray(u, v, w, ww, r0, r1, r2, x0, x1, num2, rden)
+                                                               : fast_alpha(u, v, r0, r1, r2, x0, x1, num2, rden);
                 // one comparison feeds the ballot directly (a ballot of `a && b` goes through a VGPR round trip)
                 const float alpha_in = (chunk_end - t <= bin_final) ? alpha : 0.f;
                 const bool valid = alpha_in >= ALPHA_MIN;
@@ -869,14 +874,14 @@ __global__ __launch_bounds__(RB, GSX_BWD_WAVES) void raster_bwd_fast_kernel(Rast
                 const float aw = av * rden;                            // -2 (dL/dD) / den'  (dalpha/dD = -alpha/2: the gather kernel applies the -1/2)
                 const float bw = aw * (num2 * rden);                   // the same times D (0.5 log2 e)
                 x[3] = av;
-                x[7] = aw * du; x[8] = aw * dv;                         // first-order moments, then the second-order ones from them
-                x[4] = x[7] * du; x[5] = x[7] * dv; x[6] = x[8] * dv;   // (10 products instead of 13 with du^2, du dv, dv^2 formed first)
-                x[9] = bw; x[10] = bw * du; x[11] = bw * dv;
-                x[12] = x[10] * du; x[13] = x[10] * dv; x[14] = x[11] * dv;
+                x[7] = aw * x0; x[8] = aw * x1;                         // first-order moments, then the second-order ones from them
+                x[4] = x[7] * x0; x[5] = x[7] * x1; x[6] = x[8] * x1;   // (10 products instead of 13 with x0^2, x0 x1, x1^2 formed first)
+                x[9] = bw; x[10] = bw * x0; x[11] = bw * x1;
+                x[12] = x[10] * x0; x[13] = x[10] * x1; x[14] = x[11] * x1;
                 if (KIND == CAM_OPENCV_FISHEYE) {
                     // unnormalised rays: du' = u - w u0 has d/du0 = -w and A d = w h + a0 du' + a1 dv', so the moments that multiply
                     // d/du0, d/dv0 (first-order a) and h (the b family's 1, du', dv') carry the matching powers of w; the gather
-                    // kernel's linear map is unchanged
+                    // kernel's linear map is unchanged (the whitening is linear in (du', dv'))
                     x[7] *= w; x[8] *= w; x[9] *= ww; x[10] *= w; x[11] *= w;
                 }
                 x[15] = 0.f;
@@ -993,8 +998,8 @@ GSX_DEV void rows_reduce16(float (&x)[16], float (&z)[4]) {
 // FISH: unnormalised rays (u, v, w): du' = u - w u0 has d/du0 = -w and A d = w h + a0 du' + a1 dv', so the moments that multiply d/du0,
 // d/dv0 (first-order a) and h (the b family's 1, du', dv') carry the matching powers of the pixel's w (as in raster_bwd_fast_kernel).
 template <bool CLAMP, bool ROWDV, bool FISH>
-GSX_DEV void gq_row(const GmLaneRec& g, const GmRowPix& px, const float (&du)[4], const float (&dv)[4], const float (&pw)[4], const float (&num2)[4],
-                    const float (&rden)[4], float su_, float su2, float (&acc)[16], float (&T_out)[4], float (&tb_out)[4]) {
+GSX_DEV void gq_row(const GmLaneRec& g, const GmRowPix& px, const float (&x0)[4], const float (&x1)[4], const float (&pw)[4], const float (&num2)[4],
+                    const float (&rden)[4], float st, float st2, float (&acc)[16], float (&T_out)[4], float (&tb_out)[4]) {
     float al[4], ra[4], P[4];
     // (opaque copy: the clamped and the clamp-free instantiation of this function sit in the two arms of one branch, and hipcc otherwise hoists the
     // four `idx <= last id` compares above it for the clamped arm AND recomputes them in the clamp-free one — 4 of what were 255 VALU per pass)
@@ -1035,40 +1040,41 @@ GSX_DEV void gq_row(const GmLaneRec& g, const GmRowPix& px, const float (&du)[4]
         acc[3] += av;
         if (ROWDV) {   // acc[6] / acc[8] / acc[11] collect sum aw, sum aw (again), sum bw here; the dv factors follow below
 #ifdef GSX_GQ_NO_HMOMENTS
-            const float x7 = aw * du[h], x10 = bw * du[h];
-            acc[4] = fmaf(x7, du[h], acc[4]); acc[7] += x7; acc[8] += aw;
-            acc[9] += bw; acc[10] += x10; acc[12] = fmaf(x10, du[h], acc[12]);
+            const float x7 = aw * x0[h], x10 = bw * x0[h];
+            acc[4] = fmaf(x7, x0[h], acc[4]); acc[7] += x7; acc[8] += aw;
+            acc[9] += bw; acc[10] += x10; acc[12] = fmaf(x10, x0[h], acc[12]);
 #else
-            awh[h] = aw; bwh[h] = bw;   // the du moments of the lane's four pixels are formed after the loop from moments in h (du[h] = du[0] + h su)
+            awh[h] = aw; bwh[h] = bw;   // the x0 moments of the lane's four pixels are formed after the loop from moments in h (x0[h] = x0[0] + h st)
 #endif
         } else {
-            const float x7 = aw * du[h], x8 = aw * dv[h], x10 = bw * du[h], x11 = bw * dv[h];
-            acc[4] = fmaf(x7, du[h], acc[4]); acc[5] = fmaf(x7, dv[h], acc[5]); acc[6] = fmaf(x8, dv[h], acc[6]);
+            const float x7 = aw * x0[h], x8 = aw * x1[h], x10 = bw * x0[h], x11 = bw * x1[h];
+            acc[4] = fmaf(x7, x0[h], acc[4]); acc[5] = fmaf(x7, x1[h], acc[5]); acc[6] = fmaf(x8, x1[h], acc[6]);
             if (FISH) {
                 acc[7] = fmaf(x7, pw[h], acc[7]); acc[8] = fmaf(x8, pw[h], acc[8]); acc[9] = fmaf(bw, pw[h] * pw[h], acc[9]);
                 acc[10] = fmaf(x10, pw[h], acc[10]); acc[11] = fmaf(x11, pw[h], acc[11]);
             } else {
                 acc[7] += x7; acc[8] += x8; acc[9] += bw; acc[10] += x10; acc[11] += x11;
             }
-            acc[12] = fmaf(x10, du[h], acc[12]); acc[13] = fmaf(x10, dv[h], acc[13]); acc[14] = fmaf(x11, dv[h], acc[14]);
+            acc[12] = fmaf(x10, x0[h], acc[12]); acc[13] = fmaf(x10, x1[h], acc[13]); acc[14] = fmaf(x11, x1[h], acc[14]);
         }
         T_out[h] = T[h]; tb_out[h] = tbo;
     }
     if (ROWDV) {
 #ifndef GSX_GQ_NO_HMOMENTS
-        // A lane's four pixels are one image row: du[h] = du0 + h su.  With S0 = sum w, S1 = sum h w, S2 = sum h^2 w (h = 0 .. 3: constants)
-        //     sum w du = du0 S0 + su S1,     sum w du^2 = du0 (sum w du + su S1) + su^2 S2
-        // 12 VALU per weight family instead of 16 (three per pixel + the weight's own sum), no per-pixel products with du.
+        // A lane's four pixels are one image row: du[h] = du0 + h / fx, x1 is theirs in common, so x0[h] = x0[0] + h st with st = l00 / fx.  With
+        // S0 = sum w, S1 = sum h w, S2 = sum h^2 w (h = 0 .. 3: constants)
+        //     sum w x0 = x0[0] S0 + st S1,     sum w x0^2 = x0[0] (sum w x0 + st S1) + st^2 S2
+        // 12 VALU per weight family instead of 16 (three per pixel + the weight's own sum), no per-pixel products with x0.
         {
-            const float du0 = du[0];   // su_ = 1 / fx = du[h + 1] - du[h], su2 its square: wave-uniform, formed once per kernel
+            const float xa = x0[0];
             const float S0a = (awh[0] + awh[1]) + (awh[2] + awh[3]), S1a = fmaf(3.f, awh[3], fmaf(2.f, awh[2], awh[1])), S2a = fmaf(9.f, awh[3], fmaf(4.f, awh[2], awh[1]));
             const float S0b = (bwh[0] + bwh[1]) + (bwh[2] + bwh[3]), S1b = fmaf(3.f, bwh[3], fmaf(2.f, bwh[2], bwh[1])), S2b = fmaf(9.f, bwh[3], fmaf(4.f, bwh[2], bwh[1]));
-            const float Aa = su_ * S1a, Ab = su_ * S1b;
-            acc[8] = S0a; acc[7] = fmaf(du0, S0a, Aa); acc[4] = fmaf(du0, acc[7] + Aa, su2 * S2a);
-            acc[9] = S0b; acc[10] = fmaf(du0, S0b, Ab); acc[12] = fmaf(du0, acc[10] + Ab, su2 * S2b);
+            const float Aa = st * S1a, Ab = st * S1b;
+            acc[8] = S0a; acc[7] = fmaf(xa, S0a, Aa); acc[4] = fmaf(xa, acc[7] + Aa, st2 * S2a);
+            acc[9] = S0b; acc[10] = fmaf(xa, S0b, Ab); acc[12] = fmaf(xa, acc[10] + Ab, st2 * S2b);
         }
 #endif
-        const float d = dv[0], a0 = acc[8] * d, b0 = acc[9] * d;   // sum aw dv, sum bw dv
+        const float d = x1[0], a0 = acc[8] * d, b0 = acc[9] * d;   // sum aw x1, sum bw x1
         acc[5] = acc[7] * d; acc[6] = a0 * d; acc[8] = a0;
         acc[11] = b0; acc[13] = acc[10] * d; acc[14] = b0 * d;
     }
@@ -1159,7 +1165,7 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
     const int32_t per_super = (n_total + n_super - 1) / n_super;   // balanced super-chunks (<= GS)
 
     const uint32_t prow = lane >> 4, pcol = lane & 15u;            // this lane's pixel row of the block / its Gaussian column of the batch
-    const float su = 1.f / cam.fx, sv = 1.f / cam.fy, su_sq = su * su;
+    const float su = 1.f / cam.fx, sv = 1.f / cam.fy;
     const float prow_f = (float)prow;
     // plane of value z[j] after rows_reduce16: 4 j + {0,2,1,3}[row]
     const uint32_t zplane0 = (prow == 1u) ? 2u : (prow == 2u ? 1u : prow);
@@ -1252,41 +1258,43 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
                 g.d1 = s_rec[6][slot]; g.d2 = s_rec[7][slot]; g.d3 = s_rec[8][slot]; g.d4 = s_rec[9][slot]; g.d5 = s_rec[10][slot];
                 g.cr = s_rec[11][slot]; g.cg = s_rec[12][slot]; g.cb = s_rec[13][slot];
                 const bool clamp = __builtin_amdgcn_ballot_w64(g.lo > -0.0015f) != 0ull;
-                float du[4], dv[4], num2[4], rden[4];
+                float x0[4], x1[4], num2[4], rden[4];   // (x0, x1) = L (du, dv): the whitened offsets, in which the moments are taken
+                float st = 0.f, st2 = 0.f;              // perfect pinhole: x0[h + 1] - x0[h] = l00 / fx and its square
                 if (KIND == CAM_PERFECT_PINHOLE) {
                     const float dvr = pvr - g.v0, du0 = bu - g.u0;
                     const float t1 = g.l11 * dvr, t1sq = t1 * t1, t0r = g.l01 * dvr;
                     const float Ar = fmaf(dvr, fmaf(g.d5, dvr, g.d2), 1.f), Br = fmaf(g.d4, dvr, g.d1);
+                    st = g.l00 * su; st2 = st * st;
 #pragma unroll
                     for (int h = 0; h < 4; ++h) {
-                        du[h] = h == 0 ? du0 : fmaf((float)h, su, du0); dv[h] = dvr;   // (h == 0 spelled out: hipcc emits fma(0, su, du0) otherwise)
-                        const float t0 = fmaf(g.l00, du[h], t0r);
-                        num2[h] = fmaf(t0, t0, t1sq);
-                        rden[h] = __builtin_amdgcn_rcpf(fmaf(du[h], fmaf(g.d3, du[h], Br), Ar));
+                        const float du = h == 0 ? du0 : fmaf((float)h, su, du0);   // (h == 0 spelled out: hipcc emits fma(0, su, du0) otherwise)
+                        x0[h] = fmaf(g.l00, du, t0r); x1[h] = t1;
+                        num2[h] = fmaf(x0[h], x0[h], t1sq);
+                        rden[h] = __builtin_amdgcn_rcpf(fmaf(du, fmaf(g.d3, du, Br), Ar));
                     }
                 } else if (KIND == CAM_OPENCV_FISHEYE) {   // unnormalised rays (u, v, w): fast_alpha_ray
 #pragma unroll
                     for (int h = 0; h < 4; ++h) {
-                        du[h] = fmaf(-pw[h], g.u0, pu[h]); dv[h] = fmaf(-pw[h], g.v0, pv[h]);
-                        const float t0 = fmaf(g.l01, dv[h], g.l00 * du[h]);
-                        const float t1 = g.l11 * dv[h];
-                        num2[h] = fmaf(t0, t0, t1 * t1);
-                        rden[h] = __builtin_amdgcn_rcpf(fmaf(du[h], fmaf(g.d3, du[h], fmaf(g.d4, dv[h], g.d1 * pw[h])),
-                                                             fmaf(dv[h], fmaf(g.d5, dv[h], g.d2 * pw[h]), pw[h] * pw[h])));
+                        const float du = fmaf(-pw[h], g.u0, pu[h]), dv = fmaf(-pw[h], g.v0, pv[h]);
+                        x0[h] = fmaf(g.l01, dv, g.l00 * du);
+                        x1[h] = g.l11 * dv;
+                        num2[h] = fmaf(x0[h], x0[h], x1[h] * x1[h]);
+                        rden[h] = __builtin_amdgcn_rcpf(fmaf(du, fmaf(g.d3, du, fmaf(g.d4, dv, g.d1 * pw[h])),
+                                                             fmaf(dv, fmaf(g.d5, dv, g.d2 * pw[h]), pw[h] * pw[h])));
                     }
                 } else {
 #pragma unroll
                     for (int h = 0; h < 4; ++h) {
-                        du[h] = pu[h] - g.u0; dv[h] = pv[h] - g.v0;
-                        const float t0 = fmaf(g.l01, dv[h], g.l00 * du[h]);
-                        const float t1 = g.l11 * dv[h];
-                        num2[h] = fmaf(t0, t0, t1 * t1);
-                        rden[h] = __builtin_amdgcn_rcpf(fmaf(du[h], fmaf(g.d3, du[h], fmaf(g.d4, dv[h], g.d1)), fmaf(dv[h], fmaf(g.d5, dv[h], g.d2), 1.f)));
+                        const float du = pu[h] - g.u0, dv = pv[h] - g.v0;
+                        x0[h] = fmaf(g.l01, dv, g.l00 * du);
+                        x1[h] = g.l11 * dv;
+                        num2[h] = fmaf(x0[h], x0[h], x1[h] * x1[h]);
+                        rden[h] = __builtin_amdgcn_rcpf(fmaf(du, fmaf(g.d3, du, fmaf(g.d4, dv, g.d1)), fmaf(dv, fmaf(g.d5, dv, g.d2), 1.f)));
                     }
                 }
                 float acc[16], T_out[4], tb_out[4];
-                if (clamp) gq_row<true, KIND == CAM_PERFECT_PINHOLE, KIND == CAM_OPENCV_FISHEYE>(g, px, du, dv, pw, num2, rden, su, su_sq, acc, T_out, tb_out);
-                else gq_row<false, KIND == CAM_PERFECT_PINHOLE, KIND == CAM_OPENCV_FISHEYE>(g, px, du, dv, pw, num2, rden, su, su_sq, acc, T_out, tb_out);
+                if (clamp) gq_row<true, KIND == CAM_PERFECT_PINHOLE, KIND == CAM_OPENCV_FISHEYE>(g, px, x0, x1, pw, num2, rden, st, st2, acc, T_out, tb_out);
+                else gq_row<false, KIND == CAM_PERFECT_PINHOLE, KIND == CAM_OPENCV_FISHEYE>(g, px, x0, x1, pw, num2, rden, st, st2, acc, T_out, tb_out);
                 // (round 5: instantiating the rest of the pass in both arms, so that their 24 results need not meet in the same registers, was tried
                 // for the clamp-free arm's four v_mov: 245 instead of 237 VALU per pass — the arms then disagree about more, not less)
                 acc[15] = 1.f;   // "listed" marker (summed like a moment: no separate LDS atomic)
@@ -1511,72 +1519,13 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
         }
         v_colors[g * 3] = Mo[0]; v_colors[g * 3 + 1] = Mo[1]; v_colors[g * 3 + 2] = Mo[2];
         v_opacities[g] = Mo[3] / raw.opac;
+        // moments -> (mean, quaternion, scale): once per (camera, Gaussian) (gsx_record.hpp: moments_to_gradients)
         const ShutterPoses sp(a.cams.viewmats0 + c * 16, nullptr);
         const CamFrame cf = make_cam_frame(sp);
         const float tb0[4] = {0.f, 0.f, 0.f, 0.f};
         FastRec r;
         make_record<true>(raw, cf, tb0, r);
-        const float kap = -r.inv_d0;  // 2 / d0 times the -1/2 of dalpha/dD that the blend kernel leaves out of its moment weights
-        const float Mauu = Mo[4] * kap, Mauv = Mo[5] * kap, Mavv = Mo[6] * kap, Mau = Mo[7] * kap, Mav = Mo[8] * kap;
-        const float kb = kap / HALF_LOG2E;  // b was accumulated with D scaled by 0.5 log2 e
-        const float Mb1 = Mo[9] * kb, Mbu = Mo[10] * kb, Mbv = Mo[11] * kb, Mbuu = Mo[12] * kb, Mbuv = Mo[13] * kb, Mbvv = Mo[14] * kb;
-        // direct gradients
-        const f3 G_B0 = r.B0 * Mauu + r.B1 * Mauv;
-        const f3 G_B1 = r.B0 * Mauv + r.B1 * Mavv;
-        float G_u0 = -(dot3(r.B0, r.B0) * Mau + dot3(r.B0, r.B1) * Mav);
-        float G_v0 = -(dot3(r.B0, r.B1) * Mau + dot3(r.B1, r.B1) * Mav);
-        const f3 G_h = (r.h * Mb1 + r.a0 * Mbu + r.a1 * Mbv) * -1.f;
-        f3 G_a0 = (r.h * Mbu + r.a0 * Mbuu + r.a1 * Mbuv) * -1.f;
-        f3 G_a1 = (r.h * Mbv + r.a0 * Mbuv + r.a1 * Mbvv) * -1.f;
-        // v = a0 u + a1 v + a2 does not depend on (u0,v0): fold h = a0 u0 + a1 v0 + a2 into the columns
-        G_a0 = G_a0 + G_h * r.u0;
-        G_a1 = G_a1 + G_h * r.v0;
-        f3 G_a2 = G_h;
-        // B0 = mz (c20 - v0 c01), B1 = mz (u0 c01 - c12)
-        const float mz = r.m.z, imz = 1.f / mz;
-        const f3 G_c20 = G_B0 * mz;
-        const f3 G_c01 = G_B1 * (mz * r.u0) - G_B0 * (mz * r.v0);
-        const f3 G_c12 = G_B1 * -mz;
-        G_v0 += -mz * dot3(r.c01, G_B0);
-        G_u0 += mz * dot3(r.c01, G_B1);
-        float G_mz = (dot3(r.B0, G_B0) + dot3(r.B1, G_B1)) * imz;
-        // c01 = a0 x a1, c12 = a1 x a2, c20 = a2 x a0   (c = a x b: G_a += b x G_c, G_b += G_c x a)
-        G_a0 = G_a0 + cross3(r.a1, G_c01); G_a1 = G_a1 + cross3(G_c01, r.a0);
-        G_a1 = G_a1 + cross3(r.a2, G_c12); G_a2 = G_a2 + cross3(G_c12, r.a1);
-        G_a2 = G_a2 + cross3(r.a0, G_c20); G_a0 = G_a0 + cross3(G_c20, r.a2);
-        // u0 = mx / mz, v0 = my / mz
-        const float G_mx = G_u0 * imz, G_my = G_v0 * imz;
-        G_mz += -(r.u0 * G_u0 + r.v0 * G_v0) * imz;
-        // m = Rc^T (mu - c)  ->  v_mean = Rc G_m
-        geo[0] += cf.Rc[0][0] * G_mx + cf.Rc[0][1] * G_my + cf.Rc[0][2] * G_mz;
-        geo[1] += cf.Rc[1][0] * G_mx + cf.Rc[1][1] * G_my + cf.Rc[1][2] * G_mz;
-        geo[2] += cf.Rc[2][0] * G_mx + cf.Rc[2][1] * G_my + cf.Rc[2][2] * G_mz;
-        // A = M Rc  ->  G_M(i,k) = sum_j G_A(i,j) Rc(k,j)   (G_A(i,j) = component i of G_aj)
-        const float GA[3][3] = {{G_a0.x, G_a1.x, G_a2.x}, {G_a0.y, G_a1.y, G_a2.y}, {G_a0.z, G_a1.z, G_a2.z}};
-        float vMt[3][3];
-#pragma unroll
-        for (int ii = 0; ii < 3; ++ii)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) vMt[ii][k] = GA[ii][0] * cf.Rc[k][0] + GA[ii][1] * cf.Rc[k][1] + GA[ii][2] * cf.Rc[k][2];
-        // quat_scale_to_preci_half_vjp (Utils.cuh:104-158) with v_M = vMt^T  (M here is the reference's Mt)
-        const float isv[3] = {1.f / raw.sc.x, 1.f / raw.sc.y, 1.f / raw.sc.z};
-        float w = raw.q.x, x_ = raw.q.y, y_ = raw.q.z, z_ = raw.q.w;
-        const float inv_norm = rsqrtf(x_ * x_ + y_ * y_ + z_ * z_ + w * w);
-        w *= inv_norm; x_ *= inv_norm; y_ *= inv_norm; z_ *= inv_norm;
-#define GSX_G(i, j) (vMt[i][j] * isv[i])
-        float vq[4];
-        vq[0] = 2.f * (x_ * (GSX_G(1, 2) - GSX_G(2, 1)) + y_ * (GSX_G(2, 0) - GSX_G(0, 2)) + z_ * (GSX_G(0, 1) - GSX_G(1, 0)));
-        vq[1] = 2.f * (-2.f * x_ * (GSX_G(1, 1) + GSX_G(2, 2)) + y_ * (GSX_G(0, 1) + GSX_G(1, 0)) + z_ * (GSX_G(0, 2) + GSX_G(2, 0)) + w * (GSX_G(1, 2) - GSX_G(2, 1)));
-        vq[2] = 2.f * (x_ * (GSX_G(0, 1) + GSX_G(1, 0)) - 2.f * y_ * (GSX_G(0, 0) + GSX_G(2, 2)) + z_ * (GSX_G(1, 2) + GSX_G(2, 1)) + w * (GSX_G(2, 0) - GSX_G(0, 2)));
-        vq[3] = 2.f * (x_ * (GSX_G(0, 2) + GSX_G(2, 0)) + y_ * (GSX_G(1, 2) + GSX_G(2, 1)) - 2.f * z_ * (GSX_G(0, 0) + GSX_G(1, 1)) + w * (GSX_G(0, 1) - GSX_G(1, 0)));
-#undef GSX_G
-        const float qn[4] = {w, x_, y_, z_};
-        const float dq = vq[0] * qn[0] + vq[1] * qn[1] + vq[2] * qn[2] + vq[3] * qn[3];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) geo[3 + k] += (vq[k] - dq * qn[k]) * inv_norm;
-        // v_scale[k] = -(1/s_k)^2 sum_r R(r,k) vMt[k][r],  R(r,k) = Mt[k][r] * s_k
-#pragma unroll
-        for (int k = 0; k < 3; ++k) geo[7 + k] += -isv[k] * (r.Mt[k][0] * vMt[k][0] + r.Mt[k][1] * vMt[k][1] + r.Mt[k][2] * vMt[k][2]);
+        moments_to_gradients(raw, cf, r, Mo, geo);
     }
     if (!in) return;
     v_means[(size_t)gi * 3] = geo[0]; v_means[(size_t)gi * 3 + 1] = geo[1]; v_means[(size_t)gi * 3 + 2] = geo[2];

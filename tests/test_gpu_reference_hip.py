@@ -150,7 +150,7 @@ def _explain_pixels(sc, R, g_ren, g_last, tag, ocam):
     return rec
 
 
-def _stagewise(ref, ops, sc, cam, tag, with_oracle=True, fwd_strict=True, over_frac=2e-4, bwd_f64_yardstick=False):
+def _stagewise(ref, ops, sc, cam, tag, with_oracle=True, fwd_strict=True, over_frac=2e-4, bwd_f64_yardstick=False, radius_flip_frac=2.5e-3, radius_max_diff=1):
     """Runs the reference chain, then feeds each stage's REFERENCE inputs to the HIP operator (and the oracle) and compares outputs."""
     a = _scene_args(sc, cam)
     v_rc, v_ra = _grads(sc)
@@ -232,7 +232,7 @@ def _stagewise(ref, ops, sc, cam, tag, with_oracle=True, fwd_strict=True, over_f
     n = recs["proj_hip"]["gaussians"]
     for k in [k for k in ("proj_hip", "proj_oracle") if k in recs]:
         p = recs[k]
-        assert p["cull_flips"] <= max(2, 2e-5 * n) and p["radius_max_diff_px"] <= 1 and p["radius_flips"] <= max(4, 2.5e-3 * n), p
+        assert p["cull_flips"] <= max(2, 2e-5 * n) and p["radius_max_diff_px"] <= radius_max_diff and p["radius_flips"] <= max(4, radius_flip_frac * n), p
         assert p["depth_max_rel_err"] < 1e-5 and p.get("compensation_max_err", 0.0) < 1e-4, p
     assert recs["sh_hip"]["max_err"] < 1e-5
     for k in [k for k in ("fwd_hip", "fwd_oracle") if k in recs]:
@@ -323,6 +323,47 @@ def test_opaque_gaussians_vs_reference(ref, mods, name, bwd_kernel, monkeypatch)
     worth = rel_l2(np32(R2["v_opacities"]).reshape(-1)[sel.numpy()], np32(R["v_opacities"]).reshape(-1)[sel.numpy()])
     parity_record("opaque Gaussians, %s: what the 0.999 clamp changes in the reference's own opacity gradients (rel-L2)" % name, opaque_visible=int(sel.sum()), rel_l2=worth)
     assert int(sel.sum()) > 100 and worth > 0.02, (int(sel.sum()), worth)   # measured 0.030 (fisheye) - 0.106 (rolling shutter)
+
+
+def _regime(scenes, name):
+    """Small scenes in regimes a TRAINED model reaches and the random ones (opacity 0.3 - 0.8, isotropic-ish scales 0.01 - 0.06, unit quaternions,
+    depth 2 - 3) never do."""
+    sc = ref_hip_cases.small_scene(scenes, N=3000, sh_degree=0)
+    g = torch.Generator().manual_seed(41)
+    N = 3000
+    if name == "raw_quaternions":        # Ops.h takes un-normalised rotations: every kernel normalises, the backward returns d/d(raw q) (Utils.cuh:80-126)
+        sc["quats"] = sc["quats"] * (torch.rand(N, 1, generator=g) * 4.8 + 0.2)
+    elif name == "faint":                # opacities around the 1/255 cull and the opacity-aware extent sqrt(2 ln(255 o)) -> 0 (ProjectionUT3DGSFused.cu:154-166)
+        sc["opacities"] = torch.exp(torch.rand(N, generator=g) * 5.0 - 6.9)   # 0.001 .. 0.15, a fifth below 1/255
+    elif name == "needles":              # 100:1 - 1000:1 anisotropy
+        ax = torch.randint(0, 3, (N,), generator=g)
+        sc["scales"] = sc["scales"] / 4.0
+        sc["scales"][torch.arange(N), ax] *= 120.0
+    elif name == "giants":               # a few Gaussians larger than the view
+        pick = torch.randperm(N, generator=g)[:60]
+        sc["scales"][pick] = torch.rand(60, 3, generator=g) * 2.0 + 1.0
+        sc["opacities"][pick] = 0.05
+    elif name == "close":                # Gaussians between the near plane and half a unit from the camera: sigma points behind it, footprints of hundreds of pixels
+        pick = torch.randperm(N, generator=g)[:300]
+        sc["means"][pick, 2] = torch.rand(300, generator=g) * 0.45 + 0.05
+        sc["means"][pick, :2] *= 0.2
+        sc["opacities"][pick] = 0.1
+    return sc
+
+
+@pytest.mark.parametrize("name", ["raw_quaternions", "faint", "needles", "giants", "close"])
+def test_trained_model_regimes_vs_reference(ref, mods, name):
+    """Stage by stage against the reference's kernels (and the oracle) where random scenes do not go (the opaque regime has its own test above)."""
+    ops, scenes = mods
+    sc = _regime(scenes, name)
+    # needles: the unscented transform's weights (-99 and 16.7) cancel two digits before the covariance of a 100 : 1 - 700 : 1 footprint is formed, and
+    # three fp32 evaluations of it round the 3.33 sigma extents of radii up to 300 px differently: HIP 15 / 3000 radii off by one pixel from the
+    # reference kernel's, the oracle's restatement 54 (two of them by two pixels) — conics within 0.6 % / 2.3 %
+    kw = dict(radius_flip_frac=2.5e-2, radius_max_diff=2) if name == "needles" else {}
+    recs, R = _stagewise(ref, ops, sc, {}, "regime %s" % name, fwd_strict=False, **kw)
+    assert int(R["flatten_ids"].numel()) > 3000, int(R["flatten_ids"].numel())
+    if name == "needles":   # (rounds 1 - 4: v_scales 3.2e-3 — moments in (du, dv) and the cofactor chain, gsx_record.hpp: moments_to_gradients)
+        assert recs["proj_hip"]["radius_max_diff_px"] <= 1 and recs["bwd_hip"]["v_scales"] < 3e-4, (recs["proj_hip"], recs["bwd_hip"])
 
 
 def test_s1m_full_frame(ref, mods):
