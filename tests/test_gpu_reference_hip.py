@@ -348,10 +348,26 @@ def _regime(scenes, name):
         sc["means"][pick, 2] = torch.rand(300, generator=g) * 0.45 + 0.05
         sc["means"][pick, :2] *= 0.2
         sc["opacities"][pick] = 0.1
+    elif name == "intrinsics":           # fx != fy, principal point far from the image centre (the pinhole kernels step du by 1 / fx along a row, dv by 1 / fy between rows)
+        sc["K"] = scenes.intrinsics(115.0, 70.0, 40.0, 90.0)
+    elif name == "ragged":               # image sides that are not multiples of the tile (and not of the 4 x 4 blocks either)
+        sc["width"], sc["height"] = 150, 90
+        sc["K"] = scenes.intrinsics(90.0, 90.0, 75.0, 45.0)
+    elif name == "posed":                # a camera away from the origin looking back at the cloud at an angle
+        sc["viewmat"] = scenes.look_at_viewmat((2.2, -1.1, 0.4), (0.0, 0.1, 2.6))
+    elif name == "far":                  # the same cloud 40 x further away and 40 x larger: |g| = depth / scale as before, coordinates of 100
+        sc["means"] = sc["means"] * 40.0
+        sc["scales"] = sc["scales"] * 40.0
+    elif name == "offset_world":         # world coordinates of ~1500 (a geo-referenced capture): mu - c loses 3 digits in fp32 before anything else happens
+        shift = torch.tensor([800.0, -500.0, 1200.0])
+        sc["means"] = sc["means"] + shift
+        vm = sc["viewmat"].clone()
+        vm[:3, 3] = -(vm[:3, :3] @ shift)
+        sc["viewmat"] = vm
     return sc
 
 
-@pytest.mark.parametrize("name", ["raw_quaternions", "faint", "needles", "giants", "close"])
+@pytest.mark.parametrize("name", ["raw_quaternions", "faint", "needles", "giants", "close", "intrinsics", "ragged", "posed", "far", "offset_world"])
 def test_trained_model_regimes_vs_reference(ref, mods, name):
     """Stage by stage against the reference's kernels (and the oracle) where random scenes do not go (the opaque regime has its own test above)."""
     ops, scenes = mods
