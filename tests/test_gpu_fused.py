@@ -224,6 +224,8 @@ def test_frontend_fused_is_bit_identical_to_the_separate_operators(mods, deg, di
     ey0 = torch.clamp(torch.floor(m2[:, 1] / 16.0 - rd[:, 1] / 16.0), 0, th).int()
     ey1 = torch.clamp(torch.ceil(m2[:, 1] / 16.0 + rd[:, 1] / 16.0), 0, th).int()
     assert torch.equal(x0, ex0) and torch.equal(x1, ex1) and torch.equal(y0, ey0) and torch.equal(y1, ey1)   # IntersectTile.cu:65-76
+    # the invariant the RANGES layout of the backward's records stands on: the rectangles of the visible Gaussians sum to n_isects
+    assert int(((x1 - x0).long() * (y1 - y0).long()).sum()) == int(fl.numel())
     assert bool((r_pk[:, 14:].contiguous().view(torch.int32) == -65536).all())                                # 0xFFFF0000: no restriction
     # a Gaussian the projection culled gets a NULL record (log2 opacity = -inf: alpha 0 everywhere), never uninitialised memory
     r_cull = recs(ws)[~vis[0]]

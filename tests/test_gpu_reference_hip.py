@@ -325,10 +325,10 @@ def test_opaque_gaussians_vs_reference(ref, mods, name, bwd_kernel, monkeypatch)
     assert int(sel.sum()) > 100 and worth > 0.02, (int(sel.sum()), worth)   # measured 0.030 (fisheye) - 0.106 (rolling shutter)
 
 
-def _regime(scenes, name):
+def _regime(scenes, name, sh_degree=0):
     """Small scenes in regimes a TRAINED model reaches and the random ones (opacity 0.3 - 0.8, isotropic-ish scales 0.01 - 0.06, unit quaternions,
     depth 2 - 3) never do."""
-    sc = ref_hip_cases.small_scene(scenes, N=3000, sh_degree=0)
+    sc = ref_hip_cases.small_scene(scenes, N=3000, sh_degree=sh_degree)
     g = torch.Generator().manual_seed(41)
     N = 3000
     if name == "raw_quaternions":        # Ops.h takes un-normalised rotations: every kernel normalises, the backward returns d/d(raw q) (Utils.cuh:80-126)
@@ -575,9 +575,24 @@ def test_s1m_bench_path_gradients_vs_reference_chain(ref, mods):
     kernels, with the activation Jacobians of the reference's torch glue (exp / normalize / sigmoid, splat_data.cpp:267-286) in torch.
     rel-L2 per parameter tensor < 1e-3 (north_star)."""
     ops, scenes = mods
+    _bench_path_vs_reference_chain(ref, scenes.scene_1m(), "S-1M @1080p")
+
+
+@pytest.mark.parametrize("name", ["needles", "opaque", "raw_quaternions", "close"])
+def test_regime_bench_path_gradients_vs_reference_chain(ref, mods, name):
+    """The same end-to-end comparison — fused front end (its own projection, records and lists), blend, Gaussian-major backward, gather, activation
+    Jacobians, fused SH backward against the reference chain and its torch glue — in the regimes of test_trained_model_regimes_vs_reference."""
+    ops, scenes = mods
+    if name == "opaque":   # (SH degree 3: the layout the fused front end takes)
+        sc, _ = _make_opaque(ref_hip_cases.small_scene(scenes, N=900, sh_degree=3))
+    else:
+        sc = _regime(scenes, name, sh_degree=3)
+    _bench_path_vs_reference_chain(ref, sc, "regime %s" % name)
+
+
+def _bench_path_vs_reference_chain(ref, sc, tag):
     import gsx  # noqa: F401
-    from gsx import distributed, rasterizer
-    sc = scenes.scene_1m()
+    from gsx import distributed, rasterizer, scenes
     model = scenes.to_splat_data(sc, DEV)
     W, H, deg = sc["width"], sc["height"], sc["sh_degree"]
     v_rc, v_ra = _grads(sc)
@@ -613,8 +628,8 @@ def test_s1m_bench_path_gradients_vs_reference_chain(ref, mods):
         for n in names:
             rec[("guarded_" if guarded else "exact_") + n] = rel_l2(np32(getattr(model, n).grad), np32(ref_g[n].reshape(getattr(model, n).shape)))
     err = (out.render_hwc.detach() - R["renders"]).abs().amax(-1)
-    rec = parity_record("S-1M @1080p END TO END gradients: rasterize_fused with gradient sinks (the bench path; exact and guarded lists) vs the reference "
-                        "chain's backward (rel-L2 per parameter tensor)", rgb_pixels_over_1e4=int((err > 1e-4).sum()), n_isects=int(out.n_isects),
+    rec = parity_record("%s END TO END gradients: rasterize_fused with gradient sinks (the bench path; exact and guarded lists) vs the reference "
+                        "chain's backward (rel-L2 per parameter tensor)" % tag, rgb_pixels_over_1e4=int((err > 1e-4).sum()), n_isects=int(out.n_isects),
                         n_isects_ref=int(R["flatten_ids"].numel()), **rec)
     for k, v in rec.items():
         if k.startswith(("exact_", "guarded_")):
