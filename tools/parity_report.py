@@ -27,6 +27,8 @@ def main(paths):
     print("pixels, each explained by a decision (windows 1e-3 / 4e-3) or — the deepest stacks of the diagonal cameras — priced against the float64 frame;")
     print("gradients against the reference kernel < 3e-3 and as close to the float64 backward as the reference kernel's are (fp32 is AT 1e-3 for the grazing views).  The")
     print("`reference kernel built with --use_fast_math vs reference kernel` records are the reference against ITSELF (its release flags vs IEEE).")
+    print("`regime ...`, `opaque Gaussians ...`, `trained model ...` (round 5): 3 000 / 900 Gaussians @128 x 128 in the regimes a trained model reaches (alpha clamp, raw quaternions,")
+    print("faint, needles, giants, close, odd intrinsics / image sizes / poses, a model this backend trained): same stage-by-stage comparison and tolerances (DESIGN.md section 2).")
     print("(2) `... vs oracle`: the HIP path against the CPU oracle on the BASELINE configs (tests/test_gpu_fullsize.py): forward 1e-4 L-inf on")
     print("pixels without a threshold-ambiguous decision (window 4e-4), every pixel within max colour / 255 + 1e-4; backward 1e-3 rel-L2;")
     print("projection relative to the float64 evaluation of the same formulas; binning bit-exact.  `wX_` = ambiguity window X.\n")
