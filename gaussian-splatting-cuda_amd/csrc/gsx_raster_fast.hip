@@ -963,6 +963,21 @@ GSX_DEV void thread_pixel_gm(uint32_t tid, uint32_t tile_x, uint32_t tile_y, uin
 GSX_DEV void row_scan4_mul(float (&x)[4]) { GSX_SCANR("v_mul_f32_dpp"); }
 GSX_DEV void row_scan4_add(float (&x)[4]) { GSX_SCANR("v_add_f32_dpp"); }
 #undef GSX_SCANR
+// The additive scan into OTHER registers: its first step reads the summands through DPP with bound_ctrl (a lane without a neighbour reads 0) and
+// writes the sum elsewhere, so the summands survive without four v_mov (they are needed again behind the scan).  Not for the product (0 is not its identity).
+GSX_DEV void row_scan4_add_to(const float (&e)[4], float (&x)[4]) {
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_add_f32_dpp %1, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_add_f32_dpp %2, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_add_f32_dpp %3, %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "s_nop 1\n\t"
+                 GSX_SCANR_STEP("v_add_f32_dpp", "row_shr:2 row_mask:0xf bank_mask:0xf")
+                 GSX_SCANR_STEP("v_add_f32_dpp", "row_shr:4 row_mask:0xf bank_mask:0xf")
+                 GSX_SCANR_STEP("v_add_f32_dpp", "row_shr:8 row_mask:0xf bank_mask:0xf")
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3])
+                 : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]));
+}
 #undef GSX_SCANR_STEP
 
 // lane 15 of every DPP row -> all 16 lanes of that row (ds_swizzle bit mode: lane' = (lane & 0x10) | 0x0f inside each half)
@@ -970,6 +985,8 @@ GSX_DEV float row_last(float x) { return __builtin_bit_cast(float, __builtin_amd
 
 // Sums x[0..15] over the four DPP rows (lanes l, l+16, l+32, l+48).  Afterwards z[j] of a lane in row r is the total of value
 // 4 j + {0,2,1,3}[r] for the lane's column (the first two stages of butterfly_reduce16).
+// (Round 5: the same two stages through the LDS crossbar — ds_bpermute for lane ^ 32, ds_swizzle for lane ^ 16, two selects + an add per pair instead of
+// a quarter-rate swap + an add: 246 VALU but ~46 fewer issue cycles per pass on paper — measured 0.5309 -> 0.5431 ms same-box: the LDS is the co-limit.)
 GSX_DEV void rows_reduce16(float (&x)[16], float (&z)[4]) {
     asm volatile("s_nop 1\n\t"
                  "v_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\t"
@@ -1020,9 +1037,9 @@ GSX_DEV void gq_row(const GmLaneRec& g, const GmRowPix& px, const float (&x0)[4]
         T[h] = px.T[h] * P[h];                                   // transmittance in front of this Gaussian
         fac[h] = al[h] * T[h];
         cv[h] = fmaf(g.cb, px.vb[h], fmaf(g.cg, px.vg[h], g.cr * px.vr[h]));
-        S[h] = e[h] = cv[h] * fac[h];
+        e[h] = cv[h] * fac[h];
     }
-    row_scan4_add(S);
+    row_scan4_add_to(e, S);
     float awh[4], bwh[4];
     (void)awh; (void)bwh;
 #pragma unroll
@@ -1030,9 +1047,9 @@ GSX_DEV void gq_row(const GmLaneRec& g, const GmRowPix& px, const float (&x0)[4]
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         const float tbo = px.tb[h] - S[h];                       // what the NEXT Gaussian of the row starts from (S = inclusive sum of e over the row's lanes)
-        const float tbuf = tbo + e[h];                           // tail - v . (colour accumulated behind this Gaussian)
-        const float v_alpha = fmaf(T[h], cv[h], ra[h] * tbuf);
-        float av = al[h] * v_alpha;
+        // alpha dL/dalpha = alpha (T c.v + tbuf / (1 - alpha)) with tbuf = tbo + e (tail - v . colour accumulated behind this Gaussian) and e = c.v alpha T:
+        //                 = e (1 + alpha / (1 - alpha)) + (alpha / (1 - alpha)) tbo = e ra + (alpha ra) tbo        (1 + alpha / (1 - alpha) = ra)
+        float av = fmaf(al[h] * ra[h], tbo, e[h] * ra[h]);
         if (CLAMP) av = (al[h] < 0.999f) ? av : 0.f;             // clamped alpha carries no gradient (Bwd.cu:318)
         const float aw = av * rden[h];
         const float bw = aw * (num2[h] * rden[h]);
@@ -1299,6 +1316,8 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
                 // for the clamp-free arm's four v_mov: 245 instead of 237 VALU per pass — the arms then disagree about more, not less)
                 acc[15] = 1.f;   // "listed" marker (summed like a moment: no separate LDS atomic)
                 // carries for this row's next pass: the values behind the row's last Gaussian
+                // (round 5: the eight broadcasts as `v_mov_b32_dpp ... row_newbcast:15` instead of ds_swizzle — 8 LDS-crossbar operations fewer, 8 DPP VALU more:
+                // measured 0.5367 -> 0.5400 ms same-box, not kept)
 #pragma unroll
                 for (int h = 0; h < 4; ++h) { px.T[h] = row_last(T_out[h]); px.tb[h] = row_last(tb_out[h]); }
                 // the four pixel rows' partial moments of each Gaussian -> one total per (Gaussian, moment), four moments per lane
