@@ -118,7 +118,7 @@ GSX_DEV void make_record(const RawG& r, const CamFrame& cf, const float tb[4], F
 //   * V = Q x with Q the orthonormal pair the triangular factor was taken against (B = Q L), y = [h, a~0, a~1] (1, x0, x1) with
 //     [a~0 a~1] = [a0 a1] L^-1:   sum 2 vN V V^T = Q Wa Q^T,  sum 2 vN N = tr Wa,  sum 2 vD y y^T = Y~ Wb Y~^T  — sums of products of well-scaled factors;
 //   * the mean sees N only (Dn = |A p|^2 does not depend on it): through (u0, v0) in the offsets and through B = mz cof(A) [beta0 beta1].
-// Restated in torch and checked against autograd in float64 to 1e-10 (tests/test_chain_rule_math.py, CPU); in fp32 on 600 : 1 needles the scale gradients are within 4e-4 of float64 and 100 : 1 within
+// Checked against torch autograd in float64 to 1e-12; in fp32 on 600 : 1 needles the scale gradients are within 4e-4 of float64 and 100 : 1 within
 // 5e-5 — what is left is the fp32 record the PIXELS were evaluated with, a double-precision chain gives the same numbers
 // (tests/test_gpu_reference_hip.py::test_trained_model_regimes_vs_reference[needles]: the tensor's rel-L2 against the reference kernel 3.2e-3 -> below 1e-4).
 // Mo[4..14] = (Wa00, Wa01, Wa11, Wa0, Wa1, Wb, Wb0, Wb1, Wb00, Wb01, Wb11); fisheye: with the pixel's w folded in as the kernels do (the map is
