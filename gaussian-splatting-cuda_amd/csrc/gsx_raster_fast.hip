@@ -640,6 +640,253 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_quad_kernel(Rast
     }
 }
 
+// ---- forward, two pixels per lane and eight lists per wave ("pair" variant, round 5; perfect pinhole) -----------------------------
+// The four-list kernel reads one 56 B record from LDS per (lane, step) and evaluates ONE pixel with it: 15 LDS-array cycles per step per
+// wave, four SIMDs on one LDS — the LDS is 73 % busy beside a VALU that is 71 % busy, and every lane runs one dependent chain (list entry ->
+// record -> rcp -> exp2 -> compare -> T) per step (profiles/r05_valu_issue.md).  Here a lane owns TWO horizontally adjacent pixels: the
+// tile is two waves (wave w = its rows 8 w .. 8 w + 7), eight lanes hold a 4x4 block (lane k of the eight: row k >> 1, columns 2 (k & 1),
+// 2 (k & 1) + 1), a wave walks the lists of its EIGHT blocks (4 across, 2 down) with one uniform step counter.  Per step a lane reads its
+// block's record once and composites two pixels: half the LDS reads per pair, two independent chains per lane, and the terms of the pair
+// that depend on dv alone (a lane's pixels share their image row) are formed once — by the compiler's CSE on the SAME expressions as the
+// other two kernels: every (pixel, Gaussian) pair sees the same instructions in the same order and the outputs are bit-identical
+// (tests/test_gpu_fused.py::test_forward_kernels_are_bit_identical).  45 VALU per step of two pixels (four-list kernel: 27 per pixel).
+// Chunks of PCH = 64 records (one binning batch), double buffered: 12.5 KB of LDS and 71 VGPRs per two-wave workgroup, 6 waves per SIMD (a
+// chunk of 128 fills the eight lists better — 84 % instead of 79 % — and loses more to its 3.5 waves per SIMD: 0.234 against 0.219 ms).
+// List entries are the record's BYTE OFFSET inside the chunk's buffer (16 bits): one add instead of a mask, a move and a v_mad_u32_u24.  (Entries
+// that are the LDS address itself, no add at all, measured 3 % SLOWER, and so did an s_nop in the add's place, with or without aligned loops; a
+// two-step software pipeline — the next record in flight while this one composites — 90 VGPRs, 52 VALU per step: +3 %.  NOTES.md N1.)
+// Measured (tools/fwd_quad_ab.py, same box, op incl. record packing): S-1M 0.2225 (four lists) -> 0.2110 ms; S-5M @4K 0.923 (one list) /
+// 0.994 (four lists) -> 0.854; large footprints on 32-pixel lists 0.1272 (one list) -> 0.1280; a saturated 640 x 360 frame 0.0555 (one
+// list) -> 0.0632 (a wave stops when all of its 128 pixels are finished, and 920 tiles of two waves do not fill the chip).
+constexpr int PB = 128;    // threads per workgroup of the pair kernel
+constexpr int PCH = 64;    // records per chunk
+// footprint_hits for the NX x NY blocks whose rectangles are products of NX u-ranges and NY v-ranges (hit[sy * NX + sx]): the 1-D pieces once
+// per range; the results stay compare results (the caller ballots them: no packing into bits and back)
+template <int NX, int NY>
+GSX_DEV void footprint_hits_grid(float4 c, float l00, float l01, float l11, const float (&xr)[NX][2], const float (&yr)[NY][2], bool (&hit)[NX * NY]) {
+    float xa[NX], xb[NX], lxa[NX], lxb[NX], lxc[NX], kxc[NX], ya[NY], yb[NY], m[NY], e1s[NY];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        xa[k] = xr[k][0] - c.x; xb[k] = xr[k][1] - c.x;
+        const float xc = __builtin_amdgcn_fmed3f(0.f, xa[k], xb[k]);
+        lxa[k] = l00 * xa[k]; lxb[k] = l00 * xb[k]; lxc[k] = l00 * xc; kxc[k] = c.w * xc;
+    }
+#pragma unroll
+    for (int k = 0; k < NY; ++k) {
+        ya[k] = yr[k][0] - c.y; yb[k] = yr[k][1] - c.y;
+        const float yc = __builtin_amdgcn_fmed3f(0.f, ya[k], yb[k]);
+        m[k] = l01 * yc;
+        const float e1 = l11 * yc;
+        e1s[k] = e1 * e1;
+    }
+#pragma unroll
+    for (int sy = 0; sy < NY; ++sy)
+#pragma unroll
+        for (int sx = 0; sx < NX; ++sx) {
+            const float t = __builtin_amdgcn_fmed3f(-m[sy], lxa[sx], lxb[sx]) + m[sy];
+            const float n1 = fmaf(t, t, e1s[sy]);
+            const float ys = __builtin_amdgcn_fmed3f(kxc[sx], ya[sy], yb[sy]);
+            const float t2 = fmaf(l01, ys, lxc[sx]), e2 = l11 * ys;
+            const float n2 = fmaf(t2, t2, e2 * e2);
+            hit[sy * NX + sx] = !(fminf(n1, n2) > c.z);
+        }
+}
+
+#ifndef GSX_PAIR_WAVES
+#define GSX_PAIR_WAVES 6   // (7 / 8: 0.2277 / 0.2201 against 0.2132 ms; 5 / 4: +2 %)
+#endif
+__global__ __launch_bounds__(PB, GSX_PAIR_WAVES) void raster_fwd_pair_kernel(RasterArgs a, float* __restrict__ render_colors,
+                                                                             float* __restrict__ render_alphas, int32_t* __restrict__ last_ids) {
+    constexpr int KIND = CAM_PERFECT_PINHOLE;
+    constexpr uint32_t PITCH = 80u;
+    static_assert((PCH + 1) * PITCH < 65536u, "list entries are 16-bit byte offsets");
+    __shared__ float4 s_rec[2][PCH + 1][5];   // as in raster_fwd_quad_kernel: 80 B pitch, [PCH] = the null record, [.][4] = (rad2, k2, -, -)
+    __shared__ float s_bounds[2][2];
+    __shared__ int s_wdone[2][2];
+    __shared__ __attribute__((aligned(16))) uint16_t s_list_flat[2 * 8 * PCH + 8];   // [wave][block][PCH] + the entry the last list's look-ahead reads
+    uint16_t (*s_list)[8][PCH] = reinterpret_cast<uint16_t (*)[8][PCH]>(s_list_flat);
+    const uint32_t cid = blockIdx.y;
+    uint32_t tile_id;
+    if (!swizzled_tile(blockIdx.x, a.tw * a.th, tile_id)) return;
+    const uint32_t tile_y = tile_id / a.tw, tile_x = tile_id - tile_y * a.tw;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, q8 = lane >> 3, k8 = lane & 7u;
+    const uint32_t uwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    // lane -> its two pixels: block q8 = (column q8 & 3, row q8 >> 2) of the wave's 16 x 8 half tile, lane k8 of the block = row k8 >> 1, columns 2 (k8 & 1) + {0, 1}
+    const uint32_t j0 = tile_x * TILE + (q8 & 3u) * 4u + (k8 & 1u) * 2u;
+    const uint32_t i = tile_y * TILE + wave * 8u + (q8 >> 2) * 4u + (k8 >> 1);
+    const bool inside[2] = {i < a.H && j0 < a.W, i < a.H && j0 + 1u < a.W};
+    const size_t pix0 = (size_t)cid * a.H * a.W + (size_t)i * a.W + j0;
+    const float* bg = a.backgrounds ? a.backgrounds + cid * 3 : nullptr;
+    if (a.masks != nullptr && !a.masks[(size_t)cid * a.th * a.tw + tile_id]) {  // Fwd.cu:143-150
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            if (inside[p])
+                for (int k = 0; k < 3; ++k) render_colors[(pix0 + p) * 3 + k] = bg ? bg[k] : 0.f;
+        return;
+    }
+    const Camera<KIND> cam(a.cams, cid, a.W, a.H);
+    float u[2], v;
+    pixel_uv(cam, i, j0, u[0], v);
+    { float v1; pixel_uv(cam, i, j0 + 1u, u[1], v1); }   // (same row: v1 == v)
+    // The blocks' rectangles of pixel centres are products of four u-ranges (block columns) and two v-ranges (block rows), clipped to the image:
+    // u depends on the column only, v on the row only, so the ends of a range are the (u, v) of the lanes that own its first and last valid
+    // pixel — wave-uniform lane numbers, read with v_readlane (no reductions over the lanes); a range without a valid pixel is empty (inf, -inf)
+    const int32_t wx0 = (int32_t)(tile_x * TILE), wy0 = (int32_t)(tile_y * TILE + uwave * 8u);
+    float xr[4][2], yr[2][2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int32_t last = min(3, (int32_t)a.W - 1 - (wx0 + 4 * k));   // last valid column of block column k (< 0: none)
+        const int32_t ll = max(last, 0);
+        const float first_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u[0]), 8 * k));
+        const float lu0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u[0]), 8 * k + (ll >> 1)));
+        const float lu1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u[1]), 8 * k + (ll >> 1)));
+        xr[k][0] = last >= 0 ? first_u : INFINITY;
+        xr[k][1] = last >= 0 ? ((ll & 1) ? lu1 : lu0) : -INFINITY;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int32_t last = min(3, (int32_t)a.H - 1 - (wy0 + 4 * k));   // last valid row of block row k
+        const int32_t ll = max(last, 0);
+        const float first_v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32 * k));
+        const float last_v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32 * k + 2 * ll));
+        yr[k][0] = last >= 0 ? first_v : INFINITY;
+        yr[k][1] = last >= 0 ? last_v : -INFINITY;
+    }
+    float tb[4];   // the tile's bounds (footprint()): its columns are this wave's, its rows both waves'
+    {
+        tb[0] = xr[0][0];
+        tb[1] = fmaxf(fmaxf(xr[0][1], xr[1][1]), fmaxf(xr[2][1], xr[3][1]));
+        if (lane == 0) { s_bounds[wave][0] = fminf(yr[0][0], yr[1][0]); s_bounds[wave][1] = fmaxf(yr[0][1], yr[1][1]); }
+        if (tid < 10) {   // the null records: lo' = -inf, unit denominator, empty footprint (rad2 = -1: what the binning's idle lanes test)
+            const uint32_t part = tid % 5u;
+            s_rec[tid / 5u][PCH][part] = part == 1u ? make_float4(0.f, -INFINITY, 0.f, 0.f) : (part == 4u ? make_float4(-1.f, 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+        __syncthreads();
+        tb[2] = fminf(s_bounds[0][0], s_bounds[1][0]); tb[3] = fmaxf(s_bounds[0][1], s_bounds[1][1]);
+    }
+
+    int32_t range_start, range_end;
+    tile_list_range(a, cid, tile_x, tile_y, range_start, range_end);
+    const int32_t n_chunks = (range_end - range_start + PCH - 1) / PCH;
+
+    constexpr float K999 = 0.999f, LOG2_K999 = -0.0014434168696687174f, THR = (1.f / 255.f) / 0.999f;   // see raster_fwd_fast_kernel
+    float T[2] = {1.f, 1.f};
+    uint32_t cur_idx[2] = {0u, 0u};
+    float out_r[2] = {0.f, 0.f}, out_g[2] = {0.f, 0.f}, out_b[2] = {0.f, 0.f};
+    float thr[2] = {inside[0] ? THR : INFINITY, inside[1] ? THR : INFINITY};
+    bool wave_done = __builtin_amdgcn_ballot_w64(inside[0] || inside[1]) == 0ull;
+    const uint16_t* my_list = s_list[wave][q8];
+#ifdef GSX_STATS
+    uint32_t st_tot[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+#endif
+    // wave 0 stages the chunks, one record per lane (the waves taking turns measured 1 % slower)
+    const bool stager = wave == 0u;
+    int32_t g_pre = 0;
+    bool have = stager && range_start + (int32_t)lane < range_end;
+    if (have) g_pre = a.flatten_ids[range_start + (int32_t)lane];
+    for (int32_t b = 0; b < n_chunks; ++b) {
+        const int buf = b & 1;
+        const int32_t chunk_start = range_start + PCH * b;
+        if (have) {
+            StagedRec sr;
+            stage_one(a, tb, g_pre, sr, tile_x, tile_y);
+            sr.r1.y -= LOG2_K999; sr.r2.w *= K999; sr.r3.x *= K999; sr.r3.y *= K999;
+            s_rec[buf][lane][0] = sr.r0; s_rec[buf][lane][1] = sr.r1; s_rec[buf][lane][2] = sr.r2; s_rec[buf][lane][3] = sr.r3;
+            s_rec[buf][lane][4] = make_float4(sr.cull.z, sr.cull.w, 0.f, 0.f);
+        }
+        if (lane == 0) s_wdone[buf][wave] = wave_done ? 1 : 0;
+        __syncthreads();
+        if (s_wdone[buf][0] & s_wdone[buf][1]) break;  // Fwd.cu:188-190
+        have = stager && (b + 1 < n_chunks) && (chunk_start + PCH + (int32_t)lane < range_end);
+        if (have) g_pre = a.flatten_ids[chunk_start + PCH + (int32_t)lane];  // in flight during the pixel loop
+        if (wave_done) continue;
+        const int32_t chunk_size = min(PCH, range_end - chunk_start);
+        // the eight lists of this wave for the chunk, pre-filled with the null record's entry (the shorter ones idle to the end): 8 x 64 x 2 B = one ds_write_b128 per lane
+        {
+            const uint32_t fill = 0x00010001u * (PCH * PITCH);
+            reinterpret_cast<uint4*>(&s_list[wave][0][0])[lane] = make_uint4(fill, fill, fill, fill);
+        }
+        // every lane tests a record — lanes behind the chunk's end the null record (empty footprint) —: no branch, the eight compare results
+        // ARE the ballots and the counters stay wave-uniform
+        const uint32_t cand = (int32_t)lane < chunk_size ? lane : (uint32_t)PCH;
+        bool hit[8];
+        {
+            const float4 q0 = s_rec[buf][cand][0], q1 = s_rec[buf][cand][1], q4 = s_rec[buf][cand][4];   // (u0, v0, l00, l01), (l11, ..), (rad2, k2)
+            footprint_hits_grid<4, 2>(make_float4(q0.x, q0.y, q4.x, q4.y), q0.z, q0.w, q1.x, xr, yr, hit);
+        }
+        uint32_t cnt[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit[q]);
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (hit[q]) s_list[wave][q][pos] = (uint16_t)(cand * PITCH);
+            cnt[q] = (uint32_t)__popcll(m);
+        }
+        const uint32_t steps = (uint32_t)__builtin_amdgcn_readfirstlane((int)max(max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3])), max(max(cnt[4], cnt[5]), max(cnt[6], cnt[7]))));   // (wave-uniform: the step counter stays on the SALU)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the lists are private to the wave
+        GSX_STAT_ADD(0, steps);
+        GSX_STAT_ADD(1, chunk_size);
+        GSX_STAT_ADD(4, cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[4] + cnt[5] + cnt[6] + cnt[7]);   // / (8 x steps) = how full the eight lists run
+#ifdef GSX_STATS
+#pragma unroll
+        for (int q = 0; q < 8; ++q) st_tot[q] += cnt[q];
+#endif
+        uint32_t cur[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};   // list entry (the record's byte offset inside the chunk's buffer) of the last Gaussian each pixel took
+        uint32_t t_next = my_list[0];
+        for (uint32_t k = 0; k < steps; ++k) {
+            const uint32_t t = t_next;
+            t_next = my_list[k + 1];                     // (one past the end at the last step: inside the LDS arrays, never used)
+            const float4* rp = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(&s_rec[buf][0][0]) + t);
+            const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+            bool take[2];
+            float wgt[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {   // the same expressions as raster_fwd_quad_kernel's step, per pixel
+                const float du = u[p] - r0.x;
+                const float dv = v - r0.y;
+                const float t0 = fmaf(r0.w, dv, r0.z * du);
+                const float t1 = r1.x * dv;
+                const float num2 = fmaf(t0, t0, t1 * t1);
+                const float den = fmaf(du, fmaf(r2.x, du, fmaf(r2.y, dv, r1.z)), fmaf(dv, fmaf(r2.z, dv, r1.w), 1.f));
+                const float ap = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(fmaf(-num2, __builtin_amdgcn_rcpf(den), r1.y)), 0.f, 1.f);
+                take[p] = ap >= thr[p];                  // alpha >= 1/255 and the pixel is not finished (Fwd.cu:240)
+                wgt[p] = take[p] ? ap * T[p] : 0.f;      // alpha T / 0.999
+                T[p] = fmaf(-K999, wgt[p], T[p]);        // T (1 - alpha), in place
+            }
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(T[0] <= 1e-4f || T[1] <= 1e-4f) != 0ull, 0)) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const bool stop = T[p] <= 1e-4f;     // this pixel does NOT take the Gaussian (Fwd.cu:245-248): see raster_fwd_fast_kernel
+                    take[p] = take[p] && !stop;
+                    T[p] = stop ? fmaf(K999, wgt[p], T[p]) : T[p];
+                    wgt[p] = stop ? 0.f : wgt[p];
+                    thr[p] = stop ? INFINITY : thr[p];
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                out_r[p] = fmaf(r2.w, wgt[p], out_r[p]); out_g[p] = fmaf(r3.x, wgt[p], out_g[p]); out_b[p] = fmaf(r3.y, wgt[p], out_b[p]);
+                cur[p] = take[p] ? t : cur[p];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next chunk's pre-fill stays behind this chunk's reads
+#pragma unroll
+        for (int p = 0; p < 2; ++p) cur_idx[p] = cur[p] != 0xFFFFFFFFu ? (uint32_t)chunk_start + cur[p] / PITCH : cur_idx[p];
+        if (__builtin_amdgcn_ballot_w64(thr[0] < INFINITY || thr[1] < INFINITY) == 0ull) wave_done = true;   // all 128 pixels finished
+    }
+    GSX_STAT_ADD(5, max(max(max(st_tot[0], st_tot[1]), max(st_tot[2], st_tot[3])), max(max(st_tot[4], st_tot[5]), max(st_tot[6], st_tot[7]))));   // steps if the lists ran on across chunk boundaries
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+        if (inside[p]) {
+            const size_t pix = pix0 + (size_t)p;
+            render_alphas[pix] = 1.f - T[p];
+            render_colors[pix * 3] = bg ? out_r[p] + T[p] * bg[0] : out_r[p];
+            render_colors[pix * 3 + 1] = bg ? out_g[p] + T[p] * bg[1] : out_g[p];
+            render_colors[pix * 3 + 2] = bg ? out_b[p] + T[p] * bg[2] : out_b[p];
+            last_ids[pix] = (int32_t)cur_idx[p];
+        }
+}
+
 // forward workspace, from its 256 B aligned base: packed records [C*N] x 64 B | fisheye: "no chart" bytes [C*N] | tile flags
 // ... | chain heads [NSUB][C*N] int32 of the backward's per-(camera, Gaussian) record chains: set to -1 by whoever packs the records (the
 // fused front end, pack_records_kernel) and put back to -1 by the gather kernel that walks the chains, so a backward on the forward's
@@ -708,7 +955,14 @@ const uint8_t* launch_raster_fwd_fast(int kind, RasterArgs a, float* renders, fl
         else if (kind == CAM_OPENCV_PINHOLE) hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<CAM_OPENCV_PINHOLE>), grid, block, 0, st, a, renders, alphas, last_ids); \
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<CAM_OPENCV_FISHEYE>), grid, block, 0, st, a, renders, alphas, last_ids);               \
     } while (0)
-    if (quad) GSX_BLEND_FWD(raster_fwd_quad_kernel);
+    // Two pixels per lane / eight lists per wave (raster_fwd_pair_kernel, perfect pinhole): frames with 16-pixel lists whose grid fills the chip with
+    // two-wave workgroups (>= 2048 tiles) and up to 8 intersections per Gaussian.  Same box, op incl. record packing: S-1M 0.2197 (four lists) -> 0.2094,
+    // S-5M @4K 0.875 (one list) -> 0.834, a saturated 1080p frame (6.1 intersections per Gaussian) 0.2488 (one list) -> 0.2390; NOT the same frame at
+    // 640 x 360 (920 tiles: 0.0555 -> 0.0632) and not 32-pixel lists (0.1272 -> 0.1280).  GSX_FWD=pair forces it for any perfect-pinhole frame.
+    bool pair = a.lshift == 0u && kind == CAM_PERFECT_PINHOLE && n_tiles >= 2048u && a.n_isects_expected <= 8 * (int64_t)a.C * (int64_t)a.N;
+    if (const char* e = test_switch("GSX_FWD")) pair = std::string(e) == "pair" ? kind == CAM_PERFECT_PINHOLE : (std::string(e) == "quad" || std::string(e) == "wave" ? false : pair);
+    if (pair) hipLaunchKernelGGL(raster_fwd_pair_kernel, grid, dim3(PB), 0, st, a, renders, alphas, last_ids);
+    else if (quad) GSX_BLEND_FWD(raster_fwd_quad_kernel);
     else GSX_BLEND_FWD(raster_fwd_fast_kernel);
 #undef GSX_BLEND_FWD
     return a.tile_flags;

@@ -358,11 +358,11 @@ def test_lists_per_32px_tiles_respect_the_16px_rectangles(mods, monkeypatch):
     assert n_diff > 0, "the needle scene no longer has footprints that leave their 16-px rectangles: the test above proves nothing"
 
 
-@pytest.mark.parametrize("size,list_tile", [((160, 112), 16), ((150, 100), 16), ((150, 100), 32)])
+@pytest.mark.parametrize("size,list_tile", [((160, 112), 16), ((150, 100), 16), ((131, 77), 16), ((150, 100), 32)])
 def test_forward_kernels_are_bit_identical(mods, size, list_tile, monkeypatch):
-    """The two forward kernels of the fast path (GSX_FWD=wave: one list per 8x8 quadrant; quad: four lists per wave, one per DPP row / 4x4
-    block) evaluate the same pairs in the same order with the same instructions: image, alpha and last ids are EQUAL — ragged image sizes,
-    16- and 32-pixel lists; and the launcher's own choice (no switch) is one of the two."""
+    """The three forward kernels of the fast path (GSX_FWD=wave: one list per 8x8 quadrant; quad: four lists per wave, one per DPP row / 4x4
+    block; pair: two pixels per lane, eight lists per wave) evaluate the same pairs in the same order with the same instructions: image, alpha
+    and last ids are EQUAL — ragged image sizes, 16- and 32-pixel lists; and the launcher's own choice (no switch) is one of them."""
     distributed, ops, rasterizer, scenes = mods
     sc, cam = _setup(scenes, rasterizer, 3)
     W, H = size
@@ -370,7 +370,7 @@ def test_forward_kernels_are_bit_identical(mods, size, list_tile, monkeypatch):
     bg = sc["background"].to(DEV) + 0.1
     monkeypatch.setenv("GSX_LIST_TILE", str(list_tile))
     outs = {}
-    for mode in ("wave", "quad", None):
+    for mode in ("wave", "quad", "pair", None):
         if mode is None:
             monkeypatch.delenv("GSX_FWD")
         else:
@@ -379,5 +379,5 @@ def test_forward_kernels_are_bit_identical(mods, size, list_tile, monkeypatch):
         with torch.no_grad():
             o = rasterizer.rasterize_fused(cam, model, bg)
         outs[mode] = (o.image.clone(), o.alpha.clone())
-    for k in ("quad", None):
+    for k in ("quad", "pair", None):
         assert torch.equal(outs["wave"][0], outs[k][0]) and torch.equal(outs["wave"][1], outs[k][1]), k

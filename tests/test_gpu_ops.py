@@ -155,13 +155,13 @@ def _fwd(ops, sc, b, bg=True):
         ops.ShutterType.GLOBAL, None, None, None, b["off"], b["fl"])
 
 
-@pytest.fixture(params=["fast", "fast-quad", "generic"])
+@pytest.fixture(params=["fast", "fast-quad", "fast-pair", "generic"])
 def raster_path(request):
-    """Both kernel families: the MI355X fast path — with each of its two forward kernels forced (one list per 8x8 quadrant / four lists per
-    wave; the launcher picks by footprint size) — and the reference-order generic path."""
+    """Both kernel families: the MI355X fast path — with each of its three forward kernels forced (one list per 8x8 quadrant / four lists per
+    wave / two pixels per lane and eight lists per wave; the launcher picks by footprint size and grid) — and the reference-order generic path."""
     old = {k: os.environ.get(k) for k in ("GSX_RASTER_PATH", "GSX_FWD")}
     os.environ["GSX_RASTER_PATH"] = "generic" if request.param == "generic" else "fast"
-    os.environ["GSX_FWD"] = "quad" if request.param == "fast-quad" else "wave"
+    os.environ["GSX_FWD"] = {"fast-quad": "quad", "fast-pair": "pair"}.get(request.param, "wave")
     yield "fast" if request.param.startswith("fast") else "generic"
     for k, v in old.items():
         if v is None:

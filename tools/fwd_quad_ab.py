@@ -1,5 +1,5 @@
 """A/B of the two forward blend kernels in one process (the switch GSX_FWD is read per launch): one list per 8x8 quadrant ("wave") vs
-four lists per wave ("quad").  Outputs must be bit-identical; prints the medians of n launches.   python tools/fwd_quad_ab.py [1m|5m|dense] [n]"""
+four lists per wave ("quad") vs two pixels per lane / eight lists per wave ("pair").  Outputs must be bit-identical; prints the medians of n launches.   python tools/fwd_quad_ab.py [1m|5m|dense] [n]"""
 import os
 os.environ.setdefault("GSX_TEST_SWITCHES", "1")
 import sys
@@ -14,11 +14,15 @@ from gsx import layout, ops, rasterizer, scenes  # noqa: E402
 which = sys.argv[1] if len(sys.argv) > 1 else "1m"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = "cuda:0"
+MODES = tuple(os.environ.get("GSX_AB_MODES", "wave,quad,pair").split(","))   # GSX_FWD values, the first one is the yardstick
 for cam_kind in (("pinhole", "fisheye") if len(sys.argv) <= 3 else ("pinhole",)):
     list_tile = 16
     if which == "heavy":   # large footprints, long lists (the regime of a trained capture; lists per 32x32 pixels as the fused path picks there)
         scene = scenes.scene_frustum(500_000, 1296, 840, 1000.0, (2.0, 8.0), scale_range=(0.02, 0.12), sh_degree=0, seed=5)
         list_tile = 32
+    elif which == "dense_hd":   # the saturated frame at 1920 x 1080: the same footprints in pixels and the same opacities, nine times the Gaussians
+        scene = scenes.scene_frustum(2_700_000, 1920, 1080, 900.0, (2.0, 6.0), scale_range=(0.0033, 0.027), sh_degree=0, seed=3)
+        scene["opacities"] = torch.rand(2_700_000, generator=torch.Generator().manual_seed(4)) * 0.3 + 0.69
     elif which == "dense":
         scene = scenes.scene_frustum(300_000, 640, 360, 300.0, (2.0, 6.0), scale_range=(0.01, 0.08), sh_degree=0, seed=3)
         scene["opacities"] = torch.rand(300_000, generator=torch.Generator().manual_seed(4)) * 0.3 + 0.69
@@ -65,10 +69,11 @@ for cam_kind in (("pinhole", "fisheye") if len(sys.argv) <= 3 else ("pinhole",))
 
     res = {}
     for rnd in range(2):
-        for mode in ("wave", "quad"):
+        for mode in MODES:
             os.environ["GSX_FWD"] = mode
             t, r = timeit(lambda: ops.rasterize_to_pixels_from_world_3dgs_fwd(*common))
             res[mode] = [x.clone() for x in r[:3]]
             print(f"{which} {cam_kind} lists{list_tile} n_isects={fl.numel()} GSX_FWD={mode}: fwd op {t:.4f} ms")
-    same = [bool(torch.equal(a, b)) for a, b in zip(res["wave"], res["quad"])]
-    print("   bit-identical renders / alphas / last_ids:", same, " max |d rgb| %.3g" % float((res["wave"][0] - res["quad"][0]).abs().max()))
+    for mode in MODES[1:]:
+        same = [bool(torch.equal(a, b)) for a, b in zip(res[MODES[0]], res[mode])]
+        print("   %s vs %s: bit-identical renders / alphas / last_ids:" % (MODES[0], mode), same, " max |d rgb| %.3g" % float((res[MODES[0]][0] - res[mode][0]).abs().max()))
