@@ -29,7 +29,7 @@ def main():
     find = lambda sub: next((v for n, v in k.items() if sub in n), None)  # noqa: E731
     traffic = lambda v: int((2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024) if v else 0  # noqa: E731
     pack, gather = find("pack_records"), find("gsx_bwd_gather")
-    fwd_name = "raster_fwd_quad" if find("raster_fwd_quad") else "raster_fwd_fast"   # whichever forward kernel the launcher took for this workload
+    fwd_name = next((n for n in ("raster_fwd_pair", "raster_fwd_quad") if find(n)), "raster_fwd_fast")   # whichever forward kernel the launcher took for this workload
     fwd = find(fwd_name)
     bwd = find("raster_bwd_gq") or find("raster_bwd_gm") or find("raster_bwd_fast")
     sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-cuda_amd"))

@@ -37,6 +37,7 @@ if [ -z "$SKIP_PMC" ]; then   # SKIP_PMC=1 only when the blend sources still has
 fi
 python bench.py --scene 5m --steps 10 --warmup 3 --no-cpu-baseline > "$out/bench_s5m.json" 2> "$out/bench_s5m.err"
 echo "bench 5m rc=$?"
+[ -n "$SKIP_GARDEN" ] && exit 0
 # 5. the BASELINE configs[2] stand-in, twice (the first run on a fresh box is cold)                       -> garden_standin{_cold,}.json
 timeout 150 python examples/train_garden_standin.py 4000 --json "$out/garden_standin_cold.json" > /dev/null 2> "$out/garden.err"
 timeout 150 python examples/train_garden_standin.py 4000 --json "$out/garden_standin.json" > /dev/null 2>> "$out/garden.err"
