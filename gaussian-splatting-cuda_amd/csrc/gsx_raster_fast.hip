@@ -649,15 +649,22 @@ __global__ __launch_bounds__(RB, GSX_FWD_WAVES) void raster_fwd_quad_kernel(Rast
 // block's record once and composites two pixels: half the LDS reads per pair, two independent chains per lane, and the terms of the pair
 // that depend on dv alone (a lane's pixels share their image row) are formed once — by the compiler's CSE on the SAME expressions as the
 // other two kernels: every (pixel, Gaussian) pair sees the same instructions in the same order and the outputs are bit-identical
-// (tests/test_gpu_fused.py::test_forward_kernels_are_bit_identical).  45 VALU per step of two pixels (four-list kernel: 27 per pixel).
-// Chunks of PCH = 64 records (one binning batch), double buffered: 12.5 KB of LDS and 71 VGPRs per two-wave workgroup, 6 waves per SIMD (a
+// (tests/test_gpu_fused.py::test_forward_kernels_are_bit_identical).  46 VALU per step of two pixels (four-list kernel: 27 per pixel).
+// Chunks of PCH = 64 records (one binning batch), double buffered: 12.5 KB of LDS and 76 VGPRs per two-wave workgroup, 6 waves per SIMD (a
 // chunk of 128 fills the eight lists better — 84 % instead of 79 % — and loses more to its 3.5 waves per SIMD: 0.234 against 0.219 ms).
 // List entries are the record's BYTE OFFSET inside the chunk's buffer (16 bits): one add instead of a mask, a move and a v_mad_u32_u24.  (Entries
 // that are the LDS address itself, no add at all, measured 3 % SLOWER, and so did an s_nop in the add's place, with or without aligned loops; a
 // two-step software pipeline — the next record in flight while this one composites — 90 VGPRs, 52 VALU per step: +3 %.  NOTES.md N1.)
-// Measured (tools/fwd_quad_ab.py, same box, op incl. record packing): S-1M 0.2225 (four lists) -> 0.2110 ms; S-5M @4K 0.923 (one list) /
-// 0.994 (four lists) -> 0.854; large footprints on 32-pixel lists 0.1272 (one list) -> 0.1280; a saturated 640 x 360 frame 0.0555 (one
-// list) -> 0.0632 (a wave stops when all of its 128 pixels are finished, and 920 tiles of two waves do not fill the chip).
+// Counters at S-1M (profiles/r05f_pmc_counters.md): 1.889 M steps of two pixels (four lists: 3.36 M of one), SQ_INSTS_VALU 124.6 M (127.8), LDS
+// cycles 51.9 M (73.7), SALU 14.1 M (31) — the step loop is 87 M of the VALU instructions in either kernel, the other 37 M are binning (every
+// candidate against 16 blocks: 22 M), staging and set-up.
+// Measured, same box (NOTES.md N1): the op alone in a loop (tools/fwd_quad_ab.py, incl. record packing) S-1M 0.2197 (four lists) -> 0.2094 ms,
+// S-5M @4K 0.875 (one list) / 0.93 (four lists) -> 0.834, a saturated 1080p frame 0.2488 (one list) -> 0.2390, large footprints on 32-pixel
+// lists 0.1272 (one list) -> 0.1280, the saturated frame at 640 x 360 0.0555 (one list) -> 0.0632 (a wave stops when all of its 128 pixels
+// are finished, and 920 tiles of two waves do not fill the chip).  INSIDE the training step, where the chip sits at its power limit all the
+// time, S-1M's kernel goes 198.9 -> 197.0 us only (tools/ktrace_fwd_modes.sh) — and the loop's gain disappears the same way when a 2 GiB
+// streaming kernel runs in front of every timed launch: under sustained load a kernel is paid in energy, not in utilisation.  S-5M's forward
+// inside its step: 0.842 -> 0.792 ms.
 constexpr int PB = 128;    // threads per workgroup of the pair kernel
 constexpr int PCH = 64;    // records per chunk
 // footprint_hits for the NX x NY blocks whose rectangles are products of NX u-ranges and NY v-ranges (hit[sy * NX + sx]): the 1-D pieces once
@@ -854,6 +861,12 @@ __global__ __launch_bounds__(PB, GSX_PAIR_WAVES) void raster_fwd_pair_kernel(Ras
                 T[p] = fmaf(-K999, wgt[p], T[p]);        // T (1 - alpha), in place
             }
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(T[0] <= 1e-4f || T[1] <= 1e-4f) != 0ull, 0)) {
+#ifdef GSX_STATS
+                {   // how often a wave takes the stop branch, and for how many pixels (the ballots outside the macro's `lane == 0` region)
+                    const uint32_t n_stop = (uint32_t)(__popcll(__builtin_amdgcn_ballot_w64(T[0] <= 1e-4f)) + __popcll(__builtin_amdgcn_ballot_w64(T[1] <= 1e-4f)));
+                    GSX_STAT_ADD(6, 1); GSX_STAT_ADD(7, n_stop);
+                }
+#endif
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     const bool stop = T[p] <= 1e-4f;     // this pixel does NOT take the Gaussian (Fwd.cu:245-248): see raster_fwd_fast_kernel

@@ -14,6 +14,7 @@ from gsx import layout, ops, rasterizer, scenes  # noqa: E402
 which = sys.argv[1] if len(sys.argv) > 1 else "1m"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = "cuda:0"
+FLUSH = torch.zeros(int(os.environ["GSX_AB_FLUSH"]) * 262144, device=dev) if os.environ.get("GSX_AB_FLUSH") else None
 MODES = tuple(os.environ.get("GSX_AB_MODES", "wave,quad,pair").split(","))   # GSX_FWD values, the first one is the yardstick
 for cam_kind in (("pinhole", "fisheye") if len(sys.argv) <= 3 else ("pinhole",)):
     list_tile = 16
@@ -59,6 +60,8 @@ for cam_kind in (("pinhole", "fisheye") if len(sys.argv) <= 3 else ("pinhole",))
         ts = []
         for _ in range(n):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if FLUSH is not None:
+                FLUSH.add_(1.0)   # GSX_AB_FLUSH=<MiB>: a streaming kernel over that many MiB in front of every timed launch (what the caches hold in a training step is not this kernel's own last run)
             s.record()
             r = fn()
             e.record()
