@@ -649,15 +649,18 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd_packed(
                                                                v_colors, v_opacities, workspace, workspace_bytes, packed_records, nullptr, 0, stream);
 }
 
-extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd_guarded(
+// `act` != nullptr: *act_folded tells the caller whether the gather applied the activation Jacobians (else the outputs are the five
+// activated-parameter gradients as always and the caller runs gsx_splat_activations_bwd_reg behind it)
+static int raster_bwd_impl(
     uint32_t N, int64_t n_isects, const float* means, const float* quats, const float* scales, const float* colors,
     uint32_t channels, const float* opacities, const float* backgrounds, const uint8_t* masks, uint32_t image_width,
     uint32_t image_height, uint32_t tile_size, const gsx_cameras* cams, const gsx_ut_params* ut,
     const int32_t* tile_offsets, const int32_t* flatten_ids, const float* render_alphas, const int32_t* last_ids,
     const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats, float* v_scales,
     float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes, const void* packed_records,
-    const int32_t* lists_status, int64_t n_isects_expected, void* stream) {
+    const int32_t* lists_status, int64_t n_isects_expected, void* stream, const ActEpilogue* act, bool* act_folded) {
     (void)ut;
+    if (act_folded) *act_folded = false;
     RasterArgs a;
     int rc = fill_args(a, N, n_isects, means, quats, scales, colors, channels, opacities, backgrounds, masks, image_width,
                        image_height, tile_size, cams, tile_offsets, flatten_ids, "bwd");
@@ -688,8 +691,11 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd_guarded(
     const uint8_t* only_tiles = nullptr;
     bool fast_done = false;
     if (hoist && !force_generic() && (kind != CAM_OPENCV_FISHEYE || ((size_t)a.C * a.tw * a.th <= FAST_FLAG_BYTES && a.lshift == 0))) {
+        // the activation epilogue only where the gather's outputs are final: one camera, a pinhole (a fisheye frame may add flagged tiles on top)
+        const bool fold = act != nullptr && a.C == 1 && kind != CAM_OPENCV_FISHEYE;
         fast_done = launch_raster_bwd_fast(kind, a, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors,
-                                           v_opacities, workspace, workspace_bytes, (const float4*)packed_records, st, &only_tiles);
+                                           v_opacities, workspace, workspace_bytes, (const float4*)packed_records, st, &only_tiles, fold ? act : nullptr);
+        if (fast_done && fold && act_folded) *act_folded = true;
         if (fast_done && only_tiles == nullptr) return check_launch("rasterize_to_pixels_from_world_3dgs_bwd(fast)");
         // fisheye: the gather kernel has written every output element; the reference-order kernel adds the flagged tiles on top
     }
@@ -721,6 +727,47 @@ extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd_guarded(
         hipLaunchKernelGGL(gsx_bwd_gather_grads_kernel, dim3((N + 255u) / 256u), dim3(256), 0, st, a.C, N, (const float4*)grad_rec,
                            (const int32_t*)grad_head, v_means, v_quats, v_scales, v_colors, v_opacities);
     return check_launch("rasterize_to_pixels_from_world_3dgs_bwd");
+}
+
+extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd_guarded(
+    uint32_t N, int64_t n_isects, const float* means, const float* quats, const float* scales, const float* colors,
+    uint32_t channels, const float* opacities, const float* backgrounds, const uint8_t* masks, uint32_t image_width,
+    uint32_t image_height, uint32_t tile_size, const gsx_cameras* cams, const gsx_ut_params* ut,
+    const int32_t* tile_offsets, const int32_t* flatten_ids, const float* render_alphas, const int32_t* last_ids,
+    const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats, float* v_scales,
+    float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes, const void* packed_records,
+    const int32_t* lists_status, int64_t n_isects_expected, void* stream) {
+    return raster_bwd_impl(N, n_isects, means, quats, scales, colors, channels, opacities, backgrounds, masks, image_width, image_height, tile_size, cams, ut,
+                           tile_offsets, flatten_ids, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors,
+                           v_opacities, workspace, workspace_bytes, packed_records, lists_status, n_isects_expected, stream, nullptr, nullptr);
+}
+
+// ABI 7: the blend backward of ONE camera through to the RAW SplatData parameters (scaling_raw / rotation_raw / opacity_raw): on the fast path the
+// gather kernel applies the activation Jacobians where it holds the activated-parameter gradients in registers (ActEpilogue), elsewhere
+// gsx_splat_activations_bwd_reg runs behind the blend backward — the same values either way.  v_quats / v_scales / v_opacities are scratch
+// (written only on the second route).  (means, quats, scales, opacities must be the activations of the raw tensors: splat_data.cpp:267-286.)
+extern "C" int gsx_rasterize_to_pixels_from_world_3dgs_bwd_act(
+    uint32_t N, int64_t n_isects, const float* means, const float* quats, const float* scales, const float* colors,
+    uint32_t channels, const float* opacities, const float* backgrounds, const uint8_t* masks, uint32_t image_width,
+    uint32_t image_height, uint32_t tile_size, const gsx_cameras* cams, const gsx_ut_params* ut,
+    const int32_t* tile_offsets, const int32_t* flatten_ids, const float* render_alphas, const int32_t* last_ids,
+    const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats, float* v_scales,
+    float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes, const void* packed_records,
+    const int32_t* lists_status, int64_t n_isects_expected, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+    float* v_scaling_raw, float* v_rotation_raw, float* v_opacity_raw, float scale_reg_per_element, float opacity_reg_per_element, void* stream) {
+    if (!scaling_raw || !rotation_raw || !opacity_raw || !v_scaling_raw || !v_rotation_raw || !v_opacity_raw) {
+        set_error("rasterize bwd (act): null pointer");
+        return GSX_ERR_INVALID_ARGUMENT;
+    }
+    if (cams == nullptr || cams->C != 1) { set_error("rasterize bwd (act): one camera only (opacities are per camera)"); return GSX_ERR_UNSUPPORTED; }
+    const ActEpilogue act{rotation_raw, v_scaling_raw, v_rotation_raw, v_opacity_raw, scale_reg_per_element, opacity_reg_per_element};
+    bool folded = false;
+    const int rc = raster_bwd_impl(N, n_isects, means, quats, scales, colors, channels, opacities, backgrounds, masks, image_width, image_height, tile_size, cams,
+                                   ut, tile_offsets, flatten_ids, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales,
+                                   v_colors, v_opacities, workspace, workspace_bytes, packed_records, lists_status, n_isects_expected, stream, &act, &folded);
+    if (rc != GSX_OK || folded) return rc;
+    return gsx_splat_activations_bwd_reg(N, scaling_raw, rotation_raw, opacity_raw, v_scales, v_quats, v_opacities, v_scaling_raw, v_rotation_raw,
+                                         v_opacity_raw, scale_reg_per_element, opacity_reg_per_element, stream);
 }
 
 extern "C" size_t gsx_rasterize_fwd_workspace_bytes(uint32_t C, uint32_t N) { return raster_fwd_fast_workspace_bytes(C, N); }

@@ -40,6 +40,18 @@ struct RasterArgs {
     int64_t rec_capacity;        // backward: record slots behind ws_rec (ranges: a slot beyond it is never written)
 };
 
+// Optional epilogue of the backward's gather kernel (round 6): the SplatData activation Jacobians (splat_data.cpp:267-286: scales = exp(raw),
+// quats = normalize(raw), opacities = sigmoid(raw)) applied where the gather holds v_quats / v_scales / v_opacities of a Gaussian in
+// registers — the raw-parameter gradients leave directly, the three activated-parameter gradients are never written or re-read and the
+// splat_activations_bwd launch (19 us, 124 MB at S-1M) disappears.  One camera only (C == 1: opacities are per camera).  Same arithmetic
+// as splat_activations_bwd_kernel (gsx_sh.hip), on the ACTIVATED scales / opacities the blend was given (bit-identical to exp / sigmoid
+// of the raw values: the front end computes them with the same expressions) and the RAW quaternion (its norm is not in the activated one).
+struct ActEpilogue {
+    const float* rotation_raw;   // [N,4]; nullptr = no epilogue
+    float* v_scaling_raw; float* v_rotation_raw; float* v_opacity_raw;   // [N,3], [N,4], [N]
+    float scale_reg, opacity_reg;   // regulariser gradients per element (gsx_splat_activations_bwd_reg), 0 = none
+};
+
 // end of the LAST list of the frame (every other list ends where the next one starts); `ok` = false: overflowed frame, all lists empty
 GSX_DEV int32_t lists_total(const RasterArgs& a, bool& ok) {
     ok = true;
@@ -151,7 +163,7 @@ uint32_t* raster_fwd_fast_alloc(const float4* packed, uint32_t C, uint32_t N);  
 bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, const int32_t* last_ids,
                             const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats,
                             float* v_scales, float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes,
-                            const float4* packed_from_fwd, hipStream_t st, const uint8_t** tile_flags_out);
+                            const float4* packed_from_fwd, hipStream_t st, const uint8_t** tile_flags_out, const ActEpilogue* act = nullptr);
 size_t raster_bwd_fast_workspace_bytes(uint32_t C, uint32_t N, int64_t n_isects);
 
 }  // namespace gsx

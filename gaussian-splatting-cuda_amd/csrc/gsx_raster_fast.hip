@@ -1662,11 +1662,12 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
 // (111 VGPRs, 4 waves per SIMD — set by the chain rule, not by the walk.  Holding the allocation to 5 / 6 / 8 waves (launch bounds; 52 / 128 /
 // 184 B of scratch per lane) measured +0.010 / +0.026 / +0.054 ms on the S-1M step: the kernel moves ~240 MB — 64 B records at scattered
 // slots — in ~66 us and is near what such a read pattern gets from HBM, more chains in flight do not help it.)
-template <int KIND, int NCH>
+// ACT (round 6): the activation Jacobians as the epilogue (ActEpilogue, gsx_raster_common.hpp; C == 1): v_quats / v_scales / v_opacities are not written.
+template <int KIND, int NCH, bool ACT>
 __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const float4* __restrict__ ws_rec,
                                                              int32_t* __restrict__ ws_head, float* __restrict__ v_means,
                                                              float* __restrict__ v_quats, float* __restrict__ v_scales,
-                                                             float* __restrict__ v_colors, float* __restrict__ v_opacities) {
+                                                             float* __restrict__ v_colors, float* __restrict__ v_opacities, ActEpilogue act) {
     const uint32_t gi_raw = blockIdx.x * 256u + threadIdx.x;
     const bool in = gi_raw < a.N;                       // (no early return: the long runs of the range mode are summed by the whole wave)
     const uint32_t gi = in ? gi_raw : a.N - 1u;
@@ -1678,6 +1679,9 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
     bool any = false;
     RawG raw;
     raw.g = (int32_t)gi;
+    float4 q_raw = make_float4(0.f, 0.f, 0.f, 0.f);
+    float v_opac_act = 0.f;
+    if (ACT) q_raw = reinterpret_cast<const float4*>(act.rotation_raw)[gi];   // issued before the record walk
     const size_t cn = (size_t)a.C * a.N;
     for (uint32_t c = 0; c < a.C; ++c) {
         const size_t g = (size_t)c * a.N + gi;
@@ -1800,11 +1804,12 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
         if (!in) continue;
         if (!touched) {  // no tile touched this (camera, Gaussian): every output element is written, none needs a pre-fill
             v_colors[g * 3] = 0.f; v_colors[g * 3 + 1] = 0.f; v_colors[g * 3 + 2] = 0.f;
-            v_opacities[g] = 0.f;
+            if (!ACT) v_opacities[g] = 0.f;
             continue;
         }
         v_colors[g * 3] = Mo[0]; v_colors[g * 3 + 1] = Mo[1]; v_colors[g * 3 + 2] = Mo[2];
-        v_opacities[g] = Mo[3] / raw.opac;
+        if (ACT) v_opac_act = Mo[3] / raw.opac;
+        else v_opacities[g] = Mo[3] / raw.opac;
         // moments -> (mean, quaternion, scale): once per (camera, Gaussian) (gsx_record.hpp: moments_to_gradients)
         const ShutterPoses sp(a.cams.viewmats0 + c * 16, nullptr);
         const CamFrame cf = make_cam_frame(sp);
@@ -1815,8 +1820,39 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
     }
     if (!in) return;
     v_means[(size_t)gi * 3] = geo[0]; v_means[(size_t)gi * 3 + 1] = geo[1]; v_means[(size_t)gi * 3 + 2] = geo[2];
-    reinterpret_cast<float4*>(v_quats)[gi] = make_float4(geo[3], geo[4], geo[5], geo[6]);
-    v_scales[(size_t)gi * 3] = geo[7]; v_scales[(size_t)gi * 3 + 1] = geo[8]; v_scales[(size_t)gi * 3 + 2] = geo[9];
+    if (!ACT) {
+        reinterpret_cast<float4*>(v_quats)[gi] = make_float4(geo[3], geo[4], geo[5], geo[6]);
+        v_scales[(size_t)gi * 3] = geo[7]; v_scales[(size_t)gi * 3 + 1] = geo[8]; v_scales[(size_t)gi * 3 + 2] = geo[9];
+        return;
+    }
+    // ---- activation Jacobians (the arithmetic of splat_activations_bwd_kernel, gsx_sh.hip; an untouched Gaussian has zero gradients and
+    // still gets its regulariser terms — it needs its activated scale / opacity for them: loaded here, the walk did not)
+    if (!any) {
+        raw.sc = {a.scales[(size_t)gi * 3], a.scales[(size_t)gi * 3 + 1], a.scales[(size_t)gi * 3 + 2]};
+        raw.opac = a.opacities[gi];
+    }
+    const float sc[3] = {raw.sc.x, raw.sc.y, raw.sc.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float gk = geo[7 + k] * sc[k];                                  // d exp(s) = exp(s)
+        if (act.scale_reg != 0.f) gk = fmaf(act.scale_reg, sc[k], gk);
+        act.v_scaling_raw[(size_t)gi * 3 + k] = gk;
+    }
+    const float nrm = sqrtf(q_raw.x * q_raw.x + q_raw.y * q_raw.y + q_raw.z * q_raw.z + q_raw.w * q_raw.w);
+    float4 o;
+    if (nrm > 1e-12f) {
+        const float inv = 1.f / nrm;
+        const float4 qn = make_float4(q_raw.x * inv, q_raw.y * inv, q_raw.z * inv, q_raw.w * inv);
+        const float d = geo[3] * qn.x + geo[4] * qn.y + geo[5] * qn.z + geo[6] * qn.w;
+        o = make_float4((geo[3] - d * qn.x) * inv, (geo[4] - d * qn.y) * inv, (geo[5] - d * qn.z) * inv, (geo[6] - d * qn.w) * inv);
+    } else {
+        o = make_float4(geo[3] * 1e12f, geo[4] * 1e12f, geo[5] * 1e12f, geo[6] * 1e12f);
+    }
+    reinterpret_cast<float4*>(act.v_rotation_raw)[gi] = o;
+    const float sg = raw.opac, ds = sg * (1.f - sg);
+    float go = v_opac_act * sg * (1.f - sg);
+    if (act.opacity_reg != 0.f) go = fmaf(act.opacity_reg, ds, go);
+    act.v_opacity_raw[gi] = go;
 }
 
 size_t raster_bwd_fast_workspace_bytes(uint32_t C, uint32_t N, int64_t n_isects) {
@@ -1827,7 +1863,7 @@ size_t raster_bwd_fast_workspace_bytes(uint32_t C, uint32_t N, int64_t n_isects)
 bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, const int32_t* last_ids,
                             const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats,
                             float* v_scales, float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes,
-                            const float4* packed_from_fwd, hipStream_t st, const uint8_t** tile_flags_out) {
+                            const float4* packed_from_fwd, hipStream_t st, const uint8_t** tile_flags_out, const ActEpilogue* act) {
     *tile_flags_out = nullptr;
     if (workspace == nullptr || workspace_bytes < raster_bwd_fast_workspace_bytes(a.C, a.N, a.n_isects << (2 * a.lshift))) return false;
     const uint32_t n_tiles = a.tw * a.th;
@@ -1866,12 +1902,19 @@ bool launch_raster_bwd_fast(int kind, RasterArgs a, const float* render_alphas, 
     }
 #undef GSX_BLEND_BWD
     // the moments -> gradient map only involves the camera pose: one instance serves every camera model
-    if (a.chain_mask)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_bwd_gather_kernel<CAM_PERFECT_PINHOLE, NSUB>), ggrid, gblock, 0, st, a, (const float4*)ws_rec, ws_head, v_means, v_quats,
-                           v_scales, v_colors, v_opacities);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_bwd_gather_kernel<CAM_PERFECT_PINHOLE, 1>), ggrid, gblock, 0, st, a, (const float4*)ws_rec, ws_head, v_means, v_quats,
-                           v_scales, v_colors, v_opacities);
+    // (act: the activation Jacobians as the gather's epilogue — the caller has checked C == 1 and that no reference-order kernel adds to the outputs afterwards)
+    const ActEpilogue none{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f};
+#define GSX_GATHER(NCH, ACT) \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_bwd_gather_kernel<CAM_PERFECT_PINHOLE, NCH, ACT>), ggrid, gblock, 0, st, a, (const float4*)ws_rec, ws_head, v_means, v_quats, \
+                       v_scales, v_colors, v_opacities, ACT ? *act : none)
+    if (act != nullptr && act->rotation_raw != nullptr) {
+        if (a.chain_mask) GSX_GATHER(NSUB, true);
+        else GSX_GATHER(1, true);
+    } else {
+        if (a.chain_mask) GSX_GATHER(NSUB, false);
+        else GSX_GATHER(1, false);
+    }
+#undef GSX_GATHER
     return true;
 }
 

@@ -94,7 +94,11 @@ GSX_DEV void make_record(const RawG& r, const CamFrame& cf, const float tb[4], F
     if (BWD) {
         o.a0 = a0; o.a1 = a1; o.a2 = a2; o.h = h; o.B0 = B0; o.B1 = B1; o.c01 = c01; o.c12 = c12; o.c20 = c20;
         o.m = {mx, my, mz}; o.inv_d0 = inv_d0; o.sL = sL;
-        o.q0 = B0 * (1.f / n0); o.q1 = rr * (1.f / sqrtf(dot3(rr, rr)));
+        // guarded like i00 / i11 of moments_to_gradients: B0 = 0 or B1 parallel to B0 in fp32 (a collapsed scale) must give a zero
+        // direction, not 0 * inf = NaN — one NaN gradient would poison the Gaussian's Adam state for good
+        const float nr = sqrtf(dot3(rr, rr));
+        const f3 zero3{0.f, 0.f, 0.f};
+        o.q0 = n0 > 0.f ? B0 * (1.f / n0) : zero3; o.q1 = (nr > 0.f && nr < INFINITY) ? rr * (1.f / nr) : zero3;   // (selects: a NaN rr must not pass through a multiply)
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll

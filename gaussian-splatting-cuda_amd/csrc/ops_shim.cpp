@@ -90,6 +90,9 @@ gsx_ut_params make_ut(const UnscentedTransformParameters& u) {
 // workspace (packed per-Gaussian records) to the caller, the backward of the same inputs takes it back and skips re-packing.
 static thread_local at::Tensor* g_fwd_ws_out = nullptr;
 static thread_local const at::Tensor* g_fwd_ws_in = nullptr;
+// rasterize_bwd_act (fused render path): the raw SplatData tensors and the raw-gradient outputs of the activation epilogue (include/gsx.h, ABI 7)
+struct ActArgs { at::Tensor scaling_raw, rotation_raw, opacity_raw, v_scaling_raw, v_rotation_raw, v_opacity_raw; float scale_reg, opacity_reg; };
+static thread_local const ActArgs* g_act = nullptr;
 // ... and the fused front end (gsx_ext::frontend_fused) hands the blend forward a workspace whose records are already packed
 static thread_local const at::Tensor* g_fwd_ws_ready = nullptr;
 
@@ -519,6 +522,22 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
     const void* packed = (g_fwd_ws_in && g_fwd_ws_in->defined())
                              ? gsx_rasterize_fwd_packed_records(g_fwd_ws_in->data_ptr(), (size_t)g_fwd_ws_in->numel(), C, N) : nullptr;
     const bool guarded = g_lists != nullptr && g_lists->status.defined();
+    if (g_act != nullptr) {   // through to the raw parameters (v_quats / v_scales / v_opacities are scratch: returned, not meaningful)
+        check(gsx_rasterize_to_pixels_from_world_3dgs_bwd_act(
+                  N, flatten_ids.size(0), means.data_ptr<float>(), quats.data_ptr<float>(), scales.data_ptr<float>(),
+                  colors.data_ptr<float>(), channels, opacities.data_ptr<float>(), fptr(backgrounds), bptr(masks), image_width,
+                  image_height, tile_size, &cams, &ut, tile_offsets.data_ptr<int32_t>(),
+                  flatten_ids.numel() ? flatten_ids.data_ptr<int32_t>() : nullptr, render_alphas.data_ptr<float>(),
+                  last_ids.data_ptr<int32_t>(), v_render_colors.data_ptr<float>(),
+                  v_render_alphas.defined() ? v_render_alphas.data_ptr<float>() : nullptr,
+                  v_means.data_ptr<float>(), v_quats.data_ptr<float>(), v_scales.data_ptr<float>(), v_colors.data_ptr<float>(),
+                  v_opacities.data_ptr<float>(), ws.data_ptr(), wsb, packed, guarded ? g_lists->status.data_ptr<int32_t>() : nullptr,
+                  guarded ? g_lists->expected : 0, g_act->scaling_raw.data_ptr<float>(), g_act->rotation_raw.data_ptr<float>(),
+                  g_act->opacity_raw.data_ptr<float>(), g_act->v_scaling_raw.data_ptr<float>(), g_act->v_rotation_raw.data_ptr<float>(),
+                  g_act->v_opacity_raw.data_ptr<float>(), g_act->scale_reg, g_act->opacity_reg, cur_stream()),
+              "rasterize_to_pixels_from_world_3dgs_bwd(act)");
+        return std::make_tuple(v_means, v_quats, v_scales, v_colors, v_opacities);
+    }
     check(gsx_rasterize_to_pixels_from_world_3dgs_bwd_guarded(
               N, flatten_ids.size(0), means.data_ptr<float>(), quats.data_ptr<float>(), scales.data_ptr<float>(),
               colors.data_ptr<float>(), channels, opacities.data_ptr<float>(), fptr(backgrounds), bptr(masks), image_width,
@@ -1150,6 +1169,42 @@ PYBIND11_MODULE(_gsx_ops, m) {
           py::arg("camera_model"), py::arg("ut_params"), py::arg("rs_type"), py::arg("radial_coeffs"), py::arg("tangential_coeffs"),
           py::arg("thin_prism_coeffs"), py::arg("tile_offsets"), py::arg("flatten_ids"), py::arg("render_alphas"), py::arg("last_ids"),
           py::arg("v_render_colors"), py::arg("v_render_alphas"), py::arg("fwd_ws") = at::optional<at::Tensor>(), py::arg("lists") = std::shared_ptr<IsectLists>());
+    // The blend backward of ONE camera through to the raw SplatData parameters (include/gsx.h ABI 7: the activation Jacobians ride on the gather
+    // kernel): returns (v_means, v_colors, v_scaling_raw, v_rotation_raw, v_opacity_raw); out_* = caller-provided gradient buffers (sinks).
+    m.def("rasterize_bwd_act",
+          [](const at::Tensor means, const at::Tensor quats, const at::Tensor scales, const at::Tensor colors, const at::Tensor opacities,
+             const at::optional<at::Tensor> backgrounds, const at::optional<at::Tensor> masks, uint32_t image_width, uint32_t image_height,
+             uint32_t tile_size, const at::Tensor viewmats0, const at::optional<at::Tensor> viewmats1, const at::Tensor Ks,
+             const gsplat::CameraModelType camera_model, const UnscentedTransformParameters ut_params, ShutterType rs_type,
+             const at::optional<at::Tensor> radial_coeffs, const at::optional<at::Tensor> tangential_coeffs,
+             const at::optional<at::Tensor> thin_prism_coeffs, const at::Tensor tile_offsets, const at::Tensor flatten_ids,
+             const at::Tensor render_alphas, const at::Tensor last_ids, const at::Tensor v_render_colors,
+             const at::optional<at::Tensor> v_render_alphas, const at::optional<at::Tensor> fwd_ws, std::shared_ptr<IsectLists> lists,
+             const at::Tensor scaling_raw, const at::Tensor rotation_raw, const at::Tensor opacity_raw, const at::optional<at::Tensor> out_scaling,
+             const at::optional<at::Tensor> out_rotation, const at::optional<at::Tensor> out_opacity, double scale_reg_per_element,
+             double opacity_reg_per_element) {
+              GSX_CHECK_INPUT(scaling_raw); GSX_CHECK_INPUT(rotation_raw); GSX_CHECK_INPUT(opacity_raw);
+              TORCH_CHECK(tile_offsets.size(0) == 1, "rasterize_bwd_act: one camera only");
+              const int64_t N = means.size(0);
+              TORCH_CHECK(scaling_raw.numel() == 3 * N && rotation_raw.numel() == 4 * N && opacity_raw.numel() == N, "rasterize_bwd_act: raw parameter shapes");
+              ActArgs act;
+              act.scaling_raw = scaling_raw; act.rotation_raw = rotation_raw; act.opacity_raw = opacity_raw;
+              act.v_scaling_raw = (out_scaling.has_value() && out_scaling->defined()) ? out_scaling.value() : at::empty_like(scaling_raw);
+              act.v_rotation_raw = (out_rotation.has_value() && out_rotation->defined()) ? out_rotation.value() : at::empty_like(rotation_raw);
+              act.v_opacity_raw = (out_opacity.has_value() && out_opacity->defined()) ? out_opacity.value() : at::empty_like(opacity_raw);
+              GSX_CHECK_INPUT(act.v_scaling_raw); GSX_CHECK_INPUT(act.v_rotation_raw); GSX_CHECK_INPUT(act.v_opacity_raw);
+              TORCH_CHECK(act.v_scaling_raw.numel() == 3 * N && act.v_rotation_raw.numel() == 4 * N && act.v_opacity_raw.numel() == N, "rasterize_bwd_act: gradient buffer shapes");
+              act.scale_reg = (float)scale_reg_per_element; act.opacity_reg = (float)opacity_reg_per_element;
+              struct Reset { ~Reset() { g_fwd_ws_in = nullptr; g_lists = nullptr; g_act = nullptr; } } reset;
+              g_fwd_ws_in = fwd_ws.has_value() ? &fwd_ws.value() : nullptr;
+              g_lists = lists.get();
+              g_act = &act;
+              auto r = gsplat::rasterize_to_pixels_from_world_3dgs_bwd(
+                  means, quats, scales, colors, opacities, backgrounds, masks, image_width, image_height, tile_size, viewmats0, viewmats1, Ks,
+                  camera_model, ut_params, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids,
+                  render_alphas, last_ids, v_render_colors, v_render_alphas.has_value() ? v_render_alphas.value() : at::Tensor());
+              return std::make_tuple(std::get<0>(r), std::get<3>(r), act.v_scaling_raw, act.v_rotation_raw, act.v_opacity_raw);
+          });
     m.def("quats_to_rotmats", &gsplat::quats_to_rotmats);
     m.def("relocation", &gsplat::relocation);
     m.def("add_noise", &gsplat::add_noise);

@@ -548,7 +548,7 @@ class ListsAgreement:
                         resource_tracker.unregister(self._shm._name, "shared_memory")
                     except Exception:  # noqa: BLE001
                         pass
-                self._slots = np.ndarray((world, 8), dtype=np.int64, buffer=self._shm.buf)   # [rank][0] = call number, [1] / [2] = verdicts (see __call__)
+                self._slots = np.ndarray((world, 8), dtype=np.int64, buffer=self._shm.buf)   # [rank][0 / 1] = (call number << 1) | verdict of its latest even / odd call (see __call__)
                 mapped = 1
             except Exception:  # noqa: BLE001
                 self._slots = None
@@ -567,24 +567,31 @@ class ListsAgreement:
             import time
             self._calls += 1
             n, me = self._calls, dist.get_rank()
-            # Slot of a rank (one 64 B cache line): word 0 = number of its latest call; words 1 / 2 = its verdicts of its latest odd / even call.
-            # The verdict is stored BEFORE the call number announces it (x86 keeps the order of stores and of loads).  A rank leaves call n
-            # only after it has seen EVERY rank's number reach n, so no rank can be more than one call ahead of the slowest one: while a slow
-            # rank still reads the verdicts of call n, a fast one may already have published call n + 1 — into the OTHER verdict word.
-            self._slots[me, 1 + (n & 1)] = 1 if ok else 0
-            self._slots[me, 0] = n
+            # Slot of a rank (one 64 B cache line): words 0 / 1 = its latest even / odd call as ONE aligned int64, (call number << 1) | verdict.
+            # Number and verdict travel in a single 8-byte store, so a peer that sees the number has the verdict with it: nothing relies on the
+            # order of two stores (x86 keeps it, aarch64 does not: ADVICE r05).  A rank leaves call n only after it has seen EVERY rank's word
+            # reach n, so no rank can be more than one call ahead of the slowest one: while a slow rank still reads the words of call n, a fast
+            # one may already have published call n + 1 — into the OTHER word; word n & 1 is rewritten at call n + 2, which nobody reaches
+            # before everybody has left call n.
+            w = n & 1
+            self._slots[me, w] = (n << 1) | (1 if ok else 0)
             agreed, deadline, spins = True, None, 0
             for r in range(dist.get_world_size()):
-                while int(self._slots[r, 0]) < n:
+                while True:
+                    word = int(self._slots[r, w])
+                    if (word >> 1) >= n:
+                        break
                     spins += 1
                     if spins & 0xFF == 0:
                         now = time.monotonic()
                         deadline = deadline or now + self.timeout_s
                         if now > deadline:
                             raise RuntimeError("ListsAgreement: rank %d did not vote on call %d within %.0f s (it failed before its vote, or hangs)" % (r, n, self.timeout_s))
-                    if spins > 256:
+                    if spins > 20000:
+                        time.sleep(0.0002)   # a peer that is milliseconds late is not coming back soon: stop pinning a core
+                    elif spins > 256:
                         time.sleep(0)   # a peer that is ~100 us late may be waiting for a core (oversubscribed host): yield instead of spinning on
-                agreed = agreed and bool(int(self._slots[r, 1 + (n & 1)]))
+                agreed = agreed and bool(word & 1)
         else:
             self._flag[0] = 1 if ok else 0
             dist.all_reduce(self._flag, op=dist.ReduceOp.MIN, group=self.group)

@@ -40,6 +40,13 @@ def rasterize_to_pixels_from_world_3dgs_bwd(*args, fwd_ws=None, lists=None):
     return _C.rasterize_to_pixels_from_world_3dgs_bwd(*args, fwd_ws, lists)
 
 
+def rasterize_bwd_act(*args, fwd_ws=None, lists=None, raw=None, out=(None, None, None), reg=(0.0, 0.0)):
+    """The blend backward of ONE camera through to the raw SplatData parameters (include/gsx.h, ABI 7): `args` as for
+    rasterize_to_pixels_from_world_3dgs_bwd, raw = (scaling_raw, rotation_raw, opacity_raw [N]), out = optional gradient buffers, reg = the
+    regulariser gradients per element.  Returns (v_means, v_colors, v_scaling_raw, v_rotation_raw, v_opacity_raw)."""
+    return _C.rasterize_bwd_act(*args, fwd_ws, lists, raw[0], raw[1], raw[2], out[0], out[1], out[2], float(reg[0]), float(reg[1]))
+
+
 quats_to_rotmats = _C.quats_to_rotmats
 relocation = _C.relocation
 add_noise = _C.add_noise

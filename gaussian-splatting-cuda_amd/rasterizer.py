@@ -24,6 +24,9 @@ EPS2D, NEAR_PLANE, FAR_PLANE, RADIUS_CLIP = 0.3, 0.01, 10000.0, 0.0
 # rasterize_fused: one kernel for activations -> projection -> SH colours -> packed blend records (ops.frontend_fused); False = the
 # separate launches (A/B tools, tests)
 FUSED_FRONTEND = os.environ.get("GSX_FUSED_FRONTEND", "1") != "0"
+# rasterize_fused backward: the activation Jacobians as the epilogue of the blend backward's gather kernel (ops.rasterize_bwd_act); False = the
+# separate splat_activations_bwd launch (A/B tools, tests — same values)
+ACT_EPILOGUE = os.environ.get("GSX_ACT_EPILOGUE", "1") != "0"
 
 # rasterize_fused: size of the tiles the intersection LISTS are built for.  16 = the reference's; 32 = one list per 2 x 2 pixel tiles
 # (include/gsx.h, the blend entry points' `tile_size`): same image, the intersection handles ~3x fewer keys when the Gaussians cover
@@ -421,34 +424,44 @@ class GutRenderFunction(torch.autograd.Function):
             v_renders = torch.zeros(alphas.shape[:-1] + (3,), dtype=alphas.dtype, device=alphas.device)
         s = sinks or {}
         try:
-            v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_to_pixels_from_world_3dgs_bwd(
-                means, quats, scales, colors, opac2, bg, None, width, height, ctx.list_tile, viewmat, None, K, camera_model, ut,
-                ops.ShutterType.GLOBAL, radial, tangential, None, isect_offsets, flatten_ids, alphas, last_ids,
-                v_renders.contiguous(), None if v_alphas is None else v_alphas.contiguous(), fwd_ws=ctx.fwd_ws, lists=ctx.lists)
+            # scaling / rotation / opacity gradients only need the blend backward: they are finished first, so that a multi-GPU caller can
+            # start exchanging them ("_early_ready" callback) while the SH backward — 81 % of the gradient bytes — is still running
+            # "_regularisers" = (scale_reg / numel, opacity_reg / numel): the MCMC strategy's two regulariser gradients ride on the same kernel
+            reg = s.get("_regularisers") or (0.0, 0.0)
+            bwd_args = (means, quats, scales, colors, opac2, bg, None, width, height, ctx.list_tile, viewmat, None, K, camera_model, ut,
+                        ops.ShutterType.GLOBAL, radial, tangential, None, isect_offsets, flatten_ids, alphas, last_ids,
+                        v_renders.contiguous(), None if v_alphas is None else v_alphas.contiguous())
+            if scaling_modifier == 1.0 and ACT_EPILOGUE:
+                # round 6: the activation Jacobians are the epilogue of the backward's gather kernel (include/gsx.h ABI 7): the raw-parameter
+                # gradients leave where v_quats / v_scales / v_opacities sit in registers — one launch and 124 MB at S-1M less per backward
+                v_means, v_colors, g_s, g_r, g_o = ops.rasterize_bwd_act(
+                    *bwd_args, fwd_ws=ctx.fwd_ws, lists=ctx.lists, raw=(sr, rr, orw),
+                    out=(s.get("scaling_raw"), s.get("rotation_raw"), s.get("opacity_raw")), reg=reg)
+            else:
+                v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_to_pixels_from_world_3dgs_bwd(*bwd_args, fwd_ws=ctx.fwd_ws, lists=ctx.lists)
+                if scaling_modifier != 1.0:
+                    v_scales = v_scales * scaling_modifier
+                g_s, g_r, g_o = ops.splat_activations_bwd(sr, rr, orw, v_scales, v_quats, v_opac.reshape(-1), s.get("scaling_raw"),
+                                                         s.get("rotation_raw"), s.get("opacity_raw"), float(reg[0]), float(reg[1]))
+            n_is = ok = None
+            if ctx.lists is not None and not getattr(ctx, "lists_checked", False):
+                # Guarded lists: the one place the host looks at the frame's intersection count — with the forward, the loss and the blend
+                # backward (~0.9 ms at S-1M) queued behind the 8-byte copy it waits for, so the stream never drains.  Everything so far only
+                # overwrote gradient buffers; what follows (the SH tensor's Adam step inside the SH backward, a gradient exchange) is not
+                # repeatable, so an overflowed frame stops here.  Under N ranks the verdict is agreed first ("_lists_agree": every rank
+                # repeats the iteration when any rank overflowed — the collectives below stay matched).
+                n_is, _, ok = ctx.lists.confirm()
+                _list_tile_update(ctx.lt_update[0], ctx.lt_update[1], int(n_is), ctx.lt_update[2], ctx.lt_update[3])
         except Exception:
-            # N ranks: the peers are (or will be) waiting for this rank's verdict on the frame's lists — a rank that fails before it votes must
-            # still vote, or they wait for the agreement's timeout (distributed.ListsAgreement)
+            # N ranks: the peers are (or will be) waiting for this rank's verdict on the frame's lists — a rank that fails ANYWHERE before it
+            # votes (the blend backward, the activation Jacobians, the host read of the count: an OOM or a HIP error surfacing there) must still
+            # vote, once, or they wait for the agreement's timeout (distributed.ListsAgreement)
             if ctx.lists is not None and s.get("_lists_agree") is not None and not getattr(ctx, "lists_checked", False):
                 ctx.lists_checked = True
                 s["_lists_agree"](False)
             raise
-        if scaling_modifier != 1.0:
-            v_scales = v_scales * scaling_modifier
-        # scaling / rotation / opacity gradients only need the blend backward: they are finished first, so that a multi-GPU caller can
-        # start exchanging them ("_early_ready" callback) while the SH backward — 81 % of the gradient bytes — is still running
-        # "_regularisers" = (scale_reg / numel, opacity_reg / numel): the MCMC strategy's two regulariser gradients ride on this kernel
-        reg = s.get("_regularisers") or (0.0, 0.0)
-        g_s, g_r, g_o = ops.splat_activations_bwd(sr, rr, orw, v_scales, v_quats, v_opac.reshape(-1), s.get("scaling_raw"),
-                                                 s.get("rotation_raw"), s.get("opacity_raw"), float(reg[0]), float(reg[1]))
-        if ctx.lists is not None and not getattr(ctx, "lists_checked", False):
-            # Guarded lists: the one place the host looks at the frame's intersection count — with the forward, the loss and the blend
-            # backward (~0.9 ms at S-1M) queued behind the 8-byte copy it waits for, so the stream never drains.  Everything so far only
-            # overwrote gradient buffers; what follows (the SH tensor's Adam step inside the SH backward, a gradient exchange) is not
-            # repeatable, so an overflowed frame stops here.  Under N ranks the verdict is agreed first ("_lists_agree": every rank
-            # repeats the iteration when any rank overflowed — the collectives below stay matched).
-            n_is, _, ok = ctx.lists.confirm()
+        if ok is not None:
             ctx.lists_checked = True
-            _list_tile_update(ctx.lt_update[0], ctx.lt_update[1], int(n_is), ctx.lt_update[2], ctx.lt_update[3])
             if s.get("_lists_agree") is not None:
                 ok = s["_lists_agree"](ok)
             if not ok:

@@ -34,8 +34,10 @@ extern "C" {
  *   5  gsx_intersect_bin_count(_guarded) store all ones into the pinned host word before they launch anything, and its high half is what the
  *      device writes last: the word can be POLLED by the host (no event in the stream); gsx_frontend_fused accepts NULL conics and takes `record_ranges`; gsx_splat_activations_bwd_reg added.
  *   6  gsx_rasterize_to_pixels_from_world_3dgs_bwd_guarded gained the positional `n_isects_expected` argument its forward twin already had: both
- *      choose their kernel variants from the same estimate (round 4's backward saw the capacity — 25 % above it — on guarded lists). */
-#define GSX_ABI_VERSION 6
+ *      choose their kernel variants from the same estimate (round 4's backward saw the capacity — 25 % above it — on guarded lists).
+ *   7  additions only: gsx_rasterize_to_pixels_from_world_3dgs_bwd_act — the blend backward through to the raw SplatData parameters: the activation
+ *      Jacobians as the epilogue of the gather kernel. */
+#define GSX_ABI_VERSION 7
 
 typedef enum gsx_status {
     GSX_OK = 0,
@@ -294,6 +296,28 @@ int gsx_rasterize_to_pixels_from_world_3dgs_bwd_guarded(uint32_t N, int64_t n_is
                                                         float* v_opacities, void* workspace, size_t workspace_bytes,
                                                         const void* packed_records, const int32_t* lists_status,
                                                         int64_t n_isects_expected, void* stream);
+
+/* ABI 7.  The guarded blend backward of ONE camera through to the RAW SplatData parameters (the reference applies these Jacobians with torch
+ * autograd over splat_data.cpp:267-286: scales = exp(scaling_raw), quats = normalize(rotation_raw), opacities = sigmoid(opacity_raw)).
+ * means / quats / scales / opacities must be those activations of the raw tensors.  On the fast path (global-shutter pinholes) the gather
+ * kernel applies the Jacobians where it holds v_quats / v_scales / v_opacities in registers: the three are then NOT written (scratch) and
+ * no gsx_splat_activations_bwd launch follows; elsewhere that kernel runs behind the blend backward.  v_scaling_raw [N,3], v_rotation_raw
+ * [N,4], v_opacity_raw [N] are overwritten either way, with the values of gsx_splat_activations_bwd_reg (regulariser terms included). */
+int gsx_rasterize_to_pixels_from_world_3dgs_bwd_act(uint32_t N, int64_t n_isects, const float* means,
+                                                    const float* quats, const float* scales, const float* colors,
+                                                    uint32_t channels, const float* opacities, const float* backgrounds,
+                                                    const uint8_t* masks, uint32_t image_width, uint32_t image_height,
+                                                    uint32_t tile_size, const gsx_cameras* cams, const gsx_ut_params* ut,
+                                                    const int32_t* tile_offsets, const int32_t* flatten_ids,
+                                                    const float* render_alphas, const int32_t* last_ids,
+                                                    const float* v_render_colors, const float* v_render_alphas,
+                                                    float* v_means, float* v_quats, float* v_scales, float* v_colors,
+                                                    float* v_opacities, void* workspace, size_t workspace_bytes,
+                                                    const void* packed_records, const int32_t* lists_status,
+                                                    int64_t n_isects_expected, const float* scaling_raw, const float* rotation_raw,
+                                                    const float* opacity_raw, float* v_scaling_raw, float* v_rotation_raw,
+                                                    float* v_opacity_raw, float scale_reg_per_element, float opacity_reg_per_element,
+                                                    void* stream);
 
 /* Ranked variant of the fill for frames with heavy tiles (same outputs, bit for bit; same reference interface).  The Gaussians of
  * the frame are ranked once by (depth bits, flatten index) — gsx_intersect_depth_ranks: ranks[c*N + n] = position in that order,

@@ -18,7 +18,7 @@ def test_libgsx_exports_every_declared_symbol():
     assert len(names) >= 12
     for n in names:
         assert hasattr(lib, n), "libgsx.so does not export " + n
-    assert lib.gsx_abi_version() == 6   # include/gsx.h GSX_ABI_VERSION (history in the header)
+    assert lib.gsx_abi_version() == 7   # include/gsx.h GSX_ABI_VERSION (history in the header)
     lib.gsx_last_error.restype = ctypes.c_char_p
     assert isinstance(lib.gsx_last_error(), bytes)
 

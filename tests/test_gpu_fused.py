@@ -93,6 +93,51 @@ def test_fused_keeps_distortion(mods):
         assert rel_l2(b.grad.cpu().numpy(), a.grad.cpu().numpy()) < 1e-3, n
 
 
+@pytest.mark.parametrize("camera", ["pinhole", "distorted", "fisheye"])
+def test_activation_epilogue_equals_the_separate_launch(mods, camera, monkeypatch):
+    """Round 6 (include/gsx.h ABI 7, ops.rasterize_bwd_act): the activation Jacobians applied by the backward's gather kernel against the
+    separate splat_activations_bwd launch — the raw-parameter gradients must be the same values (the two runs sum a Gaussian's moment
+    records in whatever order its tiles finished: rounding-level differences only), every element of the sinks written (NaN pre-fill,
+    Gaussians no tile touches included), the MCMC regulariser terms included.  Fisheye takes the C ABI's second route (the epilogue is
+    not folded where a reference-order kernel may add flagged tiles on top): same entry point, same values."""
+    distributed, ops, rasterizer, scenes = mods
+    sc, cam = _setup(scenes, rasterizer, 2)
+    if camera == "distorted":
+        cam = rasterizer.Camera(viewmat=cam.viewmat, K=cam.K, width=cam.width, height=cam.height, radial=torch.tensor([-0.12, 0.03]),
+                                tangential=torch.tensor([0.004, -0.003]))
+    elif camera == "fisheye":
+        cam = rasterizer.Camera(viewmat=cam.viewmat, K=cam.K, width=cam.width, height=cam.height, camera_model=ops.CameraModelType.FISHEYE,
+                                radial=torch.tensor([0.01, -0.002, 0.0, 0.0]))
+    bg = sc["background"].to(DEV) + 0.2
+    w = torch.linspace(0.5, 1.5, 160, device=DEV)
+    sc = dict(sc)
+    sc["quats"] = sc["quats"] * torch.linspace(0.3, 3.0, sc["quats"].shape[0]).unsqueeze(-1)   # raw quaternion norms != 1: the Jacobian needs them
+    sc["means"] = sc["means"].clone()
+    sc["means"][:100, 2] = -5.0     # behind the camera: no tile touches them
+    grads = {}
+    for act in (False, True):
+        monkeypatch.setattr(rasterizer, "ACT_EPILOGUE", act)
+        model = scenes.to_splat_data(sc, DEV)
+        for p in model.params():
+            p.requires_grad_(True)
+        bucket = distributed.GradBucket(model.params())
+        bucket.flat.fill_(float("nan"))
+        sinks = bucket.sinks()
+        sinks["_regularisers"] = (0.01 / model.scaling_raw.numel(), 0.02 / model.opacity_raw.numel())
+        out = rasterizer.rasterize_fused(cam, model, bg, grad_sinks=sinks)
+        ((out.image * w).sum() + 0.3 * out.alpha.sum()).backward()
+        torch.cuda.synchronize()
+        grads[act] = {n: getattr(model, n).grad.detach().clone() for n in ("means", "scaling_raw", "rotation_raw", "opacity_raw")}
+        assert all(bool(torch.isfinite(g).all()) for g in grads[act].values()), (camera, act)
+    untouched = (grads[True]["means"] == 0).all(-1)
+    assert int(untouched.sum()) > 50     # the scene has Gaussians outside the view: their regulariser terms must still arrive
+    assert float(grads[True]["scaling_raw"][untouched].abs().min()) > 0 and float(grads[True]["opacity_raw"].reshape(-1)[untouched].abs().min()) > 0
+    for n in grads[True]:
+        a, b = grads[False][n], grads[True][n]
+        assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 2e-6, (camera, n)
+        assert torch.equal(a[untouched], b[untouched]), (camera, n)   # no record sums involved: bit for bit
+
+
 def test_fused_ops_vs_torch(mods):
     """The two fused glue ops against the torch expressions they replace."""
     _, ops, _, _ = mods
@@ -140,6 +185,7 @@ def test_sh_backward_fused_with_adam_equals_separate_step(mods, iteration, deg):
         torch.cuda.synchronize()
         st = opt.state["sh"]
         results.append(dict(sh=model.sh.detach().clone(), means=model.means.detach().clone(), m=st["exp_avg"].clone(), v=st["exp_avg_sq"].clone(),
+                            v_means=opt.state["means"]["exp_avg_sq"].clone(),
                             steps=(opt.step_count("sh0"), opt.step_count("shN"), opt.step_count("means"))))
     a, b = results
     assert a["steps"] == b["steps"] == (3, 3, 3)
@@ -149,12 +195,16 @@ def test_sh_backward_fused_with_adam_equals_separate_step(mods, iteration, deg):
         # updates agree to a small fraction of one step (lr 2.5e-3 / 1.25e-4), relative to the tensor's scale.  The two runs also sum the
         # backward's moment records of a Gaussian in whatever order its tiles finished: an element whose gradient IS that
         # rounding noise can come out with either sign, and Adam moves it by a full +-lr either way (seen once in ~20 runs of the suite, on
-        # one element).  Such elements may not be many and cannot be further apart than the three steps in opposite directions.
+        # one element).  ADVICE r05: such an outlier is accepted ONLY where the gradient is below a noise floor — its second moment (which
+        # noise does not amplify; compared strictly below) says so — so a sign or indexing bug on elements with a real gradient cannot pass.
         diff = (a[k] - b[k]).abs()
         over = diff > 1e-5 * float(a[k].abs().max()) + 1e-12
         if k in ("sh", "means"):
             step3 = 2 * 3 * (2.5e-3 if k == "sh" else 1.6e-4) * 1.05
-            assert int(over.sum()) <= 3 and float(diff.max()) <= step3, (k, int(over.sum()), float(diff.max()))
+            v2 = a["v"] if k == "sh" else a["v_means"]
+            noise = v2.sqrt() < 1e-4 * float(v2.sqrt().max())
+            assert int(over.sum()) <= 3 and float(diff.max()) <= step3 and not bool((over & ~noise).any()), \
+                (k, int(over.sum()), float(diff.max()), int((over & ~noise).sum()))
         else:
             assert not bool(over.any()), (k, float(diff.max()))
     if iteration <= 1000:   # shN frozen: its block is untouched in both
