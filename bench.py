@@ -81,11 +81,12 @@ class OpTimer:
                       "intersect_offset", "rasterize_to_pixels_from_world_3dgs_fwd", "rasterize_to_pixels_from_world_3dgs_bwd",
                       "sh_colors_fwd", "sh_colors_bwd", "sh_colors_bwd_adam", "splat_activations_fwd", "splat_activations_projection_ut", "splat_activations_bwd",
                       "photometric_loss_fwd", "photometric_loss_bwd", "intersect_tile_binned", "adam_step", "adam_step_split", "adam_step_multi",
-                      "frontend_fused", "frontend_fused_render", "rasterize_fwd_packed", "intersect_tile_binned_guarded"]
+                      "frontend_fused", "frontend_fused_render", "rasterize_fwd_packed", "intersect_tile_binned_guarded", "rasterize_bwd_act"]
         # the blend forward on records the front end already packed is the same operator: one row in the table; so is the binned
         # intersection under the guarded protocol (the same kernels; the exact protocol's row additionally contains the host's wait for n_isects)
+        # (round 6: rasterize_bwd_act = the blend backward with the activation Jacobians as the gather kernel's epilogue: the same row)
         self.alias = {"rasterize_fwd_packed": "rasterize_to_pixels_from_world_3dgs_fwd", "intersect_tile_binned_guarded": "intersect_tile_binned",
-                      "frontend_fused_render": "frontend_fused"}
+                      "frontend_fused_render": "frontend_fused", "rasterize_bwd_act": "rasterize_to_pixels_from_world_3dgs_bwd"}
         self.host_delay_us = 0.0   # --host-delay-us: busy-wait after every intersection call (a slow / busy host between the count and the blend launch)
         self.orig = {n: getattr(ops_mod, n) for n in self.names}
         self.events = {n: [] for n in self.names}

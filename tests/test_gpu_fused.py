@@ -191,22 +191,24 @@ def test_sh_backward_fused_with_adam_equals_separate_step(mods, iteration, deg):
     assert a["steps"] == b["steps"] == (3, 3, 3)
     for k in ("sh", "m", "v", "means"):
         assert torch.isfinite(b[k]).all()
-        # same arithmetic in two kernels (FMA contraction may differ, and m / sqrt(v) amplifies the last bits of a tiny gradient): the
-        # updates agree to a small fraction of one step (lr 2.5e-3 / 1.25e-4), relative to the tensor's scale.  The two runs also sum the
-        # backward's moment records of a Gaussian in whatever order its tiles finished: an element whose gradient IS that
-        # rounding noise can come out with either sign, and Adam moves it by a full +-lr either way (seen once in ~20 runs of the suite, on
-        # one element).  ADVICE r05: such an outlier is accepted ONLY where the gradient is below a noise floor — its second moment (which
-        # noise does not amplify; compared strictly below) says so — so a sign or indexing bug on elements with a real gradient cannot pass.
+        # same arithmetic in two kernels (FMA contraction may differ), and the two runs sum the backward's moment records of a Gaussian in
+        # whatever order its tiles finished: the GRADIENTS agree to fp32 summation noise — a few 1e-6 of the tensor's largest
+        # gradient — and Adam turns a gradient perturbation dg into an update perturbation of lr * dg / |g| per step: nothing for an element
+        # with a real gradient, a full +-lr for one whose gradient IS that noise (either sign can come out; seen once in ~20 runs of the
+        # suite).  ADVICE r05: the bound therefore follows the element's gradient magnitude — its second moment, which noise does not
+        # amplify and which is compared strictly below — instead of allowing a few outliers anywhere: a sign or indexing bug on an element
+        # with a real gradient (sqrt(v) >= 1e-2 of the largest) has 1.5e-6 of slack, not +-lr.
         diff = (a[k] - b[k]).abs()
-        over = diff > 1e-5 * float(a[k].abs().max()) + 1e-12
+        base = 1e-5 * float(a[k].abs().max()) + 1e-12
         if k in ("sh", "means"):
-            step3 = 2 * 3 * (2.5e-3 if k == "sh" else 1.6e-4) * 1.05
-            v2 = a["v"] if k == "sh" else a["v_means"]
-            noise = v2.sqrt() < 1e-4 * float(v2.sqrt().max())
-            assert int(over.sum()) <= 3 and float(diff.max()) <= step3 and not bool((over & ~noise).any()), \
-                (k, int(over.sum()), float(diff.max()), int((over & ~noise).sum()))
+            lr = 2.5e-3 if k == "sh" else 1.6e-4
+            g = (a["v"] if k == "sh" else a["v_means"]).sqrt()
+            amp = (2e-6 * float(g.max()) / g.clamp_min(1e-30)).clamp(max=2.1)      # |dg| / |g|, capped at "opposite signs"
+            bad = diff > base + 3 * lr * amp
+            assert not bool(bad.any()), (k, int(bad.sum()), (g[bad] / g.max()).tolist()[:5], diff[bad].tolist()[:5], float(a[k].abs().max()))
+            assert int((diff > base).sum()) <= 10, (k, int((diff > base).sum()))
         else:
-            assert not bool(over.any()), (k, float(diff.max()))
+            assert not bool((diff > base).any()), (k, float(diff.max()))
     if iteration <= 1000:   # shN frozen: its block is untouched in both
         assert torch.equal(b["sh"][:, 1:], scenes.to_splat_data(dict(sc), DEV).sh[:, 1:])
     assert float((b["sh"][:, :1] - scenes.to_splat_data(dict(sc), DEV).sh[:, :1]).abs().max()) > 0
