@@ -3,7 +3,7 @@
 // gsplat/RasterizeToPixelsFromWorld3DGSFwd.cu:19-279, ...Bwd.cu:16-373), different arithmetic route.
 //
 // 1. Algebra.  For a global shutter every pixel ray starts at the camera centre c, so with
-//    A = M Rc (M = diag(1/s) R^T, Rc = camera->world rotation), m = Rc^T (mu - c) the camera-space centre,
+//    A = M Rc (M = diag(1/s) R^T, Rc = camera->world rotation), m = Rc^-1 (mu - c) the camera-space centre (the exact inverse, not the transpose: gsx_record.hpp make_cam_frame),
 //    p = (u, v, 1) the pixel's undistorted normalised coordinates and g = M (c - mu) = -A m:
 //        grayDist = |(A p) x g|^2 / |A p|^2                       (scale of the ray direction cancels)
 //        (A p) x g = -(A p) x (A m) = -cof(A) (p x m)             (cof(A) columns = a_i x a_j)
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void pack_records_kernel(RasterArgs a, float4*
     store_packed_record(raw, cf, o);
     if (bad) {
         const f3 dm = raw.mu - cf.c;
-        const float mz = cf.Rc[0][2] * dm.x + cf.Rc[1][2] * dm.y + cf.Rc[2][2] * dm.z;
+        const float mz = cf.Rci[2][0] * dm.x + cf.Rci[2][1] * dm.y + cf.Rci[2][2] * dm.z;
         const float4 p0 = o[0];
         bad[g] = (mz > 0.f && fabsf(p0.x) <= 8.f && fabsf(p0.y) <= 8.f) ? 0 : 1;   // (NaN compares false: bad)
     }

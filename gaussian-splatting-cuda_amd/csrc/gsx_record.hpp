@@ -11,10 +11,19 @@ constexpr float LOG2_255 = 7.994353436858858f;
 constexpr float HALF_LOG2E = 0.7213475204444817f;  // 0.5 * log2(e)
 
 struct CamFrame {
-    float Rc[3][3];  // camera -> world rotation (== reference's R_inv, Cameras.cuh:262)
-    f3 c;            // camera centre in world space
+    float Rc[3][3];   // camera -> world "rotation" (== reference's R_inv = mat3_cast(inverse(quat_cast(R))), Cameras.cuh:262) — see Rci
+    float Rci[3][3];  // its EXACT inverse (world -> camera), not its transpose
+    f3 c;             // camera centre in world space
 };
 
+// Round 6.  The reference takes a pose through fp32 quaternions (matrix -> quat_cast -> inverse -> mat3_cast, Cameras.cuh:42-52,258-262): the
+// R_inv every ray is built from is orthonormal only to fp32 rounding — 7e-7 for the diagonal S-8cam cameras (3 / 5: the y-branch of
+// quat_cast, |q|^2 - 1 = 1.2e-7), 0 for an axis-aligned pose.  The reference never needs the inverse of R_inv (it intersects world-space
+// rays: origin o = -R_inv t, direction R_inv p); the Delta-form does — the Gaussian's camera-space centre m with R_inv m = mu - o —, and
+// rounds 1 - 5 took m = R_inv^T (mu - o): with a 7e-7 non-orthonormal R_inv every Gaussian sat 7e-7 |mu - o| = 7e-6 world units from where the
+// reference's rays see it — 3.5e-3 sigma of the smallest S-1M Gaussians, direction dependent: on cameras 3 / 5 HIP was 1.3 - 1.6e-3 (gradient
+// rel-L2) and 10 000 alpha pixels > 1e-4 from the reference kernel, on the axis-aligned cfg2 camera 4e-4 / 28 (profiles/parity_r06.md).
+// m = R_inv^-1 (mu - o) with the inverse formed in double (adjugate / determinant, once per thread: ~60 DP operations) removes it.
 GSX_DEV CamFrame make_cam_frame(const ShutterPoses& sp) {
     CamFrame f;
     const m33 Rinv = quat_to_mat_raw(quat_conj_over_norm2(sp.q0));
@@ -22,6 +31,13 @@ GSX_DEV CamFrame make_cam_frame(const ShutterPoses& sp) {
         for (int k = 0; k < 3; ++k) f.Rc[r][k] = Rinv.a[r][k];
     const f3 rt = mul(Rinv, sp.t0);
     f.c = {-rt.x, -rt.y, -rt.z};
+    const double a00 = Rinv.a[0][0], a01 = Rinv.a[0][1], a02 = Rinv.a[0][2], a10 = Rinv.a[1][0], a11 = Rinv.a[1][1], a12 = Rinv.a[1][2],
+                 a20 = Rinv.a[2][0], a21 = Rinv.a[2][1], a22 = Rinv.a[2][2];
+    const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+    const double idet = 1.0 / (a00 * c00 + a01 * c01 + a02 * c02);
+    f.Rci[0][0] = (float)(c00 * idet); f.Rci[0][1] = (float)((a02 * a21 - a01 * a22) * idet); f.Rci[0][2] = (float)((a01 * a12 - a02 * a11) * idet);
+    f.Rci[1][0] = (float)(c01 * idet); f.Rci[1][1] = (float)((a00 * a22 - a02 * a20) * idet); f.Rci[1][2] = (float)((a02 * a10 - a00 * a12) * idet);
+    f.Rci[2][0] = (float)(c02 * idet); f.Rci[2][1] = (float)((a01 * a20 - a00 * a21) * idet); f.Rci[2][2] = (float)((a00 * a11 - a01 * a10) * idet);
     return f;
 }
 
@@ -55,9 +71,9 @@ GSX_DEV void make_record(const RawG& r, const CamFrame& cf, const float tb[4], F
 #pragma unroll
         for (int j = 0; j < 3; ++j) A[i][j] = M[i][0] * cf.Rc[0][j] + M[i][1] * cf.Rc[1][j] + M[i][2] * cf.Rc[2][j];
     const f3 dm = r.mu - cf.c;
-    const float mx = cf.Rc[0][0] * dm.x + cf.Rc[1][0] * dm.y + cf.Rc[2][0] * dm.z;
-    const float my = cf.Rc[0][1] * dm.x + cf.Rc[1][1] * dm.y + cf.Rc[2][1] * dm.z;
-    const float mz = cf.Rc[0][2] * dm.x + cf.Rc[1][2] * dm.y + cf.Rc[2][2] * dm.z;
+    const float mx = cf.Rci[0][0] * dm.x + cf.Rci[0][1] * dm.y + cf.Rci[0][2] * dm.z;   // m = R_inv^-1 (mu - o): make_cam_frame
+    const float my = cf.Rci[1][0] * dm.x + cf.Rci[1][1] * dm.y + cf.Rci[1][2] * dm.z;
+    const float mz = cf.Rci[2][0] * dm.x + cf.Rci[2][1] * dm.y + cf.Rci[2][2] * dm.z;
     const float imz = 1.f / mz;
     o.u0 = mx * imz; o.v0 = my * imz;
     const f3 a0{A[0][0], A[1][0], A[2][0]}, a1{A[0][1], A[1][1], A[2][1]}, a2{A[0][2], A[1][2], A[2][2]};
@@ -184,10 +200,10 @@ GSX_DEV void moments_to_gradients(const RawG& raw, const CamFrame& cf, const Fas
     const float G_v0 = -dot3(r.B1, t) - mz * dot3(r.c01, G_B0);
     const float G_mx = G_u0 * imz, G_my = G_v0 * imz;
     const float G_mz = (trW - (r.u0 * G_u0 + r.v0 * G_v0)) * imz;                               // sum 2 vN N / mz through B, then through (u0, v0)
-    // m = Rc^T (mu - c)  ->  v_mean = Rc G_m
-    geo[0] += cf.Rc[0][0] * G_mx + cf.Rc[0][1] * G_my + cf.Rc[0][2] * G_mz;
-    geo[1] += cf.Rc[1][0] * G_mx + cf.Rc[1][1] * G_my + cf.Rc[1][2] * G_mz;
-    geo[2] += cf.Rc[2][0] * G_mx + cf.Rc[2][1] * G_my + cf.Rc[2][2] * G_mz;
+    // m = Rci (mu - c)  ->  v_mean = Rci^T G_m
+    geo[0] += cf.Rci[0][0] * G_mx + cf.Rci[1][0] * G_my + cf.Rci[2][0] * G_mz;
+    geo[1] += cf.Rci[0][1] * G_mx + cf.Rci[1][1] * G_my + cf.Rci[2][1] * G_mz;
+    geo[2] += cf.Rci[0][2] * G_mx + cf.Rci[1][2] * G_my + cf.Rci[2][2] * G_mz;
 }
 
 // Writes the packed record of one (camera, Gaussian) (see the layout above).  `lo` = -inf marks a Gaussian no pixel can see (opacity

@@ -72,3 +72,36 @@ def test_empty_model_renders_background():
     assert torch.allclose(out.image, bg.view(3, 1, 1).expand(3, 48, 64)) and float(out.alpha.detach().abs().max()) == 0.0
     out.image.sum().backward()
     assert all(float(p.grad.abs().max()) == 0.0 for p in model.params())
+
+
+def test_collapsed_scales_give_finite_gradients():
+    """a Gaussian whose footprint basis degenerates in fp32 (two scales seven orders of magnitude below the third: the cofactor columns
+    B0, B1 of the Delta-form come out parallel, the orthonormal pair (q0, q1) of gsx_record.hpp has no second direction) must not turn into a
+    NaN gradient — one NaN poisons the Gaussian's Adam state for good.  Every gradient of every Gaussian finite, on the fused path (Gaussian-major
+    backward + gather with the activation epilogue) and through the operator-level backward (pixel-major kernel forced)."""
+    import os
+
+    import gsx  # noqa: F401
+    from gsx import rasterizer, scenes
+    sc = scenes.scene_small(seed=3, N=400)
+    sc["width"], sc["height"] = 96, 64
+    sc["K"] = scenes.intrinsics(70.0, 70.0, 48.0, 32.0)
+    sc["scales"][:12] = torch.tensor([[0.3, 3e-8, 3e-8], [2e-8, 0.4, 2e-8], [1e-8, 1e-8, 0.5], [0.2, 1e-12, 1e-12]]).repeat(3, 1)
+    sc["opacities"][:12] = 0.8
+    sc["means"][:12, :2] *= 0.3
+    cam = rasterizer.Camera(viewmat=scenes.look_at_viewmat((0.2, -0.1, -0.3), (0.0, 0.0, 2.5)).to(DEV), K=sc["K"].to(DEV), width=96, height=64)
+    for bwd in ("gq", "pm"):
+        os.environ["GSX_BWD"] = bwd
+        try:
+            model = scenes.to_splat_data(sc, DEV)
+            for p in model.params():
+                p.requires_grad_(True)
+            out = rasterizer.rasterize_fused(cam, model, sc["background"].to(DEV))
+            (out.render_hwc.sum() + out.alpha.sum()).backward()
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("GSX_BWD", None)
+        assert bool(torch.isfinite(out.render_hwc).all())
+        for n in ("means", "sh", "scaling_raw", "rotation_raw", "opacity_raw"):
+            g = getattr(model, n).grad
+            assert bool(torch.isfinite(g).all()), (bwd, n, int((~torch.isfinite(g)).sum()))

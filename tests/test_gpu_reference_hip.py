@@ -103,7 +103,7 @@ def _to_np(d, keys):
     return {k: (d[k].cpu().numpy() if d[k] is not None else None) for k in keys if k in d}
 
 
-def _explain_pixels(sc, R, g_ren, g_last, tag, ocam):
+def _explain_pixels(sc, R, g_ren, g_last, tag, ocam, g_alp=None):
     """Full frames: every pixel where the HIP blend and the REFERENCE KERNEL's frame differ by more than 1e-4 must carry a discrete
     decision that two correct fp32 evaluations can take differently — a different last Gaussian, or an alpha >= 1/255 / T <= 1e-4 test
     within a small relative window of its threshold in the reference-order evaluation of the same inputs (the oracle's per-pixel flag).
@@ -115,8 +115,13 @@ def _explain_pixels(sc, R, g_ren, g_last, tag, ocam):
     W, H = sc["width"], sc["height"]
     err = np.abs(g_ren - np32(R["renders"])).max(-1)
     over = err > 1e-4
+    # (round 6, VERDICT r05 weak #1c) alpha is held to the same account as RGB: |d alpha| > 1e-4 needs the same explanation
+    aerr = np.abs(g_alp - np32(R["alphas"]))[..., 0] if g_alp is not None else np.zeros_like(err)
+    over_a = aerr > 1e-4
+    over = over | over_a
+    err = np.maximum(err, aerr)
     last_differs = g_last != R["last_ids"].cpu().numpy()
-    out = {}
+    out = {"alpha_pixels_over_1e4": int(over_a.sum())}
     for window in (1e-3, 4e-3):
         _, _, _, frag = oracle.rasterize_fwd(f("means"), f("quats"), f("scales"), np32(R["colors"]), f("opacities")[None], f("background")[None], None, W, H, 16,
                                              f("viewmat")[None], f("K")[None], R["tile_offsets"].cpu().numpy(), R["flatten_ids"].cpu().numpy(), frag_rel=window, **ocam)
@@ -132,21 +137,27 @@ def _explain_pixels(sc, R, g_ren, g_last, tag, ocam):
         # The yardstick is the same forward in float64 (same colours and lists): on those pixels the HIP frame must be about as close to it as
         # the reference kernel's frame is (neither is within 1e-4 of it on all of them).
         f64 = lambda k: np.ascontiguousarray(sc[k].numpy(), np.float64)  # noqa: E731
-        r64 = oracle.rasterize_fwd(f64("means"), f64("quats"), f64("scales"), R["colors"].detach().cpu().numpy().astype(np.float64), f64("opacities")[None],
-                                   f64("background")[None], None, W, H, 16, f64("viewmat")[None], f64("K")[None], R["tile_offsets"].cpu().numpy(),
-                                   R["flatten_ids"].cpu().numpy(), **ocam)[0]
-        e_hip = np.abs(g_ren.astype(np.float64) - r64).max(-1)[unexpl]
-        e_ref = np.abs(np32(R["renders"]).astype(np.float64) - r64).max(-1)[unexpl]
+        r64, a64 = oracle.rasterize_fwd(f64("means"), f64("quats"), f64("scales"), R["colors"].detach().cpu().numpy().astype(np.float64), f64("opacities")[None],
+                                        f64("background")[None], None, W, H, 16, f64("viewmat")[None], f64("K")[None], R["tile_offsets"].cpu().numpy(),
+                                        R["flatten_ids"].cpu().numpy(), **ocam)[:2]
+        e_hip = np.abs(g_ren.astype(np.float64) - r64).max(-1)
+        e_ref = np.abs(np32(R["renders"]).astype(np.float64) - r64).max(-1)
+        if g_alp is not None:
+            e_hip = np.maximum(e_hip, np.abs(g_alp.astype(np.float64) - a64)[..., 0])
+            e_ref = np.maximum(e_ref, np.abs(np32(R["alphas"]).astype(np.float64) - a64)[..., 0])
+        e_hip, e_ref = e_hip[unexpl], e_ref[unexpl]
         out.update(unexplained_hip_vs_f64_max=float(e_hip.max()), unexplained_hip_vs_f64_mean=float(e_hip.mean()),
                    unexplained_reference_vs_f64_max=float(e_ref.max()), unexplained_reference_vs_f64_mean=float(e_ref.mean()))
-    rec = parity_record("%s blend forward: pixels beyond 1e-4 vs the reference kernel's frame, explained by a threshold decision" % tag,
+    rec = parity_record("%s blend forward: pixels (RGB or alpha) beyond 1e-4 vs the reference kernel's frame, explained by a threshold decision" % tag,
                         pixels_over_1e4=int(over.sum()), **out)
     if unexpl.any():
-        # measured (profiles/parity_r05.md): cameras 3 / 5: 455 / 461 such pixels (2.2e-4 of the frame), HIP 0.83 / 0.90e-4 (mean) and 3.2e-4 (max)
-        # from float64, the reference kernel 0.70e-4 and 2.3 / 3.2e-4 — both fp32 orders drift by ~1e-4 on the deepest stacks; camera 7: 5 pixels,
-        # HIP 4e-6 from float64, the reference 1.2e-4
-        assert rec["unexplained_hip_vs_f64_max"] < 5e-4 and rec["unexplained_hip_vs_f64_mean"] <= 1.5 * rec["unexplained_reference_vs_f64_mean"] + 1e-5, rec
-        assert rec["unexplained_w0.004"] <= 3e-4 * err.size and rec["unexplained_max_err_w0.004"] < 5e-4, rec
+        # measured, round 6 (profiles/parity_r06.md; RGB and alpha together, the camera frame with the exact inverse of R_inv — gsx_record.hpp):
+        # cameras 3 / 5: 75 / 84 such pixels (4e-5 of the frame; round 5: 455 / 461 in RGB alone and 8 900 in alpha), at most 2.1e-4 from the
+        # reference kernel, HIP 2.2 / 2.4e-4 (mean) from float64, the reference kernel 2.3 / 2.6e-4: both fp32 frames sit on the reference's own
+        # fp32 pose round trip there (camera centre 5e-6 from the float64 one: tools/ring_attrib.py); cameras 1 / 7: ~110 pixels, HIP 1.4e-5
+        # from float64, the reference 1.3e-4
+        assert rec["unexplained_hip_vs_f64_max"] < 1e-3 and rec["unexplained_hip_vs_f64_mean"] <= 1.1 * rec["unexplained_reference_vs_f64_mean"] + 1e-5, rec
+        assert rec["unexplained_w0.004"] <= 1.5e-4 * err.size and rec["unexplained_max_err_w0.004"] < 5e-4, rec
     return rec
 
 
@@ -214,7 +225,7 @@ def _stagewise(ref, ops, sc, cam, tag, with_oracle=True, fwd_strict=True, over_f
     for k in ("viewmats1", "radial", "tangential", "thin_prism"):
         ocam_all[k] = None if cam.get(k) is None else np.asarray(cam[k], np.float32)
     if not fwd_strict:
-        recs["fwd_explained"] = _explain_pixels(sc, R, np32(G[0]), G[2].cpu().numpy(), tag, ocam_all)
+        recs["fwd_explained"] = _explain_pixels(sc, R, np32(G[0]), G[2].cpu().numpy(), tag, ocam_all, g_alp=np32(G[1]))
     B = ops.rasterize_to_pixels_from_world_3dgs_bwd(*common, R["alphas"], R["last_ids"], v_rc, v_ra)
     recs["bwd_hip"] = parity_record("%s blend backward: HIP vs reference kernel (rel-L2)" % tag, **{n: rel_l2(np32(g), np32(R[n])) for n, g in zip(GRADS, B)})
     if with_oracle:
@@ -243,6 +254,8 @@ def _stagewise(ref, ops, sc, cam, tag, with_oracle=True, fwd_strict=True, over_f
         else:
             # measured (profiles/parity_r04.md): 8.4e-5 of the pixels (S-1M), 5.8e-5 (S-5M); the reference's own two builds differ on 9.9e-5
             assert fw["rgb_pixels_over_1e4"] <= over_frac * fw["pixels"] and fw["rgb_q999999"] < 2e-3, fw
+            # alpha too (round 6): bounded like RGB, and every such pixel explained in _explain_pixels (measured: 28 on cfg2's camera, 460 - 700 on the ring's)
+            assert fw["alpha_pixels_over_1e4"] <= over_frac * fw["pixels"], fw
     if bwd_f64_yardstick and any(recs["bwd_hip"][g] >= 1e-3 for g in GRADS):
         # Two fp32 evaluations further than 1e-3 apart: which one is off?  The yardstick is the same backward in float64 (the oracle's
         # restatement, on the reference chain's colours, lists, alphas and last ids).  Cameras that look along the slab see Gaussians whose
@@ -257,12 +270,15 @@ def _stagewise(ref, ops, sc, cam, tag, with_oracle=True, fwd_strict=True, over_f
         ref64 = {n: rel_l2(np32(R[n]).astype(np.float64), o) for n, o in zip(GRADS, o64)}
         recs["bwd_f64"] = parity_record("%s blend backward: rel-L2 against the float64 evaluation of the same backward" % tag,
                                         **{"hip_" + n: hip64[n] for n in GRADS}, **{"reference_kernel_" + n: ref64[n] for n in GRADS})
-        # measured (profiles/parity_r05.md): cameras 1 / 7 (grazing): reference kernel 1.3e-3 (quats) / 1.5e-3 (scales) from float64, HIP 0.75e-3 /
-        # 1.25e-3; cameras 3 / 5 (diagonal, the deepest stacks): both at 2.0 - 2.35e-3 (HIP 5 - 10 % behind), 1.3 - 1.55e-3 from each other — the
-        # float64 yardstick itself starts from the fp32 forward's alphas there.  fp32 is AT north_star's 1e-3 for these views: the bar is "as
-        # close to float64 as the reference kernel is" (15 % + 1e-4) and 3e-3 between the two fp32 evaluations
+        # measured, round 6 (profiles/parity_r06.md, tools/ring_attrib.py): with m = R_inv^-1 (mu - o) instead of R_inv^T (mu - o) — the reference's
+        # fp32 pose round trip leaves R_inv 7e-7 from orthonormal on cameras 3 / 5, gsx_record.hpp — HIP is 7.1 - 8.5e-4 from the reference kernel
+        # there (round 5: 1.3 - 1.55e-3) and as close to float64 as the reference kernel is (2.0 - 2.25e-3 both: the fp32 camera centre the
+        # reference defines is 5e-6 from the float64 one on these poses, a frame shift every fp32 evaluation shares).  What still exceeds 1e-3
+        # between the two fp32 evaluations is cameras 1 / 7 (grazing): 1.26 / 1.48e-3 — where the reference kernel is 1.3 / 1.5e-3 from float64
+        # (its cross product cancels |g| = depth / scale digits) and HIP 4.3e-4: the bar is "at least as close to float64 as the
+        # reference kernel" (x 1.0 + 1e-4; round 5: x 1.15) and 2e-3 between the two
         for g in GRADS:
-            assert recs["bwd_hip"][g] < 3e-3 and hip64[g] <= 1.15 * ref64[g] + 1e-4, (g, recs["bwd_f64"], recs["bwd_hip"])
+            assert recs["bwd_hip"][g] < 2e-3 and hip64[g] <= 1.0 * ref64[g] + 1e-4, (g, recs["bwd_f64"], recs["bwd_hip"])
     else:
         for g in GRADS:
             assert recs["bwd_hip"][g] < 1e-3, (g, recs["bwd_hip"])               # north_star: 1e-3 gradient rel-L2
@@ -474,9 +490,10 @@ def test_s8cam_ring_cameras_vs_reference(ref, mods, s1m_scene, cam_i):
     sc["viewmat"] = scenes.ring_cameras(8)[cam_i]
     tag = "S-8cam ring camera %d" % cam_i
     # cameras that look ALONG the slab see it at grazing depth ranges: more pixels whose last contributions sit at the alpha threshold than
-    # from cfg2's camera, and the diagonal ones (3 / 5) composite the deepest stacks (measured: up to 9.2e-4 of the pixels beyond 1e-4: _explain_pixels
-    # accounts for every one of them — a threshold decision, or an fp32 drift on which the float64 frame sides with HIP)
-    recs, R = _stagewise(ref, ops, sc, {}, tag, with_oracle=False, fwd_strict=False, over_frac=1.2e-3, bwd_f64_yardstick=True)
+    # from cfg2's camera (measured, round 6: up to 3.8e-4 of the pixels beyond 1e-4 — cameras 1 / 7; round 5: 9.2e-4 on cameras 3 / 5, which was the
+    # non-orthonormal R_inv of gsx_record.hpp: 1 863 -> 404 pixels; _explain_pixels accounts for every one of them, RGB and alpha — a threshold
+    # decision, or an fp32 drift on which the float64 frame sides with HIP)
+    recs, R = _stagewise(ref, ops, sc, {}, tag, with_oracle=False, fwd_strict=False, over_frac=6e-4, bwd_f64_yardstick=True)
     off = R["tile_offsets"].reshape(-1).cpu().numpy().astype(np.int64)
     seg = np.diff(np.concatenate([off, [int(R["flatten_ids"].numel())]]))
     parity_record("%s: workload" % tag, visible=int((R["radii"] > 0).all(-1).sum().item()), n_isects=int(R["flatten_ids"].numel()), largest_tile=int(seg.max()),
@@ -516,7 +533,7 @@ def test_s5m_4k_full_frame(ref, mods):
     _stagewise(ref, ops, scenes.scene_5m(), {}, "S-5M @4K", with_oracle=False, fwd_strict=False)
 
 
-def _blend_generic_vs_reference(ref, ops, sc, tag):
+def _blend_generic_vs_reference(ref, ops, sc, tag, over_frac=2e-4, bwd_tol=1e-3):
     """The reference-operation-order kernels (gsx_raster.hip, forced with GSX_RASTER_PATH=generic: cross-product form, no Delta-form) on the
     reference chain's own colours and lists, against the reference's blend kernels: is the fast path's handful of pixels beyond 1e-4 the
     price of its algebra, or of ANY second fp32 evaluation of the same frame?  Recorded next to the fast path's numbers."""
@@ -550,9 +567,9 @@ def _blend_generic_vs_reference(ref, ops, sc, tag):
         who = "HIP reference-order kernels (GSX_RASTER_PATH=generic)" if path == "generic" else "HIP fast kernels (same run)"
         fw = _fwd_stats(tag, who, r_ren, r_alp, r_last, np32(G[0]), np32(G[1]), G[2].cpu().numpy(), cmax)
         bw = parity_record("%s blend backward: %s vs reference kernel (rel-L2)" % (tag, who), **{n: rel_l2(np32(g), np32(R[n])) for n, g in zip(GRADS, B)})
-        assert fw["rgb_max_err"] <= fw["one_gaussian_bound"] and fw["rgb_pixels_over_1e4"] <= 2e-4 * fw["pixels"], fw
+        assert fw["rgb_max_err"] <= fw["one_gaussian_bound"] and fw["rgb_pixels_over_1e4"] <= over_frac * fw["pixels"], fw
         for g in GRADS:
-            assert bw[g] < 1e-3, (path, g, bw)
+            assert bw[g] < bwd_tol, (path, g, bw)
         out[path] = (fw, bw)
     return out
 
@@ -561,6 +578,23 @@ def test_s1m_generic_order_kernels_vs_reference(ref, mods):
     """VERDICT r03 weak #1(a): the full BASELINE frame through the reference-ORDER kernels too."""
     ops, scenes = mods
     _blend_generic_vs_reference(ref, ops, scenes.scene_1m(), "S-1M @1080p")
+
+
+@pytest.mark.parametrize("cam_i", [1, 3, 5, 7])
+def test_s8cam_generic_order_kernels_vs_reference(ref, mods, s1m_scene, cam_i):
+    """VERDICT r05 weak #1(d): the reference-ORDER kernels on the ring cameras where the two fp32 blend backwards were more than 1e-3 apart — the
+    experiment that says whether the distance is the Delta-form's or any second fp32 evaluation's.  Round 6's answer (profiles/parity_r06.md):
+    cameras 3 / 5: the reference-order kernels are 6 - 8e-4 from the reference kernel, the fast kernels WERE 1.3 - 1.6e-3 — the excess was the
+    Delta-form's use of R_inv^T for R_inv^-1 (gsx_record.hpp: the reference's fp32 pose round trip leaves R_inv 7e-7 from orthonormal on these
+    poses), now 7 - 8.5e-4; cameras 1 / 7: BOTH kernel families are 1.1 - 1.5e-3 from the reference kernel, which is itself 1.3 - 1.5e-3 from
+    float64 there (HIP 4.3e-4 / 8e-4): that distance is the reference's (test_s8cam_ring_cameras_vs_reference prices it against float64)."""
+    ops, scenes = mods
+    sc = dict(s1m_scene)
+    sc["viewmat"] = scenes.ring_cameras(8)[cam_i]
+    out = _blend_generic_vs_reference(ref, ops, sc, "S-8cam ring camera %d" % cam_i, over_frac=6e-4, bwd_tol=1e-3 if cam_i in (3, 5) else 2e-3)
+    if cam_i in (3, 5):   # the fast kernels no further from the reference kernel than ~1.5 x the reference-order ones (round 5: 2 - 2.6 x)
+        for g in GRADS:
+            assert out["fast"][1][g] <= 1.6 * out["generic"][1][g] + 1e-4, (g, out["fast"][1], out["generic"][1])
 
 
 def test_s5m_4k_generic_order_kernels_vs_reference(ref, mods):
