@@ -34,9 +34,14 @@ class FusedAdam:
     @staticmethod
     def for_splat_data(model, means_lr=0.00016, shs_lr=0.0025, scaling_lr=0.005, rotation_lr=0.001, opacity_lr=0.05,
                        scene_scale=1.0, **kw):
-        """strategy_utils.cpp:35-40 (defaults: include/core/parameters.hpp:19-23)."""
-        return FusedAdam(model, {"means": means_lr * scene_scale, "sh0": shs_lr, "shN": shs_lr / 20.0, "scaling": scaling_lr,
-                                 "rotation": rotation_lr, "opacity": opacity_lr}, **kw)
+        """strategy_utils.cpp:35-40 (defaults: include/core/parameters.hpp:19-23).  The reference's parameters are C floats and the group
+        learning rates are formed in fp32 before they are widened to the optimizer's double (`_params->means_lr * get_scene_scale()`,
+        `_params->shs_lr / 20.f`): the same here — 0.00016f is 0.00015999999595806003, not 0.00016, and the scheduler multiplies that double every
+        iteration (found by running the reference's own mcmc.cpp next to this class: tests/test_gpu_reference_strategy.py)."""
+        import numpy as np
+        f = np.float32
+        return FusedAdam(model, {"means": float(f(means_lr) * f(scene_scale)), "sh0": float(f(shs_lr)), "shN": float(f(shs_lr) / f(20.0)),
+                                 "scaling": float(f(scaling_lr)), "rotation": float(f(rotation_lr)), "opacity": float(f(opacity_lr))}, **kw)
 
     # ---- state ---------------------------------------------------------------------------------------------------------
     def _param(self, name):

@@ -132,7 +132,8 @@ class MCMC:
     @torch.no_grad()
     def inject_noise(self):
         m = self.model
-        lr = self.optimizer.groups[0]["lr"] * self.NOISE_LR
+        import numpy as np
+        lr = float(np.float32(self.optimizer.groups[0]["lr"]) * np.float32(self.NOISE_LR))   # static_cast<float>(lr) * _noise_lr: an fp32 product (mcmc.cpp:347-349)
         noise = torch.randn(m.means.shape, dtype=m.means.dtype, device=m.means.device, generator=self.generator)
         ops.add_noise(m.opacity_raw.data.reshape(-1).contiguous(), m.scaling_raw.data, m.rotation_raw.data, noise, m.means.data, float(lr))
 
