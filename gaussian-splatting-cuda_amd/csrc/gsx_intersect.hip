@@ -463,9 +463,11 @@ template <int E, typename K> GSX_DEV void bitonic_sort_regs(K (&r)[E], uint32_t 
 }
 
 // (k = E needs the lane's direction at the END of the local sort: for E == 1 there is no local stage)
+// (isect_ids != nullptr — KeyDepthIdx only, round 6: the sorted depth bits take a second trip through the same LDS words and leave as
+//  (camera | tile) << 32 | depth bits, what gsplat::intersect_tile returns to a reference build; the LDS merge sort used to serve those calls)
 template <int E, class KT>
 GSX_DEV void tile_sort_regs_segment(const KT& kt, typename KT::T* __restrict__ keys, int32_t* __restrict__ flatten_ids, int64_t begin, int n,
-                                    uint32_t lane, uint32_t* s_out) {
+                                    uint32_t lane, uint32_t* s_out, int64_t* __restrict__ isect_ids = nullptr, int64_t cam_tile = 0) {
     using K = typename KT::T;
     K r[E];
 #pragma unroll
@@ -491,12 +493,28 @@ GSX_DEV void tile_sort_regs_segment(const KT& kt, typename KT::T* __restrict__ k
             else flatten_ids[begin + i] = (int32_t)v;
         }
     }
+    if constexpr (!KT::kDeferred) if (isect_ids != nullptr) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = (int)lane * E + e;
+            s_out[i + (i >> 5)] = (uint32_t)kt.depth_bits(r[e], 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = e * 64 + (int)lane;
+            if (i < n) isect_ids[begin + i] = cam_tile | (int64_t)s_out[i + (i >> 5)];
+        }
+    }
 }
 
 template <class KT>
 __global__ __launch_bounds__(256) void tile_sort_wave_regs_kernel(uint32_t n_segments, KT kt, const int32_t* __restrict__ tile_offsets,
                                                                   typename KT::T* __restrict__ keys, int32_t* __restrict__ flatten_ids,
-                                                                  int64_t capacity) {
+                                                                  int64_t capacity, int64_t* __restrict__ isect_ids, uint32_t n_tiles, uint32_t tile_n_bits) {
     __shared__ uint32_t s_all[4][TSORT_WAVE_CAP + TSORT_WAVE_CAP / 32];
     const uint32_t seg = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (seg >= n_segments) return;
@@ -505,11 +523,12 @@ __global__ __launch_bounds__(256) void tile_sort_wave_regs_kernel(uint32_t n_seg
     if (n <= 0 || n > TSORT_WAVE_CAP || begin + n > capacity) return;
     uint32_t* s_out = s_all[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63u;
-    if (n <= 64) tile_sort_regs_segment<1>(kt, keys, flatten_ids, begin, n, lane, s_out);
-    else if (n <= 128) tile_sort_regs_segment<2>(kt, keys, flatten_ids, begin, n, lane, s_out);
-    else if (n <= 256) tile_sort_regs_segment<4>(kt, keys, flatten_ids, begin, n, lane, s_out);
-    else if (n <= 512) tile_sort_regs_segment<8>(kt, keys, flatten_ids, begin, n, lane, s_out);
-    else tile_sort_regs_segment<16>(kt, keys, flatten_ids, begin, n, lane, s_out);
+    const int64_t cam_tile = isect_ids ? ((((int64_t)(seg / n_tiles) << tile_n_bits) | (int64_t)(seg % n_tiles)) << 32) : 0;
+    if (n <= 64) tile_sort_regs_segment<1>(kt, keys, flatten_ids, begin, n, lane, s_out, isect_ids, cam_tile);
+    else if (n <= 128) tile_sort_regs_segment<2>(kt, keys, flatten_ids, begin, n, lane, s_out, isect_ids, cam_tile);
+    else if (n <= 256) tile_sort_regs_segment<4>(kt, keys, flatten_ids, begin, n, lane, s_out, isect_ids, cam_tile);
+    else if (n <= 512) tile_sort_regs_segment<8>(kt, keys, flatten_ids, begin, n, lane, s_out, isect_ids, cam_tile);
+    else tile_sort_regs_segment<16>(kt, keys, flatten_ids, begin, n, lane, s_out, isect_ids, cam_tile);
 }
 
 static bool wave_sort_merge_forced() { const char* e = test_switch("GSX_WAVE_SORT"); return e != nullptr && strcmp(e, "merge") == 0; }   // read per launch
@@ -1305,10 +1324,11 @@ extern "C" int gsx_intersect_bin_fill(uint32_t C, uint32_t N, const float* means
                        (const uint32_t*)nullptr, (float)tile_size, tile_width, tile_height, idx_bits, tile_offsets, (const uint32_t*)count_workspace,
                        keys, (uint32_t)n_isects);
     const KeyDepthIdx kt{idx_bits};
-    // segments up to 1024 keys: one wave each — the register bitonic network (isect_ids, which need the sorted depth bits, keep the LDS
-    // merge sort; GSX_WAVE_SORT=merge (test switch) forces it: second implementation in the tests)
-    if (isect_ids == nullptr && !wave_sort_merge_forced())
-        hipLaunchKernelGGL(tile_sort_wave_regs_kernel<KeyDepthIdx>, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, kt, tile_offsets, keys, flatten_ids, n_isects);
+    // segments up to 1024 keys: one wave each — the register bitonic network (round 6: isect_ids too; GSX_WAVE_SORT=merge (test switch) forces
+    // the LDS merge sort: second implementation in the tests)
+    if (!wave_sort_merge_forced())
+        hipLaunchKernelGGL(tile_sort_wave_regs_kernel<KeyDepthIdx>, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, kt, tile_offsets, keys, flatten_ids, n_isects,
+                           isect_ids, n_tiles, bit_width_u32(n_tiles));
     else
         hipLaunchKernelGGL(tile_sort_wave_kernel<KeyDepthIdx>, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, n_tiles, bit_width_u32(n_tiles), kt,
                            tile_offsets, keys, flatten_ids, isect_ids, n_isects);
@@ -1472,7 +1492,7 @@ extern "C" int gsx_intersect_bin_fill_ranked(uint32_t C, uint32_t N, const float
                        (float)tile_size, tile_width, tile_height, 0u, tile_offsets, (const uint32_t*)count_workspace, keys, (uint32_t)n_isects);
     const KeyRank kt{order, depths};
     if (!wave_sort_merge_forced())   // (deferred keys: the sorted ranks stay in place, ranked_finalize_kernel turns them into ids / isect_ids)
-        hipLaunchKernelGGL(tile_sort_wave_regs_kernel<KeyRank>, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, kt, tile_offsets, keys, flatten_ids, n_isects);
+        hipLaunchKernelGGL(tile_sort_wave_regs_kernel<KeyRank>, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, kt, tile_offsets, keys, flatten_ids, n_isects, (int64_t*)nullptr, n_tiles, bit_width_u32(n_tiles));
     else
         hipLaunchKernelGGL(tile_sort_wave_kernel<KeyRank>, dim3((nseg + 3) / 4), dim3(256), 0, st, nseg, n_tiles, bit_width_u32(n_tiles), kt, tile_offsets,
                            keys, flatten_ids, isect_ids, n_isects);

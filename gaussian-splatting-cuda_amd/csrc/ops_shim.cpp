@@ -96,6 +96,38 @@ static thread_local const ActArgs* g_act = nullptr;
 // ... and the fused front end (gsx_ext::frontend_fused) hands the blend forward a workspace whose records are already packed
 static thread_local const at::Tensor* g_fwd_ws_ready = nullptr;
 
+// Round 6: two per-thread caches behind the PLAIN Ops.h entry points — what a reference build that swapped in this backend calls, one operator at a
+// time (the reference's own render call site on the drop-in: 83 torch launches + 14 gsx launches per frame, profiles/r06_dropin_callers.md).
+// They only save work the operator sequence of gs::training::rasterize repeats; results are the same bits.  A cache holds REFERENCES to the
+// tensors it is keyed by (their storage cannot be freed and handed to another tensor meanwhile) and compares data pointers, sizes and autograd
+// version counters; GSX_SHIM_CACHE=0 (test switch) turns both off.
+static bool shim_cache_on() {
+    static const bool on = [] { const char* e = gsx_test_switch("GSX_SHIM_CACHE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+struct TensorKey {
+    at::Tensor t; const void* ptr = nullptr; uint32_t version = 0; int64_t numel = 0;
+    static uint32_t ver(const at::Tensor& x) { return x.is_inference() ? 0u : (uint32_t)x._version(); }   // (inference tensors keep no version counter)
+    void set(const at::Tensor& x) { t = x; ptr = x.defined() ? x.data_ptr() : nullptr; version = x.defined() ? ver(x) : 0; numel = x.defined() ? x.numel() : 0; }
+    bool matches(const at::Tensor& x) const { return t.defined() && x.defined() && x.data_ptr() == ptr && x.numel() == numel && ver(x) == version; }
+    void reset() { t = at::Tensor(); ptr = nullptr; }
+};
+// (a) intersect_tile through the binned pipeline has isect_offsets as a by-product; the reference asks for them in a second call,
+//     intersect_offset(isect_ids, ...) (rasterizer.cpp:305-329): answered from here when it comes with the very isect_ids tensor (one
+//     lower_bound launch over 27 MB of keys less per frame)
+struct OffsetsCache { TensorKey ids; at::Tensor offsets; uint32_t C = 0, tw = 0, th = 0; };
+static thread_local OffsetsCache g_offsets_cache;
+// (b) the blend forward packs one 64 B record per (camera, Gaussian) into its workspace; the backward of the same inputs
+//     (rasterizer_autograd.cpp:331-391 hands back the tensors the forward saved) takes the records from here instead of packing them again
+struct PackCache {
+    TensorKey means, quats, scales, colors, opacities, viewmats0, Ks;
+    at::Tensor fws; uint32_t W = 0, H = 0, C = 0, N = 0; int camera_model = -1, shutter = -1; bool distorted = false;
+    void reset() { means.reset(); fws = at::Tensor(); }
+};
+// (process-wide, under a mutex: autograd runs a CUDA node's backward on its device thread, not on the thread that ran the forward)
+static PackCache g_pack_cache;
+static std::mutex g_pack_cache_mutex;
+
 // counters for bench.py (host synchronisations and capacity-hint outcomes of intersect_tile); never read by the ops themselves
 struct ShimStats { std::atomic<int64_t> host_syncs{0}, binned_calls{0}, hint_misses{0}, hint_cold{0}, ranked_calls{0}, guarded_calls{0}, guarded_waits{0}, guarded_misses{0}; };
 static ShimStats g_stats;
@@ -343,6 +375,11 @@ static std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile_impl(const 
     if (!packed && allow_binned && sort && !force_device_sort && n_elements && gsx_intersect_bin_supported(tile_width, tile_height)) {
         // same three outputs through the binned pipeline (LDS histograms + per-tile LDS sort), ~2x faster than the device-wide sort
         auto r = gsx_ext::intersect_tile_binned(means2d, radii, depths, C, tile_size, tile_width, tile_height, true);
+        if (shim_cache_on()) {   // the pipeline's isect_offsets, for the intersect_offset call that follows with these isect_ids
+            g_offsets_cache.ids.set(std::get<1>(r));
+            g_offsets_cache.offsets = std::get<3>(r);
+            g_offsets_cache.C = C; g_offsets_cache.tw = tile_width; g_offsets_cache.th = tile_height;
+        }
         return std::make_tuple(std::get<0>(r), std::get<1>(r), std::get<2>(r));
     }
     void* st = cur_stream();
@@ -389,6 +426,13 @@ at::Tensor intersect_offset(const at::Tensor isect_ids, const uint32_t C, const 
     GSX_DEVICE_GUARD(isect_ids);
     GSX_CHECK_INPUT(isect_ids);
     TORCH_CHECK(isect_ids.scalar_type() == at::kLong, "isect_ids must be int64");
+    if (g_offsets_cache.ids.matches(isect_ids) && g_offsets_cache.C == C && g_offsets_cache.tw == tile_width && g_offsets_cache.th == tile_height &&
+        isect_ids.numel() > 0) {
+        at::Tensor cached = std::move(g_offsets_cache.offsets);   // handed out once: the caller owns it (a caller that writes into it cannot spoil a later answer)
+        g_offsets_cache.ids.reset();
+        g_offsets_cache.offsets = at::Tensor();
+        if (cached.defined()) return cached;
+    }
     at::Tensor offsets = at::empty({(int64_t)C, (int64_t)tile_height, (int64_t)tile_width}, isect_ids.options().dtype(at::kInt));
     check(gsx_intersect_offset(isect_ids.size(0), isect_ids.numel() ? isect_ids.data_ptr<int64_t>() : nullptr, C, tile_width,
                                tile_height, offsets.data_ptr<int32_t>(), cur_stream()),
@@ -468,6 +512,15 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> rasterize_to_pixels_from_world_3d
               guarded ? g_lists->status.data_ptr<int32_t>() : nullptr, guarded ? g_lists->expected : 0, cur_stream()),
           "rasterize_to_pixels_from_world_3dgs_fwd");
     if (g_fwd_ws_out) *g_fwd_ws_out = fws;
+    else if (!ready && shim_cache_on()) {   // the plain Ops.h call: keep the records for the backward of the same inputs (PackCache)
+        std::lock_guard<std::mutex> lock(g_pack_cache_mutex);
+        PackCache& pc = g_pack_cache;
+        pc.means.set(means); pc.quats.set(quats); pc.scales.set(scales); pc.colors.set(colors); pc.opacities.set(opacities);
+        pc.viewmats0.set(viewmats0); pc.Ks.set(Ks);
+        pc.fws = fws; pc.W = image_width; pc.H = image_height; pc.C = C; pc.N = N; pc.camera_model = (int)camera_model; pc.shutter = (int)rs_type;
+        auto given = [](const at::optional<at::Tensor>& o) { return o.has_value() && o->defined() && o->numel() > 0; };   // (the reference passes empty tensors for "none")
+        pc.distorted = given(radial_coeffs) || given(tangential_coeffs) || given(thin_prism_coeffs) || given(viewmats1);
+    }
     return std::make_tuple(renders, alphas, last_ids);
 }
 
@@ -521,6 +574,20 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
     at::Tensor ws = at::empty({(int64_t)wsb}, means.options().dtype(at::kByte));  // caching allocator, like CUB temp storage upstream
     const void* packed = (g_fwd_ws_in && g_fwd_ws_in->defined())
                              ? gsx_rasterize_fwd_packed_records(g_fwd_ws_in->data_ptr(), (size_t)g_fwd_ws_in->numel(), C, N) : nullptr;
+    at::Tensor cached_ws;   // (keeps the workspace alive across the launch even if another forward replaces the cache entry)
+    if (packed == nullptr && g_fwd_ws_in == nullptr) {
+        std::lock_guard<std::mutex> lock(g_pack_cache_mutex);
+        const PackCache& pc = g_pack_cache;
+        auto given = [](const at::optional<at::Tensor>& o) { return o.has_value() && o->defined() && o->numel() > 0; };
+        const bool distorted = given(radial_coeffs) || given(tangential_coeffs) || given(thin_prism_coeffs) || given(viewmats1);
+        // (distorted / rolling-shutter cameras re-pack: their records depend on more tensors than the key holds; the reference's --gut training camera is a plain pinhole)
+        if (pc.fws.defined() && !distorted && !pc.distorted && pc.C == C && pc.N == N && pc.W == image_width && pc.H == image_height && pc.camera_model == (int)camera_model &&
+            pc.shutter == (int)rs_type && pc.means.matches(means) && pc.quats.matches(quats) && pc.scales.matches(scales) && pc.colors.matches(colors) &&
+            pc.opacities.matches(opacities) && pc.viewmats0.matches(viewmats0) && pc.Ks.matches(Ks)) {
+            cached_ws = pc.fws;
+            packed = gsx_rasterize_fwd_packed_records(cached_ws.data_ptr(), (size_t)cached_ws.numel(), C, N);
+        }
+    }
     const bool guarded = g_lists != nullptr && g_lists->status.defined();
     if (g_act != nullptr) {   // through to the raw parameters (v_quats / v_scales / v_opacities are scratch: returned, not meaningful)
         check(gsx_rasterize_to_pixels_from_world_3dgs_bwd_act(

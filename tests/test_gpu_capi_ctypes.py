@@ -78,7 +78,7 @@ def test_whole_render_chain_through_the_raw_c_abi_on_a_side_stream():
     from gsx import ops, scenes
     from tests.helpers import oracle_pipeline
     lib = _lib()
-    assert lib.gsx_abi_version() == 6
+    assert lib.gsx_abi_version() == 7
     for f in ("gsx_intersect_bin_count_workspace_bytes", "gsx_intersect_bin_fill_workspace_bytes", "gsx_rasterize_fwd_workspace_bytes",
               "gsx_rasterize_bwd_workspace_bytes"):
         getattr(lib, f).restype = ctypes.c_size_t

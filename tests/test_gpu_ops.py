@@ -444,3 +444,44 @@ def test_intersect_tile_binned_segment_bound_outgrown():
         seg = torch.cat([off.flatten(), torch.tensor([flat.numel()], device=off.device, dtype=off.dtype)])
         largest.append(int((seg[1:] - seg[:-1]).max()))
     assert largest[0] <= 16384 < largest[1] and largest[2] > 1.3 * largest[1] and largest[3] == largest[0]
+
+
+def test_shim_caches_behind_the_plain_operator_calls(gsx_mod):
+    """Round 6 (csrc/ops_shim.cpp: OffsetsCache, PackCache): the plain Ops.h calls of a reference build — intersect_tile then intersect_offset on its
+    isect_ids, blend forward then blend backward on the tensors the forward saved — reuse what the first call of each pair already produced
+    (the binned pipeline's offsets, the packed records).  Same results as the uncached paths: a clone of the key tensor (another data pointer),
+    an in-place change of an input between forward and backward (a version bump) or a forward on other tensors in between take the uncached
+    path, which is the yardstick here."""
+    _, ops, _, scenes = gsx_mod
+    sc = _scene(scenes, N=3000, size=128, seed=3)
+    rng = np.random.default_rng(0)
+    v_rc, v_ra = t(rng.standard_normal((1, 128, 128, 3)).astype(np.float32)), t(rng.standard_normal((1, 128, 128, 1)).astype(np.float32))
+    o = oracle_pipeline(sc)
+    b = _blend_inputs(sc, o)
+    ut = ops.UnscentedTransformParameters()
+    # ---- (a) offsets
+    P = ops.projection_ut_3dgs_fused(b["means"], b["quats"], b["scales"], b["opac"][0].contiguous(), b["viewmat"], None, b["K"], 128, 128, 0.3, 0.01, 1e4, 0.0,
+                                     False, ops.CameraModelType.PINHOLE, ut, ops.ShutterType.GLOBAL, None, None, None)
+    radii, means2d, depths = P[0], P[1], P[2]
+    _, ids, fl = ops.intersect_tile(means2d, radii, depths, None, None, 1, 16, 8, 8, True)
+    off_cached = ops.intersect_offset(ids, 1, 8, 8)            # answered from the pipeline's by-product
+    off_again = ops.intersect_offset(ids, 1, 8, 8)             # the cache entry was handed out: the kernel
+    off_clone = ops.intersect_offset(ids.clone(), 1, 8, 8)     # another tensor: the kernel
+    assert off_cached.shape == (1, 8, 8) and torch.equal(off_cached, off_again) and torch.equal(off_cached, off_clone)
+    assert int(fl.numel()) > 3000 and int(off_cached.max()) > 0
+    # ---- (b) packed records
+    args = lambda B: (B["means"], B["quats"], B["scales"], B["colors"], B["opac"], B["bg"], None, 128, 128, 16, B["viewmat"], None, B["K"],  # noqa: E731
+                      ops.CameraModelType.PINHOLE, ut, ops.ShutterType.GLOBAL, None, None, None, B["off"], B["fl"])
+    F = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args(b))
+    g_hit = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args(b), F[1], F[2], v_rc, v_ra)                    # records from the forward
+    b2 = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+    g_miss = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args(b2), F[1], F[2], v_rc, v_ra)                  # other tensors: packs again
+    for x, y, n in zip(g_hit, g_miss, ["v_means", "v_quats", "v_scales", "v_colors", "v_opacities"]):
+        assert rel_l2(np32(x), np32(y)) < 2e-6, n
+    # an input changed in place between forward and backward (version bump): the backward must see the NEW values, not the forward's records
+    F = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args(b))
+    b["means"].add_(0.003)
+    g_new = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args(b), F[1], F[2], v_rc, v_ra)
+    b3 = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+    g_ref = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args(b3), F[1], F[2], v_rc, v_ra)
+    assert rel_l2(np32(g_new[0]), np32(g_ref[0])) < 2e-6 and rel_l2(np32(g_new[0]), np32(g_hit[0])) > 1e-3
