@@ -251,8 +251,11 @@ def main():
     ap.add_argument("--s5m-timeout", type=float, default=240.0, help="wall-time guard of that child process, seconds")
     ap.add_argument("--no-camera-batch", action="store_true", help="skip the extra leg that times 8 cameras per optimizer step on one GPU (N = 1 only)")
     ap.add_argument("--no-order-ablation", action="store_true", help="skip the extra leg that times the other memory order (N = 1 only)")
-    ap.add_argument("--repeats", type=int, default=1, help="R > 1: time R x K steps and report the MEDIAN K-step time (sub-3 %% claims need it; "
-                                                           "the contract's single K-step region is R = 1)")
+    ap.add_argument("--repeats", type=int, default=3, help="R regions of EXACTLY K timed steps each, every one started from the same state (parameters and optimizer "
+                                                           "moments restored to the end of the warm-up, outside the timed regions): `value` is the MEDIAN region; "
+                                                           "R = 1 = a single region (box-to-box and run-to-run spread of one 26 ms region is +-4 %%: VERDICT r05 weak #5)")
+    ap.add_argument("--sustained-steps", type=int, default=1500, help="extra leg behind the contract's regions: this many consecutive training iterations from the same "
+                                                                      "state (>= 2 s: the blend kernels run at the chip's power limit, a 26 ms region does not see a settled clock); 0 = skip")
     ap.add_argument("--mcmc", dest="mcmc", action="store_true", default=None, help="run the MCMC strategy's per-iteration operators inside the step (noise "
                                                                                    "injection, its lr schedule); default: on for --scene 5m (configs[4] names the MCMC strategy)")
     ap.add_argument("--no-mcmc", dest="mcmc", action="store_false")
@@ -482,8 +485,39 @@ def main():
     # in a separate pass after the timed region.
     timer.enabled = True
     timer.only = {"rasterize_to_pixels_from_world_3dgs_fwd", "rasterize_to_pixels_from_world_3dgs_bwd"}
-    elapsed_all = [timed(args.steps, True) for _ in range(max(1, args.repeats))]
-    elapsed = sorted(elapsed_all)[len(elapsed_all) // 2]   # R = 1: the contract's single region; R > 1: the median region
+    # Every region times the SAME K iterations: the state at the end of the warm-up (parameters, Adam moments, step counters, the means group's
+    # scheduled lr) is kept on the device and put back before each region, outside the timed code (training against noise targets makes the
+    # frame lighter iteration by iteration — 1.32 -> 1.15 ms over 100 iterations — so un-restored regions would not be comparable).
+    def snapshot():
+        st = {"params": [p_.detach().clone() for p_ in model.params()], "opt": {}, "lrs": [g_["lr"] for g_ in opt.groups], "i": counter["i"]}
+        for k_, v_ in opt.state.items():
+            st["opt"][k_] = {kk: vv.clone() for kk, vv in v_.items()} if isinstance(v_, dict) else v_
+        return st
+
+    def restore(st):
+        with torch.no_grad():
+            for p_, q_ in zip(model.params(), st["params"]):
+                p_.copy_(q_)
+            for k_ in list(opt.state.keys()):
+                if k_ not in st["opt"]:
+                    del opt.state[k_]
+            for k_, v_ in st["opt"].items():
+                if isinstance(v_, dict):
+                    for kk, vv in v_.items():
+                        opt.state[k_][kk].copy_(vv)
+                else:
+                    opt.state[k_] = v_
+        for g_, lr_ in zip(opt.groups, st["lrs"]):
+            g_["lr"] = lr_
+        counter["i"] = st["i"]
+        torch.cuda.synchronize()
+    snap = snapshot() if (max(1, args.repeats) > 1 or args.sustained_steps > 0) and strategy is None else None
+    elapsed_all = []
+    for rep in range(max(1, args.repeats)):
+        if rep > 0 and snap is not None:
+            restore(snap)
+        elapsed_all.append(timed(args.steps, True))
+    elapsed = sorted(elapsed_all)[len(elapsed_all) // 2]   # R = 1: a single region; R > 1: the median of R regions over the same K iterations
     timer.enabled = False
     host_syncs, binned_calls, hint_misses, hint_cold = ops.shim_stats(True)
     guarded_calls, guarded_waits, guarded_misses = ops.shim_guarded_stats(True)
@@ -499,6 +533,36 @@ def main():
     timer.enabled = False
     all_ms = timer.mean_ms()
     all_ms.update(blend_ms)                  # the blend ops keep their timed-region figures
+    # ---- sustained load (outside the contract's regions; VERDICT r05 missing #5): >= 1500 consecutive iterations from the warm-up state ----
+    sustained = None
+    if args.sustained_steps > 0 and snap is not None and not multi:
+        restore(snap)
+        n_s, blk = args.sustained_steps, 100
+        counter["isects"] = []
+        gc.collect()
+        gc.disable()
+        torch.cuda.synchronize()
+        marks, t0 = [], time.perf_counter()
+        for k_ in range(n_s):
+            step(True)
+            if k_ + 1 == blk or k_ + 1 == n_s - blk:
+                torch.cuda.synchronize()
+                marks.append((k_ + 1, time.perf_counter() - t0))
+        torch.cuda.synchronize()
+        dt_s = time.perf_counter() - t0
+        gc.enable()
+        isx = counter["isects"]
+        first = marks[0][1] / marks[0][0] * 1e3
+        last = ((dt_s - marks[-1][1]) / (n_s - marks[-1][0]) * 1e3) if len(marks) >= 2 and n_s > marks[-1][0] else None
+        sustained = {"steps": n_s, "wall_s": round(dt_s, 3), "ms_per_step": round(dt_s / n_s * 1e3, 4), "iters_per_s": round(n_s / dt_s, 2),
+                     "ms_per_step_first_%d" % blk: round(first, 4), "ms_per_step_last_block": (round(last, 4) if last else None),
+                     "n_isects_first_100_mean": round(sum(isx[:100]) / max(1, len(isx[:100])), 1), "n_isects_last_100_mean": round(sum(isx[-100:]) / max(1, len(isx[-100:])), 1),
+                     "iterations_repeated": counter["repeated"] - repeated_timed,
+                     "what": "the same training iteration, %d in a row from the state the contract's regions start from (one synchronisation after the first %d and before the last "
+                             "block, none in between).  The model trains against noise targets, so the frame gets lighter as it goes (n_isects first / last 100): "
+                             "ms_per_step_first_%d is the like-for-like figure under a settled clock, ms_per_step the whole leg" % (n_s, blk, blk)}
+        restore(snap)
+        counter["isects"] = list(isects_timed)
     # names used by the report below: the MAIN leg's configuration
     names, bucket, xch, sharded, overlap, sh_adam_ok = leg["names"], leg["bucket"], leg["xch"], leg["sharded"], leg["overlap"], leg["sh_adam_ok"]
     main_exchange_bytes = int(getattr(bucket, "last_reduced_bytes", 0)) if multi else 0
@@ -558,7 +622,10 @@ def main():
             nb_hist = 256 * tiles * 4
             moved = N * 16 + N * 4 + nb_hist + 2 * nb_hist + N * 20 + 8 * I + 8 * I + 4 * I
             row = kernels["intersect_tile_binned"]
-            row["algorithmic_bytes_is"] = "the two reference ops' bytes (60 N C + 164 I + 4 tiles): the pipeline does not perform their radix passes"
+            # (round 6, VERDICT r05 weak #5: no GBps / frac_hbm against bytes the pipeline does not move — that figure exceeded 1 at S-5M)
+            row["reference_ops_algorithmic_bytes"] = row.pop("algorithmic_bytes")
+            row.pop("GBps"); row.pop("frac_hbm")
+            row["reference_ops_algorithmic_bytes_is"] = "the two reference ops' bytes (60 N C + 164 I + 4 tiles): the pipeline does not perform their radix passes, so no rate is quoted against them"
             row["bytes_moved_estimate"] = int(moved)
             row["GBps_moved"] = round(moved / (row["ms"] * 1e-3) / 1e9, 1)
             row["frac_hbm_moved"] = round(moved / (row["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
@@ -584,6 +651,17 @@ def main():
             ab_pm = algorithmic_bytes(N, 1, pmc["n_isects"], P, tiles, deg, K)[dom]
             roofline["traffic_n_isects"] = pmc["n_isects"]
             roofline["traffic_over_algorithmic_same_frame"] = round(pm["hbm_bytes"] / ab_pm, 3)
+        proc = pmc.get("processed")
+        if proc and proc.get("n_isects"):
+            # SURVEY §0 finding 7 / VERDICT r05 missing #4: the algorithmic bytes on the intersections the kernels actually staged (counted by a -DGSX_STATS
+            # build on one frame: tools/processed_isects.py), next to all I: the blend rows above price all I
+            fr = proc["fwd_processed_frac"] if dom.endswith("_fwd") else proc["bwd_processed_frac"]
+            ab_proc = algorithmic_bytes(N, 1, I * fr, P, tiles, deg, K)[dom]
+            roofline["processed_intersections"] = {
+                "counters_frame_n_isects": proc["n_isects"], "fwd_staged_entries": proc["fwd_staged_entries"], "bwd_staged_entries": proc["bwd_staged_entries"],
+                "fwd_processed_frac": proc["fwd_processed_frac"], "bwd_processed_frac": proc["bwd_processed_frac"], "pixels_saturated_frac": proc.get("pixels_saturated_frac"),
+                "algorithmic_bytes_processed": int(ab_proc), "frac_hbm_processed": round(ab_proc / (kernels[dom]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "what": proc.get("what")}
         workload = {"1m": "S-1M (BASELINE configs[1]): 1M random Gaussians, SH deg 3, 1920x1080, one camera per GPU per iteration",
                     "5m": "S-5M (BASELINE configs[4]): 5M random Gaussians, SH deg 3, 3840x2160, one camera per GPU per iteration",
                     "small": "S-small (BASELINE configs[0]): 10k Gaussians, SH deg 0, 256x256"}[args.scene]
@@ -620,7 +698,9 @@ def main():
                        "guarded_confirms_that_waited_per_step": round(guarded_waits / (args.steps * len(elapsed_all)), 2),
                        "iterations_repeated": int(repeated_timed), "host_delay_us": args.host_delay_us,
                        "intersect_hint_misses": int(hint_misses), "intersect_cold_calls": int(hint_cold)},
-            "repeats": {"R": len(elapsed_all), "ms_per_step_each": [round(e / args.steps * 1e3, 4) for e in elapsed_all], "reported": "median"},
+            "repeats": {"R": len(elapsed_all), "ms_per_step_each": [round(e / args.steps * 1e3, 4) for e in elapsed_all], "reported": "median",
+                        "same_state_every_region": snap is not None},
+            "sustained": sustained,
             "gaussians_x_pixels_per_s": round(world * N * P / (elapsed / args.steps), 1),
             "pairs_per_s_fwd": round(256.0 * I / (all_ms.get("rasterize_to_pixels_from_world_3dgs_fwd", float("nan")) * 1e-3), 1),
             "roofline": roofline,
@@ -790,7 +870,7 @@ def main():
                 import subprocess
                 torch.cuda.empty_cache()   # (this process's S-1M model stays resident: ~2 GB of 288)
                 cmd = [sys.executable, os.path.abspath(__file__), "--scene", "5m", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-order-ablation",
-                       "--no-camera-batch", "--no-s5m"]
+                       "--no-camera-batch", "--no-s5m", "--repeats", "1", "--sustained-steps", "0"]
                 t0 = time.perf_counter()
                 cp = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=args.s5m_timeout)
                 d5 = json.loads(cp.stdout.strip().splitlines()[-1])
@@ -798,8 +878,10 @@ def main():
                     "workload": d5["config"]["workload"], "strategy": d5["config"]["strategy"], "ms_per_step": d5["ms_per_step"], "iters_per_s": d5["value"],
                     "steps": d5["steps"], "warmup": d5["warmup"], "gpu_ms_per_step": d5.get("gpu_ms_per_step"), "fwd_bwd": d5.get("fwd_bwd"),
                     "n_isects_mean": d5["config"]["n_isects_mean"], "iterations_repeated": d5["config"]["iterations_repeated"],
-                    "kernels": {k: {"ms": v["ms"], "frac_hbm": v["frac_hbm"]} for k, v in d5["kernels"].items()},
-                    "roofline": {k: d5["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms")},
+                    "kernels": {k: ({"ms": v["ms"], "frac_hbm": v["frac_hbm"]} if "frac_hbm" in v else {"ms": v["ms"], "frac_hbm_moved": v.get("frac_hbm_moved")})
+                                for k, v in d5["kernels"].items()},
+                    "roofline": {k: d5["roofline"].get(k) for k in ("kernel", "achieved", "frac", "avg_launch_ms", "traffic", "traffic_source", "traffic_over_algorithmic_same_frame",
+                                                                     "processed_intersections")},
                     "mcmc_refine": d5.get("mcmc_refine"), "ms_per_step_with_refine_amortised": d5.get("ms_per_step_with_refine_amortised"),
                     "wall_s": round(time.perf_counter() - t0, 1), "command": "python bench.py " + " ".join(cmd[2:])}
             except Exception as e:  # noqa: BLE001  (an extra leg must not cost the contract's line)
