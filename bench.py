@@ -471,23 +471,21 @@ def main():
             step(False)
         counter["i"] = 0
         fwd_bwd_ms = timed(args.steps, False) / args.steps * 1e3
-    # ---- the contract: W warm-up steps, then EXACTLY K timed training iterations ------------------------------------------
+    # ---- the contract: W warm-up steps, then EXACTLY K timed training iterations — R times, each from the same state -------
     counter["i"] = 0
-    for _ in range(args.warmup):
-        step(True)
-    torch.cuda.synchronize()
-    ops.shim_stats(True)
-    ops.shim_guarded_stats(True)
-    counter["isects"] = []
-    counter["repeated"] = 0
+    step(True)   # (the first optimizer step creates the Adam moments: they must exist in the snapshot every region starts from)
+    counter["i"] = 0
     # Only the two blend ops (the roofline kernels) are bracketed with HIP events inside the timed region — each event record opens
     # a ~5 us bubble on the stream, 24 ops x 2 events would cost ~0.1 ms per step.  The per-op table of the other ops is measured
     # in a separate pass after the timed region.
     timer.enabled = True
     timer.only = {"rasterize_to_pixels_from_world_3dgs_fwd", "rasterize_to_pixels_from_world_3dgs_bwd"}
-    # Every region times the SAME K iterations: the state at the end of the warm-up (parameters, Adam moments, step counters, the means group's
-    # scheduled lr) is kept on the device and put back before each region, outside the timed code (training against noise targets makes the
-    # frame lighter iteration by iteration — 1.32 -> 1.15 ms over 100 iterations — so un-restored regions would not be comparable).
+    # Every region is the contract's protocol from the SAME state: the state in front of the warm-up (parameters, Adam moments, step counters, the
+    # means group's scheduled lr) is kept on the device and put back before each region's W warm-up + K timed iterations, outside the timed code
+    # (training against noise targets makes the frame lighter iteration by iteration — 1.32 -> 1.15 ms over 100 iterations — so un-restored regions
+    # would not be comparable).  NB (tools/clock_ramp_probe.py, profiles/r06_clock_ramp.md): a region of 26 ms that starts behind ANY idle gap of the
+    # GPU (the synchronisation the contract asks for, the restore) runs ~12 % below the clock a training loop settles at after a few hundred
+    # milliseconds of continuous load — `sustained` below is that loop.
     def snapshot():
         st = {"params": [p_.detach().clone() for p_ in model.params()], "opt": {}, "lrs": [g_["lr"] for g_ in opt.groups], "i": counter["i"]}
         for k_, v_ in opt.state.items():
@@ -516,6 +514,16 @@ def main():
     for rep in range(max(1, args.repeats)):
         if rep > 0 and snap is not None:
             restore(snap)
+        if rep == 0 or snap is not None:
+            timer.enabled = False
+            for _ in range(args.warmup):   # the contract's W untimed warm-up steps, directly in front of each region
+                step(True)
+            torch.cuda.synchronize()
+            timer.enabled = True
+        ops.shim_stats(True)
+        ops.shim_guarded_stats(True)
+        counter["isects"] = []
+        counter["repeated"] = 0
         elapsed_all.append(timed(args.steps, True))
     elapsed = sorted(elapsed_all)[len(elapsed_all) // 2]   # R = 1: a single region; R > 1: the median of R regions over the same K iterations
     timer.enabled = False
@@ -691,11 +699,11 @@ def main():
                                           ("dense all-reduce, scaling/rotation/opacity exchanged under the SH backward" if overlap else "dense all-reduce")))),
                        "grad_exchange_bytes": main_exchange_bytes,
                        "grad_bucket_bytes": bucket.nbytes(),
-                       "host_syncs_per_step": round(host_syncs / (args.steps * len(elapsed_all)), 2),
+                       "host_syncs_per_step": round(host_syncs / args.steps, 2),
                        "intersect_protocol": ("guarded lists (include/gsx.h): the host never reads n_isects on the render path; it confirms the count inside "
                                               "backward() with the forward, the loss and the blend backward queued behind it" if guarded else
                                               "exact: the host reads n_isects inside intersect_tile (one stream-draining sync per iteration, as upstream Intersect.cpp:76)"),
-                       "guarded_confirms_that_waited_per_step": round(guarded_waits / (args.steps * len(elapsed_all)), 2),
+                       "guarded_confirms_that_waited_per_step": round(guarded_waits / args.steps, 2),
                        "iterations_repeated": int(repeated_timed), "host_delay_us": args.host_delay_us,
                        "intersect_hint_misses": int(hint_misses), "intersect_cold_calls": int(hint_cold)},
             "repeats": {"R": len(elapsed_all), "ms_per_step_each": [round(e / args.steps * 1e3, 4) for e in elapsed_all], "reported": "median",

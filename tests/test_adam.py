@@ -78,7 +78,8 @@ def test_fused_adam_reference_quirks():
     assert not torch.equal(model.sh[:, 1:], before[1][:, 1:])
     sched = optim.ExponentialLR(opt, 0.5, 0)
     sched.step()
-    assert abs(opt.groups[0]["lr"] - 0.00008) < 1e-12 and opt.groups[1]["lr"] == 0.0025
+    # (the group learning rates are the reference's C floats widened to double: 0.00016f = 0.00015999999595806003, strategy_utils.cpp:35-40)
+    assert abs(opt.groups[0]["lr"] - 0.5 * float(np.float32(0.00016))) < 1e-15 and opt.groups[1]["lr"] == float(np.float32(0.0025))
 
 
 @pytest.mark.gpu
@@ -160,12 +161,13 @@ def test_begin_fused_sh_step_bookkeeping():
     assert opt.step_count("sh0") == 0 and opt.step_count("shN") == 0   # counters are committed only once the fused kernel has run:
     opt.step(10, skip_sh=True)                                          # ... by the step() that follows the render backward
     assert opt.step_count("sh0") == 1 and opt.step_count("shN") == 1   # (the shN counter advances during its warm-up, fused_adam.cpp:66-70)
-    assert abs(step0 - 0.0025 / (1 - 0.9)) < 1e-12 and abs(stepN - 0.000125 / (1 - 0.9)) < 1e-12
+    lr0, lrN = float(np.float32(0.0025)), float(np.float32(0.0025) / np.float32(20.0))   # C floats widened to double, as upstream forms them
+    assert abs(step0 - lr0 / (1 - 0.9)) < 1e-12 and abs(stepN - lrN / (1 - 0.9)) < 1e-12
     assert abs(bc2 - 1 / math.sqrt(1 - 0.999)) < 1e-9 and (b1, b2, eps) == (0.9, 0.999, 1e-15)
     a = opt.begin_fused_sh_step(1500)
     opt.step(1500, skip_sh=True)
     assert a[4] is True and a[5] is True and opt.step_count("shN") == 2
-    assert abs(a[2] - 0.0025 / (1 - 0.9 ** 2)) < 1e-12
+    assert abs(a[2] - lr0 / (1 - 0.9 ** 2)) < 1e-12
     assert opt.step_count("means") == 0                       # the other groups are stepped by step(skip_sh=True)
     assert optim.FusedAdam.for_splat_data(model(9)).begin_fused_sh_step(1500) is None   # 27 floats per row: no 16 B vectors
     import pytest
