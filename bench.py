@@ -443,8 +443,10 @@ def main():
         # ahead of the GPU, and a 20-step region is 25 ms — one collection inside it showed up as +0.08 ms per step on the driver's kind of run
         # (first bench of a fresh box: ms_per_step 1.325 against gpu_ms_per_step 1.248; tools/host_time.py: the host needs 0.2 - 0.26 ms per step).
         # Nothing here allocates cycles; reference counting frees everything the steps create.
-        gc.collect()
-        gc.disable()
+        # Round 6: the collection happens ONCE, in front of the first timed leg (`quiesce_host` below), not here: a gc.collect() between the warm-up
+        # and the region is a few milliseconds of idle GPU, and a region that starts behind an idle gap of even 2 ms runs ~12 % slower for the next
+        # hundred milliseconds (the clock governor starts over: tools/clock_ramp_probe.py, profiles/r06_clock_ramp.md) — nothing a training loop,
+        # which never idles, would see.  What is left between the last warm-up launch and t0 is what the contract asks for: synchronize + barrier.
         torch.cuda.synchronize()
         if multi:
             dist.barrier()
@@ -457,13 +459,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        gc.enable()
         if multi:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt
 
+    def quiesce_host():
+        gc.collect()
+        gc.disable()
+    quiesce_host()   # (re-enabled behind the contract's regions)
     # ---- leg 0 (outside the contract's timed region): fwd+bwd ms/frame, no optimizer: the parameters stay the cfg2 scene ----
     fwd_bwd_ms = None
     if not args.no_fwd_bwd:
@@ -507,8 +512,7 @@ def main():
                     opt.state[k_] = v_
         for g_, lr_ in zip(opt.groups, st["lrs"]):
             g_["lr"] = lr_
-        counter["i"] = st["i"]
-        torch.cuda.synchronize()
+        counter["i"] = st["i"]   # (no synchronisation: the copies are stream-ordered in front of the next step)
     snap = snapshot() if (max(1, args.repeats) > 1 or args.sustained_steps > 0) and strategy is None else None
     elapsed_all = []
     for rep in range(max(1, args.repeats)):
@@ -518,7 +522,6 @@ def main():
             timer.enabled = False
             for _ in range(args.warmup):   # the contract's W untimed warm-up steps, directly in front of each region
                 step(True)
-            torch.cuda.synchronize()
             timer.enabled = True
         ops.shim_stats(True)
         ops.shim_guarded_stats(True)
@@ -527,6 +530,7 @@ def main():
         elapsed_all.append(timed(args.steps, True))
     elapsed = sorted(elapsed_all)[len(elapsed_all) // 2]   # R = 1: a single region; R > 1: the median of R regions over the same K iterations
     timer.enabled = False
+    gc.enable()
     host_syncs, binned_calls, hint_misses, hint_cold = ops.shim_stats(True)
     guarded_calls, guarded_waits, guarded_misses = ops.shim_guarded_stats(True)
     repeated_timed = counter["repeated"]

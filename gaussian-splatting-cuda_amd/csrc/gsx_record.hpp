@@ -31,6 +31,11 @@ GSX_DEV CamFrame make_cam_frame(const ShutterPoses& sp) {
         for (int k = 0; k < 3; ++k) f.Rc[r][k] = Rinv.a[r][k];
     const f3 rt = mul(Rinv, sp.t0);
     f.c = {-rt.x, -rt.y, -rt.z};
+#ifdef GSX_FRAME_TRANSPOSE   // A/B only (tools/): rounds 1 - 5's R_inv^T
+    for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 3; ++k) f.Rci[r][k] = Rinv.a[k][r];
+    return f;
+#endif
     const double a00 = Rinv.a[0][0], a01 = Rinv.a[0][1], a02 = Rinv.a[0][2], a10 = Rinv.a[1][0], a11 = Rinv.a[1][1], a12 = Rinv.a[1][2],
                  a20 = Rinv.a[2][0], a21 = Rinv.a[2][1], a22 = Rinv.a[2][2];
     const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;

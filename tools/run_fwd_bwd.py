@@ -6,6 +6,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
+if os.environ.get("GSX_VARIANT_LIB"):   # A/B: a variant build of libgsx.so preloaded under the same soname (tools/build_variant.sh): the extension binds to it
+    import ctypes
+    ctypes.CDLL(os.environ["GSX_VARIANT_LIB"], mode=ctypes.RTLD_GLOBAL)
+
 import gsx  # noqa: E402,F401
 from gsx import loss as gloss  # noqa: E402
 from gsx import rasterizer, scenes  # noqa: E402
