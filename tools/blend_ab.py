@@ -9,6 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
+if os.environ.get("GSX_VARIANT_LIB"):   # a variant build of libgsx.so preloaded under the same soname (tools/build_variant.sh): the extension binds to it
+    import ctypes
+    ctypes.CDLL(os.environ["GSX_VARIANT_LIB"], mode=ctypes.RTLD_GLOBAL)
+
 import gsx  # noqa: E402,F401
 from gsx import ops, rasterizer, scenes  # noqa: E402
 

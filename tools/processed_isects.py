@@ -17,7 +17,7 @@ import torch  # noqa: E402
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "1m"
-    lib = ctypes.CDLL(os.path.join(ROOT, "tools", "variants", "libgsx_stats.so"), mode=ctypes.RTLD_GLOBAL)   # preloaded under the same soname: the extension binds to it
+    lib = ctypes.CDLL(os.environ.get("GSX_STATS_LIB", os.path.join(ROOT, "tools", "variants", "libgsx_stats.so")), mode=ctypes.RTLD_GLOBAL)   # preloaded under the same soname: the extension binds to it
     import gsx  # noqa: F401
     from gsx import layout, rasterizer, scenes
     dev = "cuda:0"
