@@ -577,14 +577,15 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
     at::Tensor cached_ws;   // (keeps the workspace alive across the launch even if another forward replaces the cache entry)
     if (packed == nullptr && g_fwd_ws_in == nullptr) {
         std::lock_guard<std::mutex> lock(g_pack_cache_mutex);
-        const PackCache& pc = g_pack_cache;
+        PackCache& pc = g_pack_cache;
         auto given = [](const at::optional<at::Tensor>& o) { return o.has_value() && o->defined() && o->numel() > 0; };
         const bool distorted = given(radial_coeffs) || given(tangential_coeffs) || given(thin_prism_coeffs) || given(viewmats1);
         // (distorted / rolling-shutter cameras re-pack: their records depend on more tensors than the key holds; the reference's --gut training camera is a plain pinhole)
         if (pc.fws.defined() && !distorted && !pc.distorted && pc.C == C && pc.N == N && pc.W == image_width && pc.H == image_height && pc.camera_model == (int)camera_model &&
             pc.shutter == (int)rs_type && pc.means.matches(means) && pc.quats.matches(quats) && pc.scales.matches(scales) && pc.colors.matches(colors) &&
             pc.opacities.matches(opacities) && pc.viewmats0.matches(viewmats0) && pc.Ks.matches(Ks)) {
-            cached_ws = pc.fws;
+            cached_ws = std::move(pc.fws);   // handed out once: the workspace's record-chain heads are consumed and restored by THIS backward's gather — a second
+            pc.reset();                      // backward of the same forward (retain_graph, another thread) packs for itself instead of sharing them
             packed = gsx_rasterize_fwd_packed_records(cached_ws.data_ptr(), (size_t)cached_ws.numel(), C, N);
         }
     }
