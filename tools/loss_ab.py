@@ -3,6 +3,9 @@ import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if os.environ.get("GSX_VARIANT_LIB"):   # a variant build of libgsx.so preloaded under the same soname: the extension binds to it
+    import ctypes
+    ctypes.CDLL(os.environ["GSX_VARIANT_LIB"], mode=ctypes.RTLD_GLOBAL)
 import gsx  # noqa: F401
 from gsx import ops
 
