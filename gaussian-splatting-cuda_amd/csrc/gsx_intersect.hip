@@ -130,10 +130,13 @@ constexpr uint32_t BIN_WIDE = 16;         // count / scatter: tile rectangles ab
 __global__ __launch_bounds__(BIN_BLOCK) void bin_count_kernel(uint32_t N, uint32_t per_block, const float* __restrict__ means2d,
                                                                 const int32_t* __restrict__ radii, float tile_size, uint32_t tw,
                                                                 uint32_t th, int32_t* __restrict__ tiles_per_gauss,
-                                                                uint32_t* __restrict__ block_hist) {
+                                                                uint32_t* __restrict__ block_hist, unsigned long long* __restrict__ agg, uint32_t n_agg) {
     const uint32_t BIN_NB = gridDim.x;
     extern __shared__ uint32_t s_hist[];
     const uint32_t n_tiles = tw * th, c = blockIdx.y, b = blockIdx.x;
+    // the aggregate words of bin_prefix_scan_kernel's look-back start at "not published" (0): cleared here, one launch earlier, instead of by a memset launch
+    if (agg != nullptr && b == 0u && c == 0u)
+        for (uint32_t t = threadIdx.x; t < n_agg; t += BIN_BLOCK) agg[t] = 0ull;
     for (uint32_t t = threadIdx.x; t < n_tiles; t += BIN_BLOCK) s_hist[t] = 0u;
     __syncthreads();
     // Block b takes the chunks b, b + BIN_NB, b + 2 BIN_NB, ... of BIN_BLOCK consecutive Gaussians (not one contiguous slice): with the
@@ -200,6 +203,96 @@ __global__ __launch_bounds__(BIN_NB_MAX) void bin_prefix_kernel(uint32_t C, uint
         run += v[k];
     }
     if (grp == 0) tile_counts[g] = total;
+}
+
+// Round 6: bin_prefix_kernel and bin_scan_kernel in ONE launch.  The scan of the C*tiles totals was a single 1024-thread block behind the prefix kernel:
+// 10.5 us of launch + latency for 32 KB.  Here every workgroup (32 tiles) publishes the sum of its 32 totals and its largest total in one 8-byte word and
+// takes the sum of its predecessors' words (a look-back over ALL of them: a few hundred words, every lane a few): the exclusive offsets of its tiles follow
+// from a 32-lane scan, and the last workgroup — which then holds the grand total and the largest segment — writes what bin_scan wrote (offsets[n],
+// max_count, the guarded verdict, the host's word).  The words travel as RELAXED device-scope atomics (they resolve at the memory side: no release / L2
+// write-back, which costs ~3.5 us per block on this part — why rounds 5 and 6 first left the two launches apart); nothing but the word itself
+// has to be visible to the other workgroups.  Workgroups are dispatched in order, so a predecessor is always running or done when its successor waits.
+//   word: bit 63 = published | bits 62..36 = min(largest total, 2^27 - 1) | bits 35..0 = min(sum, 2^36 - 1)
+__global__ __launch_bounds__(BIN_NB_MAX) void bin_prefix_scan_kernel(uint32_t C, uint32_t n_tiles, uint32_t* __restrict__ block_hist, unsigned long long* __restrict__ agg,
+                                                                      int32_t* __restrict__ offsets, uint32_t* __restrict__ max_count, int64_t capacity, int64_t seg_bound,
+                                                                      int32_t* __restrict__ lists_status, unsigned long long* __restrict__ host_word) {
+    const uint32_t BIN_NB = blockDim.x;
+    __shared__ uint32_t s_sum[BIN_NB_MAX / 32][32];
+    const uint32_t tl = threadIdx.x & 31u, grp = threadIdx.x >> 5;
+    const uint32_t nseg = C * n_tiles;
+    const uint32_t g = blockIdx.x * 32u + tl;
+    const bool ok = g < nseg;
+    const uint32_t c = ok ? g / n_tiles : 0u, t = ok ? g - c * n_tiles : 0u;
+    uint32_t* col = block_hist + ((size_t)c * BIN_NB + grp * 32u) * n_tiles + t;
+    uint32_t v[32], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        v[k] = ok ? col[(size_t)k * n_tiles] : 0u;
+        sum += v[k];
+    }
+    s_sum[grp][tl] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+    for (uint32_t k = 0; k < BIN_NB / 32; ++k) {
+        const uint32_t sv = s_sum[k][tl];
+        run += k < grp ? sv : 0u;
+        total += sv;
+    }
+    // ---- wave 0 first (its word is what the successors wait for): lanes 0..31 (grp 0) hold the 32 tile totals of this workgroup
+    if (threadIdx.x < 64u) {
+        const uint32_t lane = threadIdx.x;
+        const unsigned long long mine = (lane < 32u && ok) ? (unsigned long long)total : 0ull;
+        unsigned long long incl = mine;
+        uint32_t mx = (uint32_t)mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long up = __shfl_up(incl, o);
+            if ((int)lane >= o) incl += up;
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+        }
+        const unsigned long long wg_sum = __shfl(incl, 63);
+        if (lane == 0u) {
+            const unsigned long long word = (1ull << 63) | ((unsigned long long)min(mx, (1u << 27) - 1u) << 36) | min(wg_sum, (1ull << 36) - 1ull);
+            __hip_atomic_store(agg + blockIdx.x, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // look-back: the words of all predecessors (lane l takes l, l + 64, ...)
+        unsigned long long before = 0ull;
+        uint32_t gmax = mx;
+        for (uint32_t j = lane; j < blockIdx.x; j += 64u) {
+            unsigned long long w;
+            do { w = __hip_atomic_load(agg + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((w >> 63) == 0ull);
+            before += w & ((1ull << 36) - 1ull);
+            gmax = max(gmax, (uint32_t)((w >> 36) & ((1u << 27) - 1u)));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            before += __shfl_xor(before, o);
+            gmax = max(gmax, (uint32_t)__shfl_xor((int)gmax, o));
+        }
+        // exclusive offsets of this workgroup's tiles; saturating like bin_scan (a frame beyond 2^31 - 1 intersections: offsets INT32_MAX, total -1)
+        const unsigned long long excl = before + incl - mine;
+        if (lane < 32u && ok) offsets[g] = (int32_t)(excl > 0x7FFFFFFFull ? 0x7FFFFFFFull : excl);
+        if (blockIdx.x == gridDim.x - 1u && lane == 0u) {   // the last workgroup holds the grand total and the largest segment
+            const unsigned long long grand = before + wg_sum;
+            offsets[nseg] = grand > 0x7FFFFFFFull ? -1 : (int32_t)grand;
+            if (max_count != nullptr) *max_count = gmax;
+            if (lists_status != nullptr) {
+                const bool fits = grand <= (unsigned long long)capacity && (seg_bound <= 0 || (int64_t)gmax <= seg_bound);
+                *lists_status = fits ? (int32_t)grand : -1;
+            }
+            if (host_word != nullptr) {
+                const unsigned long long lo = grand > 0x7FFFFFFFull ? 0xFFFFFFFFull : grand;
+                __hip_atomic_store(host_word, lo | ((unsigned long long)(max_count != nullptr ? gmax : 0u) << 32), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    if (ok) {   // the per-slice prefixes of the tile (what bin_scatter adds to the tile's offset)
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            col[(size_t)k * n_tiles] = run;
+            run += v[k];
+        }
+    }
 }
 
 // K = uint64_t: keys (depth bits << idx_bits | flatten index); K = uint32_t: the Gaussian's rank (ranked variant), read from `ranks`.
@@ -1261,9 +1354,14 @@ extern "C" int gsx_intersect_bin_count_guarded(uint32_t C, uint32_t N, const flo
     const uint32_t per_block = (N + bin_nb() - 1) / bin_nb();
     const size_t lds = (size_t)n_tiles * 4;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // round 6: prefix + scan in one launch (bin_prefix_scan_kernel; its per-workgroup aggregate words live where the tile totals of the two-launch form
+    // did); GSX_BIN_SCAN=separate (test switch) keeps bin_prefix_kernel + bin_scan_kernel: second implementation in the tests, A/B
+    const uint32_t n_pblocks = (nseg + 31) / 32;
+    const bool separate_scan = [] { const char* e = test_switch("GSX_BIN_SCAN"); return e != nullptr && strcmp(e, "separate") == 0; }();   // read per launch: the tests switch it
+    unsigned long long* agg = separate_scan ? nullptr : (unsigned long long*)counts;   // n_pblocks x 8 B <= (nseg + 1) x 4 B
     hipLaunchKernelGGL(bin_count_kernel, dim3(bin_nb(), C), dim3(BIN_BLOCK), lds, st, N, per_block, means2d, radii, (float)tile_size, tile_width,
-                       tile_height, tiles_per_gauss, hist);
-    hipLaunchKernelGGL(bin_prefix_kernel, dim3((nseg + 31) / 32), dim3(bin_nb()), 0, st, C, n_tiles, hist, counts);
+                       tile_height, tiles_per_gauss, hist, agg, n_pblocks);
+    if (separate_scan) hipLaunchKernelGGL(bin_prefix_kernel, dim3(n_pblocks), dim3(bin_nb()), 0, st, C, n_tiles, hist, counts);
     // offsets[t] = intersections before (camera, tile) t; offsets[nseg] = n_isects
     // (the largest segment lands in the slack word behind the counts; it travels to the host in the upper half of the pinned word)
     uint32_t* max_count = (uint32_t*)((char*)workspace + bin_hist_bytes(C, n_tiles) + align_up((size_t)(nseg + 1) * 4, 256));
@@ -1278,8 +1376,12 @@ extern "C" int gsx_intersect_bin_count_guarded(uint32_t C, uint32_t N, const flo
         if (hipHostGetDevicePointer(&dp, n_isects_host_pinned, 0) == hipSuccess && dp != nullptr) host_alias = (unsigned long long*)dp;
         else (void)hipGetLastError();
     }
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, nseg + 1, (const uint32_t*)counts, tile_offsets, max_count, capacity, max_segment,
-                       lists_status, host_alias);
+    if (separate_scan)
+        hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, nseg + 1, (const uint32_t*)counts, tile_offsets, max_count, capacity, max_segment,
+                           lists_status, host_alias);
+    else
+        hipLaunchKernelGGL(bin_prefix_scan_kernel, dim3(n_pblocks), dim3(bin_nb()), 0, st, C, n_tiles, hist, agg, tile_offsets, max_count, capacity, max_segment,
+                           lists_status, host_alias);
     if (n_isects_host_pinned && host_alias == nullptr) {
         (void)hipMemcpyAsync(n_isects_host_pinned, tile_offsets + nseg, 4, hipMemcpyDeviceToHost, st);
         (void)hipMemcpyAsync((char*)n_isects_host_pinned + 4, max_count, 4, hipMemcpyDeviceToHost, st);
