@@ -91,7 +91,9 @@ class OpTimer:
         self.orig = {n: getattr(ops_mod, n) for n in self.names}
         self.events = {n: [] for n in self.names}
         self.enabled = False
-        self.only = None  # restrict the bracketing to these ops (every event record costs a ~5 us bubble on the stream)
+        self.only = None  # restrict the bracketing to these ops (every event record costs a ~6 us bubble on the stream)
+        self.sample_every = 1   # bracket an op only on every n-th of its calls (the timed regions: the dominant op on one step in four)
+        self.calls = {}
         for n in self.names:
             setattr(ops_mod, n, self._wrap(n))
 
@@ -108,6 +110,10 @@ class OpTimer:
                 return r
             if not self.enabled or (self.only is not None and key not in self.only):
                 return fn(*a, **k)
+            if self.sample_every > 1:
+                n_call = self.calls[key] = self.calls.get(key, 0) + 1
+                if n_call % self.sample_every != 1:
+                    return fn(*a, **k)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             r = fn(*a, **k)
@@ -265,6 +271,8 @@ def main():
                                                                "stream-draining sync per step; default: guarded lists, include/gsx.h — no host read on the render path)")
     ap.add_argument("--host-delay-us", type=float, default=0.0, help="A/B tool: busy-wait this long on the host after every intersection call (what a slower or "
                                                                      "busier host adds between reading n_isects and launching the blend; disables the per-op table)")
+    ap.add_argument("--bracket-every-step", action="store_true", help="A/B tool: HIP events around BOTH blend ops on EVERY step of the timed regions, as rounds 1 - 5 placed them "
+                                                                      "(default: the dominant op only, one step in four — an event record costs the stream ~6 us)")
     ap.add_argument("--launch-check", action="store_true", help="initialise the process group, report rank / world / backend and exit "
                                                                 "(tests the N > 1 launch logic without touching a GPU)")
     args = ap.parse_args()
@@ -480,11 +488,15 @@ def main():
     counter["i"] = 0
     step(True)   # (the first optimizer step creates the Adam moments: they must exist in the snapshot every region starts from)
     counter["i"] = 0
-    # Only the two blend ops (the roofline kernels) are bracketed with HIP events inside the timed region — each event record opens
-    # a ~5 us bubble on the stream, 24 ops x 2 events would cost ~0.1 ms per step.  The per-op table of the other ops is measured
-    # in a separate pass after the timed region.
+    # Inside the timed regions only the DOMINANT op (the blend backward: `roofline`) is bracketed with HIP events on the launch stream, and only on
+    # one step in four: an event record opens a ~6 us bubble on the stream (kernel trace of round 6: four records around the two blend ops = 23.5 us
+    # of every 1.2 ms step spent on the bench's own instrumentation; rounds 1 - 5 bracketed both blend ops on every step).  5 launches per region x R
+    # regions are averaged.  Every other op — the blend forward included — is timed in the per-op pass behind the regions.
     timer.enabled = True
-    timer.only = {"rasterize_to_pixels_from_world_3dgs_fwd", "rasterize_to_pixels_from_world_3dgs_bwd"}
+    timer.only = {"rasterize_to_pixels_from_world_3dgs_bwd"}
+    timer.sample_every = 4
+    if args.bracket_every_step:
+        timer.only, timer.sample_every = {"rasterize_to_pixels_from_world_3dgs_fwd", "rasterize_to_pixels_from_world_3dgs_bwd"}, 1
     # Every region is the contract's protocol from the SAME state: the state in front of the warm-up (parameters, Adam moments, step counters, the
     # means group's scheduled lr) is kept on the device and put back before each region's W warm-up + K timed iterations, outside the timed code
     # (training against noise targets makes the frame lighter iteration by iteration — 1.32 -> 1.15 ms over 100 iterations — so un-restored regions
@@ -536,7 +548,9 @@ def main():
     repeated_timed = counter["repeated"]
     isects_timed = list(counter["isects"])
     blend_ms = timer.mean_ms()
+    n_bwd_events = len(timer.events.get("rasterize_to_pixels_from_world_3dgs_bwd", []))
     timer.reset()
+    timer.sample_every = 1
     timer.only, timer.enabled = None, True   # per-op pass (outside the timed region), same camera sequence
     counter["i"] = 0
     for _ in range(min(args.steps, 8)):
@@ -656,6 +670,7 @@ def main():
         roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": kernels[dom]["frac_hbm"], "traffic": pm.get("hbm_bytes"),
                     "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"], "avg_launch_ms": kernels[dom]["ms"],
+                    "avg_launch_ms_is": "HIP events on the launch stream around the op inside the timed regions, %d launches (one step in four: an event record costs the stream ~6 us)" % n_bwd_events,
                     "traffic_source": (pmc.get("source") if pm.get("hbm_bytes") else pmc.get("stale"))}
         if pm.get("hbm_bytes") and pmc.get("n_isects"):
             # the counters were collected on ONE frame (the cfg2 camera); the timed steps average other cameras: like for like = the algorithmic
