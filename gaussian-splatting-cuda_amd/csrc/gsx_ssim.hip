@@ -458,6 +458,181 @@ __global__ __launch_bounds__(NT) void loss_bwd_kernel(int H, int W, float l1_coe
     }
 }
 
+// ---- single-pass training loss + gradient (round 6; VERDICT r05 next #2a: built to be MEASURED against the pair above) ------------------------------
+// One kernel: the SSIM statistics are recomputed on the output tile + a 5-pixel ring, the three chained derivative maps live in LDS only, and their
+// 11 x 11 windows produce v_render for the tile — no 75 MB of maps written and re-read, one staging instead of two.  The price is the ring: on a 32 x 32
+// tile (two 256-thread blocks per CU by LDS: 57.8 KB) staging covers 52 x 52 (2.64 x the tile), the first horizontal pass 52 x 42, the first vertical pass
+// 42 x 42, the second horizontal pass 42 x 32: 22.3 convolution units per pixel against 16.2 for the pair.  Same arithmetic per output (same tap order):
+// v_render and the loss sums equal the pair's (tests/test_loss.py / test_gpu_reference_train.py compare).  `up` = the constant upstream gradient.
+namespace sp {
+constexpr int T = 32, R1 = T + 2 * HALO, R2 = T + 4 * HALO;   // tile 32, map region 42, staged region 52
+constexpr int PS = R2 + 1, PH = R1 + 1, PE = T + 1;          // odd pitches: 53 (staged), 43 (first-pass planes, maps), 33 (second-pass planes)
+constexpr int NTS = 256;
+}
+__global__ __launch_bounds__(sp::NTS, 2) void loss_single_pass_kernel(int H, int W, float chain, int crop, float l1_coeff, float up, const float* __restrict__ render,
+                                                                       const float* __restrict__ gt, float* __restrict__ v_render, float2* __restrict__ block_sums) {
+    using namespace sp;
+    constexpr float w[11] = GSX_SSIM_TAPS;
+    __shared__ float s_in[2 * R2 * PS];          // X, Y over the staged region; later the three maps [3][R1][PH]
+    __shared__ float s_cv[4 * R2 * PH];          // first horizontal pass [4][R2][PH]; later the second horizontal pass [3][R1][PE]
+    __shared__ float2 s_red[NTS / 64];
+    static_assert(3 * R1 * PH <= 2 * R2 * PS && 3 * R1 * PE <= 4 * R2 * PH, "aliases");
+    float (*sA)[PS] = reinterpret_cast<float (*)[PS]>(s_in), (*sB)[PS] = reinterpret_cast<float (*)[PS]>(s_in + R2 * PS);
+    float (*sC)[R2][PH] = reinterpret_cast<float (*)[R2][PH]>(s_cv);
+    float (*sD)[R1][PH] = reinterpret_cast<float (*)[R1][PH]>(s_in);
+    float (*sE)[R1][PE] = reinterpret_cast<float (*)[R1][PE]>(s_cv);
+    const uint32_t ntx = (uint32_t)(W + T - 1) / T, nty = (uint32_t)(H + T - 1) / T, n = ntx * nty, per = (n + 7u) / 8u, b = blockIdx.x;
+    const uint32_t tix = (b & 7u) * per + (b >> 3);   // XCD-aware: every XCD a contiguous row-major run of tiles (loss_tile)
+    if ((b >> 3) >= per || tix >= n) return;
+    const int tx0 = (int)(tix % ntx) * T, ty0 = (int)(tix / ntx) * T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ox = tid & 31, oy0 = (tid >> 5) * 4;    // this thread's four output pixels: column ox, rows oy0 .. oy0 + 3
+    const size_t npix = (size_t)H * W;
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    float l1 = 0.f, ss = 0.f, g[4][3];
+    for (int c = 0; c < 3; ++c) {
+        const size_t plane = ((size_t)blockIdx.z * 3 + c) * npix;
+        const float* rbase = render + (size_t)blockIdx.z * npix * 3 + c;
+        // ---- stage X (clamped render) and Y over 52 x 52: wave -> rows, lane -> column
+        for (int r = wave; r < R2; r += NTS / 64) {
+            const int gy = ty0 + r - 2 * HALO;
+            if (lane < R2) {
+                const int gx = tx0 + lane - 2 * HALO;
+                const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
+                const size_t p = (size_t)gy * W + gx;
+                sA[r][lane] = in ? fminf(fmaxf(rbase[p * 3], 0.f), 1.f) : 0.f;
+                sB[r][lane] = in ? gt[plane + p] : 0.f;
+            }
+        }
+        __syncthreads();
+        float p1[4], p2[4];   // X, Y of this thread's output pixels (the staged planes are overwritten by the maps below)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { p1[j] = sA[oy0 + j + 2 * HALO][ox + 2 * HALO]; p2[j] = sB[oy0 + j + 2 * HALO][ox + 2 * HALO]; }
+        // ---- first horizontal pass: 52 rows x 42 columns, strips of 3 outputs (14 per row: 728 items on 256 threads)
+        for (int it = tid; it < R2 * (R1 / 3); it += NTS) {
+            const int r = it % R2, x0 = (it / R2) * 3;
+            float X[13], Y[13], SQ[13], XY[13];
+#pragma unroll
+            for (int k = 0; k < 13; ++k) {
+                X[k] = sA[r][x0 + k]; Y[k] = sB[r][x0 + k];
+                SQ[k] = fmaf(X[k], X[k], Y[k] * Y[k]); XY[k] = X[k] * Y[k];
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; ++k) {
+                    a0 = fmaf(w[k], X[j + k], a0); a1 = fmaf(w[k], Y[j + k], a1);
+                    a2 = fmaf(w[k], SQ[j + k], a2); a3 = fmaf(w[k], XY[j + k], a3);
+                }
+                sC[0][r][x0 + j] = a0; sC[1][r][x0 + j] = a1; sC[2][r][x0 + j] = a2; sC[3][r][x0 + j] = a3;
+            }
+        }
+        __syncthreads();
+        // ---- first vertical pass + SSIM point + chained partials: 42 columns x 6 strips of 7 rows (252 items)
+        if (tid < R1 * 6) {
+            const int x = tid % R1, y0 = (tid / R1) * 7;
+            float o[7][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float V[17];
+#pragma unroll
+                for (int k = 0; k < 17; ++k) V[k] = sC[q][y0 + k][x];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) a = fmaf(w[k], V[j + k], a);
+                    o[j][q] = a;
+                }
+            }
+            const int gx = tx0 + x - HALO;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int gy = ty0 + y0 + j - HALO;
+                float val, d0, d1, d2;
+                ssim_point4(o[j], C1, C2, val, d0, d1, d2);
+                const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
+                const bool valid = in && gx >= crop && gx < W - crop && gy >= crop && gy < H - crop;
+                const float ch = valid ? chain : 0.f;
+                sD[0][y0 + j][x] = in ? d0 * ch : 0.f; sD[1][y0 + j][x] = in ? d1 * ch : 0.f; sD[2][y0 + j][x] = in ? d2 * ch : 0.f;
+                const bool own = x >= HALO && x < HALO + T && y0 + j >= HALO && y0 + j < HALO + T;   // the tile's own pixels: the loss sum
+                ss += (valid && own) ? val : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) l1 += (tx0 + ox < W && ty0 + oy0 + j < H) ? fabsf(p1[j] - p2[j]) : 0.f;
+        __syncthreads();
+        // ---- second horizontal pass over the maps: 42 rows x 32 columns, strips of 2 (16 per row: 672 items)
+        for (int it = tid; it < R1 * (T / 2); it += NTS) {
+            const int r = it % R1, x0 = (it / R1) * 2;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                float V[12];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) V[k] = sD[q][r][x0 + k];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) a = fmaf(w[k], V[j + k], a);
+                    sE[q][r][x0 + j] = a;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- second vertical pass + the gradient of the tile's pixels
+        {
+            float sv[4][3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                float V[14];
+#pragma unroll
+                for (int k = 0; k < 14; ++k) V[k] = sE[q][oy0 + k][ox];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) a = fmaf(w[k], V[j + k], a);
+                    sv[j][q] = a;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gx = tx0 + ox, gy = ty0 + oy0 + j;
+                float v = 0.f;
+                if (gx < W && gy < H) {
+                    const float raw = rbase[((size_t)gy * W + gx) * 3];
+                    const float d = p1[j] - p2[j];
+                    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+                    v = sv[j][0] + (2.f * p1[j]) * sv[j][1] + p2[j] * sv[j][2] + l1_coeff * sgn;
+                    v = (raw >= 0.f && raw <= 1.f) ? v * up : 0.f;
+                }
+                g[j][c] = v;
+            }
+        }
+        __syncthreads();   // the next channel restages over the maps / planes
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int gx = tx0 + ox, gy = ty0 + oy0 + j;
+        if (gx < W && gy < H) {
+            float* o = v_render + ((size_t)blockIdx.z * npix + (size_t)gy * W + gx) * 3;
+            o[0] = g[j][0]; o[1] = g[j][1]; o[2] = g[j][2];
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { l1 += __shfl_xor(l1, m); ss += __shfl_xor(ss, m); }
+    if (lane == 0) s_red[wave] = make_float2(l1, ss);
+    __syncthreads();
+    if (tid == 0) {
+        float2 t = s_red[0];
+#pragma unroll
+        for (int k = 1; k < NTS / 64; ++k) { t.x += s_red[k].x; t.y += s_red[k].y; }
+        block_sums[(size_t)blockIdx.z * n + tix] = t;
+    }
+}
+
 inline dim3 tile_grid(uint32_t B, uint32_t H, uint32_t W) { return dim3((W + TX - 1) / TX, (H + TY - 1) / TY, B); }
 // fused loss kernels: 1-D XCD-aware grid (block b runs on XCD b % 8): every XCD takes a contiguous row-major run of tiles, so that the halo
 // lines neighbouring tiles share are fetched into ONE L2 instead of two (a 74-float row of a 64-pixel tile touches four 128 B lines, two of
@@ -533,6 +708,27 @@ extern "C" int gsx_photometric_loss_fwd(uint32_t C, uint32_t H, uint32_t W, floa
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(NT), 0, st, loss_blocks(C, H, W), (const float2*)sums, 1.0 / n_all, 1.0 / n_valid,
                        lambda_dssim, loss3);
     return check_launch("gsx_photometric_loss_fwd");
+}
+
+// ABI 7: loss3 AND v_render = d loss / d render * grad_scale in ONE kernel (loss_single_pass_kernel); workspace: the block sums only.
+extern "C" size_t gsx_photometric_loss_single_pass_workspace_bytes(uint32_t C, uint32_t H, uint32_t W) {
+    return (size_t)C * ((W + sp::T - 1) / sp::T) * ((H + sp::T - 1) / sp::T) * sizeof(float2);
+}
+extern "C" int gsx_photometric_loss_single_pass(uint32_t C, uint32_t H, uint32_t W, float lambda_dssim, float grad_scale, const float* render, const float* gt,
+                                                float* loss3, float* v_render, void* workspace, size_t workspace_bytes, void* stream) {
+    if (C == 0 || H == 0 || W == 0) { set_error("gsx_photometric_loss_single_pass: empty image"); return GSX_ERR_INVALID_ARGUMENT; }
+    if (!render || !gt || !loss3 || !v_render || !workspace) { set_error("gsx_photometric_loss_single_pass: null pointer"); return GSX_ERR_INVALID_ARGUMENT; }
+    if (workspace_bytes < gsx_photometric_loss_single_pass_workspace_bytes(C, H, W)) { set_error("gsx_photometric_loss_single_pass: workspace too small"); return GSX_ERR_WORKSPACE_TOO_SMALL; }
+    if (C > 65535u) { set_error("gsx_photometric_loss_single_pass: more than 65535 images"); return GSX_ERR_UNSUPPORTED; }
+    const int crop = (H > 10 && W > 10) ? 5 : 0;
+    const double n_valid = (double)C * 3.0 * (double)(H - 2 * crop) * (double)(W - 2 * crop), n_all = (double)C * 3.0 * (double)H * (double)W;
+    const float chain = crop ? (float)(-(double)lambda_dssim / n_valid) : 0.f;   // (fused_ssim.cuh:85-96: no SSIM gradient for images of 10 px or less)
+    const uint32_t n_tiles = ((W + sp::T - 1) / sp::T) * ((H + sp::T - 1) / sp::T);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(loss_single_pass_kernel, dim3(((n_tiles + 7u) / 8u) * 8u, 1, C), dim3(sp::NTS), 0, st, (int)H, (int)W, chain, crop,
+                       (float)((1.0 - (double)lambda_dssim) / n_all), grad_scale, render, gt, v_render, (float2*)workspace);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(NT), 0, st, C * n_tiles, (const float2*)workspace, 1.0 / n_all, 1.0 / n_valid, lambda_dssim, loss3);
+    return check_launch("gsx_photometric_loss_single_pass");
 }
 
 extern "C" int gsx_photometric_loss_bwd(uint32_t C, uint32_t H, uint32_t W, float lambda_dssim, const float* grad_loss, float grad_scale,

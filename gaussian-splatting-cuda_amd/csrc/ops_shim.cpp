@@ -1032,6 +1032,23 @@ std::tuple<at::Tensor, at::Tensor> photometric_loss_fwd(const at::Tensor& render
     return std::make_tuple(loss3, ws);
 }
 
+// the training loss and its gradient in one kernel (include/gsx.h ABI 7): (loss3, v_render = grad_scale * d loss / d render)
+std::tuple<at::Tensor, at::Tensor> photometric_loss_single_pass(const at::Tensor& render, const at::Tensor& gt, double lambda_dssim, double grad_scale) {
+    GSX_DEVICE_GUARD(render);
+    TORCH_CHECK(render.is_cuda() && gt.is_cuda() && render.dim() == 4 && render.size(3) == 3 && render.is_contiguous(), "photometric_loss: render must be contiguous [C,H,W,3]");
+    TORCH_CHECK(gt.dim() == 4 && gt.size(0) == render.size(0) && gt.size(1) == 3 && gt.size(2) == render.size(1) && gt.size(3) == render.size(2) &&
+                    gt.is_contiguous(), "photometric_loss: gt must be contiguous [C,3,H,W]");
+    TORCH_CHECK(render.scalar_type() == at::kFloat && gt.scalar_type() == at::kFloat, "photometric_loss: float32 required");
+    const uint32_t C = (uint32_t)render.size(0), H = (uint32_t)render.size(1), W = (uint32_t)render.size(2);
+    const size_t bytes = gsx_photometric_loss_single_pass_workspace_bytes(C, H, W);
+    at::Tensor ws = at::empty({(int64_t)bytes}, render.options().dtype(at::kByte));
+    at::Tensor loss3 = at::empty({3}, render.options());
+    at::Tensor v = at::empty_like(render);
+    check(gsx_photometric_loss_single_pass(C, H, W, (float)lambda_dssim, (float)grad_scale, render.data_ptr<float>(), gt.data_ptr<float>(), loss3.data_ptr<float>(),
+                                           v.data_ptr<float>(), ws.data_ptr(), bytes, cur_stream()), "photometric_loss_single_pass");
+    return std::make_tuple(loss3, v);
+}
+
 at::Tensor photometric_loss_bwd(const at::Tensor& render, const at::Tensor& gt, const at::Tensor& ws, double lambda_dssim,
                                 const c10::optional<at::Tensor>& grad_loss, double grad_scale) {
     GSX_DEVICE_GUARD(render);
@@ -1317,5 +1334,6 @@ PYBIND11_MODULE(_gsx_ops, m) {
     m.def("fusedssim_backward", &gsx_ext::fusedssim_backward);
     m.def("photometric_loss_fwd", &gsx_ext::photometric_loss_fwd);
     m.def("photometric_loss_bwd", &gsx_ext::photometric_loss_bwd);
+    m.def("photometric_loss_single_pass", &gsx_ext::photometric_loss_single_pass);
 }
 #endif  // GSX_NO_PYBIND

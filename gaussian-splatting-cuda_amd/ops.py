@@ -74,5 +74,6 @@ fusedssim = _C.fusedssim
 fusedssim_backward = _C.fusedssim_backward
 photometric_loss_fwd = _C.photometric_loss_fwd
 photometric_loss_bwd = _C.photometric_loss_bwd
+photometric_loss_single_pass = _C.photometric_loss_single_pass   # loss3 and v_render in one kernel (include/gsx.h ABI 7)
 shim_stats = _C.shim_stats
 shim_ranked_calls = _C.shim_ranked_calls

@@ -36,7 +36,7 @@ extern "C" {
  *   6  gsx_rasterize_to_pixels_from_world_3dgs_bwd_guarded gained the positional `n_isects_expected` argument its forward twin already had: both
  *      choose their kernel variants from the same estimate (round 4's backward saw the capacity — 25 % above it — on guarded lists).
  *   7  additions only: gsx_rasterize_to_pixels_from_world_3dgs_bwd_act — the blend backward through to the raw SplatData parameters: the activation
- *      Jacobians as the epilogue of the gather kernel. */
+ *      Jacobians as the epilogue of the gather kernel; gsx_photometric_loss_single_pass — the training loss and its gradient in one kernel. */
 #define GSX_ABI_VERSION 7
 
 typedef enum gsx_status {
@@ -377,6 +377,12 @@ int gsx_photometric_loss_fwd(uint32_t C, uint32_t H, uint32_t W, float lambda_ds
 int gsx_photometric_loss_bwd(uint32_t C, uint32_t H, uint32_t W, float lambda_dssim, const float* grad_loss, float grad_scale,
                              const float* render, const float* gt, const void* workspace, size_t workspace_bytes, float* v_render,
                              void* stream);
+/* ABI 7: the training loss and its gradient in ONE kernel (the SSIM statistics recomputed on a 5-pixel ring, the derivative maps in LDS only):
+ * loss3 as gsx_photometric_loss_fwd, v_render [C,H,W,3] = grad_scale * d loss / d render as gsx_photometric_loss_bwd with grad_loss = NULL.
+ * Same values as the pair; which of the two is faster is a measurement.  Workspace: the per-tile partial sums only. */
+size_t gsx_photometric_loss_single_pass_workspace_bytes(uint32_t C, uint32_t H, uint32_t W);
+int gsx_photometric_loss_single_pass(uint32_t C, uint32_t H, uint32_t W, float lambda_dssim, float grad_scale, const float* render,
+                                     const float* gt, float* loss3, float* v_render, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- fused glue (extensions beyond gsplat/Ops.h) --------------------------------------------------
  * The reference's render glue wraps the operators in chains of small torch ops every frame; on MI355X those

@@ -137,6 +137,27 @@ def test_gpu_photometric_loss_vs_oracle(C, H, W):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("C,H,W", [(1, 64, 96), (2, 37, 53), (1, 9, 20), (1, 270, 480), (1, 1080, 1920)])
+def test_gpu_single_pass_loss_equals_the_kernel_pair(C, H, W):
+    """Round 6 (include/gsx.h ABI 7: gsx_photometric_loss_single_pass — the training loss and its gradient in ONE kernel, the SSIM statistics recomputed on
+    a 5-pixel ring, the derivative maps in LDS only) against the forward + backward pair: the same arithmetic per output in the same tap order, so v_render
+    must be the same BITS and the loss the same to the last float of the block-sum order (ragged sizes, the 10-pixel rule, pixels outside [0, 1]).  (Built to
+    be measured: at 1080p the pair takes 0.088 ms, the single pass 0.138 ms — tools/loss_single_pass_ab.py, NOTES.md N0; the pair stays the trainer's path.)"""
+    import gsx  # noqa: F401
+    from gsx import ops
+    g = torch.Generator(device="cuda").manual_seed(C * 1000 + H)
+    r = torch.rand(C, H, W, 3, device="cuda", generator=g) * 1.3 - 0.15
+    gt = torch.rand(C, 3, H, W, device="cuda", generator=g)
+    l3, ws = ops.photometric_loss_fwd(r, gt, 0.2)
+    for scale in (1.0, 0.37):
+        v = ops.photometric_loss_bwd(r, gt, ws, 0.2, None, scale)
+        l3s, vs = ops.photometric_loss_single_pass(r, gt, 0.2, scale)
+        assert torch.equal(v, vs), float((v - vs).abs().max())
+        assert torch.allclose(l3, l3s, rtol=2e-6, atol=0), (l3.tolist(), l3s.tolist())
+    assert float(v.abs().max()) > 0
+
+
+@pytest.mark.gpu
 def test_gpu_metrics_psnr_ssim():
     import gsx  # noqa: F401
     from gsx import metrics
