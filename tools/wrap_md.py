@@ -81,13 +81,24 @@ def process(lines, width):
                 out.append("")
             i = j
             continue
-        if len(ln) > width:
-            m = re.match(r"^(\s*)((?:[-*]|\d+\.)\s+)?", ln)
-            indent, bullet = m.group(1), m.group(2) or ""
-            out.append(wrap(ln[len(indent) + len(bullet):], width, indent + bullet, indent + " " * len(bullet)))
-        else:
+        if not ln.strip():
             out.append(ln)
-        i += 1
+            i += 1
+            continue
+        # a paragraph or a list item with its continuation lines: re-flowed as a whole (so that re-wrapping an edited, already wrapped text leaves no ragged lines)
+        m = re.match(r"^(\s*)((?:[-*]|\d+\.)\s+)?", ln)
+        indent, bullet = m.group(1), m.group(2) or ""
+        cont = indent + " " * len(bullet)
+        text, j = ln[len(indent) + len(bullet):].strip(), i + 1
+        while j < len(lines):
+            nx = lines[j]
+            if (not nx.strip() or nx.startswith("#") or nx.lstrip().startswith("|") or nx.lstrip().startswith("```") or re.match(r"^\s*(?:[-*]|\d+\.)\s+", nx)
+                    or (len(nx) - len(nx.lstrip())) != len(cont)):
+                break
+            text += " " + nx.strip()
+            j += 1
+        out.append(wrap(text, width, indent + bullet, cont))
+        i = j
     return out
 
 
