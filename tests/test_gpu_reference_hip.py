@@ -612,6 +612,17 @@ def test_s1m_bench_path_gradients_vs_reference_chain(ref, mods):
     _bench_path_vs_reference_chain(ref, scenes.scene_1m(), "S-1M @1080p")
 
 
+@pytest.mark.parametrize("cam_i", [3, 7])
+def test_s8cam_bench_path_gradients_vs_reference_chain(ref, mods, s1m_scene, cam_i):
+    """Round 6: the same end-to-end comparison through S-8cam ring cameras — 3 (diagonal: the reference's fp32 R_inv is 7e-7 from orthonormal there, which the Delta-form's
+    R_inv^T turned into 1.3 - 1.6e-3 of gradient distance until round 6 took the exact inverse, gsx_record.hpp) and 7 (grazing): the fused front end's own projection, records
+    and lists, the blend, the Gaussian-major backward with the activation Jacobians in its gather, the fused SH backward, against the reference chain and its torch glue: < 1e-3."""
+    ops, scenes = mods
+    sc = dict(s1m_scene)
+    sc["viewmat"] = scenes.ring_cameras(8)[cam_i]
+    _bench_path_vs_reference_chain(ref, sc, "S-8cam ring camera %d" % cam_i)
+
+
 @pytest.mark.parametrize("name", ["needles", "opaque", "raw_quaternions", "close"])
 def test_regime_bench_path_gradients_vs_reference_chain(ref, mods, name):
     """The same end-to-end comparison — fused front end (its own projection, records and lists), blend, Gaussian-major backward, gather, activation
