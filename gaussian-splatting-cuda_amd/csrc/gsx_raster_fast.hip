@@ -1496,13 +1496,6 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
             if (KIND == CAM_PERFECT_PINHOLE) {   // the blocks' (u, v) rectangles are products of two u-ranges and two v-ranges: shared 1-D pieces
                 const float xr[2][2] = {{sbb[0][0], sbb[0][1]}, {sbb[1][0], sbb[1][1]}}, yr[2][2] = {{sbb[0][2], sbb[0][3]}, {sbb[2][2], sbb[2][3]}};
                 hits4 = footprint_hits_2x2(cc, c00, c01, c11, xr, yr);
-#ifdef GSX_GQ_DOUBLE_BINTEST   // experiment (tools/): the block test evaluated twice — what it costs is what hit bits stored by the forward would save
-                {
-                    float4 cc2 = cc;
-                    asm volatile("" : "+v"(cc2.x), "+v"(cc2.y), "+v"(cc2.z), "+v"(cc2.w));
-                    hits4 &= footprint_hits_2x2(cc2, c00, c01, c11, xr, yr);
-                }
-#endif
             }
 #pragma unroll
             for (int sb = 0; sb < 4; ++sb) {
