@@ -533,6 +533,7 @@ class ListsAgreement:
         if rank == 0 and same_host:
             try:
                 self._shm = shared_memory.SharedMemory(create=True, size=64 * world)   # one cache line per rank
+                self._shm_owner = True   # (remembered here: close() may run after the process group is gone, e.g. from __del__ at interpreter exit)
                 self._shm.buf[:64 * world] = bytes(64 * world)
                 name[0] = self._shm.name
             except Exception:  # noqa: BLE001  (no /dev/shm, a sandbox without shared memory ...)
@@ -605,7 +606,7 @@ class ListsAgreement:
             self._slots = None
             try:
                 self._shm.close()
-                if dist.is_initialized() and dist.get_rank() == 0:
+                if getattr(self, "_shm_owner", False):
                     self._shm.unlink()
             except Exception:  # noqa: BLE001
                 pass
