@@ -44,6 +44,11 @@ def main():
     from oracle import ref_callers
     DEV = "cuda:0"
     sc = scenes.scene_1m()
+    if os.environ.get("GSX_TRACE_MORTON", "0") == "1":   # the bench's memory order (gsx.layout); default: the generator's order = a model as the reference leaves it
+        from gsx import layout
+        order = layout.morton_order(sc["means"])
+        for k in ("means", "quats", "scales", "opacities", "sh"):
+            sc[k] = sc[k][order].contiguous()
     H, W = sc["height"], sc["width"]
     g = torch.Generator(device=DEV).manual_seed(5)
     v_img, v_alpha = torch.randn(3, H, W, device=DEV, generator=g), torch.randn(1, H, W, device=DEV, generator=g)
