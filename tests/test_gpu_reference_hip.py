@@ -85,6 +85,10 @@ def _projection_stats(tag, who, r, got):
                means2d_max_err_px=float(np.abs(r["means2d"] - got["means2d"])[both].max()),
                depth_max_rel_err=float((np.abs(r["depths"] - got["depths"])[both] / np.abs(r["depths"][both])).max()),
                conic_max_rel_err=float(crel(got["conics"], r["conics"])[both].max()))
+    if both.any():   # where the relative depth error peaks: a Gaussian near the camera plane (z = r2 . mu + t_z cancels) or not
+        k = int(np.argmax(np.abs(r["depths"] - got["depths"])[both] / np.abs(r["depths"][both])))
+        rec["depth_at_max_rel_err"] = float(r["depths"][both][k])
+        rec["depth_max_abs_err"] = float(np.abs(r["depths"] - got["depths"])[both].max())
     if r.get("compensations") is not None and got.get("compensations") is not None:
         rec["compensation_max_err"] = float(np.abs(r["compensations"] - got["compensations"])[both].max())
     return parity_record("%s projection: %s vs reference kernel" % (tag, who), **rec)
@@ -244,7 +248,9 @@ def _stagewise(ref, ops, sc, cam, tag, with_oracle=True, fwd_strict=True, over_f
     for k in [k for k in ("proj_hip", "proj_oracle") if k in recs]:
         p = recs[k]
         assert p["cull_flips"] <= max(2, 2e-5 * n) and p["radius_max_diff_px"] <= radius_max_diff and p["radius_flips"] <= max(4, radius_flip_frac * n), p
-        assert p["depth_max_rel_err"] < 1e-5 and p.get("compensation_max_err", 0.0) < 1e-4, p
+        # depth = r2 . mu + t_z in fp32: two evaluation orders differ by a few ulp of the TERMS (|mu|, |t| ~ 10 on the ring: <= 3e-6), which is more than
+        # 1e-5 of z itself only where z cancels to a few centimetres — Gaussians beside the camera that a fisheye still sees (S-8cam camera 3, fisheye: z = 0.12, |dz| = 1.9e-6 = 2 ulp of 10)
+        assert (p["depth_max_rel_err"] < 1e-5 or p["depth_max_abs_err"] < 3e-6) and p.get("compensation_max_err", 0.0) < 1e-4, p
     assert recs["sh_hip"]["max_err"] < 1e-5
     for k in [k for k in ("fwd_hip", "fwd_oracle") if k in recs]:
         fw = recs[k]
@@ -525,6 +531,21 @@ def test_s1m_other_camera_models_vs_reference(ref, mods, s1m_scene, name):
            "fisheye": dict(camera_model=ref_hip.FISHEYE, radial=np.array([[0.02, -0.005, 0.001, 0.0]], np.float32)),
            "rolling_top_to_bottom": dict(shutter=ref_hip.ROLLING_TOP_TO_BOTTOM, viewmats1=vm1)}[name]
     _stagewise(ref, ops, sc, cam, "S-1M @1080p, %s" % name, with_oracle=False, fwd_strict=False, over_frac=6e-4, bwd_f64_yardstick=False)
+
+
+@pytest.mark.parametrize("name", ["distorted_pinhole", "fisheye"])
+@pytest.mark.parametrize("cam_i", [3, 5])
+def test_s8cam_other_camera_models_vs_reference(ref, mods, s1m_scene, name, cam_i):
+    """The distorted charts of the fast kernels (OpenCV-distorted pinhole, equidistant fisheye) on the two S-8cam ring cameras whose fp32 pose round trip
+    is furthest from orthonormal (3 / 5: the poses that exposed the Delta-form's R_inv^T in round 6; test_s1m_other_camera_models_vs_reference runs the
+    same models on cfg2's identity pose, where R_inv is exact): stage by stage against the reference's kernels, the ring's tolerances."""
+    ops, scenes = mods
+    sc = dict(s1m_scene)
+    sc["viewmat"] = scenes.ring_cameras(8)[cam_i]
+    cam = {"distorted_pinhole": dict(camera_model=ref_hip.PINHOLE, radial=np.array([[0.05, -0.02, 0.003, 0.0, 0.0, 0.0]], np.float32),
+                                     tangential=np.array([[0.002, -0.001]], np.float32), thin_prism=np.array([[0.001, 0.0, -0.001, 0.0]], np.float32)),
+           "fisheye": dict(camera_model=ref_hip.FISHEYE, radial=np.array([[0.02, -0.005, 0.001, 0.0]], np.float32))}[name]
+    _stagewise(ref, ops, sc, cam, "S-8cam ring camera %d, %s" % (cam_i, name), with_oracle=False, fwd_strict=False, over_frac=6e-4, bwd_f64_yardstick=False)
 
 
 def test_s5m_4k_full_frame(ref, mods):
