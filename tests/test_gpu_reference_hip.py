@@ -533,18 +533,21 @@ def test_s1m_other_camera_models_vs_reference(ref, mods, s1m_scene, name):
     _stagewise(ref, ops, sc, cam, "S-1M @1080p, %s" % name, with_oracle=False, fwd_strict=False, over_frac=6e-4, bwd_f64_yardstick=False)
 
 
-@pytest.mark.parametrize("name", ["distorted_pinhole", "fisheye"])
-@pytest.mark.parametrize("cam_i", [3, 5])
+@pytest.mark.parametrize("name,cam_i", [("distorted_pinhole", 3), ("distorted_pinhole", 5), ("fisheye", 3), ("fisheye", 5), ("rolling_top_to_bottom", 3)])
 def test_s8cam_other_camera_models_vs_reference(ref, mods, s1m_scene, name, cam_i):
     """The distorted charts of the fast kernels (OpenCV-distorted pinhole, equidistant fisheye) on the two S-8cam ring cameras whose fp32 pose round trip
     is furthest from orthonormal (3 / 5: the poses that exposed the Delta-form's R_inv^T in round 6; test_s1m_other_camera_models_vs_reference runs the
-    same models on cfg2's identity pose, where R_inv is exact): stage by stage against the reference's kernels, the ring's tolerances."""
+    same models on cfg2's identity pose, where R_inv is exact), and a rolling shutter between camera 3's pose and one a few centimetres on (the
+    reference-order kernels with a pose per pixel row): stage by stage against the reference's kernels, the ring's tolerances."""
     ops, scenes = mods
     sc = dict(s1m_scene)
     sc["viewmat"] = scenes.ring_cameras(8)[cam_i]
+    vm1 = sc["viewmat"].clone()
+    vm1[:3, 3] += torch.tensor([0.03, -0.02, 0.01])
     cam = {"distorted_pinhole": dict(camera_model=ref_hip.PINHOLE, radial=np.array([[0.05, -0.02, 0.003, 0.0, 0.0, 0.0]], np.float32),
                                      tangential=np.array([[0.002, -0.001]], np.float32), thin_prism=np.array([[0.001, 0.0, -0.001, 0.0]], np.float32)),
-           "fisheye": dict(camera_model=ref_hip.FISHEYE, radial=np.array([[0.02, -0.005, 0.001, 0.0]], np.float32))}[name]
+           "fisheye": dict(camera_model=ref_hip.FISHEYE, radial=np.array([[0.02, -0.005, 0.001, 0.0]], np.float32)),
+           "rolling_top_to_bottom": dict(shutter=ref_hip.ROLLING_TOP_TO_BOTTOM, viewmats1=vm1[None].numpy())}[name]
     _stagewise(ref, ops, sc, cam, "S-8cam ring camera %d, %s" % (cam_i, name), with_oracle=False, fwd_strict=False, over_frac=6e-4, bwd_f64_yardstick=False)
 
 
