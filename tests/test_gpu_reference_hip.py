@@ -533,6 +533,42 @@ def test_s1m_other_camera_models_vs_reference(ref, mods, s1m_scene, name):
     _stagewise(ref, ops, sc, cam, "S-1M @1080p, %s" % name, with_oracle=False, fwd_strict=False, over_frac=6e-4, bwd_f64_yardstick=False)
 
 
+@pytest.mark.parametrize("cam_i", [2, 3, 5])
+def test_s8cam_projection_float64_yardstick(ref, mods, s1m_scene, cam_i):
+    """The UT projection on the ring cameras where HIP and the reference kernel differ most (cameras 2 / 3 / 5: means2d up to 0.2 - 0.5 px, conics up to
+    8e-3 on Gaussians centimetres from the camera plane, ~100 radii of 1 M by one pixel; cfg2's identity pose: 0.016 px) against the SAME formulas in
+    float64 (the oracle): both are fp32 evaluations of an expression that sums seven projected points with weights -99 / +16.67 — HIP must be no further
+    from the float64 result than the reference kernel is (test_gpu_fullsize.py asserts the same against the fp32 oracle on cfg2 / cfg5)."""
+    ops, scenes = mods
+    sc = dict(s1m_scene)
+    sc["viewmat"] = scenes.ring_cameras(8)[cam_i]
+    a = _scene_args(sc, {})
+    W, H = a["width"], a["height"]
+    R = ref.projection_ut_3dgs_fused(a["means"], a["quats"], a["scales"], a["opacities"], a["viewmat"], None, a["K"], W, H, 0.3, 0.01, 1e4, 0.0, False,
+                                     ref_hip.PINHOLE, None, ref_hip.GLOBAL, None, None, None)
+    cm, shut = _hip_enums(ops, a)
+    P = ops.projection_ut_3dgs_fused(a["means"], a["quats"], a["scales"], a["opacities"], a["viewmat"], None, a["K"], W, H, 0.3, 0.01, 1e4, 0.0, False, cm,
+                                     ops.UnscentedTransformParameters(), shut, None, None, None)
+    f64 = lambda k: np.ascontiguousarray(sc[k].numpy(), np.float64)  # noqa: E731
+    r64, m64, d64, c64, _ = oracle.projection_ut(f64("means"), f64("quats"), f64("scales"), f64("opacities"), f64("viewmat")[None], f64("K")[None], W, H)
+    rr, mr, cr = R[0].cpu().numpy()[0], np32(R[1])[0], np32(R[3])[0]
+    rg, mg, cg = P[0].cpu().numpy()[0], np32(P[1])[0], np32(P[3])[0]
+    v = (r64[0] > 0).all(-1) & (rr > 0).all(-1) & (rg > 0).all(-1)
+    crel = lambda x, y: np.abs(x - y) / (np.abs(y).max(-1, keepdims=True) + 1e-30)  # noqa: E731
+    rms = lambda x: float(np.sqrt((x ** 2).mean()))  # noqa: E731
+    rec = parity_record("S-8cam ring camera %d projection: HIP and the reference kernel against the float64 evaluation of the same formulas" % cam_i,
+                        visible=int(v.sum()),
+                        means2d_max_err_px_hip=float(np.abs(mg - m64[0])[v].max()), means2d_max_err_px_reference=float(np.abs(mr - m64[0])[v].max()),
+                        means2d_rms_err_px_hip=rms((mg - m64[0])[v]), means2d_rms_err_px_reference=rms((mr - m64[0])[v]),
+                        conic_max_rel_err_hip=float(crel(cg, c64[0])[v].max()), conic_max_rel_err_reference=float(crel(cr, c64[0])[v].max()),
+                        conic_rms_rel_err_hip=rms(crel(cg, c64[0])[v]), conic_rms_rel_err_reference=rms(crel(cr, c64[0])[v]),
+                        radius_flips_hip=int((rg != r64[0])[v].any(-1).sum()), radius_flips_reference=int((rr != r64[0])[v].any(-1).sum()),
+                        cull_flips_hip=int(((rg > 0).all(-1) != (r64[0] > 0).all(-1)).sum()), cull_flips_reference=int(((rr > 0).all(-1) != (r64[0] > 0).all(-1)).sum()))
+    assert rec["means2d_rms_err_px_hip"] <= 1.25 * rec["means2d_rms_err_px_reference"] + 1e-5 and rec["conic_rms_rel_err_hip"] <= 1.25 * rec["conic_rms_rel_err_reference"] + 1e-7, rec
+    assert rec["means2d_max_err_px_hip"] <= 1.5 * rec["means2d_max_err_px_reference"] + 1e-3 and rec["conic_max_rel_err_hip"] <= 1.5 * rec["conic_max_rel_err_reference"] + 1e-4, rec
+    assert rec["radius_flips_hip"] <= 1.25 * rec["radius_flips_reference"] + 16 and rec["cull_flips_hip"] <= rec["cull_flips_reference"] + 4, rec
+
+
 @pytest.mark.parametrize("name,cam_i", [("distorted_pinhole", 3), ("distorted_pinhole", 5), ("fisheye", 3), ("fisheye", 5), ("rolling_top_to_bottom", 3)])
 def test_s8cam_other_camera_models_vs_reference(ref, mods, s1m_scene, name, cam_i):
     """The distorted charts of the fast kernels (OpenCV-distorted pinhole, equidistant fisheye) on the two S-8cam ring cameras whose fp32 pose round trip
