@@ -92,8 +92,9 @@ class OpTimer:
         self.events = {n: [] for n in self.names}
         self.enabled = False
         self.only = None  # restrict the bracketing to these ops (every event record costs a ~6 us bubble on the stream)
-        self.sample_every = 1   # bracket an op only on every n-th of its calls (the timed regions: the dominant op on one step in four)
+        self.sample_every = 1   # bracket an op only on every n-th of its calls (the timed regions: the dominant op on one step in three)
         self.calls = {}
+        self.sampled = {}   # op -> the (1-based) numbers of its enabled calls that were bracketed: which steps' launches an average is over
         for n in self.names:
             setattr(ops_mod, n, self._wrap(n))
 
@@ -110,10 +111,10 @@ class OpTimer:
                 return r
             if not self.enabled or (self.only is not None and key not in self.only):
                 return fn(*a, **k)
-            if self.sample_every > 1:
-                n_call = self.calls[key] = self.calls.get(key, 0) + 1
-                if n_call % self.sample_every != 1:
-                    return fn(*a, **k)
+            n_call = self.calls[key] = self.calls.get(key, 0) + 1
+            if self.sample_every > 1 and n_call % self.sample_every != 1:
+                return fn(*a, **k)
+            self.sampled.setdefault(key, []).append(n_call)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             r = fn(*a, **k)
@@ -126,6 +127,7 @@ class OpTimer:
 
     def reset(self):
         self.events = {n: [] for n in self.names}
+        self.calls, self.sampled = {}, {}
 
     def mean_ms(self):
         out = {}
@@ -272,7 +274,7 @@ def main():
     ap.add_argument("--host-delay-us", type=float, default=0.0, help="A/B tool: busy-wait this long on the host after every intersection call (what a slower or "
                                                                      "busier host adds between reading n_isects and launching the blend; disables the per-op table)")
     ap.add_argument("--bracket-every-step", action="store_true", help="A/B tool: HIP events around BOTH blend ops on EVERY step of the timed regions, as rounds 1 - 5 placed them "
-                                                                      "(default: the dominant op only, one step in four — an event record costs the stream ~6 us)")
+                                                                      "(default: the dominant op only, one step in three — an event record costs the stream ~6 us)")
     ap.add_argument("--launch-check", action="store_true", help="initialise the process group, report rank / world / backend and exit "
                                                                 "(tests the N > 1 launch logic without touching a GPU)")
     args = ap.parse_args()
@@ -489,12 +491,14 @@ def main():
     step(True)   # (the first optimizer step creates the Adam moments: they must exist in the snapshot every region starts from)
     counter["i"] = 0
     # Inside the timed regions only the DOMINANT op (the blend backward: `roofline`) is bracketed with HIP events on the launch stream, and only on
-    # one step in four: an event record opens a ~6 us bubble on the stream (kernel trace of round 6: four records around the two blend ops = 23.5 us
-    # of every 1.2 ms step spent on the bench's own instrumentation; rounds 1 - 5 bracketed both blend ops on every step).  5 launches per region x R
-    # regions are averaged.  Every other op — the blend forward included — is timed in the per-op pass behind the regions.
+    # one step in three: an event record opens a ~6 us bubble on the stream (kernel trace of round 6: four records around the two blend ops = 23.5 us
+    # of every 1.2 ms step spent on the bench's own instrumentation; rounds 1 - 5 bracketed both blend ops on every step).  7 launches per region x R
+    # regions are averaged — a stride that is coprime with the 8-pose camera cycle, so the sampled launches see 7 of the 8 poses (a stride of 4 saw two),
+    # and `roofline` prices them at THEIR mean n_isects, not at the mean over all K steps.  Every other op — the blend forward included — is timed in
+    # the per-op pass behind the regions.
     timer.enabled = True
     timer.only = {"rasterize_to_pixels_from_world_3dgs_bwd"}
-    timer.sample_every = 4
+    timer.sample_every = 3
     if args.bracket_every_step:
         timer.only, timer.sample_every = {"rasterize_to_pixels_from_world_3dgs_fwd", "rasterize_to_pixels_from_world_3dgs_bwd"}, 1
     # Every region is the contract's protocol from the SAME state: the state in front of the warm-up (parameters, Adam moments, step counters, the
@@ -549,14 +553,19 @@ def main():
     isects_timed = list(counter["isects"])
     blend_ms = timer.mean_ms()
     n_bwd_events = len(timer.events.get("rasterize_to_pixels_from_world_3dgs_bwd", []))
+    # the in-region step of every bracketed launch (every region runs the same K steps from the same state; a repeated iteration would shift the count)
+    bwd_sampled_steps = [(c - 1) % args.steps for c in timer.sampled.get("rasterize_to_pixels_from_world_3dgs_bwd", [])] if counter["repeated"] == 0 else []
     timer.reset()
     timer.sample_every = 1
     timer.only, timer.enabled = None, True   # per-op pass (outside the timed region), same camera sequence
     counter["i"] = 0
+    counter["isects"] = []
     for _ in range(min(args.steps, 8)):
         step(True)
     torch.cuda.synchronize()
     timer.enabled = False
+    isects_perop = list(counter["isects"])   # the frames the per-op rows were measured on
+    counter["isects"] = list(isects_timed)
     all_ms = timer.mean_ms()
     all_ms.update(blend_ms)                  # the blend ops keep their timed-region figures
     # ---- sustained load (outside the contract's regions; VERDICT r05 missing #5): >= 1500 consecutive iterations from the warm-up state ----
@@ -631,7 +640,13 @@ def main():
         P = W * H
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
         K = (deg + 1) ** 2
-        ab = algorithmic_bytes(N, 1, I, P, tiles, deg, K)
+        # every row is priced at the mean n_isects of the launches its time was measured on: the per-op pass's own frames, and — the blend backward,
+        # bracketed inside the timed regions on one step in three — the sampled steps of the regions
+        I_perop = sum(isects_perop) / len(isects_perop) if isects_perop else I
+        ab = algorithmic_bytes(N, 1, I_perop, P, tiles, deg, K)
+        I_bwd = (sum(isects_timed[j] for j in bwd_sampled_steps) / len(bwd_sampled_steps)) if (bwd_sampled_steps and max(bwd_sampled_steps) < len(isects_timed)) else I
+        if "rasterize_to_pixels_from_world_3dgs_bwd" in blend_ms:
+            ab["rasterize_to_pixels_from_world_3dgs_bwd"] = algorithmic_bytes(N, 1, I_bwd, P, tiles, deg, K)["rasterize_to_pixels_from_world_3dgs_bwd"]
         n_params = sum(p.numel() for p in model.params())
         ab["adam_step"] = ab["adam_step_split"] = ab["adam_step_multi"] = None  # priced together below
         kernels = {}
@@ -670,7 +685,8 @@ def main():
         roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": kernels[dom]["frac_hbm"], "traffic": pm.get("hbm_bytes"),
                     "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"], "avg_launch_ms": kernels[dom]["ms"],
-                    "avg_launch_ms_is": "HIP events on the launch stream around the op inside the timed regions, %d launches (one step in four: an event record costs the stream ~6 us)" % n_bwd_events,
+                    "avg_launch_ms_is": "HIP events on the launch stream around the op inside the timed regions, %d launches (one step in three: an event record costs the stream ~6 us)" % n_bwd_events,
+                    "n_isects_of_timed_launches": round(I_bwd if dom.endswith("_bwd") else I_perop, 1),
                     "traffic_source": (pmc.get("source") if pm.get("hbm_bytes") else pmc.get("stale"))}
         if pm.get("hbm_bytes") and pmc.get("n_isects"):
             # the counters were collected on ONE frame (the cfg2 camera); the timed steps average other cameras: like for like = the algorithmic
@@ -683,7 +699,7 @@ def main():
             # SURVEY §0 finding 7 / VERDICT r05 missing #4: the algorithmic bytes on the intersections the kernels actually staged (counted by a -DGSX_STATS
             # build on one frame: tools/processed_isects.py), next to all I: the blend rows above price all I
             fr = proc["fwd_processed_frac"] if dom.endswith("_fwd") else proc["bwd_processed_frac"]
-            ab_proc = algorithmic_bytes(N, 1, I * fr, P, tiles, deg, K)[dom]
+            ab_proc = algorithmic_bytes(N, 1, (I_bwd if dom.endswith("_bwd") else I_perop) * fr, P, tiles, deg, K)[dom]
             roofline["processed_intersections"] = {
                 "counters_frame_n_isects": proc["n_isects"], "fwd_staged_entries": proc["fwd_staged_entries"], "bwd_staged_entries": proc["bwd_staged_entries"],
                 "fwd_processed_frac": proc["fwd_processed_frac"], "bwd_processed_frac": proc["bwd_processed_frac"], "pixels_saturated_frac": proc.get("pixels_saturated_frac"),
