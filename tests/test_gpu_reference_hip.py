@@ -533,8 +533,8 @@ def test_s1m_other_camera_models_vs_reference(ref, mods, s1m_scene, name):
     _stagewise(ref, ops, sc, cam, "S-1M @1080p, %s" % name, with_oracle=False, fwd_strict=False, over_frac=6e-4, bwd_f64_yardstick=False)
 
 
-@pytest.mark.parametrize("cam_i", [2, 3, 5])
-def test_s8cam_projection_float64_yardstick(ref, mods, s1m_scene, cam_i):
+@pytest.mark.parametrize("cam_i,rolling", [(2, False), (3, False), (5, False), (3, True)])
+def test_s8cam_projection_float64_yardstick(ref, mods, s1m_scene, cam_i, rolling):
     """The UT projection on the ring cameras where HIP and the reference kernel differ most (cameras 2 / 3 / 5: means2d up to 0.2 - 0.5 px, conics up to
     8e-3 on Gaussians centimetres from the camera plane, ~100 radii of 1 M by one pixel; cfg2's identity pose: 0.016 px) against the SAME formulas in
     float64 (the oracle): both are fp32 evaluations of an expression that sums seven projected points with weights -99 / +16.67 — HIP must be no further
@@ -542,21 +542,27 @@ def test_s8cam_projection_float64_yardstick(ref, mods, s1m_scene, cam_i):
     ops, scenes = mods
     sc = dict(s1m_scene)
     sc["viewmat"] = scenes.ring_cameras(8)[cam_i]
-    a = _scene_args(sc, {})
+    cam, okw = {}, {}
+    if rolling:   # (3, True): the rolling shutter of test_s8cam_other_camera_models_vs_reference — ten slerp / reprojection iterations per sigma point (Cameras.cuh:386-413)
+        vm1 = sc["viewmat"].clone()
+        vm1[:3, 3] += torch.tensor([0.03, -0.02, 0.01])
+        cam = dict(shutter=ref_hip.ROLLING_TOP_TO_BOTTOM, viewmats1=vm1[None].numpy())
+        okw = dict(shutter=ref_hip.ROLLING_TOP_TO_BOTTOM, viewmats1=vm1[None].numpy().astype(np.float64))
+    a = _scene_args(sc, cam)
     W, H = a["width"], a["height"]
-    R = ref.projection_ut_3dgs_fused(a["means"], a["quats"], a["scales"], a["opacities"], a["viewmat"], None, a["K"], W, H, 0.3, 0.01, 1e4, 0.0, False,
-                                     ref_hip.PINHOLE, None, ref_hip.GLOBAL, None, None, None)
+    R = ref.projection_ut_3dgs_fused(a["means"], a["quats"], a["scales"], a["opacities"], a["viewmat"], a["viewmats1"], a["K"], W, H, 0.3, 0.01, 1e4, 0.0, False,
+                                     ref_hip.PINHOLE, None, a["shutter"], None, None, None)
     cm, shut = _hip_enums(ops, a)
-    P = ops.projection_ut_3dgs_fused(a["means"], a["quats"], a["scales"], a["opacities"], a["viewmat"], None, a["K"], W, H, 0.3, 0.01, 1e4, 0.0, False, cm,
+    P = ops.projection_ut_3dgs_fused(a["means"], a["quats"], a["scales"], a["opacities"], a["viewmat"], a["viewmats1"], a["K"], W, H, 0.3, 0.01, 1e4, 0.0, False, cm,
                                      ops.UnscentedTransformParameters(), shut, None, None, None)
     f64 = lambda k: np.ascontiguousarray(sc[k].numpy(), np.float64)  # noqa: E731
-    r64, m64, d64, c64, _ = oracle.projection_ut(f64("means"), f64("quats"), f64("scales"), f64("opacities"), f64("viewmat")[None], f64("K")[None], W, H)
+    r64, m64, d64, c64, _ = oracle.projection_ut(f64("means"), f64("quats"), f64("scales"), f64("opacities"), f64("viewmat")[None], f64("K")[None], W, H, **okw)
     rr, mr, cr = R[0].cpu().numpy()[0], np32(R[1])[0], np32(R[3])[0]
     rg, mg, cg = P[0].cpu().numpy()[0], np32(P[1])[0], np32(P[3])[0]
     v = (r64[0] > 0).all(-1) & (rr > 0).all(-1) & (rg > 0).all(-1)
     crel = lambda x, y: np.abs(x - y) / (np.abs(y).max(-1, keepdims=True) + 1e-30)  # noqa: E731
     rms = lambda x: float(np.sqrt((x ** 2).mean()))  # noqa: E731
-    rec = parity_record("S-8cam ring camera %d projection: HIP and the reference kernel against the float64 evaluation of the same formulas" % cam_i,
+    rec = parity_record("S-8cam ring camera %d%s projection: HIP and the reference kernel against the float64 evaluation of the same formulas" % (cam_i, ", rolling_top_to_bottom" if rolling else ""),
                         visible=int(v.sum()),
                         means2d_max_err_px_hip=float(np.abs(mg - m64[0])[v].max()), means2d_max_err_px_reference=float(np.abs(mr - m64[0])[v].max()),
                         means2d_rms_err_px_hip=rms((mg - m64[0])[v]), means2d_rms_err_px_reference=rms((mr - m64[0])[v]),
