@@ -710,8 +710,12 @@ __global__ __launch_bounds__(PB, GSX_PAIR_WAVES) void raster_fwd_pair_kernel(Ras
     __shared__ float4 s_rec[2][PCH + 1][5];   // as in raster_fwd_quad_kernel: 80 B pitch, [PCH] = the null record, [.][4] = (rad2, k2, -, -)
     __shared__ float s_bounds[2][2];
     __shared__ int s_wdone[2][2];
-    __shared__ __attribute__((aligned(16))) uint16_t s_list_flat[2 * 8 * PCH + 8];   // [wave][block][PCH] + the entry the last list's look-ahead reads
-    uint16_t (*s_list)[8][PCH] = reinterpret_cast<uint16_t (*)[8][PCH]>(s_list_flat);
+    // [wave][block][PCH + 8]: a list pitch of 144 B, not 128 — the step loop's ds_read_u16 is serviced in two groups of 32 lanes = four blocks each, banks
+    // (a / 4) mod 32: at a pitch of 128 B the eight lists' k-th entries sat on ONE bank (a 4-way conflict on every step: 6 of the kernel's 7.9 conflict
+    // cycles per step, profiles/r05f_pmc_counters.md); 144 B puts them four banks apart.  Entry [PCH] of a list is what the last step's look-ahead reads.
+    constexpr int LP = PCH + 8;
+    __shared__ __attribute__((aligned(16))) uint16_t s_list_flat[2 * 8 * LP];
+    uint16_t (*s_list)[8][LP] = reinterpret_cast<uint16_t (*)[8][LP]>(s_list_flat);
     const uint32_t cid = blockIdx.y;
     uint32_t tile_id;
     if (!swizzled_tile(blockIdx.x, a.tw * a.th, tile_id)) return;
@@ -811,7 +815,7 @@ __global__ __launch_bounds__(PB, GSX_PAIR_WAVES) void raster_fwd_pair_kernel(Ras
         // the eight lists of this wave for the chunk, pre-filled with the null record's entry (the shorter ones idle to the end): 8 x 64 x 2 B = one ds_write_b128 per lane
         {
             const uint32_t fill = 0x00010001u * (PCH * PITCH);
-            reinterpret_cast<uint4*>(&s_list[wave][0][0])[lane] = make_uint4(fill, fill, fill, fill);
+            reinterpret_cast<uint4*>(&s_list[wave][q8][0])[k8] = make_uint4(fill, fill, fill, fill);   // lane (q8, k8): 16 B of list q8
         }
         // every lane tests a record — lanes behind the chunk's end the null record (empty footprint) —: no branch, the eight compare results
         // ARE the ballots and the counters stay wave-uniform
