@@ -308,6 +308,16 @@ def test_small_camera_cases(ref, mods, name):
     _stagewise(ref, ops, sc, cam, name)
 
 
+@pytest.mark.parametrize("shutter", ["ROLLING_BOTTOM_TO_TOP", "ROLLING_RIGHT_TO_LEFT"])
+def test_small_rolling_shutter_other_directions(ref, mods, shutter):
+    """The two rolling-shutter directions the golden cases do not hold (Cameras.h:16-22; relative frame time from the far edge, Cameras.cuh:280-300): the small rolling case
+    with the shutter reversed, stage by stage against the reference's kernels and the oracle."""
+    ops, scenes = mods
+    sc, cam = ref_hip_cases.cases(scenes)["rolling_top_to_bottom"]
+    cam = dict(cam, shutter=getattr(ref_hip, shutter))
+    _stagewise(ref, ops, sc, cam, "small case, " + shutter.lower())
+
+
 def _make_opaque(sc, seed=29):
     """A third of the scene's Gaussians opaque (opacity 1.0 / 0.9995 / 0.9992) and ~10 px wide on screen: pixels next to their centres
     see opacity x exp(-s) above 0.999 — the alpha clamp (Fwd.cu:239) and its gradient mask (Bwd.cu:318), which no random scene reaches."""
