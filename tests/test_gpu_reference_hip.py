@@ -82,15 +82,15 @@ def _projection_stats(tag, who, r, got):
     rec = dict(gaussians=n, visible_ref=int(vr.sum()), cull_flips=int((vr != vg).sum()),
                radius_flips=int((r["radii"] != got["radii"])[both].any(-1).sum()),
                radius_max_diff_px=int(np.abs(r["radii"] - got["radii"])[both].max()) if both.any() else 0,
-               means2d_max_err_px=float(np.abs(r["means2d"] - got["means2d"])[both].max()),
-               depth_max_rel_err=float((np.abs(r["depths"] - got["depths"])[both] / np.abs(r["depths"][both])).max()),
-               conic_max_rel_err=float(crel(got["conics"], r["conics"])[both].max()))
+               means2d_max_err_px=float(np.abs(r["means2d"] - got["means2d"])[both].max()) if both.any() else 0.0,
+               depth_max_rel_err=float((np.abs(r["depths"] - got["depths"])[both] / np.abs(r["depths"][both])).max()) if both.any() else 0.0,
+               conic_max_rel_err=float(crel(got["conics"], r["conics"])[both].max()) if both.any() else 0.0)
     if both.any():   # where the relative depth error peaks: a Gaussian near the camera plane (z = r2 . mu + t_z cancels) or not
         k = int(np.argmax(np.abs(r["depths"] - got["depths"])[both] / np.abs(r["depths"][both])))
         rec["depth_at_max_rel_err"] = float(r["depths"][both][k])
         rec["depth_max_abs_err"] = float(np.abs(r["depths"] - got["depths"])[both].max())
     if r.get("compensations") is not None and got.get("compensations") is not None:
-        rec["compensation_max_err"] = float(np.abs(r["compensations"] - got["compensations"])[both].max())
+        rec["compensation_max_err"] = float(np.abs(r["compensations"] - got["compensations"])[both].max()) if both.any() else 0.0
     return parity_record("%s projection: %s vs reference kernel" % (tag, who), **rec)
 
 
@@ -316,6 +316,54 @@ def test_small_rolling_shutter_other_directions(ref, mods, shutter):
     sc, cam = ref_hip_cases.cases(scenes)["rolling_top_to_bottom"]
     cam = dict(cam, shutter=getattr(ref_hip, shutter))
     _stagewise(ref, ops, sc, cam, "small case, " + shutter.lower())
+
+
+@pytest.mark.parametrize("case", ["ut_loose", "ut_spread", "planes_clip"])
+@pytest.mark.parametrize("name", ["pinhole_sh3_comp", "fisheye"])
+def test_projection_non_default_parameters_vs_reference(ref, mods, name, case):
+    """`projection_ut_3dgs_fused` with the parameters every call site of the reference leaves at their defaults (rasterizer.cpp:176-181: UnscentedTransformParameters{},
+    eps2d 0.3, near 0.01, far 1e10, radius_clip 0) set to something else — they are part of the operator surface (Ops.h:30-50, Cameras.h:27-44): a wider sigma-point spread
+    (alpha, beta, kappa), sigma points allowed to be invalid (require_all_sigma_points_valid = false: the mean over the valid ones, Cameras.cuh:1118-1150) with another image
+    margin, and near / far planes, blur and radius clip that cull a good part of the small scene — against the reference's kernel on the same arguments, and the oracle."""
+    ops, scenes = mods
+    sc, cam = ref_hip_cases.cases(scenes)[name]
+    a = _scene_args(sc, cam)
+    W, H = a["width"], a["height"]
+    ut_vals, eps2d, near, far, clip = {"ut_loose": ((0.8, 2.0, 0.0, -0.3, False), 0.3, 0.01, 1e4, 0.0),    # wide sigma points, valid only in the inner 40 % of the image, invalid ones allowed
+                                       "ut_spread": ((0.6, 1.0, 1.5, -0.3, True), 0.3, 0.01, 1e4, 0.0),    # another spread, every sigma point must land in the inner 40 %
+                                       "planes_clip": ((0.1, 2.0, 0.0, 0.1, True), 0.7, 2.3, 2.8, 3.5)}[case]  # the scene's depths are 2 .. 3, its radii 2 .. 9 px
+    cm, shut = _hip_enums(ops, a)
+    ut = ops.UnscentedTransformParameters()
+    ut.alpha, ut.beta, ut.kappa, ut.in_image_margin_factor, ut.require_all_sigma_points_valid = ut_vals
+    dist = (a["radial"], a["tangential"], a["thin_prism"])
+    R = ref.projection_ut_3dgs_fused(a["means"], a["quats"], a["scales"], a["opacities"], a["viewmat"], a["viewmats1"], a["K"], W, H, eps2d, near, far, clip,
+                                     a["calc_compensations"], a["camera_model"], torch.tensor([float(x) for x in ut_vals]), a["shutter"], *dist)
+    P = ops.projection_ut_3dgs_fused(a["means"], a["quats"], a["scales"], a["opacities"], a["viewmat"], a["viewmats1"], a["K"], W, H, eps2d, near, far, clip,
+                                     a["calc_compensations"], cm, ut, shut, *dist)
+    pk = ["radii", "means2d", "depths", "conics", "compensations"]
+    tonp = lambda X: dict(zip(pk, [None if x is None or x.numel() == 0 else x.cpu().numpy() for x in X]))  # noqa: E731
+    Rn = tonp(R)
+    tag = "%s, projection parameters %s" % (name, case)
+    rec = _projection_stats(tag, "HIP", Rn, tonp(P))
+    f = lambda k: np.ascontiguousarray(sc[k].numpy(), np.float32)  # noqa: E731
+    okw = dict(camera_model=a["camera_model"], shutter=a["shutter"], calc_compensations=a["calc_compensations"], ut=ut_vals, eps2d=eps2d, near_plane=near, far_plane=far, radius_clip=clip)
+    for k in ("viewmats1", "radial", "tangential", "thin_prism"):
+        okw[k] = None if cam.get(k) is None else np.asarray(cam[k], np.float32)
+    O = oracle.projection_ut(f("means"), f("quats"), f("scales"), f("opacities"), f("viewmat")[None], f("K")[None], W, H, **okw)
+    rec_o = _projection_stats(tag, "oracle", Rn, dict(zip(pk, O)))
+    n = rec["gaussians"]
+    # the parameters bite: the result differs from the default call's, and not everything is gone
+    D = ops.projection_ut_3dgs_fused(a["means"], a["quats"], a["scales"], a["opacities"], a["viewmat"], a["viewmats1"], a["K"], W, H, 0.3, 0.01, 1e4, 0.0,
+                                     a["calc_compensations"], cm, ops.UnscentedTransformParameters(), shut, *dist)
+    vis_d, vis_p = (D[0] > 0).all(-1), (P[0] > 0).all(-1)
+    both_v = vis_d & vis_p
+    changed = int((vis_d != vis_p).sum()) + int(((D[1] - P[1]).abs().amax(-1) > 1e-3)[both_v].sum()) + int((D[0] != P[0]).any(-1)[both_v].sum())
+    parity_record(tag + ": what the parameters change", visible_default=int(vis_d.sum()), visible=int(vis_p.sum()), gaussians_changed=changed)
+    assert rec["visible_ref"] > 0.05 * n and changed > 0.01 * n, (rec, changed)
+    for r in (rec, rec_o):
+        assert r["cull_flips"] <= 2 and r["radius_flips"] <= max(4, 2.5e-3 * n) and r["radius_max_diff_px"] <= 1, r
+        assert r["means2d_max_err_px"] < 5e-3 and r["conic_max_rel_err"] < 2e-3 and (r["depth_max_rel_err"] < 1e-5 or r["depth_max_abs_err"] < 3e-6), r
+        assert r.get("compensation_max_err", 0.0) < 1e-4, r
 
 
 def _make_opaque(sc, seed=29):
