@@ -366,6 +366,47 @@ def test_projection_non_default_parameters_vs_reference(ref, mods, name, case):
         assert r.get("compensation_max_err", 0.0) < 1e-4, r
 
 
+@pytest.mark.parametrize("name", ["pinhole_sh3_comp", "fisheye", "rolling_top_to_bottom"])
+def test_tile_masks_vs_reference(ref, mods, name):
+    """The blend operators' optional tile masks [C, th, tw] (Ops.h:118, Fwd.cu:143-150: a masked-out tile is painted with the background and left; Bwd.cu:150: it
+    contributes no gradient) — a checkerboard over the small cases (fast kernels and the reference-order ones), forward and backward against the reference's kernels."""
+    ops, scenes = mods
+    sc, cam = ref_hip_cases.cases(scenes)[name]
+    a = _scene_args(sc, cam)
+    v_rc, v_ra = _grads(sc)
+    W, H = a["width"], a["height"]
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    cam_kw = {k: a[k] for k in ("camera_model", "shutter", "viewmats1", "radial", "tangential", "thin_prism", "calc_compensations")}
+    R = ref_hip.render_chain(ref, a["means"], a["quats"], a["scales"], a["opacities"], a["sh"], a["sh_degree"], a["viewmat"], a["K"], W, H, a["background"], **cam_kw)
+    yy, xx = torch.meshgrid(torch.arange(th), torch.arange(tw), indexing="ij")
+    masks = (((yy + xx) % 2) == 0)[None].to(DEV).contiguous()
+    dist = (a["radial"], a["tangential"], a["thin_prism"])
+    op = a["opacities"][None].contiguous()
+    rargs = (a["means"], a["quats"], a["scales"], R["colors"], op, a["background"], masks, W, H, 16, a["viewmat"], a["viewmats1"], a["K"], a["camera_model"], None,
+             a["shutter"], *dist, R["tile_offsets"], R["flatten_ids"])
+    r_ren, r_alp, r_last = ref.rasterize_to_pixels_from_world_3dgs_fwd(*rargs)
+    r_g = ref.rasterize_to_pixels_from_world_3dgs_bwd(*rargs, r_alp, r_last, v_rc, v_ra)
+    cm, shut = _hip_enums(ops, a)
+    hargs = (a["means"], a["quats"], a["scales"], R["colors"], op, a["background"], masks, W, H, 16, a["viewmat"], a["viewmats1"], a["K"], cm,
+             ops.UnscentedTransformParameters(), shut, *dist, R["tile_offsets"], R["flatten_ids"])
+    h_ren, h_alp, h_last = ops.rasterize_to_pixels_from_world_3dgs_fwd(*hargs)
+    h_g = ops.rasterize_to_pixels_from_world_3dgs_bwd(*hargs, h_alp, h_last, v_rc, v_ra)
+    pm = masks[0].repeat_interleave(16, 0).repeat_interleave(16, 1)[:H, :W].cpu().numpy()   # per pixel: its tile is rendered
+    err = np.abs(np32(h_ren) - np32(r_ren))[0].max(-1)
+    bg = np32(a["background"])[0]
+    rec = parity_record("%s with a checkerboard of tile masks: HIP vs reference kernel" % name, rendered_tiles=int(masks.sum()), tiles=int(masks.numel()),
+                        rgb_max_err_rendered=float(err[pm].max()), rgb_max_err_masked=float(err[~pm].max()),
+                        masked_is_background=bool(np.abs(np32(h_ren)[0][~pm] - bg).max() == 0.0), alpha_max_err_rendered=float(np.abs(np32(h_alp) - np32(r_alp))[0, :, :, 0][pm].max()),
+                        last_id_mismatch_rendered=int((h_last.cpu().numpy() != r_last.cpu().numpy())[0][pm].sum()),
+                        **{n: rel_l2(np32(g), np32(r)) for n, g, r in zip(GRADS, h_g, r_g)})
+    # (alpha / last ids of masked-out tiles: the reference returns there without writing them — uninitialised memory — so only the rendered tiles are compared)
+    assert rec["masked_is_background"] and rec["rgb_max_err_masked"] == 0.0 and rec["rgb_max_err_rendered"] < 1e-4 and rec["alpha_max_err_rendered"] < 1e-4, rec
+    assert rec["last_id_mismatch_rendered"] == 0 and all(rec[g] < 1e-3 for g in GRADS), rec
+    # and the masked tiles really carry no gradient: the same backward with every tile rendered differs
+    full = ref.rasterize_to_pixels_from_world_3dgs_bwd(*(rargs[:6] + (None,) + rargs[7:]), R["alphas"] if "alphas" in R else r_alp, R["last_ids"] if "last_ids" in R else r_last, v_rc, v_ra)
+    assert rel_l2(np32(r_g[3]), np32(full[3])) > 0.1
+
+
 def _make_opaque(sc, seed=29):
     """A third of the scene's Gaussians opaque (opacity 1.0 / 0.9995 / 0.9992) and ~10 px wide on screen: pixels next to their centres
     see opacity x exp(-s) above 0.999 — the alpha clamp (Fwd.cu:239) and its gradient mask (Bwd.cu:318), which no random scene reaches."""
