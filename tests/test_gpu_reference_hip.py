@@ -407,6 +407,70 @@ def test_tile_masks_vs_reference(ref, mods, name):
     assert rel_l2(np32(r_g[3]), np32(full[3])) > 0.1
 
 
+@pytest.mark.parametrize("background", [False, True])
+def test_two_cameras_per_call_vs_reference(ref, mods, background):
+    """Every reference call site passes C = 1 (rasterizer.cpp:320,328); Ops.h is batched over cameras ([C, ...] viewmats, Ks, backgrounds; flatten_ids index
+    camera * N + gaussian) and so is this backend.  Two poses in ONE call of the projection and of intersect_tile + intersect_offset against the reference's kernels
+    called the same way.  The reference's world-space blend is NOT batched ("TODO: only support 1 camera for now so it is ok to abuse the index", Fwd.cu:197-200:
+    means[g] with the flattened index — out of bounds for camera 1), so the batched blend here — forward and backward, with and without a background (optional in
+    Ops.h: Fwd.cu:258-262, Bwd.cu:309-316) — is compared with the reference's kernels called once per camera on that camera's slice of the lists: the gradients of the
+    shared tensors (means, quats, scales) are the sums over the cameras, colours and opacities are per camera."""
+    ops, scenes = mods
+    sc, cam = ref_hip_cases.cases(scenes)["pinhole_sh3_comp"]
+    a = _scene_args(sc, {})
+    W, H, N = a["width"], a["height"], a["means"].shape[0]
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    vm = torch.stack([sc["viewmat"], scenes.look_at_viewmat((0.25, -0.15, -0.2), (0.0, 0.05, 2.6))]).to(DEV).contiguous()
+    Ks = torch.stack([sc["K"], scenes.intrinsics(80.0, 95.0, W / 2.0 + 3.0, H / 2.0 - 2.0)]).to(DEV).contiguous()
+    bg = torch.tensor([[0.05, 0.1, 0.15], [0.3, 0.2, 0.1]], device=DEV) if background else None
+    ut = ops.UnscentedTransformParameters()
+    cmh, sh_h = ops.CameraModelType.PINHOLE, ops.ShutterType.GLOBAL
+    Rp = ref.projection_ut_3dgs_fused(a["means"], a["quats"], a["scales"], a["opacities"], vm, None, Ks, W, H, 0.3, 0.01, 1e4, 0.0, False, ref_hip.PINHOLE, None,
+                                      ref_hip.GLOBAL, None, None, None)
+    Pp = ops.projection_ut_3dgs_fused(a["means"], a["quats"], a["scales"], a["opacities"], vm, None, Ks, W, H, 0.3, 0.01, 1e4, 0.0, False, cmh, ut, sh_h, None, None, None)
+    pk = ["radii", "means2d", "depths", "conics", "compensations"]
+    tonp = lambda X: dict(zip(pk, [None if x is None or x.numel() == 0 else x.cpu().numpy() for x in X]))  # noqa: E731
+    tag = "two cameras per call (%s background)" % ("with" if background else "no")
+    pr = _projection_stats(tag, "HIP", tonp(Rp), tonp(Pp))
+    assert pr["cull_flips"] == 0 and pr["radius_flips"] <= 2 and pr["means2d_max_err_px"] < 5e-3, pr
+    radii, m2d, dep = Rp[0], Rp[1], Rp[2]
+    r_tpg, r_ids, r_fl = ref.intersect_tile(m2d, radii, dep, None, None, 2, 16, tw, th, True)
+    r_off = ref.intersect_offset(r_ids, 2, tw, th)
+    h_tpg, h_ids, h_fl = ops.intersect_tile(m2d, radii, dep, None, None, 2, 16, tw, th, True)
+    h_off = ops.intersect_offset(h_ids, 2, tw, th)
+    b_tpg, b_ids, b_fl, b_off = ops.intersect_tile_binned(m2d, radii, dep, 2, 16, tw, th, True)
+    exact = all(bool(torch.equal(x, y)) for x, y in ((h_tpg, r_tpg), (h_ids, r_ids), (h_fl, r_fl), (h_off, r_off), (b_ids, r_ids), (b_fl, r_fl), (b_off, r_off)))
+    rng = np.random.default_rng(11)
+    colors = dev(rng.random((2, N, 3)).astype(np.float32))
+    op = (a["opacities"][None] * torch.tensor([[1.0], [0.8]], device=DEV)).contiguous()
+    v_rc, v_ra = dev(rng.standard_normal((2, H, W, 3)).astype(np.float32)), dev(rng.standard_normal((2, H, W, 1)).astype(np.float32))
+    hargs = (a["means"], a["quats"], a["scales"], colors, op, bg, None, W, H, 16, vm, None, Ks, cmh, ut, sh_h, None, None, None, r_off, r_fl)
+    h_ren, h_alp, h_last = ops.rasterize_to_pixels_from_world_3dgs_fwd(*hargs)
+    h_g = ops.rasterize_to_pixels_from_world_3dgs_bwd(*hargs, h_alp, h_last, v_rc, v_ra)
+    n_is = int(r_fl.numel())
+    starts = [int(r_off[c, 0, 0]) for c in range(2)] + [n_is]
+    sums, per_cam, fwd_err, alpha_err, last_mis = None, [], 0.0, 0.0, 0
+    for c in range(2):
+        sl = slice(c, c + 1)
+        off_c = (r_off[sl] - starts[c]).contiguous()
+        fl_c = (r_fl[starts[c]:starts[c + 1]] - c * N).contiguous()
+        rargs = (a["means"], a["quats"], a["scales"], colors[sl].contiguous(), op[sl].contiguous(), None if bg is None else bg[sl].contiguous(), None, W, H, 16,
+                 vm[sl].contiguous(), None, Ks[sl].contiguous(), ref_hip.PINHOLE, None, ref_hip.GLOBAL, None, None, None, off_c, fl_c)
+        r_ren, r_alp, r_last = ref.rasterize_to_pixels_from_world_3dgs_fwd(*rargs)
+        g = ref.rasterize_to_pixels_from_world_3dgs_bwd(*rargs, r_alp, r_last, v_rc[sl].contiguous(), v_ra[sl].contiguous())
+        fwd_err = max(fwd_err, float((h_ren[sl] - r_ren).abs().max()))
+        alpha_err = max(alpha_err, float((h_alp[sl] - r_alp).abs().max()))
+        hit = r_alp[..., 0] > 0   # last ids are positions in the WHOLE flatten_ids array; a pixel nothing contributed to keeps 0 (SURVEY appendix A 5)
+        last_mis += int(((h_last[sl] != r_last + starts[c]) & hit).sum()) + int(((h_last[sl] != 0) & ~hit).sum())
+        sums = [x.clone() for x in g[:3]] if sums is None else [s_ + x for s_, x in zip(sums, g[:3])]
+        per_cam.append((g[3], g[4]))
+    r_g = sums + [torch.cat([p[0] for p in per_cam], 0), torch.cat([p[1] for p in per_cam], 0)]
+    rec = parity_record(tag + ": HIP (one batched call) vs reference kernel (one call per camera)", n_isects=n_is, intersection_exact=int(exact),
+                        rgb_max_err=fwd_err, alpha_max_err=alpha_err, last_id_mismatch=last_mis,
+                        **{n: rel_l2(np32(g).reshape(-1), np32(r).reshape(-1)) for n, g, r in zip(GRADS, h_g, r_g)})
+    assert exact and rec["rgb_max_err"] < 1e-4 and rec["alpha_max_err"] < 1e-4 and rec["last_id_mismatch"] == 0 and all(rec[g] < 1e-3 for g in GRADS), rec
+
+
 def _make_opaque(sc, seed=29):
     """A third of the scene's Gaussians opaque (opacity 1.0 / 0.9995 / 0.9992) and ~10 px wide on screen: pixels next to their centres
     see opacity x exp(-s) above 0.999 — the alpha clamp (Fwd.cu:239) and its gradient mask (Bwd.cu:318), which no random scene reaches."""
