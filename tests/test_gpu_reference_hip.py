@@ -471,6 +471,35 @@ def test_two_cameras_per_call_vs_reference(ref, mods, background):
     assert exact and rec["rgb_max_err"] < 1e-4 and rec["alpha_max_err"] < 1e-4 and rec["last_id_mismatch"] == 0 and all(rec[g] < 1e-3 for g in GRADS), rec
 
 
+@pytest.mark.parametrize("tile,C,W,H", [(8, 1, 128, 128), (32, 1, 150, 90), (64, 3, 200, 120), (16, 3, 150, 90), (4, 1, 64, 48)])
+def test_intersect_tile_other_tile_sizes_vs_reference(ref, mods, tile, C, W, H):
+    """intersect_tile / intersect_offset with the tile sizes, camera counts and ragged image sizes the reference's call site never passes (it uses 16, C = 1): synthetic
+    means2d / radii / depths (some Gaussians culled, some larger than the image, depths with ties), sorted and unsorted, dense layout — bit for bit against the
+    reference's IntersectTile.cu + radix sort, for the device-sort path and the binned pipeline."""
+    ops, _ = mods
+    rng = np.random.default_rng(100 + tile + C)
+    N = 3000
+    m2d = dev((rng.random((C, N, 2)) * [W * 1.2, H * 1.2] - [W * 0.1, H * 0.1]).astype(np.float32))
+    rad = rng.integers(0, 40, (C, N, 2)).astype(np.int32)
+    rad[rng.random((C, N)) < 0.2] = 0                       # culled
+    rad[:, :5] = 500                                         # larger than the image
+    radii = dev(rad)
+    dep = dev(np.round(rng.random((C, N)) * 50).astype(np.float32) / 10 + 0.5)   # many exact ties: the order inside a tile falls back to the flatten index
+    tw, th = (W + tile - 1) // tile, (H + tile - 1) // tile
+    r_tpg, r_ids, r_fl = ref.intersect_tile(m2d, radii, dep, None, None, C, tile, tw, th, True)
+    r_off = ref.intersect_offset(r_ids, C, tw, th)
+    h_tpg, h_ids, h_fl = ops.intersect_tile(m2d, radii, dep, None, None, C, tile, tw, th, True)
+    h_off = ops.intersect_offset(h_ids, C, tw, th)
+    b_tpg, b_ids, b_fl, b_off = ops.intersect_tile_binned(m2d, radii, dep, C, tile, tw, th, True)
+    ru = ref.intersect_tile(m2d, radii, dep, None, None, C, tile, tw, th, False)
+    hu = ops.intersect_tile(m2d, radii, dep, None, None, C, tile, tw, th, False)
+    exact = dict(tiles_per_gauss=bool(torch.equal(h_tpg, r_tpg)), isect_ids=bool(torch.equal(h_ids, r_ids)), flatten_ids=bool(torch.equal(h_fl, r_fl)),
+                 offsets=bool(torch.equal(h_off, r_off)), binned_isect_ids=bool(torch.equal(b_ids, r_ids)), binned_flatten_ids=bool(torch.equal(b_fl, r_fl)),
+                 binned_offsets=bool(torch.equal(b_off, r_off)), unsorted_isect_ids=bool(torch.equal(hu[1], ru[1])), unsorted_flatten_ids=bool(torch.equal(hu[2], ru[2])))
+    rec = parity_record("intersect_tile, tile %d, %d camera(s), %d x %d: HIP vs reference kernel" % (tile, C, W, H), n_isects=int(r_fl.numel()), **{k: int(v) for k, v in exact.items()})
+    assert all(exact.values()) and rec["n_isects"] > 1000, rec
+
+
 def _make_opaque(sc, seed=29):
     """A third of the scene's Gaussians opaque (opacity 1.0 / 0.9995 / 0.9992) and ~10 px wide on screen: pixels next to their centres
     see opacity x exp(-s) above 0.999 — the alpha clamp (Fwd.cu:239) and its gradient mask (Bwd.cu:318), which no random scene reaches."""
