@@ -500,6 +500,36 @@ def test_intersect_tile_other_tile_sizes_vs_reference(ref, mods, tile, C, W, H):
     assert all(exact.values()) and rec["n_isects"] > 1000, rec
 
 
+@pytest.mark.parametrize("deg", [0, 1, 2, 3, 4])
+def test_spherical_harmonics_operators_vs_reference(ref, mods, deg):
+    """`gsplat::spherical_harmonics_fwd / _bwd` (Ops.h:14-28) called directly, on their own: every degree 0 .. 4 out of K = 25 stored bases (degrees_to_use below the stored
+    degree), un-normalised directions of all magnitudes, with and without masks, with and without the direction gradient — against the reference's SphericalHarmonicsCUDA.cu."""
+    ops, _ = mods
+    rng = np.random.default_rng(40 + deg)
+    N, K = 5000, 25
+    dirs = dev((rng.standard_normal((N, 3)) * np.exp(rng.uniform(-3, 3, (N, 1)))).astype(np.float32))
+    coeffs = dev((rng.standard_normal((N, K, 3)) * 0.5).astype(np.float32))
+    v_col = dev(rng.standard_normal((N, 3)).astype(np.float32))
+    masks = dev(rng.random(N) < 0.7)
+    worst = dict(fwd=0.0, v_coeffs=0.0, v_dirs=0.0)
+    for m in (None, masks):
+        r_col = ref.spherical_harmonics_fwd(deg, dirs, coeffs, m)
+        h_col = ops.spherical_harmonics_fwd(deg, dirs, coeffs, m)
+        sel = slice(None) if m is None else m
+        worst["fwd"] = max(worst["fwd"], float((h_col[sel] - r_col[sel]).abs().max()))
+        for with_dirs in (True, False):
+            r_vc, r_vd = ref.spherical_harmonics_bwd(K, deg, dirs, coeffs, m, v_col, with_dirs)
+            h_vc, h_vd = ops.spherical_harmonics_bwd(K, deg, dirs, coeffs, m, v_col, with_dirs)
+            assert tuple(h_vc.shape) == tuple(r_vc.shape) and bool((h_vc[:, (deg + 1) ** 2:] == 0).all())   # bases above the degree in use get no gradient
+            if m is not None:
+                assert bool((h_vc[~m] == 0).all())
+            worst["v_coeffs"] = max(worst["v_coeffs"], rel_l2(np32(h_vc), np32(r_vc)))
+            if with_dirs and deg > 0:
+                worst["v_dirs"] = max(worst["v_dirs"], rel_l2(np32(h_vd[sel]), np32(r_vd[sel])))
+    rec = parity_record("spherical_harmonics_fwd / _bwd, degree %d of K = 25: HIP vs reference kernel" % deg, fwd_max_err=worst["fwd"], v_coeffs_rel_l2=worst["v_coeffs"], v_dirs_rel_l2=worst["v_dirs"])
+    assert rec["fwd_max_err"] < 1e-5 and rec["v_coeffs_rel_l2"] < 1e-5 and rec["v_dirs_rel_l2"] < 1e-4, rec
+
+
 def _make_opaque(sc, seed=29):
     """A third of the scene's Gaussians opaque (opacity 1.0 / 0.9995 / 0.9992) and ~10 px wide on screen: pixels next to their centres
     see opacity x exp(-s) above 0.999 — the alpha clamp (Fwd.cu:239) and its gradient mask (Bwd.cu:318), which no random scene reaches."""
