@@ -492,7 +492,33 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> rasterize_to_pixels_from_world_3d
     TORCH_CHECK(means.scalar_type() == at::kFloat && colors.scalar_type() == at::kFloat, "float32 only");
     const uint32_t C = tile_offsets.size(0), N = means.size(0);
     const uint32_t channels = colors.size(-1);
-    TORCH_CHECK(channels == 3, "Unsupported number of channels: ", channels);
+    if (channels != 3) {
+        // The reference's --gut call site only passes 3 channels (rasterizer_autograd.cpp:285 stops its depth render modes), but the operator behind it
+        // dispatches CDIM = 1, 2, 3, 4, 5, 8, ... (Rasterization.cpp:106-127; the assert(channels == 3) at :65 is compiled out in a Release build).
+        // The blend is linear in the colours and its weights, alphas and last ids do not depend on them: any channel count = the 3-channel operator
+        // on groups of three channels (the last group zero-padded).  The RGB hot path never comes through here.
+        TORCH_CHECK(channels >= 1, "Unsupported number of channels: ", channels);
+        TORCH_CHECK(g_fwd_ws_ready == nullptr && g_fwd_ws_out == nullptr && g_lists == nullptr, "the fused render path blends 3 channels");
+        at::Tensor renders = at::empty({C, image_height, image_width, channels}, means.options()), alphas, last_ids;
+        std::vector<int64_t> csz = colors.sizes().vec();
+        csz.back() = 3;
+        for (uint32_t c0 = 0; c0 < channels; c0 += 3) {
+            const int64_t k = std::min<uint32_t>(3u, channels - c0);
+            at::Tensor col3 = at::zeros(csz, colors.options());
+            col3.narrow(-1, 0, k).copy_(colors.narrow(-1, c0, k));
+            at::optional<at::Tensor> bg3;
+            if (backgrounds.has_value()) {
+                at::Tensor b = at::zeros({backgrounds->size(0), 3}, backgrounds->options());
+                b.narrow(-1, 0, k).copy_(backgrounds->narrow(-1, c0, k));
+                bg3 = b;
+            }
+            auto r = rasterize_to_pixels_from_world_3dgs_fwd(means, quats, scales, col3, opacities, bg3, masks, image_width, image_height, tile_size, viewmats0, viewmats1, Ks,
+                                                             camera_model, ut_params, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids);
+            renders.narrow(-1, c0, k).copy_(std::get<0>(r).narrow(-1, 0, k));
+            if (c0 == 0) { alphas = std::get<1>(r); last_ids = std::get<2>(r); }
+        }
+        return std::make_tuple(renders, alphas, last_ids);
+    }
     const gsx_cameras cams = make_cams(viewmats0, viewmats1, Ks, camera_model, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, C);
     const gsx_ut_params ut = make_ut(ut_params);
     at::Tensor renders = at::empty({C, image_height, image_width, channels}, means.options());
@@ -549,7 +575,35 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
     if (masks.has_value()) { GSX_CHECK_INPUT(masks.value()); }
     const uint32_t C = tile_offsets.size(0), N = means.size(0);
     const uint32_t channels = colors.size(-1);
-    TORCH_CHECK(channels == 3, "Unsupported number of channels: ", channels);
+    if (channels != 3) {
+        // (see the forward) the loss is a sum over the channels: the gradients of the shared tensors are the sums over the channel groups — the alpha
+        // output's gradient rides on the first group only —, v_colors is per channel
+        TORCH_CHECK(channels >= 1, "Unsupported number of channels: ", channels);
+        TORCH_CHECK(g_fwd_ws_in == nullptr && g_lists == nullptr && g_act == nullptr, "the fused render path blends 3 channels");
+        at::Tensor v_means = at::zeros_like(means), v_quats = at::zeros_like(quats), v_scales = at::zeros_like(scales), v_opacities = at::zeros_like(opacities);
+        at::Tensor v_colors = at::empty_like(colors);
+        std::vector<int64_t> csz = colors.sizes().vec();
+        csz.back() = 3;
+        for (uint32_t c0 = 0; c0 < channels; c0 += 3) {
+            const int64_t k = std::min<uint32_t>(3u, channels - c0);
+            at::Tensor col3 = at::zeros(csz, colors.options());
+            col3.narrow(-1, 0, k).copy_(colors.narrow(-1, c0, k));
+            at::optional<at::Tensor> bg3;
+            if (backgrounds.has_value()) {
+                at::Tensor b = at::zeros({backgrounds->size(0), 3}, backgrounds->options());
+                b.narrow(-1, 0, k).copy_(backgrounds->narrow(-1, c0, k));
+                bg3 = b;
+            }
+            at::Tensor v3 = at::zeros({C, image_height, image_width, 3}, v_render_colors.options());
+            v3.narrow(-1, 0, k).copy_(v_render_colors.narrow(-1, c0, k));
+            auto r = rasterize_to_pixels_from_world_3dgs_bwd(means, quats, scales, col3, opacities, bg3, masks, image_width, image_height, tile_size, viewmats0, viewmats1, Ks,
+                                                             camera_model, ut_params, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids,
+                                                             render_alphas, last_ids, v3, c0 == 0 ? v_render_alphas : at::Tensor());
+            v_means += std::get<0>(r); v_quats += std::get<1>(r); v_scales += std::get<2>(r); v_opacities += std::get<4>(r);
+            v_colors.narrow(-1, c0, k).copy_(std::get<3>(r).narrow(-1, 0, k));
+        }
+        return std::make_tuple(v_means, v_quats, v_scales, v_colors, v_opacities);
+    }
     const gsx_cameras cams = make_cams(viewmats0, viewmats1, Ks, camera_model, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, C);
     const gsx_ut_params ut = make_ut(ut_params);
     at::Tensor v_means = at::empty_like(means);  // the C ABI overwrites all five (zero-fills itself where it scatters)

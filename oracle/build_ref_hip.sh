@@ -41,7 +41,9 @@ for f in IntersectTile ProjectionUT3DGSFused RasterizeToPixelsFromWorld3DGSFwd R
   ( "$HIPCC" -x hip --offload-arch=gfx950 -O3 $EXTRA -include "$SHIM/prelude.h" $COMMON -c "$REF/gsplat/$f.cu" -o "$OBJ/$f.o" ) & pids+=($!)
 done
 for f in Intersect Projection Rasterization SphericalHarmonics QuatToRotmat Relocation; do
-  ( g++ -O2 $COMMON -c "$REF/gsplat/$f.cpp" -o "$OBJ/$f.host.o" ) & pids+=($!)
+  # -DNDEBUG: the reference's Release configuration (CMake adds it).  Rasterization.cpp:65 asserts channels == 3 in front of a dispatch over CDIM = 1, 2, 3, 4, 5, 8, ...
+  # (:106-127): with the assert compiled out, as in the binaries the reference ships, its depth render modes (1 and 4 channels, rasterizer.cpp:272-294) reach the kernels
+  ( g++ -O2 -DNDEBUG $COMMON -c "$REF/gsplat/$f.cpp" -o "$OBJ/$f.host.o" ) & pids+=($!)
 done
 ( g++ -O2 $COMMON -I"$PYINC" -I"$PB11" -DTORCH_EXTENSION_NAME=$NAME -DPYBIND11_MODULE_NAME=$NAME -c "$SHIM/ref_bind.cpp" -o "$OBJ/ref_bind.o" ) & pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done

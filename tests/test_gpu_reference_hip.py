@@ -530,6 +530,43 @@ def test_spherical_harmonics_operators_vs_reference(ref, mods, deg):
     assert rec["fwd_max_err"] < 1e-5 and rec["v_coeffs_rel_l2"] < 1e-5 and rec["v_dirs_rel_l2"] < 1e-4, rec
 
 
+@pytest.mark.parametrize("channels", [1, 2, 4, 5])
+@pytest.mark.parametrize("name", ["pinhole_sh3_comp", "rolling_top_to_bottom"])
+def test_blend_channel_counts_vs_reference(ref, mods, name, channels):
+    """The blend operators with channel counts other than 3.  The reference's `--gut` call site only ever passes 3 (rasterizer_autograd.cpp:285: "Only 3 colors are
+    supported currently" — its depth render modes stop there), but the operator it calls dispatches CDIM = 1, 2, 3, 4, 5, 8, ... (Rasterization.cpp:106-127; the
+    `assert(channels == 3)` in front of it is compiled out in a Release build, and in oracle/build_ref_hip.sh).  The drop-in serves any count with its 3-channel operators
+    on groups of three channels (csrc/ops_shim.cpp): forward and backward against the reference's CDIM kernels, with a background and a gradient through the alpha output;
+    the last channel carries the per-Gaussian depths (what a depth render mode would blend)."""
+    ops, scenes = mods
+    sc, cam = ref_hip_cases.cases(scenes)[name]
+    a = _scene_args(sc, cam)
+    W, H, N = a["width"], a["height"], a["means"].shape[0]
+    cam_kw = {k: a[k] for k in ("camera_model", "shutter", "viewmats1", "radial", "tangential", "thin_prism", "calc_compensations")}
+    R = ref_hip.render_chain(ref, a["means"], a["quats"], a["scales"], a["opacities"], a["sh"], a["sh_degree"], a["viewmat"], a["K"], W, H, a["background"], **cam_kw)
+    rng = np.random.default_rng(70 + channels)
+    colors = dev(np.concatenate([rng.random((1, N, channels - 1)), np32(R["depths"])[..., None]], -1).astype(np.float32))   # the last channel: the depths, as the depth modes pass them
+    bg = dev(rng.random((1, channels)).astype(np.float32))
+    v_rc, v_ra = dev(rng.standard_normal((1, H, W, channels)).astype(np.float32)), dev(rng.standard_normal((1, H, W, 1)).astype(np.float32))
+    op = a["opacities"][None].contiguous()
+    dist = (a["radial"], a["tangential"], a["thin_prism"])
+    rargs = (a["means"], a["quats"], a["scales"], colors, op, bg, None, W, H, 16, a["viewmat"], a["viewmats1"], a["K"], a["camera_model"], None, a["shutter"], *dist,
+             R["tile_offsets"], R["flatten_ids"])
+    cm, shut = _hip_enums(ops, a)
+    hargs = (a["means"], a["quats"], a["scales"], colors, op, bg, None, W, H, 16, a["viewmat"], a["viewmats1"], a["K"], cm, ops.UnscentedTransformParameters(), shut, *dist,
+             R["tile_offsets"], R["flatten_ids"])
+    r_ren, r_alp, r_last = ref.rasterize_to_pixels_from_world_3dgs_fwd(*rargs)
+    h_ren, h_alp, h_last = ops.rasterize_to_pixels_from_world_3dgs_fwd(*hargs)
+    r_g = ref.rasterize_to_pixels_from_world_3dgs_bwd(*rargs, r_alp, r_last, v_rc, v_ra)
+    h_g = ops.rasterize_to_pixels_from_world_3dgs_bwd(*hargs, h_alp, h_last, v_rc, v_ra)
+    scale = float(colors.max())
+    rec = parity_record("%s, %d channel(s): HIP vs reference kernel" % (name, channels), render_max_err_rel=float((h_ren - r_ren).abs().max()) / scale,
+                        alpha_max_err=float((h_alp - r_alp).abs().max()), last_id_mismatch=int((h_last != r_last).sum()),
+                        **{n: rel_l2(np32(g), np32(r)) for n, g, r in zip(GRADS, h_g, r_g)})
+    assert tuple(h_ren.shape) == tuple(r_ren.shape) == (1, H, W, channels) and [tuple(g.shape) for g in h_g] == [tuple(g.shape) for g in r_g]
+    assert rec["render_max_err_rel"] < 1e-4 and rec["alpha_max_err"] < 1e-4 and rec["last_id_mismatch"] == 0 and all(rec[g] < 1e-3 for g in GRADS), rec
+
+
 def _make_opaque(sc, seed=29):
     """A third of the scene's Gaussians opaque (opacity 1.0 / 0.9995 / 0.9992) and ~10 px wide on screen: pixels next to their centres
     see opacity x exp(-s) above 0.999 — the alpha clamp (Fwd.cu:239) and its gradient mask (Bwd.cu:318), which no random scene reaches."""
