@@ -318,7 +318,7 @@ def test_small_rolling_shutter_other_directions(ref, mods, shutter):
     _stagewise(ref, ops, sc, cam, "small case, " + shutter.lower())
 
 
-@pytest.mark.parametrize("case", ["ut_loose", "ut_spread", "planes_clip"])
+@pytest.mark.parametrize("case", ["ut_loose", "ut_spread", "planes_clip", "no_opacities"])
 @pytest.mark.parametrize("name", ["pinhole_sh3_comp", "fisheye"])
 def test_projection_non_default_parameters_vs_reference(ref, mods, name, case):
     """`projection_ut_3dgs_fused` with the parameters every call site of the reference leaves at their defaults (rasterizer.cpp:176-181: UnscentedTransformParameters{},
@@ -331,14 +331,16 @@ def test_projection_non_default_parameters_vs_reference(ref, mods, name, case):
     W, H = a["width"], a["height"]
     ut_vals, eps2d, near, far, clip = {"ut_loose": ((0.8, 2.0, 0.0, -0.3, False), 0.3, 0.01, 1e4, 0.0),    # wide sigma points, valid only in the inner 40 % of the image, invalid ones allowed
                                        "ut_spread": ((0.6, 1.0, 1.5, -0.3, True), 0.3, 0.01, 1e4, 0.0),    # another spread, every sigma point must land in the inner 40 %
-                                       "planes_clip": ((0.1, 2.0, 0.0, 0.1, True), 0.7, 2.3, 2.8, 3.5)}[case]  # the scene's depths are 2 .. 3, its radii 2 .. 9 px
+                                       "planes_clip": ((0.1, 2.0, 0.0, 0.1, True), 0.7, 2.3, 2.8, 3.5),      # the scene's depths are 2 .. 3, its radii 2 .. 9 px
+                                       "no_opacities": ((0.1, 2.0, 0.0, 0.1, True), 0.3, 0.01, 1e4, 0.0)}[case]  # opacities = None (optional, Ops.h:79): the 3.33-sigma extent for everybody
+    opac = None if case == "no_opacities" else a["opacities"]
     cm, shut = _hip_enums(ops, a)
     ut = ops.UnscentedTransformParameters()
     ut.alpha, ut.beta, ut.kappa, ut.in_image_margin_factor, ut.require_all_sigma_points_valid = ut_vals
     dist = (a["radial"], a["tangential"], a["thin_prism"])
-    R = ref.projection_ut_3dgs_fused(a["means"], a["quats"], a["scales"], a["opacities"], a["viewmat"], a["viewmats1"], a["K"], W, H, eps2d, near, far, clip,
+    R = ref.projection_ut_3dgs_fused(a["means"], a["quats"], a["scales"], opac, a["viewmat"], a["viewmats1"], a["K"], W, H, eps2d, near, far, clip,
                                      a["calc_compensations"], a["camera_model"], torch.tensor([float(x) for x in ut_vals]), a["shutter"], *dist)
-    P = ops.projection_ut_3dgs_fused(a["means"], a["quats"], a["scales"], a["opacities"], a["viewmat"], a["viewmats1"], a["K"], W, H, eps2d, near, far, clip,
+    P = ops.projection_ut_3dgs_fused(a["means"], a["quats"], a["scales"], opac, a["viewmat"], a["viewmats1"], a["K"], W, H, eps2d, near, far, clip,
                                      a["calc_compensations"], cm, ut, shut, *dist)
     pk = ["radii", "means2d", "depths", "conics", "compensations"]
     tonp = lambda X: dict(zip(pk, [None if x is None or x.numel() == 0 else x.cpu().numpy() for x in X]))  # noqa: E731
@@ -349,7 +351,7 @@ def test_projection_non_default_parameters_vs_reference(ref, mods, name, case):
     okw = dict(camera_model=a["camera_model"], shutter=a["shutter"], calc_compensations=a["calc_compensations"], ut=ut_vals, eps2d=eps2d, near_plane=near, far_plane=far, radius_clip=clip)
     for k in ("viewmats1", "radial", "tangential", "thin_prism"):
         okw[k] = None if cam.get(k) is None else np.asarray(cam[k], np.float32)
-    O = oracle.projection_ut(f("means"), f("quats"), f("scales"), f("opacities"), f("viewmat")[None], f("K")[None], W, H, **okw)
+    O = oracle.projection_ut(f("means"), f("quats"), f("scales"), None if opac is None else f("opacities"), f("viewmat")[None], f("K")[None], W, H, **okw)
     rec_o = _projection_stats(tag, "oracle", Rn, dict(zip(pk, O)))
     n = rec["gaussians"]
     # the parameters bite: the result differs from the default call's, and not everything is gone
