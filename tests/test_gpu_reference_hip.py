@@ -473,11 +473,12 @@ def test_two_cameras_per_call_vs_reference(ref, mods, background):
     assert exact and rec["rgb_max_err"] < 1e-4 and rec["alpha_max_err"] < 1e-4 and rec["last_id_mismatch"] == 0 and all(rec[g] < 1e-3 for g in GRADS), rec
 
 
-@pytest.mark.parametrize("tile,C,W,H", [(8, 1, 128, 128), (32, 1, 150, 90), (64, 3, 200, 120), (16, 3, 150, 90), (4, 1, 64, 48)])
+@pytest.mark.parametrize("tile,C,W,H", [(8, 1, 128, 128), (32, 1, 150, 90), (64, 3, 200, 120), (16, 3, 150, 90), (4, 1, 64, 48), (16, 1, 7680, 4320)])
 def test_intersect_tile_other_tile_sizes_vs_reference(ref, mods, tile, C, W, H):
     """intersect_tile / intersect_offset with the tile sizes, camera counts and ragged image sizes the reference's call site never passes (it uses 16, C = 1): synthetic
     means2d / radii / depths (some Gaussians culled, some larger than the image, depths with ties), sorted and unsorted, dense layout — bit for bit against the
-    reference's IntersectTile.cu + radix sort, for the device-sort path and the binned pipeline."""
+    reference's IntersectTile.cu + radix sort, for the device-sort path and the binned pipeline (the 8K frame has 129 600 tiles: above the binned pipeline's
+    36 864-tile limit, where it hands over to the device-wide sort)."""
     ops, _ = mods
     rng = np.random.default_rng(100 + tile + C)
     N = 3000
