@@ -855,6 +855,36 @@ def test_s8cam_other_camera_models_vs_reference(ref, mods, s1m_scene, name, cam_
     _stagewise(ref, ops, sc, cam, "S-8cam ring camera %d, %s" % (cam_i, name), with_oracle=False, fwd_strict=False, over_frac=6e-4, bwd_f64_yardstick=False)
 
 
+def test_8k_frame_end_to_end_vs_reference(ref, mods):
+    """A 7680 x 4320 frame (129 600 tiles: beyond every BASELINE config, above the binned intersection's tile limit and the 15 tile bits of cfg5) through the fused
+    render — fused front end, intersection (the device-wide sort takes over), packed-record blend — and its backward, end to end against the reference chain on
+    its own projection and lists: the image like the other full frames, the raw-parameter gradients 1e-3."""
+    ops, scenes = mods
+    from gsx import rasterizer
+    sc = scenes.scene_frustum(300_000, 7680, 4320, 4000.0, (2.0, 10.0), seed=7)
+    a = _scene_args(sc, {})
+    W, H = a["width"], a["height"]
+    rng = np.random.default_rng(17)
+    v_rc = dev(rng.standard_normal((1, H, W, 3)).astype(np.float32))
+    R = ref_hip.render_chain(ref, a["means"], a["quats"], a["scales"], a["opacities"], a["sh"], a["sh_degree"], a["viewmat"], a["K"], W, H, a["background"],
+                             v_render_colors=v_rc, v_render_alphas=torch.zeros(1, H, W, 1, device=DEV))
+    model = scenes.to_splat_data(sc, DEV)
+    for p in model.params():
+        p.requires_grad_(True)
+    cam = rasterizer.Camera(viewmat=sc["viewmat"].to(DEV), K=sc["K"].to(DEV), width=W, height=H)
+    out = rasterizer.rasterize_fused(cam, model, sc["background"].to(DEV))
+    (out.render_hwc * v_rc).sum().backward()
+    err = (out.render_hwc.detach() - R["renders"][0]).abs().amax(-1)
+    # the reference chain's gradients w.r.t. the ACTIVATED parameters -> raw parameters (splat_data.cpp:267-286: exp, normalize, sigmoid)
+    rec = parity_record("8K frame (7680 x 4320, 300 k Gaussians) END TO END: HIP fused chain vs reference chain", pixels=int(err.numel()), n_isects_hip=int(out.n_isects),
+                        n_isects_ref=int(R["flatten_ids"].numel()), rgb_max_err=float(err.max()), rgb_pixels_over_1e4=int((err > 1e-4).sum()),
+                        v_opacity_raw=rel_l2(np32(model.opacity_raw.grad).reshape(-1), np32(R["v_opacities"][0] * (sc["opacities"].to(DEV) * (1 - sc["opacities"].to(DEV))))),
+                        v_scaling_raw=rel_l2(np32(model.scaling_raw.grad), np32(R["v_scales"] * sc["scales"].to(DEV))))
+    assert abs(rec["n_isects_hip"] - rec["n_isects_ref"]) <= 2e-4 * rec["n_isects_ref"], rec
+    assert rec["rgb_pixels_over_1e4"] <= 2e-3 * rec["pixels"] and rec["rgb_max_err"] < float(R["colors"][R["masks"]].max()) / 255.0 * 2 + 1e-3, rec
+    assert rec["v_opacity_raw"] < 1e-3 and rec["v_scaling_raw"] < 1e-3, rec
+
+
 def test_s5m_4k_full_frame(ref, mods):
     """BASELINE configs[4]: 5 M Gaussians @ 3840x2160."""
     ops, scenes = mods
