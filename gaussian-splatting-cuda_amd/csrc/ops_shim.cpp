@@ -76,6 +76,15 @@ gsx_cameras make_cams(const at::Tensor& viewmats0, const at::optional<at::Tensor
     c.camera_model = (int32_t)model;
     c.shutter = (int32_t)rs;
     c.radial = fptr(radial);
+    // The pinhole model reads SIX radial coefficients per camera (Cameras.cuh: OpenCVPinholeCameraModel, k1 .. k6 of the rational model); the reference's glue pads what a
+    // camera carries to FOUR (rasterizer.cpp:183-194: a COLMAP OPENCV camera has k1, k2) and its kernels then read two floats past the tensor.  Here the missing
+    // coefficients are zeros: the tensor is padded to six per camera (kept alive until this thread's next call: the launch that follows reads it).
+    if (model == gsplat::PINHOLE && radial.has_value() && radial->defined() && radial->numel() > 0 && radial->numel() < (int64_t)6 * C && radial->numel() % C == 0) {
+        static thread_local at::Tensor padded;
+        const int64_t per = radial->numel() / C;
+        padded = at::constant_pad_nd(radial->reshape({(int64_t)C, per}), {0, 6 - per}, 0).contiguous();
+        c.radial = padded.data_ptr<float>();
+    }
     c.tangential = fptr(tangential);
     c.thin_prism = fptr(thin_prism);
     return c;

@@ -76,6 +76,51 @@ def _compare(mods, sc, tag, strict):
     return P, v_img, v_alpha
 
 
+def _render_cam(mod, P, sc, v_img, v_alpha, radial, tangential, camera_model):
+    vm, K = sc["viewmat"], sc["K"]
+    for t in P.values():
+        t.grad = None
+    img, alpha, radii = mod.render(P["means"], P["sh0"], P["shN"], P["scaling_raw"], P["rotation_raw"], P["opacity_raw"], sc["sh_degree"],
+                                   vm[:3, :3].contiguous(), vm[:3, 3].contiguous(), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]),
+                                   sc["width"], sc["height"], sc["background"].to(DEV), radial, tangential, camera_model)
+    ((img * v_img).sum() + (alpha * v_alpha).sum()).backward()
+    torch.cuda.synchronize()
+    return img.detach(), alpha.detach(), {k: P[k].grad.detach().clone() for k in NAMES}
+
+
+@pytest.mark.parametrize("camera", ["opencv_pinhole", "fisheye"])
+def test_distorted_cameras_through_the_reference_callers(mods, camera):
+    """gs::training::rasterize with a distorted camera (rasterizer.cpp:183-207 hands the camera's radial / tangential coefficients to every operator): a COLMAP
+    OPENCV-style pinhole (k1, k2, p1, p2) and an equidistant fisheye (k1 .. k4) on the drop-in against the same call on the reference's kernels.  The pinhole
+    kernels read SIX radial coefficients; the reference's glue pads a camera's to FOUR and its kernels read two floats past the tensor — the drop-in pads to six
+    (csrc/ops_shim.cpp: make_cams), so the two-coefficient camera must give, bit for bit, what the same camera with six explicit coefficients gives; the reference
+    side is given the six explicit ones (defined behaviour on both sides)."""
+    import gsx  # noqa: F401
+    from gsx import scenes
+    gsx_mod, ref_mod = mods
+    sc = scenes.scene_small()
+    H, W = sc["height"], sc["width"]
+    g = torch.Generator(device=DEV).manual_seed(9)
+    v_img, v_alpha = torch.randn(3, H, W, device=DEV, generator=g), torch.randn(1, H, W, device=DEV, generator=g)
+    P = _raw_params(sc)
+    if camera == "opencv_pinhole":
+        short, full, tang, model = torch.tensor([0.05, -0.02]), torch.tensor([0.05, -0.02, 0.0, 0.0, 0.0, 0.0]), torch.tensor([0.002, -0.001]), 0
+    else:
+        short = full = torch.tensor([0.02, -0.005, 0.001, 0.0])
+        tang, model = torch.empty(0), 2
+    img_r, alp_r, grad_r = _render_cam(ref_mod, P, sc, v_img, v_alpha, full, tang, model)
+    img_g, alp_g, grad_g = _render_cam(gsx_mod, P, sc, v_img, v_alpha, short, tang, model)
+    img_f, alp_f, grad_f = _render_cam(gsx_mod, P, sc, v_img, v_alpha, full, tang, model)
+    assert torch.equal(img_g, img_f) and torch.equal(alp_g, alp_f)   # short coefficient vectors = zero-padded ones
+    img_p, _, _ = _render_cam(gsx_mod, P, sc, v_img, v_alpha, torch.empty(0), torch.empty(0), model)
+    rec = parity_record("cfg1 through a distorted camera (%s): the reference's gs::training::rasterize on the gsx drop-in vs on the reference's own kernels" % camera,
+                        rgb_max_err=float((img_g - img_r).abs().max()), alpha_max_err=float((alp_g - alp_r).abs().max()),
+                        distortion_moves_the_image_by=float((img_g - img_p).abs().max()), **{k: rel_l2(grad_g[k].cpu().numpy(), grad_r[k].cpu().numpy()) for k in NAMES})
+    assert rec["rgb_max_err"] < 1e-4 and rec["alpha_max_err"] < 1e-4 and rec["distortion_moves_the_image_by"] > 1e-2, rec
+    for k in NAMES:
+        assert rec[k] < 1e-3, (k, rec)
+
+
 def test_cfg1_reference_callers_on_the_drop_in(mods):
     """BASELINE configs[0]: 10 k Gaussians, SH degree 0, 256 x 256."""
     import gsx  # noqa: F401
