@@ -18,6 +18,20 @@ static std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> render(torch::Ten
     return {out.image, out.alpha, out.radii};
 }
 
+// the same call with `antialiased = true` (the reference's --antialiasing): the projection also returns the compensation factors and the glue multiplies the
+// opacities with them (rasterizer.cpp:181,236-246)
+static std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> render_antialiased(torch::Tensor means, torch::Tensor sh0, torch::Tensor shN, torch::Tensor scaling_raw,
+                                                                                   torch::Tensor rotation_raw, torch::Tensor opacity_raw, int sh_degree, torch::Tensor R,
+                                                                                   torch::Tensor T, float fx, float fy, float cx, float cy, int width, int height,
+                                                                                   torch::Tensor bg) {
+    gs::SplatData model(sh_degree, means, sh0, shN, scaling_raw, rotation_raw, opacity_raw, 1.0f);
+    model.set_active_sh_degree(sh_degree);
+    gs::Camera cam(R, T, fx, fy, cx, cy, torch::empty({0}), torch::empty({0}), gsplat::CameraModelType::PINHOLE, "parity", "", width, height, 0);
+    auto out = gs::training::rasterize(cam, model, bg, 1.0f, false, true);
+    return {out.image, out.alpha, out.radii};
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("render", &render, "gs::training::rasterize of the reference, RGB mode: (image [3,H,W], alpha [1,H,W], radii [N])");
+    m.def("render_antialiased", &render_antialiased, "the same with antialiased = true");
 }
