@@ -18,8 +18,8 @@ static std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> render(torch::Ten
     return {out.image, out.alpha, out.radii};
 }
 
-// the same call with `antialiased = true` (the reference's --antialiasing): the projection also returns the compensation factors and the glue multiplies the
-// opacities with them (rasterizer.cpp:181,236-246)
+// the same call with `antialiased = true` (the reference's --antialiasing): the projection is asked for the compensation factors (rasterizer.cpp:181,241);
+// on this path the glue never applies them
 static std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> render_antialiased(torch::Tensor means, torch::Tensor sh0, torch::Tensor shN, torch::Tensor scaling_raw,
                                                                                    torch::Tensor rotation_raw, torch::Tensor opacity_raw, int sh_degree, torch::Tensor R,
                                                                                    torch::Tensor T, float fx, float fy, float cx, float cy, int width, int height,

@@ -122,8 +122,8 @@ def test_distorted_cameras_through_the_reference_callers(mods, camera):
 
 
 def test_antialiased_render_through_the_reference_callers(mods):
-    """gs::training::rasterize(..., antialiased = true) — the reference's `--antialiasing`: projection with calc_compensations, opacities x compensations in its glue
-    (rasterizer.cpp:181,236-246) — on the drop-in against the same call on the reference's kernels."""
+    """gs::training::rasterize(..., antialiased = true) — the reference's `--antialiasing`: the projection is called with calc_compensations (rasterizer.cpp:181,241;
+    the glue of this path then leaves the factors unused) — on the drop-in against the same call on the reference's kernels."""
     import gsx  # noqa: F401
     from gsx import scenes
     gsx_mod, ref_mod = mods
