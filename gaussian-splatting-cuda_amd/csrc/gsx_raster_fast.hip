@@ -1678,6 +1678,8 @@ __global__ __launch_bounds__(RB, GSX_GM_WAVES) void raster_bwd_gq_kernel(RasterA
 // 184 B of scratch per lane) measured +0.010 / +0.026 / +0.054 ms on the S-1M step: the kernel moves ~240 MB — 64 B records at scattered
 // slots — in ~66 us and is near what such a read pattern gets from HBM, more chains in flight do not help it.)
 // ACT (round 6): the activation Jacobians as the epilogue (ActEpilogue, gsx_raster_common.hpp; C == 1): v_quats / v_scales / v_opacities are not written.
+// (the walk hides its 64 B pointer chases behind other waves: the kernel must stay at 4 waves / SIMD, <= 128 VGPRs — at 132, three waves, the S-1M gather
+// went from 69 to 79 us; a forced bound spills and costs the same.  -Rpass-analysis=kernel-resource-usage after every change to this kernel.)
 template <int KIND, int NCH, bool ACT>
 __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const float4* __restrict__ ws_rec,
                                                              int32_t* __restrict__ ws_head, float* __restrict__ v_means,
@@ -1692,11 +1694,11 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
 #pragma unroll
     for (int k = 0; k < 10; ++k) geo[k] = 0.f;
     bool any = false;
+    uint32_t clamped = 0u;
     RawG raw;
     raw.g = (int32_t)gi;
     float4 q_raw = make_float4(0.f, 0.f, 0.f, 0.f);
     float v_opac_act = 0.f;
-    if (ACT) q_raw = reinterpret_cast<const float4*>(act.rotation_raw)[gi];   // issued before the record walk
     const size_t cn = (size_t)a.C * a.N;
     for (uint32_t c = 0; c < a.C; ++c) {
         const size_t g = (size_t)c * a.N + gi;
@@ -1830,10 +1832,20 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
         const CamFrame cf = make_cam_frame(sp);
         const float tb0[4] = {0.f, 0.f, 0.f, 0.f};
         FastRec r;
+        {   // from here on raw.sc holds the conditioned scales (gsx_record.hpp: MAX_SCALE_RATIO; idempotent: a second camera adds no bits)
+            const f3 sc_c = conditioned_scales(raw.sc);
+            clamped |= clamped_axes(raw.sc, sc_c);
+            raw.sc = sc_c;
+        }
         make_record<true>(raw, cf, tb0, r);
-        moments_to_gradients(raw, cf, r, Mo, geo);
+        moments_to_gradients(raw, cf, r, Mo, geo, clamped);
     }
     if (!in) return;
+    // One non-finite gradient poisons a Gaussian's Adam state for good, and a NaN opacity takes the next refine event's multinomial down with it (a device
+    // assert).  The known source — records of splats thinner than fp32 can condition, gsx_record.hpp: MAX_SCALE_RATIO — is closed at the record; this is the
+    // net under whatever else fp32 can do to ONE Gaussian: its geometric gradient is dropped for the iteration instead of written.
+#pragma unroll
+    for (int k = 0; k < 10; ++k) geo[k] = fabsf(geo[k]) < INFINITY ? geo[k] : 0.f;
     v_means[(size_t)gi * 3] = geo[0]; v_means[(size_t)gi * 3 + 1] = geo[1]; v_means[(size_t)gi * 3 + 2] = geo[2];
     if (!ACT) {
         reinterpret_cast<float4*>(v_quats)[gi] = make_float4(geo[3], geo[4], geo[5], geo[6]);
@@ -1842,9 +1854,9 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
     }
     // ---- activation Jacobians (the arithmetic of splat_activations_bwd_kernel, gsx_sh.hip; an untouched Gaussian has zero gradients and
     // still gets its regulariser terms — it needs its activated scale / opacity for them: loaded here, the walk did not)
-    if (!any) {
+    if (!any || clamped != 0u) {   // (a clamped axis: the chain rule and the regulariser below want the TRUE activated scale back — a rare reload)
         raw.sc = {a.scales[(size_t)gi * 3], a.scales[(size_t)gi * 3 + 1], a.scales[(size_t)gi * 3 + 2]};
-        raw.opac = a.opacities[gi];
+        if (!any) raw.opac = a.opacities[gi];
     }
     const float sc[3] = {raw.sc.x, raw.sc.y, raw.sc.z};
 #pragma unroll
@@ -1853,6 +1865,7 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
         if (act.scale_reg != 0.f) gk = fmaf(act.scale_reg, sc[k], gk);
         act.v_scaling_raw[(size_t)gi * 3 + k] = gk;
     }
+    q_raw = reinterpret_cast<const float4*>(act.rotation_raw)[gi];   // (loaded here, not in front of the record walk: four registers less across the walk and the chain rule keep the kernel at 4 waves / SIMD)
     const float nrm = sqrtf(q_raw.x * q_raw.x + q_raw.y * q_raw.y + q_raw.z * q_raw.z + q_raw.w * q_raw.w);
     float4 o;
     if (nrm > 1e-12f) {

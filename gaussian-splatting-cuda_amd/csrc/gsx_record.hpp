@@ -62,6 +62,24 @@ struct FastRec {
     float Mt[3][3];  // M(r,c) = (1/s_r) R(c,r)
 };
 
+// Round 6: the Delta-form's conditioning limit.  Its record is built from the cofactors of A = diag(1/s) R^T Rc, whose entries differ by the SQUARE of
+// the scale ratio: up to ~1e4 : 1 (needles, discs a trained model normally holds) fp32 carries it — the regimes of tests/test_gpu_reference_hip.py —,
+// at 3e4 : 1 the forward is 8e-3 off and the Gaussian-major backward returns NaN, at 3e5 : 1 the image is 0.05 off (tools/pancake_probe.py).  Long MCMC
+// runs DO get there: the scale regulariser drives the normal of a flat surface splat to 1e-6 .. 1e-9 of its extent (25 000 iterations of
+// examples/train_synthetic.py: ratios to 2e7, and every second run ended in non-finite parameters).  A disc of thickness s_max / 8192 and one of
+// thickness 0 are the same splat to a pixel's ray — the response is the in-plane Gaussian at the piercing point, the thickness enters with
+// (s_thin / s_wide)^2 tan^2(incidence) ~ 1.5e-8 tan^2 —, so the record is built from scales clamped to s_max / 8192 from below: a no-op (bit for bit)
+// for every ratio below it, the reference's image (1.6e-4, the threshold-decision floor) beyond it.  The clamped axis carries no scale gradient.
+constexpr float MAX_SCALE_RATIO = 8192.f;
+GSX_DEV f3 conditioned_scales(f3 s) {
+    const float lo = fmaxf(fmaxf(s.x, s.y), s.z) * (1.f / MAX_SCALE_RATIO);
+    return {fmaxf(s.x, lo), fmaxf(s.y, lo), fmaxf(s.z, lo)};
+}
+
+// bit k: axis k of `s` is held by the clamp (its scale gradient is dropped)
+GSX_DEV uint32_t clamped_axes(f3 s, f3 c) { return (s.x < c.x ? 1u : 0u) | (s.y < c.y ? 2u : 0u) | (s.z < c.z ? 4u : 0u); }
+
+// r.sc: CONDITIONED scales (the callers — store_packed_record, the backward's gather — pass conditioned_scales(scales))
 template <bool BWD>
 GSX_DEV void make_record(const RawG& r, const CamFrame& cf, const float tb[4], FastRec& o) {
     const m33 R = quat_to_rotmat(r.q.x, r.q.y, r.q.z, r.q.w);
@@ -148,7 +166,8 @@ GSX_DEV void make_record(const RawG& r, const CamFrame& cf, const float tb[4], F
 // (tests/test_gpu_reference_hip.py::test_trained_model_regimes_vs_reference[needles]: the tensor's rel-L2 against the reference kernel 3.2e-3 -> below 1e-4).
 // Mo[4..14] = (Wa00, Wa01, Wa11, Wa0, Wa1, Wb, Wb0, Wb1, Wb00, Wb01, Wb11); fisheye: with the pixel's w folded in as the kernels do (the map is
 // the same).  geo[0..2] += v_mean, geo[3..6] += v_quat (raw, wxyz), geo[7..9] += v_scale.
-GSX_DEV void moments_to_gradients(const RawG& raw, const CamFrame& cf, const FastRec& r, const float* __restrict__ Mo, float* __restrict__ geo) {
+// raw.sc: the conditioned scales the record was made from; `clamped` = clamped_axes(): those axes get no scale gradient.
+GSX_DEV void moments_to_gradients(const RawG& raw, const CamFrame& cf, const FastRec& r, const float* __restrict__ Mo, float* __restrict__ geo, uint32_t clamped = 0u) {
     const float kap = -r.inv_d0;                 // 2 / d0 times the -1/2 of dalpha/dD that the blend kernel leaves out of its weights
     const float kb = kap / HALF_LOG2E;           // b was accumulated with D scaled by 0.5 log2 e
     const float isL = 1.f / r.sL;                // the kernels' x carries sL = sqrt(0.5 log2 e / d0)
@@ -174,7 +193,7 @@ GSX_DEV void moments_to_gradients(const RawG& raw, const CamFrame& cf, const Fas
     const float sv[3] = {raw.sc.x, raw.sc.y, raw.sc.z};
     const float isv[3] = {1.f / raw.sc.x, 1.f / raw.sc.y, 1.f / raw.sc.z};
 #pragma unroll
-    for (int k = 0; k < 3; ++k) geo[7 + k] += -G[k][k] * isv[k];
+    for (int k = 0; k < 3; ++k) geo[7 + k] += ((clamped >> k) & 1u) ? 0.f : -G[k][k] * isv[k];
     float vMt[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -242,7 +261,9 @@ GSX_DEV void store_null_record(float4* __restrict__ o) {
 GSX_DEV void store_packed_record(const RawG& raw, const CamFrame& cf, float4* __restrict__ o, uint32_t rect_x = RECT_ALL, uint32_t rect_y = RECT_ALL) {
     const float tb0[4] = {0.f, 0.f, 0.f, 0.f};
     FastRec r;
-    make_record<false>(raw, cf, tb0, r);
+    RawG rc = raw;
+    rc.sc = conditioned_scales(raw.sc);
+    make_record<false>(rc, cf, tb0, r);
     if (!(r.hx > -INFINITY) && !(r.lo + LOG2_255 > 0.f)) r.lo = -INFINITY;  // never visible (opacity <= 1/255)
     if (!(fabsf(r.l00) < INFINITY)) r.lo = -INFINITY;                       // camera-space z == 0: skipped
     o[0] = make_float4(r.u0, r.v0, r.l00, r.l01);

@@ -570,6 +570,60 @@ def test_blend_channel_counts_vs_reference(ref, mods, name, channels):
     assert rec["render_max_err_rel"] < 1e-4 and rec["alpha_max_err"] < 1e-4 and rec["last_id_mismatch"] == 0 and all(rec[g] < 1e-3 for g in GRADS), rec
 
 
+@pytest.mark.parametrize("bwd_kernel", ["gq", "pm"])
+@pytest.mark.parametrize("thin_exp", [-5.0, -7.0, -9.0])
+def test_thin_discs_vs_reference_and_float64(ref, mods, thin_exp, bwd_kernel, monkeypatch):
+    """Splats a long MCMC run flattens to nothing: 300 of 3 000 Gaussians with one scale axis at 1e-5 / 1e-7 / 1e-9 and the other two at 0.2 - 0.4 (scale
+    ratios 3e4 .. 3e8; 25 000 iterations of examples/train_synthetic.py reach 2e7).  Found in round 6 (tools/soak_run.py, tools/pancake_probe.py): the
+    Delta-form's record lost the image by 8e-3 .. 0.4 there and its Gaussian-major backward returned NaN — every second long run ended in non-finite
+    parameters.  With the record built from scales clamped to s_max / 8192 (gsx_record.hpp): the image against the reference's kernel like any other
+    frame; every gradient finite; means / quats / colours / opacities and the scale gradients of every axis but the thin ones within 1e-3 of the reference
+    kernel — and the thin axes, where the reference kernel's own fp32 gradient is noise (0.1 .. 1e8 x the float64 value), are no further from float64
+    than the reference kernel is (they come back as zeros)."""
+    ops, scenes = mods
+    monkeypatch.setenv("GSX_TEST_SWITCHES", "1")
+    monkeypatch.setenv("GSX_BWD", bwd_kernel)
+    sc = ref_hip_cases.small_scene(scenes, N=3000)
+    g = torch.Generator().manual_seed(3)
+    N = 3000
+    pick = torch.randperm(N, generator=g)[:300]
+    sc["scales"][pick] = torch.rand(300, 3, generator=g) * 0.2 + 0.2
+    ax = torch.randint(0, 3, (300,), generator=g)
+    sc["scales"][pick, ax] = 10.0 ** thin_exp
+    sc["opacities"][pick] = torch.rand(300, generator=g) * 0.15 + 0.05
+    a = _scene_args(sc, {})
+    W, H = a["width"], a["height"]
+    v_rc, v_ra = _grads(sc)
+    R = ref_hip.render_chain(ref, a["means"], a["quats"], a["scales"], a["opacities"], a["sh"], a["sh_degree"], a["viewmat"], a["K"], W, H, a["background"],
+                             v_render_colors=v_rc, v_render_alphas=v_ra)
+    op = a["opacities"][None].contiguous()
+    hargs = (a["means"], a["quats"], a["scales"], R["colors"], op, a["background"], None, W, H, 16, a["viewmat"], None, a["K"], ops.CameraModelType.PINHOLE,
+             ops.UnscentedTransformParameters(), ops.ShutterType.GLOBAL, None, None, None, R["tile_offsets"], R["flatten_ids"])
+    h_ren, h_alp, h_last = ops.rasterize_to_pixels_from_world_3dgs_fwd(*hargs)
+    h_g = ops.rasterize_to_pixels_from_world_3dgs_bwd(*hargs, h_alp, h_last, v_rc, v_ra)
+    f64 = lambda t: np.ascontiguousarray(t.detach().cpu().numpy(), np.float64)  # noqa: E731
+    oargs = (f64(a["means"]), f64(a["quats"]), f64(a["scales"]), f64(R["colors"]), f64(op), f64(a["background"]), None, W, H, 16, f64(a["viewmat"]), f64(a["K"]),
+             R["tile_offsets"].cpu().numpy(), R["flatten_ids"].cpu().numpy())
+    o_ren, o_alp, o_last = oracle.rasterize_fwd(*oargs)
+    o_g = oracle.rasterize_bwd(*oargs, o_alp, o_last, f64(v_rc), f64(v_ra))
+    pk, axn = pick.numpy(), ax.numpy()
+    wide = np.ones((N, 3), bool)
+    wide[pk, axn] = False
+    err = (h_ren - R["renders"]).abs().amax(-1)
+    hs, rs = np32(h_g[2]).astype(np.float64), np32(R["v_scales"]).astype(np.float64)
+    rec = parity_record("thin discs (one axis 1e%g, backward %s): HIP vs reference kernel and float64" % (thin_exp, bwd_kernel), thin_discs_visible=int((R["radii"][0][pick.to(DEV)] > 0).all(-1).sum()),
+                        n_isects=int(R["flatten_ids"].numel()), rgb_max_err=float(err.max()), rgb_pixels_over_1e4=int((err > 1e-4).sum()), alpha_max_err=float((h_alp - R["alphas"]).abs().max()),
+                        non_finite_gradients=int(sum((~torch.isfinite(x)).sum() for x in h_g)),
+                        v_means=rel_l2(np32(h_g[0]), np32(R["v_means"])), v_quats=rel_l2(np32(h_g[1]), np32(R["v_quats"])), v_scales_all_but_thin_axes=rel_l2(hs[wide], rs[wide]),
+                        v_colors=rel_l2(np32(h_g[3]), np32(R["v_colors"])), v_opacities=rel_l2(np32(h_g[4]), np32(R["v_opacities"])),
+                        thin_axes_vs_f64_hip=rel_l2(hs[pk, axn], o_g[2][pk, axn]), thin_axes_vs_f64_reference=rel_l2(rs[pk, axn], o_g[2][pk, axn]))
+    assert rec["thin_discs_visible"] > 250 and rec["non_finite_gradients"] == 0, rec
+    assert rec["rgb_pixels_over_1e4"] <= 4 and rec["rgb_max_err"] < 1e-3 and rec["alpha_max_err"] < 4e-3, rec   # (one or two threshold decisions, as on every frame)
+    for k in ("v_means", "v_quats", "v_scales_all_but_thin_axes", "v_colors", "v_opacities"):
+        assert rec[k] < 1e-3, (k, rec)
+    assert rec["thin_axes_vs_f64_hip"] <= max(1.0 + 1e-6, rec["thin_axes_vs_f64_reference"]), rec
+
+
 def _make_opaque(sc, seed=29):
     """A third of the scene's Gaussians opaque (opacity 1.0 / 0.9995 / 0.9992) and ~10 px wide on screen: pixels next to their centres
     see opacity x exp(-s) above 0.999 — the alpha clamp (Fwd.cu:239) and its gradient mask (Bwd.cu:318), which no random scene reaches."""
