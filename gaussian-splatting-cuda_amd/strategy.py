@@ -67,6 +67,21 @@ class MCMC:
         m = self.model
         opac = m.get_opacity()
         dead = (opac <= self.params.min_opacity) | ((m.rotation_raw * m.rotation_raw).sum(-1) < 1e-8)
+        # A Gaussian with a non-finite parameter is dead too (upstream has no such case: its multinomial asserts on the NaN opacity and the run ends).  Its Adam
+        # moments are reset with it.  Reported once per event on stderr: it should not happen, and when it does the pattern says where from.
+        finite = torch.isfinite(opac) & torch.isfinite(m.means.data).all(-1) & torch.isfinite(m.scaling_raw.data).all(-1) & torch.isfinite(m.rotation_raw.data).all(-1) \
+            & torch.isfinite(m.sh.data.reshape(m.sh.shape[0], -1)).all(-1)
+        n_bad = int((~finite).sum())
+        if n_bad:
+            import sys
+            bad_idx = (~finite).nonzero().squeeze(-1)
+            per = {n: int((~torch.isfinite(getattr(m, n).data.reshape(m.means.shape[0], -1))).any(-1).sum()) for n in ("means", "sh", "scaling_raw", "rotation_raw", "opacity_raw")}
+            runs = int((bad_idx[1:] - bad_idx[:-1] != 1).sum()) + 1
+            print("gsx.strategy.MCMC: %d of %d Gaussians hold non-finite parameters %s (indices %d .. %d in %d contiguous runs, first %s): relocated as dead" % (
+                n_bad, m.means.shape[0], per, int(bad_idx.min()), int(bad_idx.max()), runs, bad_idx[:8].tolist()), file=sys.stderr, flush=True)
+            opac = torch.where(finite, opac, torch.zeros_like(opac))
+            dead = dead | ~finite
+            self.nonfinite_relocated = getattr(self, "nonfinite_relocated", 0) + n_bad
         dead_idx = dead.nonzero().squeeze(-1)
         n_dead = dead_idx.numel()
         if n_dead == 0:
@@ -84,6 +99,8 @@ class MCMC:
         for t in m.params():
             t.data[dead_idx] = t.data.index_select(0, sampled)
         self.optimizer.reset_state(sampled)
+        if n_bad:
+            self.optimizer.reset_state(bad_idx)   # (their moments are as non-finite as they were)
         return n_dead
 
     # ---- mcmc.cpp:191-340 ------------------------------------------------------------------------------------------------

@@ -66,6 +66,8 @@ class Trainer:
         if self.sharded is not None:   # rows change owner when the strategy permutes / removes them: complete the moments on every rank first
             self.strategy.before_reindex = self.sharded.merge_moments
         self.last_loss = None
+        self.check_finite = os.environ.get("GSX_CHECK_FINITE", "0") == "1"
+        self.check_finite_async, self._finite_flags = os.environ.get("GSX_CHECK_FINITE", "0") == "2", []
 
     def _rebuild_bucket(self, model):
         if getattr(self, "exchange", None) == "colors":   # SH gradient first: the all-reduced remainder is one contiguous span
@@ -121,6 +123,10 @@ class Trainer:
                     print("iteration %d (%d Gaussians): %s" % (it, self.model.means.shape[0], e), file=sys.stderr)
                 if attempt == 3:
                     raise
+        if self.check_finite:
+            self._check_finite(it, out, loss, "gradients")
+        if self.check_finite_async:
+            self._flag_finite(it, "gradients", loss)
         if self.sharded is not None:
             # the regularisers are the same on every rank, so adding them before the mean over the ranks gives the same sum; the
             # exchange itself (reduce-scatter ... all-gather) brackets the optimizer step and is skipped with it when the model grew
@@ -135,8 +141,63 @@ class Trainer:
             self._add_regularisers()  # identical on every rank (functions of the replicated parameters): added after the reduction
             self.strategy.post_backward(it, out)
             self.strategy.step(it, optimizer_step=(lambda k: self.strategy.optimizer.step(k, skip_sh=True)) if fuse else None)
+        if self.check_finite:
+            self._check_finite(it, out, loss, "parameters")
+        if self.check_finite_async:
+            self._flag_finite(it, "parameters", loss)
         self.last_loss = loss.detach()
         return self.last_loss
+
+    _NAMES = ("means", "sh", "scaling_raw", "rotation_raw", "opacity_raw")
+
+    def _flag_finite(self, it, what, loss):
+        """GSX_CHECK_FINITE=2: the same question without a synchronisation per iteration (a run whose timing stays what it is): one flag word per tensor and
+        iteration is left on the device and read where the loop synchronises anyway (every 250 iterations here); the first flagged iteration is reported."""
+        m = self.model
+        ts = [(getattr(m, n).grad if what == "gradients" else getattr(m, n)) for n in self._NAMES]
+        flags = torch.stack([(~torch.isfinite(t)).any() if t is not None else torch.zeros((), dtype=torch.bool, device=m.means.device) for t in ts] +
+                            [~torch.isfinite(loss.detach()).all()])
+        self._finite_flags.append((it, what, m.means.shape[0], flags))
+        if what == "parameters" and it % 250 == 0:
+            allf = torch.stack([f for _, _, _, f in self._finite_flags]).cpu()
+            if bool(allf.any()):
+                k = int(allf.any(-1).nonzero()[0])
+                it0, w0, n0, _ = self._finite_flags[k]
+                bad = [n for n, b in zip(self._NAMES + ("loss",), allf[k].tolist()) if b]
+                later = [(self._finite_flags[j][0], self._finite_flags[j][1], [n for n, b in zip(self._NAMES + ("loss",), allf[j].tolist()) if b]) for j in range(k + 1, min(k + 6, len(self._finite_flags)))]
+                raise FloatingPointError("first non-finite values: iteration %d (%s, %d Gaussians), %s of %s; then %s" % (
+                    it0, "refine" if self.strategy.is_refining(it0) else "plain", n0, w0, bad, later))
+            self._finite_flags = []
+
+    def _check_finite(self, it, out, loss, what):
+        """GSX_CHECK_FINITE=1 (a debugging run: it synchronises every iteration): stops at the first iteration whose loss / gradients (after the backward) or
+        parameters (after refine events, noise and the optimizer step) hold a non-finite value, and says where."""
+        names = self._NAMES
+        m = self.model
+        if what == "gradients":
+            bad = {n: int((~torch.isfinite(getattr(m, n).grad)).sum()) for n in names if getattr(m, n).grad is not None and n != ("sh" if self.sinks.get("_sh_adam") is not None else "")}
+            bad["loss"] = 0 if bool(torch.isfinite(loss)) else 1
+            bad["render"] = int((~torch.isfinite(out.render_hwc)).sum())
+        else:
+            bad = {n: int((~torch.isfinite(getattr(m, n))).sum()) for n in names}
+        if sum(bad.values()) == 0:
+            return
+        rows = torch.zeros(m.means.shape[0], dtype=torch.bool, device=m.means.device)
+        for n in names:
+            t = getattr(m, n).grad if what == "gradients" else getattr(m, n)
+            if t is not None and t.shape[0] == rows.shape[0]:
+                rows |= ~torch.isfinite(t.reshape(t.shape[0], -1)).all(-1)
+        idx = rows.nonzero().flatten()
+        k = idx[:6]
+        sc, op = m.get_scaling(), m.get_opacity().flatten()
+        msg = ["iteration %d (%s, %d Gaussians): non-finite %s: %s; %d Gaussians affected" % (it, "refine" if self.strategy.is_refining(it) else "plain", m.means.shape[0], what, bad, idx.numel())]
+        if k.numel():
+            msg.append("  e.g. Gaussians %s: opacity %s scales %s |rotation_raw| %s radii %s" % (k.tolist(), op[k].tolist(), sc[k].tolist(), m.rotation_raw[k].norm(dim=-1).tolist(),
+                                                                                              out.aux["radii_full"].reshape(-1, 2)[k].tolist() if out is not None and k.max() < out.aux["radii_full"].numel() // 2 else "-"))
+        fin = torch.isfinite(sc).all(-1)
+        msg.append("  model: scales %.3g .. %.3g (ratio max %.3g), opacity %.3g .. %.3g, n_isects %s" % (float(sc[fin].min()), float(sc[fin].max()), float((sc[fin].max(-1).values / sc[fin].min(-1).values).max()),
+                                                                                                     float(op[torch.isfinite(op)].min()), float(op[torch.isfinite(op)].max()), getattr(out, "n_isects", "-")))
+        raise FloatingPointError("\n".join(msg))
 
     def train(self, iterations=None, start=1, log_every=0):
         n = iterations or self.params.iterations

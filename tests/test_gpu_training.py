@@ -103,6 +103,39 @@ def test_mcmc_relocate_moves_dead_gaussians_onto_live_ones():
 
 
 @pytest.mark.gpu
+def test_mcmc_relocate_treats_non_finite_gaussians_as_dead(capfd):
+    """Upstream has no such case (its multinomial asserts on a NaN opacity, mcmc.cpp:114-189): here a Gaussian holding a non-finite parameter is relocated
+    like a dead one, its moments are cleared, and the event is reported on stderr; a finite model takes the unchanged path."""
+    import gsx  # noqa: F401
+    from gsx import strategy
+    dev = "cuda:0"
+    sc, model, cams = _scene(dev, N=500)
+    for p in model.params():
+        p.requires_grad_(True)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0)
+    mc = strategy.MCMC(model, strategy.OptimizationParameters(), 1.0, gen)
+    for p in model.params():
+        p.grad = torch.ones_like(p)
+    mc.optimizer.step(1)
+    assert mc.relocate_gs() == 0 and getattr(mc, "nonfinite_relocated", 0) == 0
+    with torch.no_grad():
+        model.means[3, 1] = float("nan")
+        model.opacity_raw[7] = float("nan")
+        model.scaling_raw[11, 0] = float("inf")
+        model.sh[13, 2, 1] = float("nan")
+        mc.optimizer.state["means"]["exp_avg"][3] = float("nan")
+    assert mc.relocate_gs() == 4
+    assert mc.nonfinite_relocated == 4
+    assert "4 of 500 Gaussians hold non-finite parameters" in capfd.readouterr().err
+    for p in model.params():
+        assert bool(torch.isfinite(p.detach()).all())
+    for st in (st for st in mc.optimizer.state.values() if isinstance(st, dict)):
+        assert bool(torch.isfinite(st["exp_avg"]).all()) and bool(torch.isfinite(st["exp_avg_sq"]).all())
+    assert float(mc.optimizer.state["means"]["exp_avg"][3].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
 def test_fused_regularisers_equal_the_separate_ones():
     """Trainer(fused_regularisers=True) adds the scale / opacity regulariser gradients inside the render backward's activation kernel;
     False adds them with elementwise ops behind the backward (trainer.cpp:103-127 puts both terms into the loss): same parameters after
