@@ -125,7 +125,8 @@ def run(args):
            "evaluated_on": "held-out test split (every %d-th image)" % args.test_every if test_idx else "every 8th training image",
            "psnr_before": round(before["psnr"], 2), "psnr_after": round(after["psnr"], 2), "ssim_before": round(before["ssim"], 4),
            "ssim_after": round(after["ssim"], 4), "active_sh_degree": model.active_sh_degree,
-           "iterations_repeated_for_list_capacity": int(tr.capacity_misses), "scene_scale": round(float(scene_scale), 4)}
+           "iterations_repeated_for_list_capacity": int(tr.capacity_misses),
+           "non_finite_gaussians_relocated": int(getattr(tr.strategy, "nonfinite_relocated", 0)), "scene_scale": round(float(scene_scale), 4)}
     if args.output:
         os.makedirs(args.output, exist_ok=True)
         res["ply"] = io_ply.save_ply(model, os.path.join(args.output, "splat_%d.ply" % params.iterations))

@@ -117,7 +117,8 @@ def main():
            "psnr_before": round(before["psnr"], 2), "psnr_after": round(after["psnr"], 2),
            "ssim_before": round(before["ssim"], 4), "ssim_after": round(after["ssim"], 4),
            "active_sh_degree": model.active_sh_degree, "means_lr_end": tr.strategy.optimizer.groups[0]["lr"],
-           "intersect_protocol": "guarded lists" if tr.guarded else "exact", "iterations_repeated_for_list_capacity": int(tr.capacity_misses)}
+           "intersect_protocol": "guarded lists" if tr.guarded else "exact", "iterations_repeated_for_list_capacity": int(tr.capacity_misses),
+           "non_finite_gaussians_relocated": int(getattr(tr.strategy, "nonfinite_relocated", 0))}
     if "--profile-ops" in sys.argv:   # per-operator HIP-event times of 48 more iterations at the final model size (bench.OpTimer)
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import bench
