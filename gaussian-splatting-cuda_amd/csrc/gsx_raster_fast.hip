@@ -1700,17 +1700,6 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
     float4 q_raw = make_float4(0.f, 0.f, 0.f, 0.f);
     float v_opac_act = 0.f;
     const size_t cn = (size_t)a.C * a.N;
-#ifdef GSX_GATHER_QSTASH
-    // the raw quaternion of the activation epilogue: loaded in front of the walk, beside camera 0's first head word (one trip to memory for both), and parked in
-    // LDS across the walk — four registers the walk does not hold, no exposed load behind it
-    __shared__ float4 s_qraw[ACT ? 256 : 1];
-    int32_t head0 = 0;
-    if (ACT) {
-        const float4 q_early = reinterpret_cast<const float4*>(act.rotation_raw)[gi];
-        head0 = ranges ? (in ? ws_head[cn + gi] : 0) : (in ? ws_head[gi] : -1);
-        s_qraw[threadIdx.x] = q_early;
-    }
-#endif
     for (uint32_t c = 0; c < a.C; ++c) {
         const size_t g = (size_t)c * a.N + gi;
         float Mo[15];
@@ -1734,11 +1723,7 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
         if (ranges) {
             // ---- ranges: the records of this (camera, Gaussian) are the slots [first, cursor) ----
             constexpr int32_t RUN_T = 12;   // longer runs are summed by the whole wave
-#ifdef GSX_GATHER_QSTASH
-            const int32_t n_claimed = (ACT && c == 0) ? head0 : (in ? ws_head[cn + g] : 0);   // plane 1: records the backward claimed
-#else
             const int32_t n_claimed = in ? ws_head[cn + g] : 0;   // plane 1: records the backward claimed
-#endif
             const int32_t first = n_claimed > 0 ? range_first_slot(a, ws_head, g) : 0;
             // the same bound as the writers' guard (claim_record_slot's callers): a slot at or beyond rec_capacity was never written.  By
             // construction no run reaches it (a run is at most the Gaussian's rectangle of 16-px tiles, the slots are their sum); if the
@@ -1785,11 +1770,7 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
             int32_t it[NCH];
             int32_t all = -1;
 #pragma unroll
-#ifdef GSX_GATHER_QSTASH
-            for (int k = 0; k < NCH; ++k) { it[k] = (ACT && c == 0 && k == 0) ? head0 : (in ? ws_head[(size_t)k * cn + g] : -1); all &= it[k]; }
-#else
             for (int k = 0; k < NCH; ++k) { it[k] = in ? ws_head[(size_t)k * cn + g] : -1; all &= it[k]; }
-#endif
             touched = all >= 0;   // some chain has a record (an index has its sign bit clear)
             if (touched) {
 #pragma unroll
@@ -1884,11 +1865,7 @@ __global__ __launch_bounds__(256) void gsx_bwd_gather_kernel(RasterArgs a, const
         if (act.scale_reg != 0.f) gk = fmaf(act.scale_reg, sc[k], gk);
         act.v_scaling_raw[(size_t)gi * 3 + k] = gk;
     }
-#ifdef GSX_GATHER_QSTASH
-    q_raw = s_qraw[threadIdx.x];
-#else
     q_raw = reinterpret_cast<const float4*>(act.rotation_raw)[gi];   // (loaded here, not in front of the record walk: four registers less across the walk and the chain rule keep the kernel at 4 waves / SIMD)
-#endif
     const float nrm = sqrtf(q_raw.x * q_raw.x + q_raw.y * q_raw.y + q_raw.z * q_raw.z + q_raw.w * q_raw.w);
     float4 o;
     if (nrm > 1e-12f) {
