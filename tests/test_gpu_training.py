@@ -136,6 +136,32 @@ def test_mcmc_relocate_treats_non_finite_gaussians_as_dead(capfd):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_check_finite_switches_name_the_first_non_finite_iteration(monkeypatch, mode):
+    """GSX_CHECK_FINITE=1 (a synchronisation per iteration) / =2 (flag words read every 250 iterations): a clean run passes untouched, a NaN planted in a
+    parameter is reported with the iteration it first showed up in."""
+    import gsx  # noqa: F401
+    from gsx import rasterizer, strategy, trainer
+    monkeypatch.setenv("GSX_CHECK_FINITE", mode)
+    dev = "cuda:0"
+    sc, model, cams = _scene(dev, N=800)
+    bg = sc["background"].to(dev)
+    with torch.no_grad():
+        images = [rasterizer.rasterize_fused(c, model, bg).image.clone() for c in cams]
+    params = strategy.OptimizationParameters(iterations=600, start_refine=10_000, refine_every=100, stop_refine=20_000, max_cap=1000, sh_degree_interval=1000)
+    tr = trainer.Trainer(model, cams, images, params, bg, seed=1)
+    assert tr.check_finite == (mode == "1") and tr.check_finite_async == (mode == "2")
+    for it in range(1, 251):
+        tr.train_step(it)                       # (mode 2 reads its flag words at iteration 250: nothing flagged)
+    with torch.no_grad():
+        model.sh[5, 0, 0] = float("nan")        # (a colour coefficient: the geometry stays what it was)
+    with pytest.raises(FloatingPointError) as e:
+        for it in range(251, 501):
+            tr.train_step(it)
+    assert "iteration 251" in str(e.value), str(e.value)
+
+
+@pytest.mark.gpu
 def test_fused_regularisers_equal_the_separate_ones():
     """Trainer(fused_regularisers=True) adds the scale / opacity regulariser gradients inside the render backward's activation kernel;
     False adds them with elementwise ops behind the backward (trainer.cpp:103-127 puts both terms into the loss): same parameters after
