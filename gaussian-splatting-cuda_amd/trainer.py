@@ -151,7 +151,7 @@ class Trainer:
     _NAMES = ("means", "sh", "scaling_raw", "rotation_raw", "opacity_raw")
 
     def _flag_finite(self, it, what, loss):
-        """GSX_CHECK_FINITE=2: the same question without a synchronisation per iteration (a run whose timing stays what it is): one flag word per tensor and
+        """GSX_CHECK_FINITE=2: the same question without a synchronisation per iteration (its reductions cost the garden stand-in's iteration a third on top): one flag word per tensor and
         iteration is left on the device and read where the loop synchronises anyway (every 250 iterations here); the first flagged iteration is reported."""
         m = self.model
         ts = [(getattr(m, n).grad if what == "gradients" else getattr(m, n)) for n in self._NAMES]
