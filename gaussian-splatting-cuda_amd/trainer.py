@@ -151,14 +151,20 @@ class Trainer:
     _NAMES = ("means", "sh", "scaling_raw", "rotation_raw", "opacity_raw")
 
     def _flag_finite(self, it, what, loss):
-        """GSX_CHECK_FINITE=2: the same question without a synchronisation per iteration (its reductions cost the garden stand-in's iteration a third on top): one flag word per tensor and
-        iteration is left on the device and read where the loop synchronises anyway (every 250 iterations here); the first flagged iteration is reported."""
+        """GSX_CHECK_FINITE=2: the same question without a synchronisation per iteration (its reductions cost the garden stand-in's iteration a third on top):
+        one flag word per tensor and iteration is left on the device and read every 250 iterations and at the end of train(); the first flagged iteration is
+        reported."""
         m = self.model
         ts = [(getattr(m, n).grad if what == "gradients" else getattr(m, n)) for n in self._NAMES]
         flags = torch.stack([(~torch.isfinite(t)).any() if t is not None else torch.zeros((), dtype=torch.bool, device=m.means.device) for t in ts] +
                             [~torch.isfinite(loss.detach()).all()])
         self._finite_flags.append((it, what, m.means.shape[0], flags))
         if what == "parameters" and it % 250 == 0:
+            self._read_finite_flags()
+
+    def _read_finite_flags(self):
+        """One device -> host copy of the flag words left since the last read (every 250 iterations and at the end of train()); raises on the first flagged one."""
+        if self._finite_flags:
             allf = torch.stack([f for _, _, _, f in self._finite_flags]).cpu()
             if bool(allf.any()):
                 k = int(allf.any(-1).nonzero()[0])
@@ -214,4 +220,6 @@ class Trainer:
                           f"{self.capacity_misses} = {1e3 * self.capacity_misses / done:.2f} per 1000")
         finally:
             gc.unfreeze()
+        if self.check_finite_async:
+            self._read_finite_flags()   # (a run that does not end on a multiple of 250)
         return self.last_loss
