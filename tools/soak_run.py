@@ -1,5 +1,5 @@
 """examples/train_synthetic.py's run with the trainer's switches from the environment (SOAK_GUARDED / SOAK_FUSED_SH / SOAK_FUSED_REG = 0 | 1, SOAK_REFINE = 0: no refine
-events), ending in one line: ok | non-finite | (a crash prints nothing).    python tools/soak_run.py [iterations]"""
+events, SOAK_CAMERA = pinhole | fisheye | distorted, SOAK_INSIDE = 1: cameras inside the cloud), ending in one line: ok | non-finite | (a crash prints nothing).    python tools/soak_run.py [iterations]"""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,7 +16,18 @@ cams = []
 for k in range(8):
     vm = sc["viewmat"].clone()
     vm[0, 3] += 0.2 * math.cos(k * math.pi / 4); vm[1, 3] += 0.2 * math.sin(k * math.pi / 4)
-    cams.append(rasterizer.Camera(viewmat=vm.to(dev), K=sc["K"].to(dev), width=W, height=H))
+    if os.environ.get("SOAK_INSIDE"):   # the cameras INSIDE the cloud (its depths are 2 .. 3): Gaussians at, around and behind the camera plane, screen-filling footprints
+        vm[2, 3] -= 2.3 + 0.05 * k
+    # SOAK_CAMERA=fisheye | distorted: the same poses through an equidistant fisheye / a pinhole with radial + tangential distortion (the fast path's chart flags and
+    # generic tiles, resp. the distorted projection, under 30 000 iterations of MCMC)
+    kind = os.environ.get("SOAK_CAMERA", "pinhole")
+    extra = {}
+    if kind == "fisheye":
+        from gsx import ops
+        extra = dict(camera_model=ops.CameraModelType.FISHEYE, radial=torch.tensor([0.01, -0.002, 0.0, 0.0], device=dev))
+    elif kind == "distorted":
+        extra = dict(radial=torch.tensor([0.05, -0.01, 0.002, 0.0], device=dev), tangential=torch.tensor([0.002, -0.001], device=dev))
+    cams.append(rasterizer.Camera(viewmat=vm.to(dev), K=sc["K"].to(dev), width=W, height=H, **extra))
 bg = sc["background"].to(dev)
 with torch.no_grad():
     images = [rasterizer.rasterize_fused(c, gt, bg).image.clone() for c in cams]
