@@ -69,8 +69,8 @@ class MCMC:
         dead = (opac <= self.params.min_opacity) | ((m.rotation_raw * m.rotation_raw).sum(-1) < 1e-8)
         # A Gaussian with a non-finite parameter is dead too (upstream has no such case: its multinomial asserts on the NaN opacity and the run ends).  Its Adam
         # moments are reset with it.  Reported once per event on stderr: it should not happen, and when it does the pattern says where from.
-        finite = torch.isfinite(opac) & torch.isfinite(m.means.data).all(-1) & torch.isfinite(m.scaling_raw.data).all(-1) & torch.isfinite(m.rotation_raw.data).all(-1) \
-            & torch.isfinite(m.sh.data.reshape(m.sh.shape[0], -1)).all(-1)
+        # (row sums: one pass over each tensor and an [N] result — NaN and +-inf survive a sum, and inf - inf is NaN; no [N, 48] boolean temporaries at 5 M Gaussians)
+        finite = torch.isfinite(opac + m.means.data.sum(-1) + m.scaling_raw.data.sum(-1) + m.rotation_raw.data.sum(-1) + m.sh.data.reshape(m.sh.shape[0], -1).sum(-1))
         n_bad = int((~finite).sum())
         if n_bad:
             import sys
